@@ -1,0 +1,163 @@
+/*
+ * vitx.h -- C ABI of libvitx.so, the MI355X (gfx950) ViT forward/backward engine.
+ *
+ * This is the drop-in boundary for the hot path named in BASELINE.json: everything the
+ * reference's Python classes hand to TensorFlow is handed to this library instead.
+ * The reference exposes no FFI of its own (it is 24 files of Keras model definitions);
+ * each entry point below cites the reference interface it replaces (paths relative to
+ * /root/reference).  Plain C: pointers and sizes only, no C++/torch types, no exceptions.
+ *
+ * Conventions
+ *   - every function returns int32 status: 0 = VITX_OK, <0 = error; the message of the last
+ *     failure on the calling thread is available from vitx_last_error().
+ *   - host buffers are borrowed for the duration of the call; the library owns all device memory
+ *     (params, grads, saved activations, workspaces) unless arenas are bound with vitx_bind_arenas.
+ *   - "_dev" variants take device pointers (inputs already resident in HBM) and are asynchronous
+ *     on the handle's stream; the host-pointer variants synchronise before returning.
+ *   - one handle <-> one GPU <-> one host thread at a time; different handles may be driven from
+ *     different threads / processes (data parallel = one process per GPU, one handle each).
+ *   - tensors are row-major fp32 at the boundary; images are NHWC like the reference's
+ *     tf.random.normal([b, H, W, 3]) (vit_tensorflow/vit.py:193).
+ */
+#ifndef VITX_H_
+#define VITX_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VITX_OK 0
+#define VITX_ERR_INVALID (-1)      /* bad argument / config (mirrors the reference's AssertionError sites) */
+#define VITX_ERR_HIP (-2)          /* HIP runtime failure */
+#define VITX_ERR_UNSUPPORTED (-3)  /* valid in the reference, not yet handled by the engine */
+#define VITX_ERR_STATE (-4)        /* call order (e.g. backward without forward) */
+#define VITX_ERR_COMM (-5)         /* RCCL failure */
+
+enum { VITX_VARIANT_VIT = 0, VITX_VARIANT_DEEPVIT = 1, VITX_VARIANT_CAIT = 2 };
+enum { VITX_POOL_CLS = 0, VITX_POOL_MEAN = 1 };
+/* FP32_PARITY: fp32 storage and fp32 FMA everywhere (gates "logits within 1e-3 of the reference").
+ * BF16: bf16 GEMM/attention operands on MFMA, fp32 accumulation, statistics and residual stream. */
+enum { VITX_COMPUTE_FP32_PARITY = 0, VITX_COMPUTE_BF16 = 1 };
+
+/* Mirrors the constructor kwargs 1:1:
+ *   ViT(image_size, patch_size, num_classes, dim, depth, heads, mlp_dim, pool, dim_head, dropout,
+ *       emb_dropout)                                   vit_tensorflow/vit.py:107-108
+ *   DeepViT(... same ...)                              vit_tensorflow/deepvit.py:113-114
+ *   CaiT(..., cls_depth, ..., layer_dropout)           vit_tensorflow/cait.py:156-157 */
+typedef struct vitx_config {
+  int32_t variant;
+  int32_t image_h, image_w;   /* pair(image_size)  vit.py:133 */
+  int32_t patch_h, patch_w;   /* pair(patch_size)  vit.py:134 */
+  int32_t channels;           /* 3 (the reference's Rearrange infers it from the input) */
+  int32_t num_classes, dim, depth, cls_depth, heads, dim_head, mlp_dim;
+  int32_t pool;               /* vit.py:139 */
+  float dropout, emb_dropout, layer_dropout;
+  float ln_eps;               /* Keras LayerNormalization default 1e-3 */
+  int32_t compute;
+  int32_t max_batch;          /* device buffers are sized once for this batch */
+  int32_t device_id;
+  int32_t reserved[8];
+} vitx_config;
+
+typedef struct vitx_engine* vitx_handle;
+
+/* per-kernel-class timing collected between vitx_profile_begin/_end (HIP events on the handle's stream) */
+typedef struct vitx_kernel_stat {
+  char name[48];
+  int64_t launches;
+  double total_ms;
+  double flops;   /* algorithmic FLOPs issued by these launches */
+  double bytes;   /* algorithmic HBM bytes (compulsory reads + writes) */
+} vitx_kernel_stat;
+
+/* called from vitx_backward* on the host as soon as every kernel producing grads[offset, offset+count)
+ * has been enqueued on the handle's stream (gradient buckets for overlapped all-reduce) */
+typedef void (*vitx_grad_ready_fn)(void* user, int64_t offset_elems, int64_t count_elems);
+
+const char* vitx_version(void);
+const char* vitx_last_error(void);
+
+/* ---- parameter table (host only, no GPU needed).  Replaces Keras' model.weights / get_weights()
+ * ordering (inherited from tf.keras.Model, used by mae.py:36-38).  Order is explicit and documented
+ * in DESIGN.md; layouts are Keras': Dense kernel [in,out], bias [out], LN gamma/beta [d]. */
+int32_t vitx_param_table_size(const vitx_config* cfg, int64_t* n_tensors, int64_t* n_elems);
+int32_t vitx_param_table_entry(const vitx_config* cfg, int64_t index, char* name, int32_t name_cap,
+                               int64_t shape[4], int32_t* rank, int64_t* offset_elems);
+
+/* ---- lifetime: ViT.__init__ (vit.py:107-157), DeepViT.__init__ (deepvit.py:113-137),
+ * CaiT.__init__ (cait.py:156-178).  Validation errors carry the reference's assertion text. */
+int32_t vitx_create(const vitx_config* cfg, vitx_handle* out);
+int32_t vitx_destroy(vitx_handle h);
+
+/* ---- weights: Keras set_weights/get_weights (flat fp32 blob in table order) */
+int32_t vitx_set_params(vitx_handle h, const float* host_blob, int64_t n_elems);
+int32_t vitx_get_params(vitx_handle h, float* host_blob, int64_t n_elems);
+int32_t vitx_get_grads(vitx_handle h, float* host_blob, int64_t n_elems);
+/* device arenas (fp32, table order) -- for optimizers / collectives living outside the library */
+int32_t vitx_params_dev(vitx_handle h, float** dev_ptr, int64_t* n_elems);
+int32_t vitx_grads_dev(vitx_handle h, float** dev_ptr, int64_t* n_elems);
+/* use caller-owned device arenas (e.g. torch tensors) instead of the library's; either may be NULL */
+int32_t vitx_bind_arenas(vitx_handle h, float* params_dev, float* grads_dev);
+/* tell the engine the fp32 params changed on device (re-derives the bf16 operand copies) */
+int32_t vitx_params_changed(vitx_handle h);
+
+/* ---- forward: ViT.call / DeepViT.call / CaiT.call (vit.py:159-177, deepvit.py:139-157,
+ * cait.py:180-194).  img NHWC fp32 [b,H,W,C]; H,W may be smaller than the configured image as long
+ * as they divide by the patch (pos_embedding is sliced, vit.py:165).  logits [b,num_classes]. */
+int32_t vitx_forward(vitx_handle h, const float* img_host, int32_t b, int32_t H, int32_t W,
+                     int32_t training, uint64_t seed, float* logits_host);
+int32_t vitx_forward_dev(vitx_handle h, const float* img_dev, int32_t b, int32_t H, int32_t W,
+                         int32_t training, uint64_t seed, float* logits_dev);
+
+/* ---- backward: the VJP TensorFlow's GradientTape would compute for the forward above
+ * (README.md:746-749 is the reference's only mention).  Requires a preceding forward with the same
+ * b; fills the gradient arena (overwrites, no accumulation).  dimg may be NULL (TF does not
+ * differentiate w.r.t. an un-watched image). */
+int32_t vitx_backward(vitx_handle h, const float* dlogits_host, float* dimg_host_or_null);
+int32_t vitx_backward_dev(vitx_handle h, const float* dlogits_dev, float* dimg_dev_or_null);
+
+/* ---- encoder.transformer(tokens) on arbitrary [b,n,dim] tokens (mae.py:69, simmim.py:116,
+ * mpp.py:212).  ViT / DeepViT only. */
+int32_t vitx_transformer_forward(vitx_handle h, const float* tokens_host, int32_t b, int32_t n,
+                                 float* out_host);
+
+/* ---- stand-alone patch unfold: Rearrange('b (h p1) (w p2) c -> b (h w) (p1 p2 c)') (vit.py:142,
+ * deepvit.py:122, cait.py:164).  Pure index arithmetic: bit-exact. */
+int32_t vitx_patch_unfold(const float* img_host, int32_t b, int32_t H, int32_t W, int32_t C,
+                          int32_t ph, int32_t pw, float* out_host);
+
+/* ---- loss gradient on device: d/dlogits of mean softmax cross-entropy
+ * (tf.keras.losses.categorical_crossentropy(from_logits=True), distill.py:119).  Writes the
+ * engine's internal dlogits (used by vitx_backward_dev(h, NULL, ...)) and optionally the mean loss. */
+int32_t vitx_ce_loss_grad_dev(vitx_handle h, const int32_t* labels_dev, float inv_global_batch,
+                              float* loss_dev_or_null);
+
+/* ---- streams / sync */
+int32_t vitx_set_stream(vitx_handle h, void* hip_stream); /* NULL = the handle's own stream */
+int32_t vitx_sync(vitx_handle h);
+
+/* ---- data parallel (no reference counterpart: batch-sharded replicas, mean-reduced gradients) */
+int32_t vitx_set_grad_ready_callback(vitx_handle h, vitx_grad_ready_fn fn, void* user);
+int32_t vitx_comm_unique_id(void* out_128_bytes);
+int32_t vitx_comm_init(vitx_handle h, int32_t rank, int32_t world, const void* unique_id_128_bytes);
+int32_t vitx_allreduce_grads(vitx_handle h); /* RCCL sum over ranks, then x 1/world */
+
+/* ---- measurement / debugging */
+int32_t vitx_profile_begin(vitx_handle h);
+int32_t vitx_profile_end(vitx_handle h, vitx_kernel_stat* out, int32_t cap, int32_t* n_out);
+int32_t vitx_workspace_bytes(vitx_handle h, int64_t* bytes);
+/* copy a saved activation of the last forward to the host as fp32 (bisecting parity failures);
+ * `which` in {"embed","x_in","y1","qkv","attn_out","x_mid","y2","hpre","act","x_out","pooled"} */
+int32_t vitx_debug_read(vitx_handle h, const char* which, int32_t layer, float* out_host,
+                        int64_t cap_elems, int64_t* n_elems);
+/* raw GEMM micro-benchmark on the handle's stream: C[M,N] = A[M,K] * B[N,K]^T (bf16 operands,
+ * random data), returns the average ms over `iters` launches; `kernel` selects the tile variant */
+int32_t vitx_bench_gemm(vitx_handle h, int32_t M, int32_t N, int32_t K, int32_t kernel,
+                        int32_t epilogue, int32_t iters, float* avg_ms, float* max_abs_err);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VITX_H_ */

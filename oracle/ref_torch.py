@@ -1,0 +1,146 @@
+"""TEST INFRASTRUCTURE -- NOT PRODUCT CODE.  PARITY UNPINNED (see oracle/spec.py).
+
+Independent torch-CPU twin of oracle/ref_numpy.py (plain reshape/permute instead of einops)
+with autograd, used as the gradient oracle (the reference has no backward code: gradients are
+TF autodiff of vit.py:159-177) and, in fp32 with all host threads, as the
+"reference-restatement CPU baseline" that bench.py times.
+
+`q` is an optional rounding hook applied wherever the bf16 throughput mode of the engine stores
+a bf16 tensor (GEMM operands, saved activations); q=None is the exact oracle.
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, Optional
+
+import torch
+
+LN_EPS = 1e-3
+
+
+def bf16_round(t: torch.Tensor) -> torch.Tensor:
+    """Round-to-nearest-even to bf16 and back, straight-through for autograd."""
+    r = t.detach().to(torch.bfloat16).to(t.dtype)
+    return t + (r - t.detach())
+
+
+def _ident(t):
+    return t
+
+
+def layer_norm(x, g, b):
+    mu = x.mean(dim=-1, keepdim=True)
+    var = ((x - mu) ** 2).mean(dim=-1, keepdim=True)
+    return (x - mu) * torch.rsqrt(var + LN_EPS) * g + b
+
+
+def gelu(x):
+    return 0.5 * x * (1.0 + torch.erf(x / 1.4142135623730951))
+
+
+def patch_unfold(img, ph, pw):
+    b, H, W, c = img.shape
+    x = img.reshape(b, H // ph, ph, W // pw, pw, c)
+    x = x.permute(0, 1, 3, 2, 4, 5)
+    return x.reshape(b, (H // ph) * (W // pw), ph * pw * c)
+
+
+def _heads(t, h):
+    b, n, _ = t.shape
+    return t.reshape(b, n, h, -1).permute(0, 2, 1, 3)
+
+
+def _merge(t):
+    b, h, n, d = t.shape
+    return t.permute(0, 2, 1, 3).reshape(b, n, h * d)
+
+
+def _dense(x, P, name, q, bias=True):
+    y = q(x) @ q(P[f"{name}.kernel"])
+    if bias:
+        y = y + P[f"{name}.bias"]
+    return y
+
+
+def _attention(x, P, pre, cfg, q, context=None):
+    v, h, dh = cfg["variant"], cfg["heads"], cfg["dim_head"]
+    scale = dh ** -0.5
+    if v == "cait":
+        ctx = x if context is None else torch.cat([x, q(context)], dim=1)
+        qq = q(_dense(x, P, f"{pre}.to_q", q, bias=False))
+        kv = q(_dense(ctx, P, f"{pre}.to_kv", q, bias=False))
+        kk, vv = kv.chunk(2, dim=-1)
+    else:
+        qkv = q(_dense(x, P, f"{pre}.to_qkv", q, bias=False))
+        qq, kk, vv = qkv.chunk(3, dim=-1)
+    qq, kk, vv = _heads(qq, h), _heads(kk, h), _heads(vv, h)
+    dots = (qq @ kk.transpose(-1, -2)) * scale
+    if v == "cait":
+        dots = torch.einsum('bhij,hg->bgij', dots, P[f"{pre}.mix_heads_pre_attn"])
+    attn = torch.softmax(dots, dim=-1)
+    if v == "cait":
+        attn = torch.einsum('bhij,hg->bgij', attn, P[f"{pre}.mix_heads_post_attn"])
+    elif v == "deepvit":
+        attn = torch.einsum('bhij,hg->bgij', attn, P[f"{pre}.reattn_weights"])
+        attn = layer_norm(attn.permute(0, 2, 3, 1), P[f"{pre}.reattn_norm.gamma"],
+                          P[f"{pre}.reattn_norm.beta"]).permute(0, 3, 1, 2)
+    out = q(_merge(q(attn) @ vv))
+    if f"{pre}.to_out.kernel" in P:
+        out = _dense(out, P, f"{pre}.to_out", q)
+    return out
+
+
+def _transformer(x, P, cfg, prefix, depth, q, context=None):
+    cait = cfg["variant"] == "cait"
+    for i in range(depth):
+        pa, pm = f"{prefix}.{i}.attn", f"{prefix}.{i}.mlp"
+        a = _attention(q(layer_norm(x, P[f"{pa}.norm.gamma"], P[f"{pa}.norm.beta"])), P, pa, cfg, q, context)
+        if cait:
+            a = a * P[f"{pa}.scale"]
+        x = a + x
+        hpre = q(_dense(q(layer_norm(x, P[f"{pm}.norm.gamma"], P[f"{pm}.norm.beta"])), P, f"{pm}.fc1", q))
+        f = _dense(q(gelu(hpre)), P, f"{pm}.fc2", q)
+        if cait:
+            f = f * P[f"{pm}.scale"]
+        x = f + x
+    return x
+
+
+def forward(cfg: dict, P: Dict[str, torch.Tensor], img: torch.Tensor,
+            q: Optional[Callable] = None) -> torch.Tensor:
+    q = q or _ident
+    ph, pw = cfg["patch_size"]
+    x = _dense(q(patch_unfold(img, ph, pw)), P, "patch_embedding", q)
+    b, n, d = x.shape
+    cls = P["cls_token"].expand(b, 1, d)
+    if cfg["variant"] == "cait":
+        x = x + P["pos_embedding"][:, :n]
+        x = _transformer(x, P, cfg, "patch_transformer", cfg["depth"], q)
+        x = _transformer(cls, P, cfg, "cls_transformer", cfg["cls_depth"], q, context=x)
+        x = x[:, 0]
+    else:
+        x = torch.cat([cls, x], dim=1) + P["pos_embedding"][:, :n + 1]
+        x = _transformer(x, P, cfg, "transformer", cfg["depth"], q)
+        x = x.mean(dim=1) if cfg["pool"] == "mean" else x[:, 0]
+    x = q(layer_norm(x, P["mlp_head.norm.gamma"], P["mlp_head.norm.beta"]))
+    return _dense(x, P, "mlp_head", q)
+
+
+def to_torch(params, dtype=torch.float64, requires_grad=False):
+    return {k: torch.tensor(v, dtype=dtype, requires_grad=requires_grad) for k, v in params.items()}
+
+
+def forward_backward(cfg, params, img, dlogits, dtype=torch.float64, q=None, want_dimg=False):
+    """Returns (logits, {name: grad}, dimg|None): VJP of forward() for the cotangent `dlogits`."""
+    P = to_torch(params, dtype, requires_grad=True)
+    x = torch.tensor(img, dtype=dtype, requires_grad=want_dimg)
+    logits = forward(cfg, P, x, q)
+    logits.backward(torch.tensor(dlogits, dtype=dtype))
+    grads = {k: (v.grad if v.grad is not None else torch.zeros_like(v)).numpy() for k, v in P.items()}
+    return logits.detach().numpy(), grads, (x.grad.numpy() if want_dimg else None)
+
+
+def ce_dlogits(logits: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
+    """d/dlogits of mean softmax cross-entropy (the only loss in the reference: distill.py:119)."""
+    p = torch.softmax(logits, dim=-1)
+    p[torch.arange(logits.shape[0]), labels] -= 1.0
+    return p / logits.shape[0]

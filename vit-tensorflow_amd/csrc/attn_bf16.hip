@@ -1,0 +1,351 @@
+// Fused multi-head self-attention for the bf16 path (vit.py:73-82: split -> QK^T*scale -> softmax -> AV
+// -> merge heads) and its VJP.  The [b,h,n,n] score matrix is never written to HBM.
+//
+// Layout: packed qkv [b, n, 3, h, 64] bf16 exactly as the to_qkv Dense emits it (vit.py:72-74: the
+// 'b n (h d) -> b h n d' rearranges become addressing), output o [b, n, h*64] (vit.py:82).
+//
+// gfx950 mapping (wave = 64, v_mfma_f32_16x16x32_bf16):
+//   * one workgroup per (image, head); that head's K (row-major, XOR-swizzled 16-B chunks) and V
+//     (transposed) live in LDS; each wave owns 16-query blocks.
+//   * scores are computed TRANSPOSED (S^T = K Q^T) so a lane owns one query column: softmax row
+//     reductions are in-lane + two xor-shuffles, and the bf16 P registers are directly the MFMA
+//     B operand of O^T = V^T P^T.  The k-slot <-> key mapping of that second MFMA is a permutation
+//     (slot (g,e) <-> key 32u + 4g + e, 16 + ...), applied identically to the V^T operand reads --
+//     a contraction does not care about the order of its terms.
+//   * backward = dQ kernel (wave per query block, same S^T layout) + dK/dV kernel (wave per 16-key
+//     tile, S layout so a lane owns one key column); P is recomputed from the saved row LSE.
+#include "kernels.h"
+
+namespace {
+
+constexpr int DH = 64;
+constexpr int ROWB = DH * 2;  // 128-byte rows
+
+__device__ __forceinline__ int swz_chunk(int row, int chunk) { return (chunk ^ ((row >> 1) & 7)) << 4; }
+
+__device__ __forceinline__ bf16x8 zero8() {
+  bf16x8 z;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) z[i] = (bf16_t)0.f;
+  return z;
+}
+
+// rows [0, npad) of a [*, 64] bf16 matrix (row stride `stride` elements) -> LDS row-major swizzled image
+// and/or transposed image T[dh][vs]; rows >= nvalid are zero-filled.
+template <bool ROWMAJOR, bool TRANSPOSED>
+__device__ __forceinline__ void stage_head(const bf16_t* src, int64_t stride, int nvalid, int npad, char* rm, bf16_t* tr, int vs,
+                                           int tid, int nthreads) {
+  for (int idx = tid; idx < npad * 8; idx += nthreads) {
+    const int row = idx >> 3, c = idx & 7;
+    bf16x8 v = zero8();
+    if (row < nvalid) v = *(const bf16x8*)(src + (int64_t)row * stride + c * 8);
+    if (ROWMAJOR) *(bf16x8*)(rm + row * ROWB + swz_chunk(row, c)) = v;
+    if (TRANSPOSED) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) tr[(c * 8 + e) * vs + row] = v[e];
+    }
+  }
+}
+
+__device__ __forceinline__ bf16x8 frag_rm(const char* rm, int row, int chunk) {
+  return *(const bf16x8*)(rm + row * ROWB + swz_chunk(row, chunk));
+}
+// transposed-image operand: row dh, k-slots (g,e): e<4 -> col 32u+4g+e, e>=4 -> col 32u+16+4g+(e-4)
+__device__ __forceinline__ bf16x8 frag_tr(const bf16_t* tr, int vs, int dh, int u, int g) {
+  const bf16x4 lo = *(const bf16x4*)(tr + dh * vs + 32 * u + 4 * g);
+  const bf16x4 hi = *(const bf16x4*)(tr + dh * vs + 32 * u + 16 + 4 * g);
+  bf16x8 r;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { r[e] = lo[e]; r[4 + e] = hi[e]; }
+  return r;
+}
+__device__ __forceinline__ bf16x8 pack8(const f32x4& a, const f32x4& b) {
+  bf16x8 r;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { r[e] = (bf16_t)a[e]; r[4 + e] = (bf16_t)b[e]; }
+  return r;
+}
+__device__ __forceinline__ f32x4 mfma16(const bf16x8& a, const bf16x8& b, const f32x4& c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+// ------------------------------------------------------------------------------------------ forward
+// NTP = number of 16-key tiles (even); keys padded to 16*NTP.
+template <int NTP>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o, float* __restrict__ lse,
+                                                       int n, int h, float scale) {
+  constexpr int NKP = 16 * NTP, VS = NKP + 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* k_rm = smem;                                   // [NKP][128 B]
+  bf16_t* v_tr = (bf16_t*)(smem + NKP * ROWB);         // [64][VS]
+  const int bh = blockIdx.x, bi = bh / h, hi = bh - bi * h;
+  const int inner = h * DH;
+  const int64_t tok_stride = 3 * (int64_t)inner;
+  const bf16_t* qbase = qkv + (int64_t)bi * n * tok_stride + hi * DH;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+  stage_head<true, false>(qbase + inner, tok_stride, n, NKP, k_rm, nullptr, 0, tid, blockDim.x);
+  stage_head<false, true>(qbase + 2 * inner, tok_stride, n, NKP, nullptr, v_tr, VS, tid, blockDim.x);
+  __syncthreads();
+
+  const int qi = lane & 15, g = lane >> 4;
+  const int nqb = (n + 15) >> 4;
+  const float sl2 = scale * 1.44269504088896340736f;
+  for (int qb = wave; qb < nqb; qb += nwaves) {
+    const int q = qb * 16 + qi;
+    const int qc = min(q, n - 1);
+    bf16x8 qf[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) qf[ks] = *(const bf16x8*)(qbase + (int64_t)qc * tok_stride + (g + 4 * ks) * 8);
+    f32x4 s[NTP];
+    float m = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < NTP; ++t) {
+      f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) a = mfma16(frag_rm(k_rm, t * 16 + qi, g + 4 * ks), qf[ks], a);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = t * 16 + 4 * g + r;
+        a[r] = key < n ? a[r] * sl2 : -INFINITY;   // log2-domain scores
+        m = fmaxf(m, a[r]);
+      }
+      s[t] = a;
+    }
+    m = fmaxf(m, __shfl_xor(m, 16, 64));
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float l = 0.f;
+#pragma unroll
+    for (int t = 0; t < NTP; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { const float p = exp2f(s[t][r] - m); s[t][r] = p; l += p; }
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    const float inv_l = 1.0f / l;
+    if (g == 0 && q < n) lse[(int64_t)bh * n + q] = (m + log2f(l)) * 0.69314718055994530942f;  // natural-log LSE of scaled scores
+    f32x4 oacc[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) oacc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < NTP / 2; ++u) {
+      const bf16x8 pf = pack8(s[2 * u], s[2 * u + 1]);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) oacc[c] = mfma16(frag_tr(v_tr, VS, 16 * c + qi, u, g), pf, oacc[c]);
+    }
+    if (q < n) {
+      bf16_t* op = o + ((int64_t)bi * n + q) * inner + hi * DH;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        bf16x4 ov;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ov[r] = (bf16_t)(oacc[c][r] * inv_l);
+        *(bf16x4*)(op + 16 * c + 4 * g) = ov;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------ backward: dQ (+ row sums D)
+template <int NTP>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
+                                                          const bf16_t* __restrict__ d_o, const float* __restrict__ lse,
+                                                          float* __restrict__ dsum, bf16_t* __restrict__ dqkv, int n, int h, float scale) {
+  constexpr int NKP = 16 * NTP, VS = NKP + 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* k_rm = smem;
+  char* v_rm = smem + NKP * ROWB;
+  bf16_t* k_tr = (bf16_t*)(smem + 2 * NKP * ROWB);
+  const int bh = blockIdx.x, bi = bh / h, hi = bh - bi * h;
+  const int inner = h * DH;
+  const int64_t tok_stride = 3 * (int64_t)inner;
+  const bf16_t* qbase = qkv + (int64_t)bi * n * tok_stride + hi * DH;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+  stage_head<true, true>(qbase + inner, tok_stride, n, NKP, k_rm, k_tr, VS, tid, blockDim.x);
+  stage_head<true, false>(qbase + 2 * inner, tok_stride, n, NKP, v_rm, nullptr, 0, tid, blockDim.x);
+  __syncthreads();
+
+  const int qi = lane & 15, g = lane >> 4;
+  const int nqb = (n + 15) >> 4;
+  const float sl2 = scale * 1.44269504088896340736f;
+  for (int qb = wave; qb < nqb; qb += nwaves) {
+    const int q = qb * 16 + qi;
+    const int qc = min(q, n - 1);
+    const int64_t orow = ((int64_t)bi * n + qc) * inner + hi * DH;
+    bf16x8 qf[2], dof[2];
+    float dpart = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      qf[ks] = *(const bf16x8*)(qbase + (int64_t)qc * tok_stride + (g + 4 * ks) * 8);
+      dof[ks] = *(const bf16x8*)(d_o + orow + (g + 4 * ks) * 8);
+      const bf16x8 of = *(const bf16x8*)(o + orow + (g + 4 * ks) * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dpart += (float)dof[ks][e] * (float)of[e];
+    }
+    dpart += __shfl_xor(dpart, 16, 64);
+    dpart += __shfl_xor(dpart, 32, 64);   // D[q] = sum_d dO*O
+    if (g == 0 && q < n) dsum[(int64_t)bh * n + q] = dpart;
+    const float l2 = lse[(int64_t)bh * n + qc] * 1.44269504088896340736f;
+    f32x4 dq[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) dq[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int u = 0; u < NTP / 2; ++u) {
+      f32x4 ds[2];
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) {
+        const int t = 2 * u + tt;
+        f32x4 sa = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          sa = mfma16(frag_rm(k_rm, t * 16 + qi, g + 4 * ks), qf[ks], sa);
+          dp = mfma16(frag_rm(v_rm, t * 16 + qi, g + 4 * ks), dof[ks], dp);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = t * 16 + 4 * g + r;
+          const float p = (key < n && q < n) ? exp2f(sa[r] * sl2 - l2) : 0.f;
+          ds[tt][r] = p * (dp[r] - dpart) * scale;
+        }
+      }
+      const bf16x8 dsf = pack8(ds[0], ds[1]);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) dq[c] = mfma16(frag_tr(k_tr, VS, 16 * c + qi, u, g), dsf, dq[c]);
+    }
+    if (q < n) {
+      bf16_t* dp_out = dqkv + ((int64_t)bi * n + q) * tok_stride + hi * DH;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        bf16x4 ov;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ov[r] = (bf16_t)dq[c][r];
+        *(bf16x4*)(dp_out + 16 * c + 4 * g) = ov;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------ backward: dK, dV
+template <int NTP>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ d_o,
+                                                           const float* __restrict__ lse, const float* __restrict__ dsum,
+                                                           bf16_t* __restrict__ dqkv, int n, int h, float scale) {
+  constexpr int NQP = 16 * NTP, VS = NQP + 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* q_rm = smem;
+  char* do_rm = smem + NQP * ROWB;
+  bf16_t* q_tr = (bf16_t*)(smem + 2 * NQP * ROWB);
+  bf16_t* do_tr = q_tr + DH * VS;
+  float* lse_s = (float*)(do_tr + DH * VS);   // [NQP] (log2 domain)
+  float* d_s = lse_s + NQP;                   // [NQP]
+  const int bh = blockIdx.x, bi = bh / h, hi = bh - bi * h;
+  const int inner = h * DH;
+  const int64_t tok_stride = 3 * (int64_t)inner;
+  const bf16_t* qbase = qkv + (int64_t)bi * n * tok_stride + hi * DH;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+  stage_head<true, true>(qbase, tok_stride, n, NQP, q_rm, q_tr, VS, tid, blockDim.x);
+  stage_head<true, true>(d_o + (int64_t)bi * n * inner + hi * DH, inner, n, NQP, do_rm, do_tr, VS, tid, blockDim.x);
+  for (int i = tid; i < NQP; i += blockDim.x) {
+    lse_s[i] = i < n ? lse[(int64_t)bh * n + i] * 1.44269504088896340736f : 0.f;
+    d_s[i] = i < n ? dsum[(int64_t)bh * n + i] : 0.f;
+  }
+  __syncthreads();
+
+  const int ki = lane & 15, g = lane >> 4;
+  const int nkb = (n + 15) >> 4;
+  const float sl2 = scale * 1.44269504088896340736f;
+  for (int kb = wave; kb < nkb; kb += nwaves) {
+    const int key = kb * 16 + ki;
+    const int kc = min(key, n - 1);
+    bf16x8 kf[2], vf[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      kf[ks] = *(const bf16x8*)(qbase + inner + (int64_t)kc * tok_stride + (g + 4 * ks) * 8);
+      vf[ks] = *(const bf16x8*)(qbase + 2 * inner + (int64_t)kc * tok_stride + (g + 4 * ks) * 8);
+    }
+    f32x4 dk[4], dv[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { dk[c] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[c] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll 1
+    for (int u = 0; u < NTP / 2; ++u) {
+      f32x4 pp[2], ds[2];
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) {
+        const int t = 2 * u + tt;
+        f32x4 sa = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          sa = mfma16(frag_rm(q_rm, t * 16 + ki, g + 4 * ks), kf[ks], sa);    // S[query 16t+4g+r][key ki]
+          dp = mfma16(frag_rm(do_rm, t * 16 + ki, g + 4 * ks), vf[ks], dp);   // dP same layout
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int qq = t * 16 + 4 * g + r;
+          const float p = (qq < n && key < n) ? exp2f(sa[r] * sl2 - lse_s[qq]) : 0.f;
+          pp[tt][r] = p;
+          ds[tt][r] = p * (dp[r] - d_s[qq]) * scale;
+        }
+      }
+      const bf16x8 pf = pack8(pp[0], pp[1]), dsf = pack8(ds[0], ds[1]);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        dv[c] = mfma16(frag_tr(do_tr, VS, 16 * c + ki, u, g), pf, dv[c]);
+        dk[c] = mfma16(frag_tr(q_tr, VS, 16 * c + ki, u, g), dsf, dk[c]);
+      }
+    }
+    if (key < n) {
+      bf16_t* dkp = dqkv + ((int64_t)bi * n + key) * tok_stride + inner + hi * DH;
+      bf16_t* dvp = dkp + inner;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        bf16x4 a, b2;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { a[r] = (bf16_t)dk[c][r]; b2[r] = (bf16_t)dv[c][r]; }
+        *(bf16x4*)(dkp + 16 * c + 4 * g) = a;
+        *(bf16x4*)(dvp + 16 * c + 4 * g) = b2;
+      }
+    }
+  }
+}
+
+template <typename K>
+void set_smem(K kern, int bytes) {   // one attribute call per distinct kernel (function-pointer keyed)
+  static const void* done[32];
+  static int ndone = 0;
+  for (int i = 0; i < ndone; ++i) if (done[i] == (const void*)kern) return;
+  (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (ndone < 32) done[ndone++] = (const void*)kern;
+}
+
+inline int pick_ntp(int n) { return n <= 64 ? 4 : n <= 96 ? 6 : n <= 224 ? 14 : 18; }
+
+}  // namespace
+
+bool attn_bf16_supported(int n, int dim_head) { return dim_head == DH && n >= 1 && n <= 288; }
+
+#define VITX_NTP_DISPATCH(ntp, CALL) \
+  do { if ((ntp) == 4) { CALL(4); } else if ((ntp) == 6) { CALL(6); } else if ((ntp) == 14) { CALL(14); } else { CALL(18); } } while (0)
+
+void launch_attn_bf16_fwd(const bf16_t* qkv, bf16_t* o, float* lse, int b, int n, int h, float scale, hipStream_t s) {
+  const int ntp = pick_ntp(n);
+  const int nkp = 16 * ntp;
+  const int smem = nkp * ROWB + DH * (nkp + 4) * 2;
+#define CALL(NTP) { set_smem(attn_fwd_kernel<NTP>, smem); hipLaunchKernelGGL(attn_fwd_kernel<NTP>, dim3(b * h), dim3(256), smem, s, qkv, o, lse, n, h, scale); }
+  VITX_NTP_DISPATCH(ntp, CALL);
+#undef CALL
+}
+
+void launch_attn_bf16_bwd(const bf16_t* qkv, const bf16_t* o, const bf16_t* d_o, const float* lse, float* dsum_ws, bf16_t* dqkv, int b,
+                          int n, int h, float scale, hipStream_t s) {
+  const int ntp = pick_ntp(n);
+  const int np = 16 * ntp;
+  const int smem_dq = 2 * np * ROWB + DH * (np + 4) * 2;
+  const int smem_dkv = 2 * np * ROWB + 2 * DH * (np + 4) * 2 + 2 * np * 4;
+#define CALL(NTP)                                                                                                                  \
+  {                                                                                                                                \
+    set_smem(attn_bwd_dq_kernel<NTP>, smem_dq);                                                                                    \
+    set_smem(attn_bwd_dkv_kernel<NTP>, smem_dkv);                                                                                  \
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<NTP>, dim3(b * h), dim3(256), smem_dq, s, qkv, o, d_o, lse, dsum_ws, dqkv, n, h, scale);   \
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<NTP>, dim3(b * h), dim3(256), smem_dkv, s, qkv, d_o, lse, dsum_ws, dqkv, n, h, scale);    \
+  }
+  VITX_NTP_DISPATCH(ntp, CALL);
+#undef CALL
+}

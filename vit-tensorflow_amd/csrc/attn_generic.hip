@@ -1,0 +1,308 @@
+// Pieces of the materialised attention path (scores in fp32 in a workspace), used by the FP32_PARITY
+// mode and by the DeepViT / CaiT variants whose attention mixes information ACROSS heads:
+//   softmax (vit.py:58,78), DeepViT re-attention head mix + LayerNorm over heads (deepvit.py:57-63,83-84),
+//   CaiT talking heads (cait.py:97-98,123-125), context concat (cait.py:109-112), LayerScale VJP
+//   (cait.py:47-48).  Score tensors are [b, h, nq, ld] fp32 with ld = round_up(nk, 4).
+#include "kernels.h"
+
+namespace {
+
+constexpr int MAXH = 32;  // head-axis kernels keep one value per head in registers
+
+// one wave per row; rows are short (nk <= a few hundred)
+__global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ sc, int64_t rows, int n, int64_t ld) {
+  const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  float* r = sc + row * ld;
+  float m = -INFINITY;
+  for (int c = lane; c < n; c += 64) m = fmaxf(m, r[c]);
+  m = wave_max(m);
+  float s = 0.f;
+  for (int c = lane; c < n; c += 64) { const float e = expf(r[c] - m); r[c] = e; s += e; }
+  s = wave_sum(s);
+  const float inv = 1.0f / s;
+  for (int c = lane; c < n; c += 64) r[c] *= inv;
+}
+// dS = P * (dP - sum_j dP*P)   (in place on dP)
+__global__ __launch_bounds__(256) void softmax_bwd_rows_kernel(const float* __restrict__ p, float* __restrict__ dp, int64_t rows, int n,
+                                                               int64_t ld) {
+  const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* pr = p + row * ld;
+  float* dr = dp + row * ld;
+  float s = 0.f;
+  for (int c = lane; c < n; c += 64) s += pr[c] * dr[c];
+  s = wave_sum(s);
+  for (int c = lane; c < n; c += 64) dr[c] = pr[c] * (dr[c] - s);
+}
+
+// out[b,g,i,j] = sum_h in[b,h,i,j] W[h,g]    -- one thread per (b,i,j)
+__global__ __launch_bounds__(256) void headmix_fwd_kernel(const float* __restrict__ in, const float* __restrict__ w,
+                                                          float* __restrict__ out, int b, int h, int64_t plane, int64_t nvalid_per_row,
+                                                          int64_t ld) {
+  __shared__ float ws[MAXH * MAXH];
+  for (int i = threadIdx.x; i < h * h; i += blockDim.x) ws[i] = w[i];
+  __syncthreads();
+  const int64_t total = (int64_t)b * plane;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t bi = e / plane, ij = e - bi * plane;
+    if ((ij % ld) >= nvalid_per_row) continue;
+    const float* ip = in + bi * h * plane + ij;
+    float* op = out + bi * h * plane + ij;
+    float v[MAXH];
+#pragma unroll 4
+    for (int hh = 0; hh < h; ++hh) v[hh] = ip[(int64_t)hh * plane];
+    for (int gg = 0; gg < h; ++gg) {
+      float a = 0.f;
+      for (int hh = 0; hh < h; ++hh) a = fmaf(v[hh], ws[hh * h + gg], a);
+      op[(int64_t)gg * plane] = a;
+    }
+  }
+}
+
+// din[b,h,i,j] = sum_g dout[b,g,i,j] W[h,g];  per-block partial of dW[h,g] = sum in[h]*dout[g]
+__global__ __launch_bounds__(256) void headmix_bwd_kernel(const float* __restrict__ in, const float* __restrict__ dout,
+                                                          const float* __restrict__ w, float* __restrict__ din,
+                                                          float* __restrict__ dw_partial, int b, int h, int64_t plane,
+                                                          int64_t nvalid_per_row, int64_t ld) {
+  __shared__ float ws[MAXH * MAXH];
+  extern __shared__ float pts[];   // [256][2h]: in[h], dout[h] of each point handled by this block iteration
+  for (int i = threadIdx.x; i < h * h; i += blockDim.x) ws[i] = w[i];
+  float dwacc[4] = {0.f, 0.f, 0.f, 0.f};  // thread t owns (h,g) pairs t, t+256, ... (h*h <= 1024)
+  const int64_t total = (int64_t)b * plane;
+  const int64_t span = (int64_t)gridDim.x * blockDim.x;
+  const int64_t iters = (total + span - 1) / span;
+  for (int64_t it = 0; it < iters; ++it) {
+    const int64_t e = it * span + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool valid = e < total;
+    int64_t bi = 0, ij = 0;
+    if (valid) { bi = e / plane; ij = e - bi * plane; valid = (ij % ld) < nvalid_per_row; }
+    __syncthreads();
+    float* mine = pts + (int64_t)threadIdx.x * 2 * h;
+    if (valid) {
+      float dv[MAXH];
+      for (int gg = 0; gg < h; ++gg) { dv[gg] = dout[(bi * h + gg) * plane + ij]; mine[h + gg] = dv[gg]; }
+      for (int hh = 0; hh < h; ++hh) {
+        mine[hh] = in[(bi * h + hh) * plane + ij];
+        float a = 0.f;
+        for (int gg = 0; gg < h; ++gg) a = fmaf(dv[gg], ws[hh * h + gg], a);
+        din[(bi * h + hh) * plane + ij] = a;
+      }
+    } else {
+      for (int k = 0; k < 2 * h; ++k) mine[k] = 0.f;
+    }
+    __syncthreads();
+    for (int k = 0; k < 4; ++k) {
+      const int pair = threadIdx.x + 256 * k;
+      if (pair < h * h) {
+        const int hh = pair / h, gg = pair - hh * h;
+        float a = dwacc[k];
+        for (int p = 0; p < 256; ++p) a = fmaf(pts[p * 2 * h + hh], pts[p * 2 * h + h + gg], a);
+        dwacc[k] = a;
+      }
+    }
+  }
+  for (int k = 0; k < 4; ++k) {
+    const int pair = threadIdx.x + 256 * k;
+    if (pair < h * h) dw_partial[(int64_t)blockIdx.x * h * h + pair] = dwacc[k];
+  }
+}
+
+// LayerNorm over heads at every (b,i,j)  (deepvit.py:59-63)
+__global__ __launch_bounds__(256) void headnorm_fwd_kernel(const float* __restrict__ in, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float* __restrict__ out, int b, int h,
+                                                           int64_t plane, int64_t nvalid_per_row, int64_t ld, float eps) {
+  const int64_t total = (int64_t)b * plane;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t bi = e / plane, ij = e - bi * plane;
+    if ((ij % ld) >= nvalid_per_row) continue;
+    float v[MAXH];
+    float mu = 0.f;
+    for (int hh = 0; hh < h; ++hh) { v[hh] = in[(bi * h + hh) * plane + ij]; mu += v[hh]; }
+    mu /= (float)h;
+    float var = 0.f;
+    for (int hh = 0; hh < h; ++hh) var += (v[hh] - mu) * (v[hh] - mu);
+    const float rs = rsqrtf(var / (float)h + eps);
+    for (int hh = 0; hh < h; ++hh) out[(bi * h + hh) * plane + ij] = (v[hh] - mu) * rs * gamma[hh] + beta[hh];
+  }
+}
+__global__ __launch_bounds__(256) void headnorm_bwd_kernel(const float* __restrict__ in, const float* __restrict__ dout,
+                                                           const float* __restrict__ gamma, float* __restrict__ din,
+                                                           float* __restrict__ partial, int b, int h, int64_t plane,
+                                                           int64_t nvalid_per_row, int64_t ld, float eps) {
+  __shared__ float red[256];
+  float ag[MAXH], ab[MAXH];
+  for (int hh = 0; hh < h; ++hh) { ag[hh] = 0.f; ab[hh] = 0.f; }
+  const int64_t total = (int64_t)b * plane;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t bi = e / plane, ij = e - bi * plane;
+    if ((ij % ld) >= nvalid_per_row) continue;
+    float xh[MAXH], gg[MAXH];
+    float mu = 0.f;
+    for (int hh = 0; hh < h; ++hh) { xh[hh] = in[(bi * h + hh) * plane + ij]; mu += xh[hh]; }
+    mu /= (float)h;
+    float var = 0.f;
+    for (int hh = 0; hh < h; ++hh) { xh[hh] -= mu; var += xh[hh] * xh[hh]; }
+    const float rs = rsqrtf(var / (float)h + eps);
+    float s1 = 0.f, s2 = 0.f;
+    for (int hh = 0; hh < h; ++hh) {
+      xh[hh] *= rs;
+      const float d = dout[(bi * h + hh) * plane + ij];
+      ab[hh] += d;
+      ag[hh] += d * xh[hh];
+      gg[hh] = d * gamma[hh];
+      s1 += gg[hh];
+      s2 += gg[hh] * xh[hh];
+    }
+    s1 /= (float)h;
+    s2 /= (float)h;
+    for (int hh = 0; hh < h; ++hh) din[(bi * h + hh) * plane + ij] = rs * (gg[hh] - s1 - xh[hh] * s2);
+  }
+  // fixed-order block reduction of the 2h accumulators
+  for (int k = 0; k < 2 * h; ++k) {
+    __syncthreads();
+    red[threadIdx.x] = k < h ? ag[k] : ab[k - h];
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+      if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[(int64_t)blockIdx.x * 2 * h + k] = red[0];
+  }
+}
+
+template <typename TY, typename TC>
+__global__ void concat_ctx_kernel(const TY* __restrict__ y, const float* __restrict__ context, TC* __restrict__ ctx, int b, int nq, int nc,
+                                  int d) {
+  const int64_t total = (int64_t)b * (nq + nc) * d;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(e % d);
+    const int64_t r = e / d;
+    const int64_t bi = r / (nq + nc);
+    const int t = (int)(r - bi * (nq + nc));
+    const float v = t < nq ? ldf<TY>(y + (bi * nq + t) * d + c) : context[(bi * nc + (t - nq)) * d + c];
+    stf<TC>(ctx + e, v);
+  }
+}
+template <typename T>
+__global__ void split_ctx_bwd_kernel(const T* __restrict__ dctx, T* __restrict__ dy, float* __restrict__ dcontext, int b, int nq, int nc,
+                                     int d) {
+  const int64_t total = (int64_t)b * (nq + nc) * d;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(e % d);
+    const int64_t r = e / d;
+    const int64_t bi = r / (nq + nc);
+    const int t = (int)(r - bi * (nq + nc));
+    const float v = ldf<T>(dctx + e);
+    if (t < nq) stf<T>(dy + (bi * nq + t) * d + c, v);
+    else dcontext[(bi * nc + (t - nq)) * d + c] += v;
+  }
+}
+template <typename T>
+__global__ void add_T_kernel(T* __restrict__ a, const T* __restrict__ b2, int64_t n) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x)
+    stf<T>(a + e, ldf<T>(a + e) + ldf<T>(b2 + e));
+}
+// partial[chunk][c] = sum_{rows in chunk} g[r][c] * fx[r][c]
+template <typename T>
+__global__ __launch_bounds__(256) void scale_grad_kernel(const T* __restrict__ fx, int64_t ldf_, const float* __restrict__ g, int64_t ldg,
+                                                         int rows, int d, float* __restrict__ partial) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= d) return;
+  const int rows_per = (rows + gridDim.y - 1) / gridDim.y;
+  const int r0 = blockIdx.y * rows_per, r1 = min(rows, r0 + rows_per);
+  float a = 0.f;
+  for (int r = r0; r < r1; ++r) a = fmaf(g[(int64_t)r * ldg + c], ldf<T>(fx + (int64_t)r * ldf_ + c), a);
+  partial[(int64_t)blockIdx.y * d + c] = a;
+}
+template <typename TO>
+__global__ void mul_scale_kernel(const float* __restrict__ g, int64_t ldg, const float* __restrict__ scale, TO* __restrict__ out,
+                                 int64_t ldo, int rows, int d) {
+  const int64_t total = (int64_t)rows * d;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = e / d;
+    const int c = (int)(e - r * d);
+    stf<TO>(out + r * ldo + c, g[r * ldg + c] * scale[c]);
+  }
+}
+__global__ void broadcast_rows_kernel(const float* __restrict__ src, int d, float* __restrict__ dst, int rows) {
+  const int64_t total = (int64_t)rows * d;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x)
+    dst[e] = src[e % d];
+}
+
+inline int grid_for(int64_t total, int block = 256) { return (int)std::max<int64_t>(1, std::min<int64_t>(ceil_div(total, block), 256 * 8)); }
+constexpr int HM_BLOCKS = 256;
+constexpr int SG_CHUNKS = 64;
+
+}  // namespace
+
+void launch_softmax_rows(float* sc, int64_t rows, int n, int64_t ld, hipStream_t s) {
+  if (rows == 0) return;
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)ceil_div(rows, 4)), dim3(256), 0, s, sc, rows, n, ld);
+}
+void launch_softmax_bwd_rows(const float* p, float* dp, int64_t rows, int n, int64_t ld, hipStream_t s) {
+  if (rows == 0) return;
+  hipLaunchKernelGGL(softmax_bwd_rows_kernel, dim3((unsigned)ceil_div(rows, 4)), dim3(256), 0, s, p, dp, rows, n, ld);
+}
+void launch_headmix_fwd(const float* in, const float* w, float* out, int b, int h, int nq, int nk, int64_t ld, hipStream_t s) {
+  const int64_t plane = (int64_t)nq * ld;
+  hipLaunchKernelGGL(headmix_fwd_kernel, dim3(grid_for((int64_t)b * plane)), dim3(256), 0, s, in, w, out, b, h, plane, (int64_t)nk, ld);
+}
+int64_t headmix_ws_elems(int b, int h, int nq, int nk) { return (int64_t)HM_BLOCKS * h * h; }
+void launch_headmix_bwd(const float* in, const float* dout, const float* w, float* din, float* dw_partial_ws, float* dw, int b, int h,
+                        int nq, int nk, int64_t ld, hipStream_t s) {
+  const int64_t plane = (int64_t)nq * ld;
+  const int nblk = (int)std::max<int64_t>(1, std::min<int64_t>(HM_BLOCKS, ceil_div((int64_t)b * plane, 256)));
+  const size_t shm = (size_t)256 * 2 * h * sizeof(float);
+  hipLaunchKernelGGL(headmix_bwd_kernel, dim3(nblk), dim3(256), shm, s, in, dout, w, din, dw_partial_ws, b, h, plane, (int64_t)nk, ld);
+  launch_reduce_partials(dw_partial_ws, nblk, (int64_t)h * h, (int64_t)h * h, dw, 1.0f, s);
+}
+void launch_headnorm_fwd(const float* in, const float* gamma, const float* beta, float* out, int b, int h, int nq, int nk, int64_t ld,
+                         float eps, hipStream_t s) {
+  const int64_t plane = (int64_t)nq * ld;
+  hipLaunchKernelGGL(headnorm_fwd_kernel, dim3(grid_for((int64_t)b * plane)), dim3(256), 0, s, in, gamma, beta, out, b, h, plane,
+                     (int64_t)nk, ld, eps);
+}
+void launch_headnorm_bwd(const float* in, const float* dout, const float* gamma, float* din, float* partial_ws, float* dgamma, float* dbeta,
+                         int b, int h, int nq, int nk, int64_t ld, float eps, hipStream_t s) {
+  const int64_t plane = (int64_t)nq * ld;
+  const int nblk = (int)std::max<int64_t>(1, std::min<int64_t>(HM_BLOCKS, ceil_div((int64_t)b * plane, 256)));
+  hipLaunchKernelGGL(headnorm_bwd_kernel, dim3(nblk), dim3(256), 0, s, in, dout, gamma, din, partial_ws, b, h, plane, (int64_t)nk, ld, eps);
+  launch_reduce_partials(partial_ws, nblk, (int64_t)2 * h, h, dgamma, 1.0f, s);
+  launch_reduce_partials(partial_ws + h, nblk, (int64_t)2 * h, h, dbeta, 1.0f, s);
+}
+void launch_concat_ctx(const void* y, int y_bf16, const float* context, void* ctx, int ctx_bf16, int b, int nq, int nc, int d, hipStream_t s) {
+  const int64_t total = (int64_t)b * (nq + nc) * d;
+  if (y_bf16 && ctx_bf16) hipLaunchKernelGGL((concat_ctx_kernel<bf16_t, bf16_t>), dim3(grid_for(total)), dim3(256), 0, s, (const bf16_t*)y, context, (bf16_t*)ctx, b, nq, nc, d);
+  else hipLaunchKernelGGL((concat_ctx_kernel<float, float>), dim3(grid_for(total)), dim3(256), 0, s, (const float*)y, context, (float*)ctx, b, nq, nc, d);
+}
+void launch_split_ctx_bwd(const void* dctx, int is_bf16, void* dy, float* dcontext, int b, int nq, int nc, int d, hipStream_t s) {
+  const int64_t total = (int64_t)b * (nq + nc) * d;
+  if (is_bf16) hipLaunchKernelGGL(split_ctx_bwd_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, s, (const bf16_t*)dctx, (bf16_t*)dy, dcontext, b, nq, nc, d);
+  else hipLaunchKernelGGL(split_ctx_bwd_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, (const float*)dctx, (float*)dy, dcontext, b, nq, nc, d);
+}
+void launch_add_T(void* a, const void* b2, int is_bf16, int64_t n, hipStream_t s) {
+  if (n == 0) return;
+  if (is_bf16) hipLaunchKernelGGL(add_T_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, s, (bf16_t*)a, (const bf16_t*)b2, n);
+  else hipLaunchKernelGGL(add_T_kernel<float>, dim3(grid_for(n)), dim3(256), 0, s, (float*)a, (const float*)b2, n);
+}
+void launch_scale_grad(const void* fx, int is_bf16, int64_t ldf_, const float* g, int64_t ldg, int rows, int d, float* partial_ws,
+                       float* dscale, hipStream_t s) {
+  const int chunks = (int)std::max<int64_t>(1, std::min<int64_t>(SG_CHUNKS, ceil_div(rows, 8)));
+  dim3 grid((unsigned)ceil_div(d, 256), chunks), block(256);
+  if (is_bf16) hipLaunchKernelGGL(scale_grad_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)fx, ldf_, g, ldg, rows, d, partial_ws);
+  else hipLaunchKernelGGL(scale_grad_kernel<float>, grid, block, 0, s, (const float*)fx, ldf_, g, ldg, rows, d, partial_ws);
+  launch_reduce_partials(partial_ws, chunks, d, d, dscale, 1.0f, s);
+}
+void launch_mul_scale(const float* g, int64_t ldg, const float* scale, void* out, int out_bf16, int64_t ldo, int rows, int d, hipStream_t s) {
+  const int64_t total = (int64_t)rows * d;
+  if (total == 0) return;
+  if (out_bf16) hipLaunchKernelGGL(mul_scale_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, s, g, ldg, scale, (bf16_t*)out, ldo, rows, d);
+  else hipLaunchKernelGGL(mul_scale_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, g, ldg, scale, (float*)out, ldo, rows, d);
+}
+void launch_broadcast_rows(const float* src, int d, float* dst, int rows, hipStream_t s) {
+  hipLaunchKernelGGL(broadcast_rows_kernel, dim3(grid_for((int64_t)rows * d)), dim3(256), 0, s, src, d, dst, rows);
+}

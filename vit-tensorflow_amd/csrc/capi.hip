@@ -1,0 +1,453 @@
+// extern "C" surface declared in include/vitx.h.  No exceptions cross this boundary.
+#include <dlfcn.h>
+
+#include <cstring>
+#include <map>
+
+#include "engine.h"
+
+static thread_local std::string g_last_error;
+
+static int fail(int code, const std::string& msg) {
+  g_last_error = msg;
+  return code;
+}
+#define CAPI_HIP(x)                                                                                    \
+  do {                                                                                                 \
+    hipError_t e_ = (x);                                                                               \
+    if (e_ != hipSuccess) return fail(VITX_ERR_HIP, std::string(#x) + ": " + hipGetErrorString(e_));   \
+  } while (0)
+#define CAPI_TRY try {
+#define CAPI_CATCH                                                       \
+  }                                                                      \
+  catch (const std::exception& ex) { return fail(VITX_ERR_INVALID, ex.what()); } \
+  catch (...) { return fail(VITX_ERR_INVALID, "unknown C++ exception"); }
+
+extern "C" {
+
+const char* vitx_version(void) { return "vitx 0.1.0 (gfx950)"; }
+const char* vitx_last_error(void) { return g_last_error.c_str(); }
+
+int32_t vitx_param_table_size(const vitx_config* cfg, int64_t* n_tensors, int64_t* n_elems) {
+  CAPI_TRY
+  if (!cfg) return fail(VITX_ERR_INVALID, "null config");
+  vitx_config c = *cfg;
+  if (c.channels <= 0) c.channels = 3;
+  std::vector<ParamDesc> t;
+  std::string err = build_param_table(c, t);
+  if (!err.empty()) return fail(VITX_ERR_INVALID, err);
+  if (n_tensors) *n_tensors = (int64_t)t.size();
+  if (n_elems) *n_elems = t.back().offset + t.back().count;
+  return VITX_OK;
+  CAPI_CATCH
+}
+
+int32_t vitx_param_table_entry(const vitx_config* cfg, int64_t index, char* name, int32_t name_cap, int64_t shape[4], int32_t* rank,
+                               int64_t* offset_elems) {
+  CAPI_TRY
+  if (!cfg) return fail(VITX_ERR_INVALID, "null config");
+  vitx_config c = *cfg;
+  if (c.channels <= 0) c.channels = 3;
+  std::vector<ParamDesc> t;
+  std::string err = build_param_table(c, t);
+  if (!err.empty()) return fail(VITX_ERR_INVALID, err);
+  if (index < 0 || index >= (int64_t)t.size()) return fail(VITX_ERR_INVALID, "parameter index out of range");
+  const ParamDesc& p = t[(size_t)index];
+  if (name && name_cap > 0) {
+    std::strncpy(name, p.name.c_str(), (size_t)name_cap - 1);
+    name[name_cap - 1] = 0;
+  }
+  if (shape) for (int i = 0; i < 4; ++i) shape[i] = i < (int)p.shape.size() ? p.shape[(size_t)i] : 1;
+  if (rank) *rank = (int32_t)p.shape.size();
+  if (offset_elems) *offset_elems = p.offset;
+  return VITX_OK;
+  CAPI_CATCH
+}
+
+int32_t vitx_create(const vitx_config* cfg, vitx_handle* out) {
+  CAPI_TRY
+  if (!cfg || !out) return fail(VITX_ERR_INVALID, "null argument");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+    return fail(VITX_ERR_HIP, "no HIP device available: libvitx has no CPU fallback (the product path is HIP-only)");
+  std::string err;
+  vitx_engine* e = nullptr;
+  int rc = engine_create(*cfg, &e, err);
+  if (rc != VITX_OK) return fail(rc, err);
+  *out = e;
+  return VITX_OK;
+  CAPI_CATCH
+}
+
+int32_t vitx_destroy(vitx_handle h) {
+  CAPI_TRY
+  engine_destroy(h);
+  return VITX_OK;
+  CAPI_CATCH
+}
+
+// packed host blob <-> aligned device arena
+static int copy_blob(vitx_engine* e, float* arena, float* host, int64_t n, bool to_device) {
+  if (n != e->n_params) return fail(VITX_ERR_INVALID, "blob size does not match the parameter table");
+  if (e->n_arena == e->n_params) {
+    if (to_device) CAPI_HIP(hipMemcpyAsync(arena, host, (size_t)n * 4, hipMemcpyHostToDevice, e->stream));
+    else CAPI_HIP(hipMemcpyAsync(host, arena, (size_t)n * 4, hipMemcpyDeviceToHost, e->stream));
+  } else {
+    for (auto& p : e->table) {
+      if (to_device) CAPI_HIP(hipMemcpyAsync(arena + p.aoff, host + p.offset, (size_t)p.count * 4, hipMemcpyHostToDevice, e->stream));
+      else CAPI_HIP(hipMemcpyAsync(host + p.offset, arena + p.aoff, (size_t)p.count * 4, hipMemcpyDeviceToHost, e->stream));
+    }
+  }
+  CAPI_HIP(hipStreamSynchronize(e->stream));
+  return VITX_OK;
+}
+
+int32_t vitx_set_params(vitx_handle h, const float* host_blob, int64_t n) {
+  CAPI_TRY
+  if (!h || !host_blob) return fail(VITX_ERR_INVALID, "null argument");
+  int rc = copy_blob(h, h->params, const_cast<float*>(host_blob), n, true);
+  h->params_dirty = true;
+  return rc;
+  CAPI_CATCH
+}
+int32_t vitx_get_params(vitx_handle h, float* host_blob, int64_t n) {
+  CAPI_TRY
+  if (!h || !host_blob) return fail(VITX_ERR_INVALID, "null argument");
+  return copy_blob(h, h->params, host_blob, n, false);
+  CAPI_CATCH
+}
+int32_t vitx_get_grads(vitx_handle h, float* host_blob, int64_t n) {
+  CAPI_TRY
+  if (!h || !host_blob) return fail(VITX_ERR_INVALID, "null argument");
+  return copy_blob(h, h->grads, host_blob, n, false);
+  CAPI_CATCH
+}
+int32_t vitx_params_dev(vitx_handle h, float** p, int64_t* n) {
+  if (!h) return fail(VITX_ERR_INVALID, "null handle");
+  if (p) *p = h->params;
+  if (n) *n = h->n_arena;
+  return VITX_OK;
+}
+int32_t vitx_grads_dev(vitx_handle h, float** p, int64_t* n) {
+  if (!h) return fail(VITX_ERR_INVALID, "null handle");
+  if (p) *p = h->grads;
+  if (n) *n = h->n_arena;
+  return VITX_OK;
+}
+int32_t vitx_bind_arenas(vitx_handle h, float* params_dev, float* grads_dev) {
+  CAPI_TRY
+  if (!h) return fail(VITX_ERR_INVALID, "null handle");
+  if (params_dev && params_dev != h->params) {
+    CAPI_HIP(hipMemcpyAsync(params_dev, h->params, (size_t)h->n_arena * 4, hipMemcpyDeviceToDevice, h->stream));
+    CAPI_HIP(hipStreamSynchronize(h->stream));
+    h->params = params_dev;
+    h->params_dirty = true;
+  }
+  if (grads_dev && grads_dev != h->grads) {
+    CAPI_HIP(hipMemsetAsync(grads_dev, 0, (size_t)h->n_arena * 4, h->stream));
+    CAPI_HIP(hipStreamSynchronize(h->stream));
+    h->grads = grads_dev;
+  }
+  return VITX_OK;
+  CAPI_CATCH
+}
+int32_t vitx_params_changed(vitx_handle h) {
+  if (!h) return fail(VITX_ERR_INVALID, "null handle");
+  h->params_dirty = true;
+  return VITX_OK;
+}
+
+int32_t vitx_forward_dev(vitx_handle h, const float* img_dev, int32_t b, int32_t H, int32_t W, int32_t training, uint64_t seed,
+                         float* logits_dev) {
+  CAPI_TRY
+  if (!h || !img_dev) return fail(VITX_ERR_INVALID, "null argument");
+  std::string err;
+  int rc = engine_forward(h, img_dev, b, H, W, training, seed, logits_dev, err);
+  if (rc != VITX_OK) return fail(rc, err);
+  return VITX_OK;
+  CAPI_CATCH
+}
+
+int32_t vitx_forward(vitx_handle h, const float* img_host, int32_t b, int32_t H, int32_t W, int32_t training, uint64_t seed,
+                     float* logits_host) {
+  CAPI_TRY
+  if (!h || !img_host || !logits_host) return fail(VITX_ERR_INVALID, "null argument");
+  if (b <= 0 || b > h->cfg.max_batch) return fail(VITX_ERR_INVALID, "batch must be in [1, max_batch]");
+  if (H <= 0 || W <= 0 || H > h->cfg.image_h || W > h->cfg.image_w)
+    return fail(VITX_ERR_INVALID, "image larger than the configured image_size");
+  CAPI_HIP(hipMemcpyAsync(h->img_dev, img_host, (size_t)b * H * W * h->cfg.channels * 4, hipMemcpyHostToDevice, h->stream));
+  std::string err;
+  int rc = engine_forward(h, h->img_dev, b, H, W, training, seed, nullptr, err);
+  if (rc != VITX_OK) return fail(rc, err);
+  CAPI_HIP(hipMemcpy2DAsync(logits_host, (size_t)h->cfg.num_classes * 4, h->logits, (size_t)h->nc_k * 4, (size_t)h->cfg.num_classes * 4,
+                            (size_t)b, hipMemcpyDeviceToHost, h->stream));
+  CAPI_HIP(hipStreamSynchronize(h->stream));
+  return VITX_OK;
+  CAPI_CATCH
+}
+
+int32_t vitx_backward_dev(vitx_handle h, const float* dlogits_dev, float* dimg_dev) {
+  CAPI_TRY
+  if (!h) return fail(VITX_ERR_INVALID, "null handle");
+  std::string err;
+  int rc = engine_backward(h, dlogits_dev, dimg_dev, err);
+  if (rc != VITX_OK) return fail(rc, err);
+  return VITX_OK;
+  CAPI_CATCH
+}
+
+int32_t vitx_backward(vitx_handle h, const float* dlogits_host, float* dimg_host) {
+  CAPI_TRY
+  if (!h || !dlogits_host) return fail(VITX_ERR_INVALID, "null argument");
+  if (!h->have_fwd) return fail(VITX_ERR_STATE, "backward requires a preceding forward");
+  const int b = h->last_b, nc = h->cfg.num_classes;
+  CAPI_HIP(hipMemcpy2DAsync(h->dlogits, (size_t)h->nc_k * 4, dlogits_host, (size_t)nc * 4, (size_t)nc * 4, (size_t)b, hipMemcpyHostToDevice,
+                            h->stream));
+  float* dimg_dev = nullptr;
+  const size_t img_bytes = (size_t)b * h->last_H * h->last_W * h->cfg.channels * 4;
+  if (dimg_host) dimg_dev = h->img_dev;   // the staged image is no longer needed once patches are unfolded
+  std::string err;
+  int rc = engine_backward(h, nullptr, dimg_dev, err);
+  if (rc != VITX_OK) return fail(rc, err);
+  if (dimg_host) CAPI_HIP(hipMemcpyAsync(dimg_host, dimg_dev, img_bytes, hipMemcpyDeviceToHost, h->stream));
+  CAPI_HIP(hipStreamSynchronize(h->stream));
+  return VITX_OK;
+  CAPI_CATCH
+}
+
+int32_t vitx_transformer_forward(vitx_handle h, const float* tokens_host, int32_t b, int32_t n, float* out_host) {
+  CAPI_TRY
+  if (!h || !tokens_host || !out_host) return fail(VITX_ERR_INVALID, "null argument");
+  if (b <= 0 || b > h->cfg.max_batch || n <= 0 || n > h->ntok_max) return fail(VITX_ERR_INVALID, "transformer_forward: b or n out of range");
+  const size_t bytes = (size_t)b * n * h->cfg.dim * 4;
+  float* tmp = h->g;   // [>= mp, d] fp32 scratch that no forward kernel touches
+  CAPI_HIP(hipMemcpyAsync(tmp, tokens_host, bytes, hipMemcpyHostToDevice, h->stream));
+  std::string err;
+  int rc = engine_transformer_forward(h, tmp, b, n, tmp, err);
+  if (rc != VITX_OK) return fail(rc, err);
+  CAPI_HIP(hipMemcpyAsync(out_host, tmp, bytes, hipMemcpyDeviceToHost, h->stream));
+  CAPI_HIP(hipStreamSynchronize(h->stream));
+  return VITX_OK;
+  CAPI_CATCH
+}
+
+int32_t vitx_patch_unfold(const float* img_host, int32_t b, int32_t H, int32_t W, int32_t C, int32_t ph, int32_t pw, float* out_host) {
+  CAPI_TRY
+  if (!img_host || !out_host) return fail(VITX_ERR_INVALID, "null argument");
+  if (b < 0 || H <= 0 || W <= 0 || C <= 0 || ph <= 0 || pw <= 0) return fail(VITX_ERR_INVALID, "sizes must be positive");
+  if (H % ph || W % pw) return fail(VITX_ERR_INVALID, "Image dimensions must be divisible by the patch size.");
+  if (b == 0) return VITX_OK;   // empty batch: nothing to do
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(VITX_ERR_HIP, "no HIP device available (no CPU fallback)");
+  const size_t n = (size_t)b * H * W * C;
+  float *din = nullptr, *dout = nullptr;
+  CAPI_HIP(hipMalloc((void**)&din, n * 4));
+  CAPI_HIP(hipMalloc((void**)&dout, n * 4));
+  CAPI_HIP(hipMemcpy(din, img_host, n * 4, hipMemcpyHostToDevice));
+  launch_unfold(din, dout, 0, b, H, W, C, ph, pw, (int64_t)ph * pw * C, nullptr);
+  CAPI_HIP(hipMemcpy(out_host, dout, n * 4, hipMemcpyDeviceToHost));
+  (void)hipFree(din);
+  (void)hipFree(dout);
+  return VITX_OK;
+  CAPI_CATCH
+}
+
+int32_t vitx_ce_loss_grad_dev(vitx_handle h, const int32_t* labels_dev, float inv_global_batch, float* loss_dev) {
+  CAPI_TRY
+  if (!h || !labels_dev) return fail(VITX_ERR_INVALID, "null argument");
+  if (!h->have_fwd) return fail(VITX_ERR_STATE, "loss gradient requires a preceding forward");
+  launch_ce_grad(h->logits, h->nc_k, labels_dev, h->last_b, h->cfg.num_classes, inv_global_batch, h->dlogits, h->loss_rows, h->stream);
+  if (loss_dev) launch_sum_rows(h->loss_rows, h->last_b, 1, loss_dev, h->stream);
+  return VITX_OK;
+  CAPI_CATCH
+}
+
+int32_t vitx_set_stream(vitx_handle h, void* s) {
+  if (!h) return fail(VITX_ERR_INVALID, "null handle");
+  (void)hipStreamSynchronize(h->stream);
+  h->stream = s ? (hipStream_t)s : h->own_stream;
+  return VITX_OK;
+}
+int32_t vitx_sync(vitx_handle h) {
+  if (!h) return fail(VITX_ERR_INVALID, "null handle");
+  CAPI_HIP(hipStreamSynchronize(h->stream));
+  return VITX_OK;
+}
+
+int32_t vitx_set_grad_ready_callback(vitx_handle h, vitx_grad_ready_fn fn, void* user) {
+  if (!h) return fail(VITX_ERR_INVALID, "null handle");
+  h->grad_cb = fn;
+  h->grad_cb_user = user;
+  return VITX_OK;
+}
+
+// ---- RCCL (loaded lazily: libvitx itself does not link against it)
+struct uid128_t { char b[128]; };   // ncclUniqueId (NCCL_UNIQUE_ID_BYTES = 128), passed by value to ncclCommInitRank
+static void* rccl_handle() {
+  static void* lib = nullptr;
+  if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+  if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+  if (!lib) lib = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_LOCAL);
+  return lib;
+}
+
+int32_t vitx_comm_unique_id(void* out128) {
+  CAPI_TRY
+  void* lib = rccl_handle();
+  if (!lib) return fail(VITX_ERR_COMM, "cannot dlopen librccl.so");
+  auto get = (int (*)(uid128_t*))dlsym(lib, "ncclGetUniqueId");
+  if (!get) return fail(VITX_ERR_COMM, "ncclGetUniqueId not found");
+  uid128_t id;
+  if (get(&id) != 0) return fail(VITX_ERR_COMM, "ncclGetUniqueId failed");
+  std::memcpy(out128, &id, 128);
+  return VITX_OK;
+  CAPI_CATCH
+}
+
+int32_t vitx_comm_init(vitx_handle h, int32_t rank, int32_t world, const void* uid) {
+  CAPI_TRY
+  if (!h || !uid) return fail(VITX_ERR_INVALID, "null argument");
+  void* lib = rccl_handle();
+  if (!lib) return fail(VITX_ERR_COMM, "cannot dlopen librccl.so");
+  auto init = (int (*)(void**, int, uid128_t, int))dlsym(lib, "ncclCommInitRank");
+  if (!init) return fail(VITX_ERR_COMM, "ncclCommInitRank not found");
+  uid128_t id;
+  std::memcpy(&id, uid, 128);
+  CAPI_HIP(hipSetDevice(h->cfg.device_id));
+  void* comm = nullptr;
+  if (init(&comm, world, id, rank) != 0) return fail(VITX_ERR_COMM, "ncclCommInitRank failed");
+  h->rccl_lib = lib;
+  h->comm = comm;
+  h->rank = rank;
+  h->world = world;
+  return VITX_OK;
+  CAPI_CATCH
+}
+
+int32_t vitx_allreduce_grads(vitx_handle h) {
+  CAPI_TRY
+  if (!h) return fail(VITX_ERR_INVALID, "null handle");
+  if (!h->comm) return fail(VITX_ERR_STATE, "vitx_comm_init has not been called");
+  // ncclAllReduce(sendbuff, recvbuff, count, ncclFloat32 = 7, ncclSum = 0, comm, stream)
+  auto ar = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))dlsym(h->rccl_lib, "ncclAllReduce");
+  if (!ar) return fail(VITX_ERR_COMM, "ncclAllReduce not found");
+  if (ar(h->grads, h->grads, (size_t)h->n_arena, 7, 0, h->comm, h->stream) != 0) return fail(VITX_ERR_COMM, "ncclAllReduce failed");
+  if (h->world > 1) {
+    // x 1/world: reuse the partial reducer as a scale kernel (nparts = 1)
+    launch_reduce_partials(h->grads, 1, 0, h->n_arena, h->grads, 1.0f / (float)h->world, h->stream);
+  }
+  return VITX_OK;
+  CAPI_CATCH
+}
+
+int32_t vitx_profile_begin(vitx_handle h) {
+  if (!h) return fail(VITX_ERR_INVALID, "null handle");
+  h->prof_events.clear();
+  h->profiling = true;
+  return VITX_OK;
+}
+
+int32_t vitx_profile_end(vitx_handle h, vitx_kernel_stat* out, int32_t cap, int32_t* n_out) {
+  CAPI_TRY
+  if (!h) return fail(VITX_ERR_INVALID, "null handle");
+  h->profiling = false;
+  CAPI_HIP(hipStreamSynchronize(h->stream));
+  std::vector<vitx_kernel_stat> stats(h->prof_names.size());
+  for (size_t i = 0; i < stats.size(); ++i) {
+    std::memset(&stats[i], 0, sizeof(vitx_kernel_stat));
+    std::strncpy(stats[i].name, h->prof_names[i].c_str(), sizeof(stats[i].name) - 1);
+  }
+  for (auto& pe : h->prof_events) {
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, pe.e0, pe.e1);
+    auto& s = stats[(size_t)pe.cls];
+    s.launches += 1;
+    s.total_ms += ms;
+    s.flops += pe.flops;
+    s.bytes += pe.bytes;
+    (void)hipEventDestroy(pe.e0);
+    (void)hipEventDestroy(pe.e1);
+  }
+  h->prof_events.clear();
+  int n = 0;
+  for (auto& s : stats) {
+    if (s.launches == 0) continue;
+    if (out && n < cap) out[n] = s;
+    ++n;
+  }
+  if (n_out) *n_out = n;
+  return VITX_OK;
+  CAPI_CATCH
+}
+
+int32_t vitx_workspace_bytes(vitx_handle h, int64_t* bytes) {
+  if (!h) return fail(VITX_ERR_INVALID, "null handle");
+  if (bytes) *bytes = h->ws_bytes;
+  return VITX_OK;
+}
+
+int32_t vitx_debug_read(vitx_handle h, const char* which, int32_t layer, float* out_host, int64_t cap, int64_t* n_elems) {
+  CAPI_TRY
+  if (!h || !which) return fail(VITX_ERR_INVALID, "null argument");
+  const vitx_config& c = h->cfg;
+  const int b = h->last_b;
+  // layer indexes the concatenation of all stages (CaiT: patch blocks then cls blocks)
+  Stage* st = nullptr;
+  int l = layer, nq = h->last_ntok, nk = h->last_ntok;
+  for (auto& s : h->stages) {
+    if (l < s.depth) { st = &s; break; }
+    l -= s.depth;
+  }
+  const std::string w(which);
+  const void* src = nullptr;
+  int64_t rows = 0, cols = 0, ld = 0;
+  bool is_t = false;
+  if (w == "pooled_ln") { src = h->yh; rows = b; cols = ld = c.dim; is_t = true; }
+  else if (w == "logits") { src = h->logits; rows = b; cols = c.num_classes; ld = h->nc_k; }
+  else if (w == "patches") { src = h->patches; rows = (int64_t)b * h->last_np; cols = h->pd; ld = h->pd_k; is_t = true; }
+  else {
+    if (!st) return fail(VITX_ERR_INVALID, "layer out of range");
+    if (c.variant == VITX_VARIANT_CAIT) { nq = st->nq_max == 1 ? 1 : h->last_np; nk = st->nq_max == 1 ? 1 + h->last_np : h->last_np; }
+    BlockActs& ba = st->ba[(size_t)l];
+    rows = (int64_t)b * nq;
+    if (w == "x_in" || w == "embed") { src = ba.x_in; cols = ld = c.dim; }
+    else if (w == "x_mid") { src = ba.x_mid; cols = ld = c.dim; }
+    else if (w == "x_out") { src = ba.x_out; cols = ld = c.dim; }
+    else if (w == "y1") { src = ba.y1; cols = ld = c.dim; is_t = true; }
+    else if (w == "y2") { src = ba.y2; cols = ld = c.dim; is_t = true; }
+    else if (w == "qkv") { src = ba.qkv; cols = ld = 3 * h->inner; is_t = true; }
+    else if (w == "q") { src = ba.q; cols = ld = h->inner; is_t = true; }
+    else if (w == "kv") { src = ba.kv; rows = (int64_t)b * nk; cols = ld = 2 * h->inner; is_t = true; }
+    else if (w == "attn_out") { src = ba.o; cols = ld = h->inner; is_t = true; }
+    else if (w == "hpre") { src = ba.hpre; cols = ld = c.mlp_dim; is_t = true; }
+    else if (w == "act") { src = ba.act; cols = ld = c.mlp_dim; is_t = true; }
+    else return fail(VITX_ERR_INVALID, "unknown activation name");
+  }
+  if (!src) return fail(VITX_ERR_INVALID, "activation not available for this variant");
+  const int64_t n = rows * cols;
+  if (n_elems) *n_elems = n;
+  if (!out_host || cap < n) return n <= cap ? VITX_OK : fail(VITX_ERR_INVALID, "output buffer too small");
+  float* tmp = nullptr;
+  CAPI_HIP(hipMalloc((void**)&tmp, (size_t)std::max<int64_t>(n, 1) * 4));
+  launch_to_f32(src, is_t && h->bf16, ld, tmp, cols, (int)rows, (int)cols, h->stream);
+  CAPI_HIP(hipMemcpyAsync(out_host, tmp, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
+  CAPI_HIP(hipStreamSynchronize(h->stream));
+  (void)hipFree(tmp);
+  return VITX_OK;
+  CAPI_CATCH
+}
+
+int32_t vitx_bench_gemm(vitx_handle h, int32_t M, int32_t N, int32_t K, int32_t kernel, int32_t epilogue, int32_t iters, float* avg_ms,
+                        float* max_abs_err) {
+  CAPI_TRY
+  if (!h || !avg_ms) return fail(VITX_ERR_INVALID, "null argument");
+  std::string err;
+  float me = -1.f;
+  int rc = engine_bench_gemm(h, M, N, K, kernel, epilogue, iters, avg_ms, &me, err);
+  if (max_abs_err) *max_abs_err = me;
+  if (rc != VITX_OK) return fail(rc, err);
+  return VITX_OK;
+  CAPI_CATCH
+}
+
+}  // extern "C"

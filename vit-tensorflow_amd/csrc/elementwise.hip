@@ -1,0 +1,521 @@
+// HBM-bound kernels of the ViT path: patch unfold, LayerNorm fwd/bwd, bias-gradient column sums,
+// operand conversion/transposes, cls/pos rows, pooling, loss gradient.  One wave (64 lanes) per
+// token row with float4 accesses wherever a row is reduced; reductions are two-stage and
+// fixed-order (deterministic, no atomics).
+#include "kernels.h"
+
+namespace {
+
+// ------------------------------------------------------------------ patch unfold (vit.py:142)
+// out[(b*Hp + hi)*Wp + wi][(r*pw + s)*C + c] = img[b][hi*ph + r][wi*pw + s][c]   -- pure indexing.
+// Consecutive threads walk the (s,c) run, which is contiguous in both img and out.
+template <typename TO>
+__global__ void unfold_kernel(const float* __restrict__ img, TO* __restrict__ out, int b, int H, int W, int C, int ph, int pw,
+                              int64_t ldo) {
+  const int Hp = H / ph, Wp = W / pw;
+  const int pd = ph * pw * C;
+  const int run = pw * C;
+  const int64_t total = (int64_t)b * Hp * Wp * ldo;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = e / ldo;
+    const int f = (int)(e - row * ldo);
+    float v = 0.f;
+    if (f < pd) {
+      const int r = f / run, sc = f - r * run;
+      const int wi = (int)(row % Wp);
+      const int64_t t = row / Wp;
+      const int hi = (int)(t % Hp);
+      const int64_t bi = t / Hp;
+      v = img[((bi * H + (int64_t)hi * ph + r) * W + (int64_t)wi * pw) * C + sc];
+    }
+    stf<TO>(out + e, v);
+  }
+}
+
+// dimg[b][hi*ph+r][wi*pw+s][c] = dpatches[(b,hi,wi)][(r,s,c)]   (inverse of the unfold; bijective)
+__global__ void fold_kernel(const float* __restrict__ dp, int64_t ld, float* __restrict__ dimg, int b, int H, int W, int C, int ph,
+                            int pw) {
+  const int Hp = H / ph, Wp = W / pw;
+  const int pd = ph * pw * C, run = pw * C;
+  const int64_t total = (int64_t)b * Hp * Wp * pd;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = e / pd;
+    const int f = (int)(e - row * pd);
+    const int r = f / run, sc = f - r * run;
+    const int wi = (int)(row % Wp);
+    const int64_t t = row / Wp;
+    const int hi = (int)(t % Hp);
+    const int64_t bi = t / Hp;
+    dimg[((bi * H + (int64_t)hi * ph + r) * W + (int64_t)wi * pw) * C + sc] = dp[row * ld + f];
+  }
+}
+
+// x[b*ntok + 0][:] = cls + pos[0]   (vit.py:163-165)
+__global__ void cls_pos_row_kernel(float* x, const float* cls, const float* pos, int b, int ntok, int d, int64_t ldx) {
+  const int64_t total = (int64_t)b * d;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t bi = e / d;
+    const int c = (int)(e - bi * d);
+    x[bi * ntok * ldx + c] = cls[c] + pos[c];
+  }
+}
+
+// ------------------------------------------------------------------ LayerNorm (vit.py:18,22,155; Keras eps 1e-3, biased var)
+template <typename TO, int VPL>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, TO* __restrict__ y, int64_t ldy,
+                                                            float* __restrict__ mean, float* __restrict__ rstd, int rows, int d,
+                                                            float eps) {
+  const int row = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* xr = x + (int64_t)row * ldx;
+  float4 v[VPL];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    const int c = (lane + 64 * i) * 4;
+    if (c < d) { v[i] = *(const float4*)(xr + c); s += (v[i].x + v[i].y) + (v[i].z + v[i].w); }
+    else v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  const float mu = wave_sum(s) / (float)d;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    const int c = (lane + 64 * i) * 4;
+    if (c < d) {
+      const float a = v[i].x - mu, b2 = v[i].y - mu, c2 = v[i].z - mu, d2 = v[i].w - mu;
+      q += (a * a + b2 * b2) + (c2 * c2 + d2 * d2);
+    }
+  }
+  const float rs = rsqrtf(wave_sum(q) / (float)d + eps);
+  if (lane == 0) {
+    if (mean) mean[row] = mu;
+    if (rstd) rstd[row] = rs;
+  }
+  TO* yr = y + (int64_t)row * ldy;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    const int c = (lane + 64 * i) * 4;
+    if (c < d) {
+      const float4 g = *(const float4*)(gamma + c), bb = *(const float4*)(beta + c);
+      st4<TO>(yr + c, make_float4((v[i].x - mu) * rs * g.x + bb.x, (v[i].y - mu) * rs * g.y + bb.y,
+                                  (v[i].z - mu) * rs * g.z + bb.z, (v[i].w - mu) * rs * g.w + bb.w));
+    }
+  }
+}
+
+constexpr int LNB_BLOCKS = 512;
+
+// dx = r * (g*gamma - mean_d(g*gamma) - xhat * mean_d(g*gamma*xhat));  dgamma += g*xhat; dbeta += g
+template <typename TD, typename TL, int VPL>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TD* __restrict__ dy, int64_t lddy, const float* __restrict__ x,
+                                                            int64_t ldx, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                            const float* __restrict__ gamma, const float* g_in, int64_t ldgi,
+                                                            float* g_out, int64_t ldgo, TL* g_lp, int64_t ldglp,
+                                                            float* __restrict__ partial, int rows, int d) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int wib = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int nw = blockDim.x >> 6;
+  float4 ag[VPL], ab[VPL], gm[VPL];
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    ag[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    ab[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int c = (lane + 64 * i) * 4;
+    gm[i] = (c < d) ? *(const float4*)(gamma + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  const float invd = 1.0f / (float)d;
+  for (int row = blockIdx.x * nw + wib; row < rows; row += gridDim.x * nw) {
+    const float mu = mean[row], rs = rstd[row];
+    const float* xr = x + (int64_t)row * ldx;
+    const TD* dr = dy + (int64_t)row * lddy;
+    float4 xh[VPL], gg[VPL];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      const int c = (lane + 64 * i) * 4;
+      if (c < d) {
+        const float4 xv = *(const float4*)(xr + c);
+        const float4 dv = ld4<TD>(dr + c);
+        xh[i] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
+        ab[i].x += dv.x; ab[i].y += dv.y; ab[i].z += dv.z; ab[i].w += dv.w;
+        ag[i].x += dv.x * xh[i].x; ag[i].y += dv.y * xh[i].y; ag[i].z += dv.z * xh[i].z; ag[i].w += dv.w * xh[i].w;
+        gg[i] = make_float4(dv.x * gm[i].x, dv.y * gm[i].y, dv.z * gm[i].z, dv.w * gm[i].w);
+        s1 += (gg[i].x + gg[i].y) + (gg[i].z + gg[i].w);
+        s2 += (gg[i].x * xh[i].x + gg[i].y * xh[i].y) + (gg[i].z * xh[i].z + gg[i].w * xh[i].w);
+      }
+    }
+    s1 = wave_sum(s1) * invd;
+    s2 = wave_sum(s2) * invd;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      const int c = (lane + 64 * i) * 4;
+      if (c < d) {
+        float4 dx = make_float4(rs * (gg[i].x - s1 - xh[i].x * s2), rs * (gg[i].y - s1 - xh[i].y * s2),
+                                rs * (gg[i].z - s1 - xh[i].z * s2), rs * (gg[i].w - s1 - xh[i].w * s2));
+        if (g_in) {
+          const float4 gi = *(const float4*)(g_in + (int64_t)row * ldgi + c);
+          dx.x += gi.x; dx.y += gi.y; dx.z += gi.z; dx.w += gi.w;
+        }
+        *(float4*)(g_out + (int64_t)row * ldgo + c) = dx;
+        if (g_lp) st4<TL>(g_lp + (int64_t)row * ldglp + c, dx);
+      }
+    }
+  }
+  // fixed-order combine of the block's waves: dgamma then dbeta, through LDS [nw][d]
+  for (int pass = 0; pass < 2; ++pass) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      const int c = (lane + 64 * i) * 4;
+      if (c < d) *(float4*)(lds + (int64_t)wib * d + c) = pass == 0 ? ag[i] : ab[i];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < d; c += blockDim.x) {
+      float a = 0.f;
+      for (int w = 0; w < nw; ++w) a += lds[(int64_t)w * d + c];
+      partial[((int64_t)blockIdx.x * 2 + pass) * d + c] = a;
+    }
+  }
+}
+
+// out[c] = alpha * sum_p partial[p*stride + c]; 64 columns x 4 part-groups per block, fixed order
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial, int nparts, int64_t stride, int64_t n,
+                                                              float* __restrict__ out, float alpha) {
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, pg = threadIdx.x >> 6;
+  const int64_t c = (int64_t)blockIdx.x * 64 + lane;
+  float a = 0.f;
+  if (c < n)
+    for (int p = pg; p < nparts; p += 4) a += partial[(int64_t)p * stride + c];
+  red[pg][lane] = a;
+  __syncthreads();
+  if (pg == 0 && c < n) out[c] = alpha * ((red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]));
+}
+
+// ------------------------------------------------------------------ column sums (Dense bias gradients: db = sum_rows dY)
+constexpr int CS_CHUNKS = 64;
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, int64_t ld, int rows, int cols, float* __restrict__ partial) {
+  __shared__ float4 red[4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int c = (blockIdx.x * 64 + lane) * 4;
+  const int rows_per = (rows + gridDim.y - 1) / gridDim.y;
+  const int r0 = blockIdx.y * rows_per, r1 = min(rows, r0 + rows_per);
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (c < cols) {
+    for (int r = r0 + w; r < r1; r += 4) {
+      if (c + 3 < cols) {
+        const float4 v = ld4<T>(x + (int64_t)r * ld + c);
+        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+      } else {
+        float* ap = (float*)&a;
+        for (int i = 0; i < 4 && c + i < cols; ++i) ap[i] += ldf<T>(x + (int64_t)r * ld + c + i);
+      }
+    }
+  }
+  red[w][lane] = a;
+  __syncthreads();
+  if (w == 0 && c < cols) {
+    float4 t = red[0][lane];
+    for (int k = 1; k < 4; ++k) { t.x += red[k][lane].x; t.y += red[k][lane].y; t.z += red[k][lane].z; t.w += red[k][lane].w; }
+    float* o = partial + (int64_t)blockIdx.y * cols + c;
+    const float tv[4] = {t.x, t.y, t.z, t.w};
+    for (int i = 0; i < 4 && c + i < cols; ++i) o[i] = tv[i];
+  }
+}
+
+// ------------------------------------------------------------------ operand preparation
+// fp32 Keras kernel W[in][out] -> bf16 copies: wn[in][ldwn] (dgrad operand) and wt[out][ldwt] (forward operand)
+__global__ __launch_bounds__(256) void convert_weight_kernel(const float* __restrict__ w, int in, int out, bf16_t* __restrict__ wn,
+                                                             int64_t ldwn, bf16_t* __restrict__ wt, int64_t ldwt) {
+  __shared__ float tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const int i0 = blockIdx.y * 32, o0 = blockIdx.x * 32;
+  for (int r = ty; r < 32; r += 8) {
+    const int i = i0 + r, o = o0 + tx;
+    float v = 0.f;
+    if (i < in && o < out) {
+      v = w[(int64_t)i * out + o];
+      wn[(int64_t)i * ldwn + o] = (bf16_t)v;
+    }
+    tile[r][tx] = v;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int o = o0 + r, i = i0 + tx;
+    if (i < in && o < out) wt[(int64_t)o * ldwt + i] = (bf16_t)tile[tx][r];
+  }
+}
+
+// out[c][r] = in[r][c]  (bf16, 64x64 tiles through LDS); covers rows x cols exactly (both multiples of 64 by construction)
+__global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __restrict__ in, int64_t ldi, int rows, int cols,
+                                                             bf16_t* __restrict__ out, int64_t ldo) {
+  __shared__ unsigned short tile[64][66];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 64 x 4
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const unsigned short* ip = (const unsigned short*)in;
+  unsigned short* op = (unsigned short*)out;
+  for (int r = ty; r < 64; r += 4) {
+    const int rr = r0 + r, cc = c0 + tx;
+    tile[r][tx] = (rr < rows && cc < cols) ? ip[(int64_t)rr * ldi + cc] : (unsigned short)0;
+  }
+  __syncthreads();
+  for (int c = ty; c < 64; c += 4) {
+    const int cc = c0 + c, rr = r0 + tx;
+    if (cc < cols && rr < rows) op[(int64_t)cc * ldo + rr] = tile[tx][c];
+  }
+}
+
+template <typename TO>
+__global__ void convert_kernel(const float* __restrict__ in, int64_t ldi, TO* __restrict__ out, int64_t ldo, int rows, int cols,
+                               int64_t zero_to) {
+  const int64_t total = (int64_t)rows * zero_to;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = e / zero_to;
+    const int c = (int)(e - r * zero_to);
+    stf<TO>(out + r * ldo + c, c < cols ? in[r * ldi + c] : 0.f);
+  }
+}
+
+template <typename TI>
+__global__ void to_f32_kernel(const TI* __restrict__ in, int64_t ldi, float* __restrict__ out, int64_t ldo, int rows, int cols) {
+  const int64_t total = (int64_t)rows * cols;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = e / cols;
+    const int c = (int)(e - r * cols);
+    out[r * ldo + c] = ldf<TI>(in + r * ldi + c);
+  }
+}
+
+// ------------------------------------------------------------------ pooling (vit.py:170-173)
+__global__ void mean_pool_kernel(const float* __restrict__ x, int b, int ntok, int d, float* __restrict__ out) {
+  const int64_t total = (int64_t)b * d;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t bi = e / d;
+    const int c = (int)(e - bi * d);
+    float a = 0.f;
+    for (int t = 0; t < ntok; ++t) a += x[(bi * ntok + t) * d + c];
+    out[e] = a / (float)ntok;
+  }
+}
+__global__ void mean_pool_bwd_kernel(const float* __restrict__ dp, int b, int ntok, int d, float* __restrict__ g) {
+  const int64_t total = (int64_t)b * ntok * d;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(e % d);
+    const int64_t bi = e / ((int64_t)ntok * d);
+    g[e] = dp[bi * d + c] / (float)ntok;
+  }
+}
+// out[j][c] = sum_b g[b][j0+j][c]   (dpos / dcls: vit.py:163-165 VJP)
+__global__ void batch_reduce_kernel(const float* __restrict__ g, int b, int ntok, int d, int j0, int nj, float* __restrict__ out) {
+  const int64_t total = (int64_t)nj * d;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t j = e / d;
+    const int c = (int)(e - j * d);
+    float a = 0.f;
+    for (int bi = 0; bi < b; ++bi) a += g[((int64_t)bi * ntok + j0 + j) * d + c];
+    out[e] = a;
+  }
+}
+// out[b*np + t][:] = g[b*ntok + tok_off + t][:]  (dE = g[:, 1:, :]) with conversion to T
+template <typename TO>
+__global__ void extract_rows_kernel(const float* __restrict__ g, int b, int ntok, int tok_off, int np, int d, TO* __restrict__ out,
+                                    int64_t ldo) {
+  const int64_t total = (int64_t)b * np * d;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(e % d);
+    const int64_t r = e / d;
+    const int64_t bi = r / np;
+    const int t = (int)(r - bi * np);
+    stf<TO>(out + r * ldo + c, g[((bi * ntok) + tok_off + t) * d + c]);
+  }
+}
+__global__ void sum_rows_kernel(const float* __restrict__ in, int rows, int d, float* __restrict__ out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= d) return;
+  float a = 0.f;
+  for (int r = 0; r < rows; ++r) a += in[(int64_t)r * d + c];
+  out[c] = a;
+}
+
+// ------------------------------------------------------------------ softmax cross-entropy gradient (distill.py:119)
+__global__ __launch_bounds__(64) void ce_grad_kernel(const float* __restrict__ logits, int64_t ld, const int32_t* __restrict__ labels,
+                                                     int b, int nc, float inv_batch, float* __restrict__ dlogits,
+                                                     float* __restrict__ loss_rows) {
+  const int row = blockIdx.x, lane = threadIdx.x;
+  if (row >= b) return;
+  const float* l = logits + (int64_t)row * ld;
+  float m = -INFINITY;
+  for (int c = lane; c < nc; c += 64) m = fmaxf(m, l[c]);
+  m = wave_max(m);
+  float s = 0.f;
+  for (int c = lane; c < nc; c += 64) s += __expf(l[c] - m);
+  s = wave_sum(s);
+  const int lab = labels[row];
+  const float inv = 1.0f / s;
+  for (int c = lane; c < nc; c += 64) dlogits[(int64_t)row * ld + c] = (__expf(l[c] - m) * inv - (c == lab ? 1.f : 0.f)) * inv_batch;
+  if (loss_rows && lane == 0) loss_rows[row] = (m + __logf(s) - l[lab]) * inv_batch;
+}
+
+__device__ __forceinline__ uint32_t hash32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  return x;
+}
+__global__ void fill_random_bf16_kernel(bf16_t* p, int64_t n, uint32_t seed, float scale) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+    const uint32_t h = hash32((uint32_t)e * 2654435761U + seed);
+    p[e] = (bf16_t)(((float)(h >> 8) * (1.0f / 8388608.0f) - 1.0f) * scale);  // uniform [-scale, scale)
+  }
+}
+// inverted dropout (vit.py:41,43,64,148), counter-based mask keyed by (seed, site, element): x *= m/(1-rate)
+__global__ void dropout_kernel(float* x, int64_t n, float rate, uint32_t seed_lo, uint32_t seed_hi, uint32_t site) {
+  const float keep_scale = 1.0f / (1.0f - rate);
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+    const uint32_t h = hash32(hash32((uint32_t)e ^ seed_lo) + hash32((uint32_t)(e >> 32) ^ seed_hi ^ (site * 0x9e3779b9U)));
+    const float u = (float)(h >> 8) * (1.0f / 16777216.0f);
+    x[e] = u < rate ? 0.f : x[e] * keep_scale;
+  }
+}
+
+template <typename T>
+__global__ void resid_add_kernel(const float* __restrict__ resid, const T* __restrict__ t, float* __restrict__ out, int64_t n) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x)
+    out[e] = resid[e] + ldf<T>(t + e);
+}
+
+inline int grid_for(int64_t total, int block = 256) { return (int)std::min<int64_t>(ceil_div(total, block), 256 * 8); }
+
+}  // namespace
+
+void launch_unfold(const float* img, void* out, int out_bf16, int b, int H, int W, int C, int ph, int pw, int64_t ldo, hipStream_t s) {
+  const int64_t total = (int64_t)b * (H / ph) * (W / pw) * ldo;
+  if (total == 0) return;
+  if (out_bf16) hipLaunchKernelGGL(unfold_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, s, img, (bf16_t*)out, b, H, W, C, ph, pw, ldo);
+  else hipLaunchKernelGGL(unfold_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, img, (float*)out, b, H, W, C, ph, pw, ldo);
+}
+void launch_fold_add(const float* dp, int64_t ld, float* dimg, int b, int H, int W, int C, int ph, int pw, hipStream_t s) {
+  const int64_t total = (int64_t)b * H * W * C;
+  if (total == 0) return;
+  hipLaunchKernelGGL(fold_kernel, dim3(grid_for(total)), dim3(256), 0, s, dp, ld, dimg, b, H, W, C, ph, pw);
+}
+void launch_cls_pos_row(float* x, const float* cls, const float* pos, int b, int ntok, int d, int64_t ldx, hipStream_t s) {
+  hipLaunchKernelGGL(cls_pos_row_kernel, dim3(grid_for((int64_t)b * d)), dim3(256), 0, s, x, cls, pos, b, ntok, d, ldx);
+}
+
+#define VITX_VPL_DISPATCH(d, CALL)                      \
+  do {                                                  \
+    const int vpl_ = (int)ceil_div((d), 256);           \
+    if (vpl_ <= 1) { CALL(1); }                         \
+    else if (vpl_ == 2) { CALL(2); }                    \
+    else if (vpl_ == 3) { CALL(3); }                    \
+    else if (vpl_ == 4) { CALL(4); }                    \
+    else if (vpl_ <= 6) { CALL(6); }                    \
+    else if (vpl_ <= 8) { CALL(8); }                    \
+    else { CALL(16); }                                  \
+  } while (0)
+
+void launch_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, void* y, int y_bf16, int64_t ldy,
+                          float* mean, float* rstd, int rows, int d, float eps, hipStream_t s) {
+  if (rows == 0) return;
+  dim3 grid((unsigned)ceil_div(rows, 4)), block(256);
+#define CALL(V)                                                                                                             \
+  if (y_bf16) hipLaunchKernelGGL((layernorm_fwd_kernel<bf16_t, V>), grid, block, 0, s, x, ldx, gamma, beta, (bf16_t*)y, ldy, \
+                                 mean, rstd, rows, d, eps);                                                                 \
+  else hipLaunchKernelGGL((layernorm_fwd_kernel<float, V>), grid, block, 0, s, x, ldx, gamma, beta, (float*)y, ldy, mean, rstd, rows, d, eps)
+  VITX_VPL_DISPATCH(d, CALL);
+#undef CALL
+}
+
+int64_t layernorm_bwd_ws_elems(int d) { return (int64_t)LNB_BLOCKS * 2 * d; }
+
+void launch_layernorm_bwd(const void* dy, int dy_bf16, int64_t lddy, const float* x, int64_t ldx, const float* mean, const float* rstd,
+                          const float* gamma, const float* g_in, int64_t ldgi, float* g_out, int64_t ldgo, void* g_lp, int64_t ldglp,
+                          float* partial_ws, float* dgamma, float* dbeta, int rows, int d, hipStream_t s) {
+  if (rows == 0) return;
+  const int nblk = (int)std::min<int64_t>(LNB_BLOCKS, ceil_div(rows, 4));
+  dim3 grid(nblk), block(256);
+  const size_t shm = (size_t)4 * d * sizeof(float);
+#define CALL(V)                                                                                                                  \
+  if (dy_bf16) hipLaunchKernelGGL((layernorm_bwd_kernel<bf16_t, bf16_t, V>), grid, block, shm, s, (const bf16_t*)dy, lddy, x, ldx, \
+                                  mean, rstd, gamma, g_in, ldgi, g_out, ldgo, (bf16_t*)g_lp, ldglp, partial_ws, rows, d);          \
+  else hipLaunchKernelGGL((layernorm_bwd_kernel<float, float, V>), grid, block, shm, s, (const float*)dy, lddy, x, ldx, mean, rstd, \
+                          gamma, g_in, ldgi, g_out, ldgo, (float*)g_lp, ldglp, partial_ws, rows, d)
+  VITX_VPL_DISPATCH(d, CALL);
+#undef CALL
+  // partial layout [blk][2][d]: dgamma = sum_blk partial[blk][0], dbeta = sum_blk partial[blk][1]
+  launch_reduce_partials(partial_ws, nblk, (int64_t)2 * d, d, dgamma, 1.0f, s);
+  launch_reduce_partials(partial_ws + d, nblk, (int64_t)2 * d, d, dbeta, 1.0f, s);
+}
+
+void launch_reduce_partials(const float* partial, int nparts, int64_t stride, int64_t n, float* out, float alpha, hipStream_t s) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)ceil_div(n, 64)), dim3(256), 0, s, partial, nparts, stride, n, out, alpha);
+}
+
+int64_t colsum_ws_elems(int cols) { return (int64_t)CS_CHUNKS * cols; }
+void launch_colsum(const void* x, int is_bf16, int64_t ld, int rows, int cols, float* partial_ws, float* out, hipStream_t s) {
+  const int chunks = (int)std::max<int64_t>(1, std::min<int64_t>(CS_CHUNKS, ceil_div(rows, 16)));
+  dim3 grid((unsigned)ceil_div(cols, 256), chunks), block(256);
+  if (is_bf16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)x, ld, rows, cols, partial_ws);
+  else hipLaunchKernelGGL(colsum_kernel<float>, grid, block, 0, s, (const float*)x, ld, rows, cols, partial_ws);
+  launch_reduce_partials(partial_ws, chunks, cols, cols, out, 1.0f, s);
+}
+
+void launch_convert_weight(const float* w, int in, int out, bf16_t* wn, int64_t ldwn, bf16_t* wt, int64_t ldwt, hipStream_t s) {
+  dim3 grid((unsigned)ceil_div(out, 32), (unsigned)ceil_div(in, 32)), block(256);
+  hipLaunchKernelGGL(convert_weight_kernel, grid, block, 0, s, w, in, out, wn, ldwn, wt, ldwt);
+}
+void launch_transpose_bf16(const bf16_t* in, int64_t ldi, int rows, int cols, bf16_t* out, int64_t ldo, hipStream_t s) {
+  dim3 grid((unsigned)ceil_div(cols, 64), (unsigned)ceil_div(rows, 64)), block(256);
+  hipLaunchKernelGGL(transpose_bf16_kernel, grid, block, 0, s, in, ldi, rows, cols, out, ldo);
+}
+void launch_convert(const float* in, int64_t ldi, void* out, int out_bf16, int64_t ldo, int rows, int cols, int64_t zero_to,
+                    hipStream_t s) {
+  const int64_t total = (int64_t)rows * zero_to;
+  if (total == 0) return;
+  if (out_bf16) hipLaunchKernelGGL(convert_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, s, in, ldi, (bf16_t*)out, ldo, rows, cols, zero_to);
+  else hipLaunchKernelGGL(convert_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, in, ldi, (float*)out, ldo, rows, cols, zero_to);
+}
+void launch_to_f32(const void* in, int in_bf16, int64_t ldi, float* out, int64_t ldo, int rows, int cols, hipStream_t s) {
+  const int64_t total = (int64_t)rows * cols;
+  if (total == 0) return;
+  if (in_bf16) hipLaunchKernelGGL(to_f32_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, s, (const bf16_t*)in, ldi, out, ldo, rows, cols);
+  else hipLaunchKernelGGL(to_f32_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, (const float*)in, ldi, out, ldo, rows, cols);
+}
+void launch_mean_pool(const float* x, int b, int ntok, int d, float* out, hipStream_t s) {
+  hipLaunchKernelGGL(mean_pool_kernel, dim3(grid_for((int64_t)b * d)), dim3(256), 0, s, x, b, ntok, d, out);
+}
+void launch_mean_pool_bwd(const float* dp, int b, int ntok, int d, float* g, hipStream_t s) {
+  hipLaunchKernelGGL(mean_pool_bwd_kernel, dim3(grid_for((int64_t)b * ntok * d)), dim3(256), 0, s, dp, b, ntok, d, g);
+}
+void launch_batch_reduce(const float* g, int b, int ntok, int d, int j0, int nj, float* out, hipStream_t s) {
+  if (nj <= 0) return;
+  hipLaunchKernelGGL(batch_reduce_kernel, dim3(grid_for((int64_t)nj * d)), dim3(256), 0, s, g, b, ntok, d, j0, nj, out);
+}
+void launch_extract_rows(const float* g, int b, int ntok, int tok_off, int np, int d, void* out, int out_bf16, int64_t ldo, hipStream_t s) {
+  const int64_t total = (int64_t)b * np * d;
+  if (total == 0) return;
+  if (out_bf16) hipLaunchKernelGGL(extract_rows_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, s, g, b, ntok, tok_off, np, d, (bf16_t*)out, ldo);
+  else hipLaunchKernelGGL(extract_rows_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, g, b, ntok, tok_off, np, d, (float*)out, ldo);
+}
+void launch_sum_rows(const float* in, int rows, int d, float* out, hipStream_t s) {
+  hipLaunchKernelGGL(sum_rows_kernel, dim3((unsigned)ceil_div(d, 256)), dim3(256), 0, s, in, rows, d, out);
+}
+void launch_ce_grad(const float* logits, int64_t ld, const int32_t* labels, int b, int nc, float inv_batch, float* dlogits, float* loss,
+                    hipStream_t s) {
+  hipLaunchKernelGGL(ce_grad_kernel, dim3(b), dim3(64), 0, s, logits, ld, labels, b, nc, inv_batch, dlogits, loss);
+}
+void launch_fill_random_bf16(bf16_t* p, int64_t n, uint32_t seed, float scale, hipStream_t s) {
+  hipLaunchKernelGGL(fill_random_bf16_kernel, dim3(grid_for(n)), dim3(256), 0, s, p, n, seed, scale);
+}
+void launch_dropout(float* x, int64_t n, float rate, uint64_t seed, uint32_t site, hipStream_t s) {
+  if (n == 0 || rate <= 0.f) return;
+  hipLaunchKernelGGL(dropout_kernel, dim3(grid_for(n)), dim3(256), 0, s, x, n, rate, (uint32_t)seed, (uint32_t)(seed >> 32), site);
+}
+void launch_resid_add(const float* resid, const void* t, int t_bf16, float* out, int64_t n, hipStream_t s) {
+  if (n == 0) return;
+  if (t_bf16) hipLaunchKernelGGL(resid_add_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, s, resid, (const bf16_t*)t, out, n);
+  else hipLaunchKernelGGL(resid_add_kernel<float>, dim3(grid_for(n)), dim3(256), 0, s, resid, (const float*)t, out, n);
+}

@@ -1,0 +1,134 @@
+// Host-side engine behind the C ABI: parameter table, device memory plan, and the launch sequences
+// that replace ViT.call / DeepViT.call / CaiT.call (vit.py:159-177, deepvit.py:139-157,
+// cait.py:180-194) and their autodiff.
+#pragma once
+#include <string>
+#include <vector>
+
+#include "../../include/vitx.h"
+#include "kernels.h"
+
+struct ParamDesc {
+  std::string name;
+  std::vector<int64_t> shape;
+  int64_t offset = 0, count = 0;   // offset in the packed host blob (API order)
+  int64_t aoff = 0;                // offset in the device arena (every tensor starts 16-B aligned)
+};
+
+// Builds the explicit parameter order (must match oracle/spec.py:param_spec; tests compare them).
+// Returns "" on success or the reference's assertion text on an invalid config.
+std::string build_param_table(const vitx_config& c, std::vector<ParamDesc>& out);
+
+struct Dense {
+  int in = 0, out = 0;
+  int in_k = 0, out_k = 0;          // padded to 64 (K extents of the bf16 GEMMs)
+  int64_t w = -1, b = -1;           // arena offsets (Keras kernel [in,out], bias [out])
+  bf16_t* wt = nullptr;             // [round_up(out,256)][in_k]   forward operand  (W^T)
+  bf16_t* wn = nullptr;             // [round_up(in,256)][out_k]   dgrad operand    (W)
+};
+
+struct BlockParams {
+  int64_t a_scale = -1, ln1_g = -1, ln1_b = -1;
+  Dense qkv, q, kv, out;
+  bool has_out = true;
+  int64_t mix_pre = -1, mix_post = -1, re_w = -1, re_g = -1, re_b = -1;
+  int64_t m_scale = -1, ln2_g = -1, ln2_b = -1;
+  Dense fc1, fc2;
+  int64_t p_begin = 0, p_end = 0;   // arena range of this block's parameters
+};
+
+struct BlockActs {
+  float *x_in = nullptr, *x_mid = nullptr, *x_out = nullptr;
+  void *y1 = nullptr, *qkv = nullptr, *q = nullptr, *kv = nullptr, *ctx = nullptr, *o = nullptr, *fa = nullptr;
+  void *y2 = nullptr, *hpre = nullptr, *act = nullptr, *fm = nullptr;
+  float *mean1 = nullptr, *rstd1 = nullptr, *mean2 = nullptr, *rstd2 = nullptr, *lse = nullptr;
+};
+
+struct Stage {
+  std::string prefix;
+  int depth = 0;
+  int nq_max = 0, nc_max = 0;       // query tokens per image, extra context tokens per image
+  std::vector<BlockParams> bp;
+  std::vector<BlockActs> ba;
+};
+
+struct ProfEvent {
+  int cls;
+  hipEvent_t e0, e1;
+  double flops, bytes;
+};
+
+struct vitx_engine {
+  vitx_config cfg{};
+  std::vector<ParamDesc> table;
+  int64_t n_params = 0;              // packed element count (host blob)
+  int64_t n_arena = 0;               // device arena element count (>= n_params, zero padding between tensors)
+  bool bf16 = false;
+  int esz = 4;                       // bytes per "T" element
+
+  // derived sizes (configured image)
+  int np_max = 0, ntok_max = 0, pd = 0, pd_k = 0, inner = 0, nc_k = 0;
+  int64_t mp = 0;                    // max token rows, padded to 256
+  int64_t mpp = 0;                   // max patch rows, padded to 256
+  int64_t bp = 0;                    // max batch padded to 256
+
+  hipStream_t own_stream = nullptr, stream = nullptr;
+  float* params = nullptr;
+  float* grads = nullptr;
+  bool own_params = true, own_grads = true;
+  bool params_dirty = true;
+
+  // parameter handles
+  int64_t pos = -1, cls = -1, head_g = -1, head_b = -1;
+  Dense patch, head;
+  std::vector<Stage> stages;
+
+  // buffers
+  std::vector<void*> allocs;
+  std::vector<std::pair<void*, size_t>> t_buffers;   // re-zeroed when the batch geometry changes
+  int64_t ws_bytes = 0;
+  float* img_dev = nullptr;
+  void* patches = nullptr;
+  float* pooled = nullptr; void* yh = nullptr; float *mean_h = nullptr, *rstd_h = nullptr;
+  float *logits = nullptr, *dlogits = nullptr; void* dl_lp = nullptr; void* dyh = nullptr; float* dpooled = nullptr;
+  float* g = nullptr; void* g_lp = nullptr; float* g_ctx = nullptr;  // residual gradient stream (+T copy), CaiT patch-output grad
+  void *d_h = nullptr, *d_y = nullptr, *d_o = nullptr, *d_qkv = nullptr, *d_ctx = nullptr, *d_br = nullptr;
+  bf16_t *xt = nullptr, *dyt = nullptr; int64_t t_rows = 0;
+  float* partial_ws = nullptr; int64_t partial_elems = 0;
+  float* red_ws = nullptr; int64_t red_elems = 0;
+  float* sc[4] = {nullptr, nullptr, nullptr, nullptr}; int64_t sc_elems = 0;
+  float* dsum = nullptr;
+  float* tmp_f32 = nullptr;          // [mp, max(d, pd)] fp32 scratch (dropout / dimg paths)
+  float* loss_rows = nullptr;
+  bf16_t *bench_a = nullptr, *bench_b = nullptr; float* bench_c = nullptr; int64_t bench_elems = 0;
+
+  // state of the last forward
+  bool have_fwd = false;
+  int last_b = 0, last_np = 0, last_ntok = 0, last_H = 0, last_W = 0, last_training = 0;
+  uint64_t last_seed = 0;
+  int64_t zero_geom = -1;
+
+  // env switches
+  bool force_generic_gemm = false, force_generic_attn = false, wgrad_via_transpose = true;
+  int gemm_kernel = 0;
+
+  // profiling
+  bool profiling = false;
+  std::vector<ProfEvent> prof_events;
+  std::vector<std::string> prof_names;
+
+  // data parallel
+  vitx_grad_ready_fn grad_cb = nullptr; void* grad_cb_user = nullptr;
+  void* rccl_lib = nullptr; void* comm = nullptr; int rank = 0, world = 1;
+};
+
+int engine_create(const vitx_config& cfg, vitx_engine** out, std::string& err);
+void engine_destroy(vitx_engine* e);
+int engine_forward(vitx_engine* e, const float* img_dev, int b, int H, int W, int training, uint64_t seed, float* logits_dev,
+                   std::string& err);
+int engine_backward(vitx_engine* e, const float* dlogits_dev, float* dimg_dev, std::string& err);
+int engine_transformer_forward(vitx_engine* e, const float* tokens_dev, int b, int n, float* out_dev, std::string& err);
+void engine_refresh_weights(vitx_engine* e);
+int engine_bench_gemm(vitx_engine* e, int M, int N, int K, int kernel, int epilogue, int iters, float* avg_ms, float* max_err,
+                      std::string& err);
+int prof_class(vitx_engine* e, const char* name);

@@ -1,0 +1,1052 @@
+// Engine: parameter table, memory plan and launch sequences (see engine.h).
+#include "engine.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#define HIPCHK(x)                                                                                   \
+  do {                                                                                              \
+    hipError_t e_ = (x);                                                                            \
+    if (e_ != hipSuccess) {                                                                         \
+      err = std::string(#x) + ": " + hipGetErrorString(e_);                                         \
+      return VITX_ERR_HIP;                                                                          \
+    }                                                                                               \
+  } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// parameter table
+// ------------------------------------------------------------------------------------------------
+std::string build_param_table(const vitx_config& c, std::vector<ParamDesc>& out) {
+  out.clear();
+  if (c.variant < 0 || c.variant > 2) return "unknown variant";
+  if (c.patch_h <= 0 || c.patch_w <= 0 || c.image_h <= 0 || c.image_w <= 0) return "image/patch size must be positive";
+  if (c.image_h % c.patch_h != 0 || c.image_w % c.patch_w != 0)
+    return "Image dimensions must be divisible by the patch size.";   // vit.py:136, deepvit.py:117, cait.py:160
+  if (c.variant != VITX_VARIANT_CAIT && c.pool != VITX_POOL_CLS && c.pool != VITX_POOL_MEAN)
+    return "pool type must be either cls (cls token) or mean (mean pooling)";  // vit.py:139
+  if (c.dim <= 0 || c.depth < 0 || c.heads <= 0 || c.dim_head <= 0 || c.mlp_dim <= 0 || c.num_classes <= 0 || c.channels <= 0)
+    return "dim/depth/heads/dim_head/mlp_dim/num_classes must be positive";
+  const int64_t d = c.dim, h = c.heads, dh = c.dim_head, m = c.mlp_dim, nc = c.num_classes, inner = h * dh;
+  const int64_t np = (int64_t)(c.image_h / c.patch_h) * (c.image_w / c.patch_w);
+  const int64_t pd = (int64_t)c.patch_h * c.patch_w * c.channels;
+  int64_t off = 0, aoff = 0;
+  auto add = [&](const std::string& n, std::vector<int64_t> s) {
+    ParamDesc p;
+    p.name = n;
+    p.shape = s;
+    p.count = 1;
+    for (auto v : s) p.count *= v;
+    p.offset = off;
+    p.aoff = aoff;
+    off += p.count;
+    aoff += round_up(p.count, 4);
+    out.push_back(p);
+  };
+  const bool cait = c.variant == VITX_VARIANT_CAIT, deep = c.variant == VITX_VARIANT_DEEPVIT;
+  add("pos_embedding", {1, cait ? np : np + 1, d});
+  add("cls_token", {1, 1, d});
+  add("patch_embedding.kernel", {pd, d});
+  add("patch_embedding.bias", {d});
+  auto block = [&](const std::string& pre) {
+    if (cait) add(pre + ".attn.scale", {1, 1, d});
+    add(pre + ".attn.norm.gamma", {d});
+    add(pre + ".attn.norm.beta", {d});
+    if (cait) {
+      add(pre + ".attn.to_q.kernel", {d, inner});
+      add(pre + ".attn.to_kv.kernel", {d, 2 * inner});
+      add(pre + ".attn.mix_heads_pre_attn", {h, h});
+      add(pre + ".attn.mix_heads_post_attn", {h, h});
+    } else {
+      add(pre + ".attn.to_qkv.kernel", {d, 3 * inner});
+    }
+    if (deep) {
+      add(pre + ".attn.reattn_weights", {h, h});
+      add(pre + ".attn.reattn_norm.gamma", {h});
+      add(pre + ".attn.reattn_norm.beta", {h});
+    }
+    const bool project_out = !(c.variant == VITX_VARIANT_VIT && h == 1 && dh == d);  // vit.py:53
+    if (project_out) {
+      add(pre + ".attn.to_out.kernel", {inner, d});
+      add(pre + ".attn.to_out.bias", {d});
+    }
+    if (cait) add(pre + ".mlp.scale", {1, 1, d});
+    add(pre + ".mlp.norm.gamma", {d});
+    add(pre + ".mlp.norm.beta", {d});
+    add(pre + ".mlp.fc1.kernel", {d, m});
+    add(pre + ".mlp.fc1.bias", {m});
+    add(pre + ".mlp.fc2.kernel", {m, d});
+    add(pre + ".mlp.fc2.bias", {d});
+  };
+  if (cait) {
+    for (int i = 0; i < c.depth; ++i) block("patch_transformer." + std::to_string(i));
+    for (int i = 0; i < c.cls_depth; ++i) block("cls_transformer." + std::to_string(i));
+  } else {
+    for (int i = 0; i < c.depth; ++i) block("transformer." + std::to_string(i));
+  }
+  add("mlp_head.norm.gamma", {d});
+  add("mlp_head.norm.beta", {d});
+  add("mlp_head.kernel", {d, nc});
+  add("mlp_head.bias", {nc});
+  return "";
+}
+
+// ------------------------------------------------------------------------------------------------
+// profiling scope
+// ------------------------------------------------------------------------------------------------
+int prof_class(vitx_engine* e, const char* name) {
+  for (size_t i = 0; i < e->prof_names.size(); ++i)
+    if (e->prof_names[i] == name) return (int)i;
+  e->prof_names.push_back(name);
+  return (int)e->prof_names.size() - 1;
+}
+struct Prof {
+  vitx_engine* e;
+  ProfEvent pe;
+  bool on;
+  Prof(vitx_engine* e_, const char* name, double flops, double bytes) : e(e_), on(e_->profiling) {
+    if (!on) return;
+    pe.cls = prof_class(e, name);
+    pe.flops = flops;
+    pe.bytes = bytes;
+    (void)hipEventCreate(&pe.e0);
+    (void)hipEventCreate(&pe.e1);
+    (void)hipEventRecord(pe.e0, e->stream);
+  }
+  ~Prof() {
+    if (!on) return;
+    (void)hipEventRecord(pe.e1, e->stream);
+    e->prof_events.push_back(pe);
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+// small helpers
+// ------------------------------------------------------------------------------------------------
+static inline char* boff(void* p, int64_t elems, int esz) { return (char*)p + elems * esz; }
+static inline const char* boff(const void* p, int64_t elems, int esz) { return (const char*)p + elems * esz; }
+
+static void finalize_epi(EpiParams& ep) {
+  auto al = [](const void* p) { return p == nullptr || (((uintptr_t)p) & 15) == 0; };
+  ep.vec_ok = (ep.ldo % 4 == 0) && (ep.ldo2 % 4 == 0) && (ep.ldr % 4 == 0) && (ep.ldaux % 4 == 0) && al(ep.out) && al(ep.out2) &&
+              al(ep.bias) && al(ep.resid) && al(ep.scale) && al(ep.aux) && al(ep.pos) && (ep.out_batch_stride % 4 == 0) &&
+              (ep.out_head_stride % 4 == 0) && (ep.partial_stride % 4 == 0);
+}
+
+static int dalloc(vitx_engine* e, void** p, size_t bytes, bool t_buffer, std::string& err) {
+  if (bytes == 0) bytes = 16;
+  bytes = (size_t)round_up((int64_t)bytes, 256);
+  HIPCHK(hipMalloc(p, bytes));
+  HIPCHK(hipMemsetAsync(*p, 0, bytes, e->stream));
+  e->allocs.push_back(*p);
+  if (t_buffer) e->t_buffers.push_back({*p, bytes});
+  e->ws_bytes += (int64_t)bytes;
+  return VITX_OK;
+}
+#define DALLOC(ptr, bytes, tb)                                             \
+  do {                                                                     \
+    int rc_ = dalloc(e, (void**)&(ptr), (size_t)(bytes), tb, err);         \
+    if (rc_ != VITX_OK) return rc_;                                        \
+  } while (0)
+
+static int64_t find_param(const vitx_engine* e, const std::string& name) {
+  for (auto& p : e->table)
+    if (p.name == name) return p.aoff;
+  return -1;
+}
+
+static int init_dense(vitx_engine* e, Dense& w, const std::string& kname, const std::string& bname, int in, int out, std::string& err) {
+  w.in = in;
+  w.out = out;
+  w.in_k = (int)round_up(in, 64);
+  w.out_k = (int)round_up(out, 64);
+  w.w = find_param(e, kname);
+  w.b = bname.empty() ? -1 : find_param(e, bname);
+  if (w.w < 0) { err = "missing parameter " + kname; return VITX_ERR_INVALID; }
+  if (e->bf16) {
+    DALLOC(w.wt, (size_t)round_up(out, 256) * w.in_k * 2, false);
+    DALLOC(w.wn, (size_t)round_up(in, 256) * w.out_k * 2, false);
+  }
+  return VITX_OK;
+}
+
+void engine_refresh_weights(vitx_engine* e) {
+  if (!e->bf16) { e->params_dirty = false; return; }
+  Prof pr(e, "convert_weights", 0, (double)e->n_params * 8);
+  auto conv = [&](const Dense& w) {
+    if (w.w >= 0 && w.wt) launch_convert_weight(e->params + w.w, w.in, w.out, w.wn, w.out_k, w.wt, w.in_k, e->stream);
+  };
+  conv(e->patch);
+  conv(e->head);
+  for (auto& st : e->stages)
+    for (auto& b : st.bp) { conv(b.qkv); conv(b.q); conv(b.kv); conv(b.out); conv(b.fc1); conv(b.fc2); }
+  e->params_dirty = false;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Dense layer = x @ kernel[in,out] + bias (Keras nn.Dense; vit.py:39,42,59,63,143,156) and its VJPs
+// ------------------------------------------------------------------------------------------------
+static void dense_fwd(vitx_engine* e, const void* X, int64_t ldx, int rows, const Dense& w, int mode, EpiParams ep) {
+  ep.M = rows;
+  ep.N = w.out;
+  if (w.b >= 0 && mode != EPI_GELU_BWD) ep.bias = e->params + w.b;
+  const double flops = 2.0 * rows * (double)w.out * w.in;
+  const double bytes = (double)rows * w.in * e->esz + (double)rows * w.out * e->esz + (double)w.in * w.out * e->esz;
+  if (e->bf16 && !e->force_generic_gemm) {
+    Bf16GemmArgs g;
+    g.A = (const bf16_t*)X; g.lda = ldx;
+    g.B = w.wt; g.ldb = w.in_k;
+    g.M = rows; g.N = w.out; g.K = w.in_k; g.kernel = e->gemm_kernel;
+    ep.zero_pad = 1;
+    finalize_epi(ep);
+    Prof pr(e, "gemm_bf16_mfma", flops, bytes);
+    launch_gemm_bf16(g, ep, mode, e->stream);
+  } else {
+    GenericGemmArgs g;
+    g.A = X; g.B = e->params + w.w;
+    g.M = rows; g.N = w.out; g.K = w.in;
+    g.sam = ldx; g.sak = 1; g.sbk = w.out; g.sbn = 1;
+    ep.zero_pad = 1;
+    finalize_epi(ep);
+    Prof pr(e, "gemm_generic_fma", flops, bytes);
+    launch_gemm_generic(g, ep, mode, e->bf16, 0, e->bf16, e->stream);
+  }
+}
+
+// dX[rows,in] = dY[rows,out] @ W^T
+static void dense_dgrad(vitx_engine* e, const void* dY, int64_t ldy, int rows, const Dense& w, int mode, EpiParams ep) {
+  ep.M = rows;
+  ep.N = w.in;
+  ep.bias = nullptr;
+  const double flops = 2.0 * rows * (double)w.out * w.in;
+  const double bytes = (double)rows * w.in * e->esz + (double)rows * w.out * e->esz + (double)w.in * w.out * e->esz;
+  if (e->bf16 && !e->force_generic_gemm) {
+    Bf16GemmArgs g;
+    g.A = (const bf16_t*)dY; g.lda = ldy;
+    g.B = w.wn; g.ldb = w.out_k;
+    g.M = rows; g.N = w.in; g.K = w.out_k; g.kernel = e->gemm_kernel;
+    ep.zero_pad = 1;
+    finalize_epi(ep);
+    Prof pr(e, "gemm_bf16_mfma", flops, bytes);
+    launch_gemm_bf16(g, ep, mode, e->stream);
+  } else {
+    GenericGemmArgs g;
+    g.A = dY; g.B = e->params + w.w;
+    g.M = rows; g.N = w.in; g.K = w.out;
+    g.sam = ldy; g.sak = 1; g.sbk = 1; g.sbn = w.out;
+    ep.zero_pad = 1;
+    finalize_epi(ep);
+    Prof pr(e, "gemm_generic_fma", flops, bytes);
+    launch_gemm_generic(g, ep, mode, e->bf16, 0, e->bf16, e->stream);
+  }
+}
+
+// dW[in,out] = X^T[in,rows] @ dY[rows,out]   (reduction over every token row of the batch)
+static void dense_wgrad(vitx_engine* e, const void* X, int64_t ldx, const void* dY, int64_t ldy, int rows, const Dense& w) {
+  float* dW = e->grads + w.w;
+  const double flops = 2.0 * rows * (double)w.out * w.in;
+  const double bytes = (double)rows * w.in * e->esz + (double)rows * w.out * e->esz + (double)w.in * w.out * 4;
+  if (e->bf16 && !e->force_generic_gemm) {
+    const int kext = (int)round_up(rows, 64);
+    {
+      Prof pr(e, "transpose_bf16", 0, 2.0 * ((double)kext * w.in + (double)kext * w.out) * 2);
+      launch_transpose_bf16((const bf16_t*)X, ldx, kext, w.in, e->xt, kext, e->stream);
+      launch_transpose_bf16((const bf16_t*)dY, ldy, kext, w.out, e->dyt, kext, e->stream);
+    }
+    Bf16GemmArgs g;
+    g.A = e->xt; g.lda = kext;
+    g.B = e->dyt; g.ldb = kext;
+    g.M = w.in; g.N = w.out; g.K = kext; g.kernel = e->gemm_kernel;
+    const int tm = gemm_bf16_tile_m(g.kernel, g.M, g.N), tn = gemm_bf16_tile_n(g.kernel, g.M, g.N);
+    const int64_t tiles = ceil_div(w.in, tm) * ceil_div(w.out, tn);
+    const int nk = kext / 64;
+    int split = (int)std::max<int64_t>(1, std::min<int64_t>(ceil_div(nk, 4), ceil_div(512, tiles)));
+    while (split > 1 && (int64_t)split * w.in * w.out > e->partial_elems) --split;
+    g.split_k = split;
+    const int slices = gemm_bf16_num_slices(kext, split);
+    EpiParams ep;
+    ep.out = e->partial_ws; ep.ldo = w.out; ep.partial_stride = (int64_t)w.in * w.out;
+    ep.M = w.in; ep.N = w.out;
+    finalize_epi(ep);
+    {
+      Prof pr(e, "gemm_bf16_mfma", flops, bytes);
+      launch_gemm_bf16(g, ep, EPI_PARTIAL, e->stream);
+    }
+    Prof pr(e, "reduce_partials", 0, (double)(slices + 1) * w.in * w.out * 4);
+    launch_reduce_partials(e->partial_ws, slices, (int64_t)w.in * w.out, (int64_t)w.in * w.out, dW, 1.0f, e->stream);
+  } else {
+    GenericGemmArgs g;
+    g.A = X; g.B = dY;
+    g.M = w.in; g.N = w.out; g.K = rows;
+    g.sam = 1; g.sak = ldx; g.sbk = ldy; g.sbn = 1;
+    EpiParams ep;
+    ep.out = dW; ep.ldo = w.out; ep.M = w.in; ep.N = w.out;
+    finalize_epi(ep);
+    Prof pr(e, "gemm_generic_fma", flops, bytes);
+    launch_gemm_generic(g, ep, EPI_STORE_F32, e->bf16, e->bf16, 0, e->stream);
+  }
+}
+
+static void bias_grad(vitx_engine* e, const void* dY, int is_bf16, int64_t ld, int rows, const Dense& w) {
+  if (w.b < 0) return;
+  Prof pr(e, "colsum", 0, (double)rows * w.out * (is_bf16 ? 2 : 4));
+  launch_colsum(dY, is_bf16, ld, rows, w.out, e->red_ws, e->grads + w.b, e->stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+// attention
+// ------------------------------------------------------------------------------------------------
+struct AttnView {   // per-head-addressable views into [b, n, (h d)]-style tensors (vit.py:74,82 as addressing)
+  const void *q = nullptr, *k = nullptr, *v = nullptr;
+  int64_t ldq = 0, ldk = 0, ldv = 0, qb = 0, kb = 0, vb = 0;   // row strides / per-image strides (elements)
+  void* o = nullptr; int64_t ldo = 0, ob = 0;
+  int nq = 0, nk = 0;
+};
+
+static int ensure_scores(vitx_engine* e, int count, int64_t elems, std::string& err) {
+  if (elems > e->sc_elems) {
+    // (re)allocate all score workspaces at the larger size
+    for (int i = 0; i < 4; ++i) e->sc[i] = nullptr;
+    e->sc_elems = elems;
+  }
+  for (int i = 0; i < count; ++i)
+    if (!e->sc[i]) DALLOC(e->sc[i], (size_t)e->sc_elems * 4, false);
+  return VITX_OK;
+}
+
+static void bgemm(vitx_engine* e, const void* A, int ta, int64_t sam, int64_t sak, int64_t sAb, int64_t sAh, const void* B, int tb,
+                  int64_t sbk, int64_t sbn, int64_t sBb, int64_t sBh, int M, int N, int K, int nb, int nh, int mode, int to, void* out,
+                  int64_t ldo, int64_t ob, int64_t oh, float alpha) {
+  GenericGemmArgs g;
+  g.A = A; g.B = B; g.M = M; g.N = N; g.K = K;
+  g.sam = sam; g.sak = sak; g.sbk = sbk; g.sbn = sbn;
+  g.nb = nb; g.nh = nh; g.sAb = sAb; g.sAh = sAh; g.sBb = sBb; g.sBh = sBh;
+  EpiParams ep;
+  ep.out = out; ep.ldo = ldo; ep.out_batch_stride = ob; ep.out_head_stride = oh; ep.alpha = alpha;
+  ep.M = M; ep.N = N;
+  finalize_epi(ep);
+  Prof pr(e, "attn_generic_bgemm", 2.0 * M * (double)N * K * nb * nh, 0);
+  launch_gemm_generic(g, ep, mode, ta, tb, to, e->stream);
+}
+
+// forward chain into the score workspaces; returns the index of the workspace holding the matrix that multiplies V
+static int attn_generic_scores(vitx_engine* e, const BlockParams& bp, const AttnView& a, int b) {
+  const int h = e->cfg.heads, dh = e->cfg.dim_head;
+  const int T = e->bf16;
+  const int64_t ld = round_up(a.nk, 4);
+  const int64_t hs = (int64_t)a.nq * ld, bs = (int64_t)h * hs;
+  const float scale = 1.0f / std::sqrt((float)dh);
+  // dots = q k^T * scale   (vit.py:77, deepvit.py:79, cait.py:121)
+  bgemm(e, a.q, T, a.ldq, 1, a.qb, dh, a.k, T, 1, a.ldk, a.kb, dh, a.nq, a.nk, dh, b, h, EPI_STORE_F32, 0, e->sc[0], ld, bs, hs, scale);
+  const int64_t rows = (int64_t)b * h * a.nq;
+  if (e->cfg.variant == VITX_VARIANT_CAIT) {
+    Prof pr(e, "attn_generic_headops", 0, 0);
+    launch_headmix_fwd(e->sc[0], e->params + bp.mix_pre, e->sc[1], b, h, a.nq, a.nk, ld, e->stream);    // cait.py:123
+    launch_softmax_rows(e->sc[1], rows, a.nk, ld, e->stream);                                            // cait.py:124
+    launch_headmix_fwd(e->sc[1], e->params + bp.mix_post, e->sc[2], b, h, a.nq, a.nk, ld, e->stream);   // cait.py:125
+    return 2;
+  }
+  {
+    Prof pr(e, "attn_generic_softmax", 0, 0);
+    launch_softmax_rows(e->sc[0], rows, a.nk, ld, e->stream);                                            // vit.py:78
+  }
+  if (e->cfg.variant == VITX_VARIANT_DEEPVIT) {
+    Prof pr(e, "attn_generic_headops", 0, 0);
+    launch_headmix_fwd(e->sc[0], e->params + bp.re_w, e->sc[1], b, h, a.nq, a.nk, ld, e->stream);       // deepvit.py:83
+    launch_headnorm_fwd(e->sc[1], e->params + bp.re_g, e->params + bp.re_b, e->sc[2], b, h, a.nq, a.nk, ld, e->cfg.ln_eps,
+                        e->stream);                                                                      // deepvit.py:84
+    return 2;
+  }
+  return 0;
+}
+
+static void attn_generic_fwd(vitx_engine* e, const BlockParams& bp, const AttnView& a, int b) {
+  const int h = e->cfg.heads, dh = e->cfg.dim_head, T = e->bf16;
+  const int64_t ld = round_up(a.nk, 4);
+  const int64_t hs = (int64_t)a.nq * ld, bs = (int64_t)h * hs;
+  const int pi = attn_generic_scores(e, bp, a, b);
+  // out = attn v   (vit.py:81, deepvit.py:87, cait.py:127)
+  bgemm(e, e->sc[pi], 0, ld, 1, bs, hs, a.v, T, a.ldv, 1, a.vb, dh, a.nq, dh, a.nk, b, h, EPI_STORE, T, a.o, a.ldo, a.ob, dh, 1.0f);
+}
+
+struct AttnGrad {   // gradients, same addressing conventions as AttnView
+  const void* d_o = nullptr; int64_t ldo = 0, ob = 0;
+  void *dq = nullptr, *dk = nullptr, *dv = nullptr;
+  int64_t lddq = 0, lddk = 0, lddv = 0, dqb = 0, dkb = 0, dvb = 0;
+};
+
+static void attn_generic_bwd(vitx_engine* e, const BlockParams& bp, const AttnView& a, const AttnGrad& gr, int b) {
+  const int h = e->cfg.heads, dh = e->cfg.dim_head, T = e->bf16;
+  const int64_t ld = round_up(a.nk, 4);
+  const int64_t hs = (int64_t)a.nq * ld, bs = (int64_t)h * hs;
+  const float scale = 1.0f / std::sqrt((float)dh);
+  const int64_t rows = (int64_t)b * h * a.nq;
+  const int pi = attn_generic_scores(e, bp, a, b);   // recompute the forward chain (P is not stored)
+  float* dA = e->sc[3];
+  // d(attn) = dO v^T ; dV = attn^T dO
+  bgemm(e, gr.d_o, T, gr.ldo, 1, gr.ob, dh, a.v, T, 1, a.ldv, a.vb, dh, a.nq, a.nk, dh, b, h, EPI_STORE_F32, 0, dA, ld, bs, hs, 1.0f);
+  bgemm(e, e->sc[pi], 0, 1, ld, bs, hs, gr.d_o, T, gr.ldo, 1, gr.ob, dh, a.nk, dh, a.nq, b, h, EPI_STORE, T, gr.dv, gr.lddv, gr.dvb, dh, 1.0f);
+  {
+    Prof pr(e, "attn_generic_headops", 0, 0);
+    if (e->cfg.variant == VITX_VARIANT_CAIT) {
+      launch_headmix_bwd(e->sc[1], dA, e->params + bp.mix_post, dA, e->red_ws, e->grads + bp.mix_post, b, h, a.nq, a.nk, ld, e->stream);
+      launch_softmax_bwd_rows(e->sc[1], dA, rows, a.nk, ld, e->stream);
+      launch_headmix_bwd(e->sc[0], dA, e->params + bp.mix_pre, dA, e->red_ws, e->grads + bp.mix_pre, b, h, a.nq, a.nk, ld, e->stream);
+    } else if (e->cfg.variant == VITX_VARIANT_DEEPVIT) {
+      launch_headnorm_bwd(e->sc[1], dA, e->params + bp.re_g, dA, e->red_ws, e->grads + bp.re_g, e->grads + bp.re_b, b, h, a.nq, a.nk, ld,
+                          e->cfg.ln_eps, e->stream);
+      launch_headmix_bwd(e->sc[0], dA, e->params + bp.re_w, dA, e->red_ws, e->grads + bp.re_w, b, h, a.nq, a.nk, ld, e->stream);
+      launch_softmax_bwd_rows(e->sc[0], dA, rows, a.nk, ld, e->stream);
+    } else {
+      launch_softmax_bwd_rows(e->sc[0], dA, rows, a.nk, ld, e->stream);
+    }
+  }
+  // dQ = scale dS k ; dK = scale dS^T q
+  bgemm(e, dA, 0, ld, 1, bs, hs, a.k, T, a.ldk, 1, a.kb, dh, a.nq, dh, a.nk, b, h, EPI_STORE, T, gr.dq, gr.lddq, gr.dqb, dh, scale);
+  bgemm(e, dA, 0, 1, ld, bs, hs, a.q, T, a.ldq, 1, a.qb, dh, a.nk, dh, a.nq, b, h, EPI_STORE, T, gr.dk, gr.lddk, gr.dkb, dh, scale);
+}
+
+static bool use_fused_attn(const vitx_engine* e, int n) {
+  return e->bf16 && e->cfg.variant == VITX_VARIANT_VIT && !e->force_generic_attn && attn_bf16_supported(n, e->cfg.dim_head);
+}
+
+// ------------------------------------------------------------------------------------------------
+// one transformer block: x = attn(LN(x)) [*scale] + x ; x = mlp(LN(x)) [*scale] + x
+//   (vit.py:99-104, deepvit.py:106-110, cait.py:146-153)
+// ------------------------------------------------------------------------------------------------
+static int block_forward(vitx_engine* e, Stage& st, int l, int b, int nq, int nc, const float* context, std::string& err) {
+  const BlockParams& bp = st.bp[l];
+  BlockActs& ba = st.ba[l];
+  const vitx_config& c = e->cfg;
+  const int d = c.dim, inner = e->inner, m = c.mlp_dim, T = e->bf16, esz = e->esz;
+  const int rows = b * nq;
+  const int nk = nq + nc;
+  const double lnb = (double)rows * d * (4 + esz);
+  {
+    Prof pr(e, "layernorm_fwd", 0, lnb);
+    launch_layernorm_fwd(ba.x_in, d, e->params + bp.ln1_g, e->params + bp.ln1_b, ba.y1, T, d, ba.mean1, ba.rstd1, rows, d, c.ln_eps, e->stream);
+  }
+  AttnView av;
+  av.nq = nq; av.nk = nk; av.o = ba.o; av.ldo = inner; av.ob = (int64_t)nq * inner;
+  if (c.variant == VITX_VARIANT_CAIT) {
+    EpiParams ep; ep.out = ba.q; ep.ldo = inner;
+    dense_fwd(e, ba.y1, d, rows, bp.q, EPI_STORE, ep);                       // cait.py:114
+    const void* ctx = ba.y1;
+    if (nc > 0) {                                                            // cait.py:109-112
+      Prof pr(e, "concat_ctx", 0, 0);
+      launch_concat_ctx(ba.y1, T, context, ba.ctx, T, b, nq, nc, d, e->stream);
+      ctx = ba.ctx;
+    }
+    EpiParams ep2; ep2.out = ba.kv; ep2.ldo = 2 * inner;
+    dense_fwd(e, ctx, d, b * nk, bp.kv, EPI_STORE, ep2);                      // cait.py:115
+    av.q = ba.q; av.ldq = inner; av.qb = (int64_t)nq * inner;
+    av.k = ba.kv; av.ldk = 2 * inner; av.kb = (int64_t)nk * 2 * inner;
+    av.v = boff(ba.kv, inner, esz); av.ldv = 2 * inner; av.vb = av.kb;       // cait.py:116
+  } else {
+    EpiParams ep; ep.out = ba.qkv; ep.ldo = 3 * inner;
+    dense_fwd(e, ba.y1, d, rows, bp.qkv, EPI_STORE, ep);                     // vit.py:72
+    av.q = ba.qkv; av.k = boff(ba.qkv, inner, esz); av.v = boff(ba.qkv, 2 * inner, esz);   // vit.py:73
+    av.ldq = av.ldk = av.ldv = 3 * inner;
+    av.qb = av.kb = av.vb = (int64_t)nq * 3 * inner;
+  }
+  if (use_fused_attn(e, nq)) {
+    Prof pr(e, "attn_bf16_fwd", 4.0 * b * c.heads * (double)nq * nq * c.dim_head, (double)rows * inner * 4 * esz);
+    launch_attn_bf16_fwd((const bf16_t*)ba.qkv, (bf16_t*)ba.o, ba.lse, b, nq, c.heads, 1.0f / std::sqrt((float)c.dim_head), e->stream);
+  } else {
+    const int need = c.variant == VITX_VARIANT_VIT ? 1 : 3;
+    int rc = ensure_scores(e, need, (int64_t)b * c.heads * nq * round_up(nk, 4), err);
+    if (rc != VITX_OK) return rc;
+    attn_generic_fwd(e, bp, av, b);
+  }
+  if (bp.has_out) {
+    EpiParams ep;
+    ep.out = ba.x_mid; ep.ldo = d; ep.resid = ba.x_in; ep.ldr = d;
+    if (bp.a_scale >= 0) { ep.scale = e->params + bp.a_scale; ep.out2 = ba.fa; ep.ldo2 = d; }
+    dense_fwd(e, ba.o, inner, rows, bp.out, EPI_BIAS_RESID, ep);             // vit.py:83,101
+  } else {
+    Prof pr(e, "resid_add", 0, 0);
+    launch_resid_add(ba.x_in, ba.o, T, ba.x_mid, (int64_t)rows * d, e->stream);   // vit.py:53 (to_out is identity)
+  }
+  {
+    Prof pr(e, "layernorm_fwd", 0, lnb);
+    launch_layernorm_fwd(ba.x_mid, d, e->params + bp.ln2_g, e->params + bp.ln2_b, ba.y2, T, d, ba.mean2, ba.rstd2, rows, d, c.ln_eps, e->stream);
+  }
+  {
+    EpiParams ep; ep.out = ba.hpre; ep.ldo = m; ep.out2 = ba.act; ep.ldo2 = m;
+    dense_fwd(e, ba.y2, d, rows, bp.fc1, EPI_BIAS_GELU, ep);                  // vit.py:39,34
+  }
+  {
+    EpiParams ep;
+    ep.out = ba.x_out; ep.ldo = d; ep.resid = ba.x_mid; ep.ldr = d;
+    if (bp.m_scale >= 0) { ep.scale = e->params + bp.m_scale; ep.out2 = ba.fm; ep.ldo2 = d; }
+    dense_fwd(e, ba.act, m, rows, bp.fc2, EPI_BIAS_RESID, ep);                // vit.py:42,102
+  }
+  return VITX_OK;
+}
+
+// g (fp32 [rows,d]) holds dL/dx_out on entry and dL/dx_in on exit; g_lp is its T copy (bf16 mode).
+static int block_backward(vitx_engine* e, Stage& st, int l, int b, int nq, int nc, std::string& err) {
+  const BlockParams& bp = st.bp[l];
+  BlockActs& ba = st.ba[l];
+  const vitx_config& c = e->cfg;
+  const int d = c.dim, inner = e->inner, m = c.mlp_dim, T = e->bf16, esz = e->esz;
+  const int rows = b * nq, nk = nq + nc;
+  const void* gT = T ? e->g_lp : (const void*)e->g;   // T view of the residual gradient
+  const double lnb = (double)rows * d * (4 + 4 + 4 + esz + esz);
+
+  // ---- MLP branch: x_out = x_mid + scale * fc2(gelu(fc1(LN(x_mid))))
+  const void* dbranch = gT;
+  if (bp.m_scale >= 0) {            // LayerScale VJP (cait.py:47-48): dscale = sum g*f(x), d f = g*scale
+    Prof pr(e, "layerscale_bwd", 0, 0);
+    launch_scale_grad(ba.fm, T, d, e->g, d, rows, d, e->red_ws, e->grads + bp.m_scale, e->stream);
+    launch_mul_scale(e->g, d, e->params + bp.m_scale, e->d_br, T, d, rows, d, e->stream);
+    dbranch = e->d_br;
+  }
+  {
+    EpiParams ep; ep.out = e->d_h; ep.ldo = m; ep.aux = ba.hpre; ep.ldaux = m;
+    dense_dgrad(e, dbranch, d, rows, bp.fc2, EPI_GELU_BWD, ep);             // d hpre = (d act) * gelu'(hpre)
+  }
+  dense_wgrad(e, ba.act, m, dbranch, d, rows, bp.fc2);
+  if (bp.m_scale >= 0) bias_grad(e, e->d_br, T, d, rows, bp.fc2); else bias_grad(e, e->g, 0, d, rows, bp.fc2);
+  {
+    EpiParams ep; ep.out = e->d_y; ep.ldo = d;
+    dense_dgrad(e, e->d_h, m, rows, bp.fc1, EPI_STORE, ep);
+  }
+  dense_wgrad(e, ba.y2, d, e->d_h, m, rows, bp.fc1);
+  bias_grad(e, e->d_h, T, m, rows, bp.fc1);
+  {
+    Prof pr(e, "layernorm_bwd", 0, lnb);
+    launch_layernorm_bwd(e->d_y, T, d, ba.x_mid, d, ba.mean2, ba.rstd2, e->params + bp.ln2_g, e->g, d, e->g, d, T ? e->g_lp : nullptr, d,
+                         e->red_ws, e->grads + bp.ln2_g, e->grads + bp.ln2_b, rows, d, e->stream);
+  }
+
+  // ---- attention branch: x_mid = x_in + scale * to_out(attn(LN(x_in)))
+  dbranch = gT;
+  if (bp.a_scale >= 0) {
+    Prof pr(e, "layerscale_bwd", 0, 0);
+    launch_scale_grad(ba.fa, T, d, e->g, d, rows, d, e->red_ws, e->grads + bp.a_scale, e->stream);
+    launch_mul_scale(e->g, d, e->params + bp.a_scale, e->d_br, T, d, rows, d, e->stream);
+    dbranch = e->d_br;
+  }
+  const void* d_o = dbranch;   // when to_out is the identity (vit.py:53) the branch gradient IS d(attn_out)
+  if (bp.has_out) {
+    EpiParams ep; ep.out = e->d_o; ep.ldo = inner;
+    dense_dgrad(e, dbranch, d, rows, bp.out, EPI_STORE, ep);
+    dense_wgrad(e, ba.o, inner, dbranch, d, rows, bp.out);
+    if (bp.a_scale >= 0) bias_grad(e, e->d_br, T, d, rows, bp.out); else bias_grad(e, e->g, 0, d, rows, bp.out);
+    d_o = e->d_o;
+  }
+  AttnView av;
+  av.nq = nq; av.nk = nk; av.o = ba.o; av.ldo = inner; av.ob = (int64_t)nq * inner;
+  AttnGrad ag;
+  ag.d_o = d_o; ag.ldo = inner; ag.ob = (int64_t)nq * inner;
+  if (c.variant == VITX_VARIANT_CAIT) {
+    av.q = ba.q; av.ldq = inner; av.qb = (int64_t)nq * inner;
+    av.k = ba.kv; av.ldk = 2 * inner; av.kb = (int64_t)nk * 2 * inner;
+    av.v = boff(ba.kv, inner, esz); av.ldv = 2 * inner; av.vb = av.kb;
+    // d_qkv buffer reused as [dq | dkv]: dq [rows, inner], then dkv [b*nk, 2*inner]
+    void* dq = e->d_qkv;
+    void* dkv = boff(e->d_qkv, round_up((int64_t)rows, 256) * inner, esz);
+    ag.dq = dq; ag.lddq = inner; ag.dqb = (int64_t)nq * inner;
+    ag.dk = dkv; ag.lddk = 2 * inner; ag.dkb = (int64_t)nk * 2 * inner;
+    ag.dv = boff(dkv, inner, esz); ag.lddv = 2 * inner; ag.dvb = ag.dkb;
+    int rc = ensure_scores(e, 4, (int64_t)b * c.heads * nq * round_up(nk, 4), err);
+    if (rc != VITX_OK) return rc;
+    attn_generic_bwd(e, bp, av, ag, b);
+    // to_q / to_kv VJPs
+    const void* ctx = nc > 0 ? ba.ctx : ba.y1;
+    EpiParams ep; ep.out = e->d_y; ep.ldo = d;
+    dense_dgrad(e, dq, inner, rows, bp.q, EPI_STORE, ep);                       // d y1 (via q)
+    dense_wgrad(e, ba.y1, d, dq, inner, rows, bp.q);
+    EpiParams ep2; ep2.out = e->d_ctx; ep2.ldo = d;
+    dense_dgrad(e, dkv, 2 * inner, b * nk, bp.kv, EPI_STORE, ep2);              // d ctx (via k, v)
+    dense_wgrad(e, ctx, d, dkv, 2 * inner, b * nk, bp.kv);
+    Prof pr(e, "ctx_bwd", 0, 0);
+    if (nc > 0) {
+      // d ctx = [d y1 part | d context part]  (cait.py:109-112 VJP); context is the un-normalised patch output
+      launch_split_ctx_bwd(e->d_ctx, T, e->d_br, e->g_ctx, b, nq, nc, d, e->stream);
+      launch_add_T(e->d_y, e->d_br, T, (int64_t)rows * d, e->stream);
+    } else {
+      launch_add_T(e->d_y, e->d_ctx, T, (int64_t)rows * d, e->stream);
+    }
+  } else {
+    av.q = ba.qkv; av.k = boff(ba.qkv, inner, esz); av.v = boff(ba.qkv, 2 * inner, esz);
+    av.ldq = av.ldk = av.ldv = 3 * inner;
+    av.qb = av.kb = av.vb = (int64_t)nq * 3 * inner;
+    ag.dq = e->d_qkv; ag.dk = boff(e->d_qkv, inner, esz); ag.dv = boff(e->d_qkv, 2 * inner, esz);
+    ag.lddq = ag.lddk = ag.lddv = 3 * inner;
+    ag.dqb = ag.dkb = ag.dvb = (int64_t)nq * 3 * inner;
+    if (use_fused_attn(e, nq)) {
+      Prof pr(e, "attn_bf16_bwd", 14.0 * b * c.heads * (double)nq * nq * c.dim_head, (double)rows * inner * 8 * esz);
+      launch_attn_bf16_bwd((const bf16_t*)ba.qkv, (const bf16_t*)ba.o, (const bf16_t*)d_o, ba.lse, e->dsum, (bf16_t*)e->d_qkv, b, nq,
+                           c.heads, 1.0f / std::sqrt((float)c.dim_head), e->stream);
+    } else {
+      int rc = ensure_scores(e, 4, (int64_t)b * c.heads * nq * round_up(nk, 4), err);
+      if (rc != VITX_OK) return rc;
+      attn_generic_bwd(e, bp, av, ag, b);
+    }
+    EpiParams ep; ep.out = e->d_y; ep.ldo = d;
+    dense_dgrad(e, e->d_qkv, 3 * inner, rows, bp.qkv, EPI_STORE, ep);
+    dense_wgrad(e, ba.y1, d, e->d_qkv, 3 * inner, rows, bp.qkv);
+  }
+  {
+    Prof pr(e, "layernorm_bwd", 0, lnb);
+    launch_layernorm_bwd(e->d_y, T, d, ba.x_in, d, ba.mean1, ba.rstd1, e->params + bp.ln1_g, e->g, d, e->g, d, T ? e->g_lp : nullptr, d,
+                         e->red_ws, e->grads + bp.ln1_g, e->grads + bp.ln1_b, rows, d, e->stream);
+  }
+  if (e->grad_cb) e->grad_cb(e->grad_cb_user, bp.p_begin, bp.p_end - bp.p_begin);
+  return VITX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// creation
+// ------------------------------------------------------------------------------------------------
+static bool env_flag(const char* n) { const char* v = getenv(n); return v && v[0] && v[0] != '0'; }
+
+int engine_create(const vitx_config& cfg, vitx_engine** out, std::string& err) {
+  vitx_engine* e = new vitx_engine();
+  e->cfg = cfg;
+  if (e->cfg.ln_eps <= 0.f) e->cfg.ln_eps = 1e-3f;
+  if (e->cfg.channels <= 0) e->cfg.channels = 3;
+  if (e->cfg.max_batch <= 0) e->cfg.max_batch = 1;
+  const vitx_config& c = e->cfg;
+  std::string perr = build_param_table(c, e->table);
+  if (!perr.empty()) { err = perr; delete e; return VITX_ERR_INVALID; }
+  e->n_params = e->table.back().offset + e->table.back().count;
+  e->n_arena = e->table.back().aoff + round_up(e->table.back().count, 4);
+  e->bf16 = c.compute == VITX_COMPUTE_BF16;
+  e->esz = e->bf16 ? 2 : 4;
+  e->inner = c.heads * c.dim_head;
+  e->np_max = (c.image_h / c.patch_h) * (c.image_w / c.patch_w);
+  const bool cait = c.variant == VITX_VARIANT_CAIT;
+  e->ntok_max = cait ? e->np_max : e->np_max + 1;
+  e->pd = c.patch_h * c.patch_w * c.channels;
+  e->pd_k = (int)round_up(e->pd, 64);
+  e->nc_k = (int)round_up(c.num_classes, 64);
+  if (c.dim % 4 != 0 || c.dim > 4096) { err = "dim must be a multiple of 4 and <= 4096"; delete e; return VITX_ERR_UNSUPPORTED; }
+  if (c.heads > 32 && c.variant != VITX_VARIANT_VIT) { err = "heads > 32 unsupported for DeepViT/CaiT"; delete e; return VITX_ERR_UNSUPPORTED; }
+  if (e->bf16 && (c.dim % 64 || e->inner % 64 || c.mlp_dim % 64)) {
+    err = "BF16 compute needs dim, heads*dim_head and mlp_dim to be multiples of 64 (use FP32_PARITY otherwise)";
+    delete e; return VITX_ERR_UNSUPPORTED;
+  }
+  if (cait && c.cls_depth < 0) { err = "cls_depth must be >= 0"; delete e; return VITX_ERR_INVALID; }
+  e->force_generic_gemm = env_flag("VITX_GENERIC_GEMM");
+  e->force_generic_attn = env_flag("VITX_GENERIC_ATTN");
+  if (const char* k = getenv("VITX_GEMM_KERNEL")) e->gemm_kernel = atoi(k);
+
+  HIPCHK(hipSetDevice(c.device_id));
+  HIPCHK(hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking));
+  e->stream = e->own_stream;
+
+  const int d = c.dim, inner = e->inner, m = c.mlp_dim, esz = e->esz;
+  const int64_t B = c.max_batch;
+  e->mp = round_up(B * e->ntok_max, 256);
+  e->mpp = round_up(B * e->np_max, 256);
+  e->bp = round_up(B, 256);
+
+  DALLOC(e->params, (size_t)e->n_arena * 4, false);
+  DALLOC(e->grads, (size_t)e->n_arena * 4, false);
+
+  e->pos = find_param(e, "pos_embedding");
+  e->cls = find_param(e, "cls_token");
+  e->head_g = find_param(e, "mlp_head.norm.gamma");
+  e->head_b = find_param(e, "mlp_head.norm.beta");
+  int rc;
+  if ((rc = init_dense(e, e->patch, "patch_embedding.kernel", "patch_embedding.bias", e->pd, d, err)) != VITX_OK) return rc;
+  if ((rc = init_dense(e, e->head, "mlp_head.kernel", "mlp_head.bias", d, c.num_classes, err)) != VITX_OK) return rc;
+
+  // stages
+  auto make_stage = [&](const std::string& prefix, int depth, int nq, int nc) -> int {
+    Stage st;
+    st.prefix = prefix; st.depth = depth; st.nq_max = nq; st.nc_max = nc;
+    st.bp.resize(depth);
+    st.ba.resize(depth);
+    const int64_t rows = round_up(B * nq, 256), crow = round_up(B * (nq + nc), 256);
+    float* x_prev = nullptr;
+    for (int l = 0; l < depth; ++l) {
+      BlockParams& bp = st.bp[l];
+      BlockActs& ba = st.ba[l];
+      const std::string pre = prefix + "." + std::to_string(l);
+      bp.a_scale = find_param(e, pre + ".attn.scale");
+      bp.ln1_g = find_param(e, pre + ".attn.norm.gamma");
+      bp.ln1_b = find_param(e, pre + ".attn.norm.beta");
+      if (cait) {
+        if ((rc = init_dense(e, bp.q, pre + ".attn.to_q.kernel", "", d, inner, err)) != VITX_OK) return rc;
+        if ((rc = init_dense(e, bp.kv, pre + ".attn.to_kv.kernel", "", d, 2 * inner, err)) != VITX_OK) return rc;
+        bp.mix_pre = find_param(e, pre + ".attn.mix_heads_pre_attn");
+        bp.mix_post = find_param(e, pre + ".attn.mix_heads_post_attn");
+      } else {
+        if ((rc = init_dense(e, bp.qkv, pre + ".attn.to_qkv.kernel", "", d, 3 * inner, err)) != VITX_OK) return rc;
+      }
+      bp.re_w = find_param(e, pre + ".attn.reattn_weights");
+      bp.re_g = find_param(e, pre + ".attn.reattn_norm.gamma");
+      bp.re_b = find_param(e, pre + ".attn.reattn_norm.beta");
+      bp.has_out = find_param(e, pre + ".attn.to_out.kernel") >= 0;
+      if (bp.has_out && (rc = init_dense(e, bp.out, pre + ".attn.to_out.kernel", pre + ".attn.to_out.bias", inner, d, err)) != VITX_OK) return rc;
+      if (!bp.has_out && inner != d) { err = "to_out missing but inner_dim != dim"; return VITX_ERR_INVALID; }
+      bp.m_scale = find_param(e, pre + ".mlp.scale");
+      bp.ln2_g = find_param(e, pre + ".mlp.norm.gamma");
+      bp.ln2_b = find_param(e, pre + ".mlp.norm.beta");
+      if ((rc = init_dense(e, bp.fc1, pre + ".mlp.fc1.kernel", pre + ".mlp.fc1.bias", d, m, err)) != VITX_OK) return rc;
+      if ((rc = init_dense(e, bp.fc2, pre + ".mlp.fc2.kernel", pre + ".mlp.fc2.bias", m, d, err)) != VITX_OK) return rc;
+      bp.p_begin = cait ? bp.a_scale : bp.ln1_g;
+      bp.p_end = bp.fc2.b + d;
+      // activations
+      if (x_prev) ba.x_in = x_prev; else DALLOC(ba.x_in, (size_t)rows * d * 4, false);
+      DALLOC(ba.x_mid, (size_t)rows * d * 4, false);
+      DALLOC(ba.x_out, (size_t)rows * d * 4, false);
+      x_prev = ba.x_out;
+      DALLOC(ba.y1, (size_t)rows * d * esz, true);
+      if (cait) {
+        DALLOC(ba.q, (size_t)rows * inner * esz, true);
+        DALLOC(ba.kv, (size_t)crow * 2 * inner * esz, true);
+        if (nc > 0) DALLOC(ba.ctx, (size_t)crow * d * esz, true);
+        DALLOC(ba.fa, (size_t)rows * d * esz, true);
+        DALLOC(ba.fm, (size_t)rows * d * esz, true);
+      } else {
+        DALLOC(ba.qkv, (size_t)rows * 3 * inner * esz, true);
+      }
+      DALLOC(ba.o, (size_t)rows * inner * esz, true);
+      DALLOC(ba.y2, (size_t)rows * d * esz, true);
+      DALLOC(ba.hpre, (size_t)rows * m * esz, true);
+      DALLOC(ba.act, (size_t)rows * m * esz, true);
+      DALLOC(ba.mean1, (size_t)rows * 4, false);
+      DALLOC(ba.rstd1, (size_t)rows * 4, false);
+      DALLOC(ba.mean2, (size_t)rows * 4, false);
+      DALLOC(ba.rstd2, (size_t)rows * 4, false);
+      DALLOC(ba.lse, (size_t)B * c.heads * nq * 4 + 16, false);
+    }
+    e->stages.push_back(std::move(st));
+    return VITX_OK;
+  };
+  if (cait) {
+    if ((rc = make_stage("patch_transformer", c.depth, e->np_max, 0)) != VITX_OK) return rc;
+    if ((rc = make_stage("cls_transformer", c.cls_depth, 1, e->np_max)) != VITX_OK) return rc;
+  } else {
+    if ((rc = make_stage("transformer", c.depth, e->ntok_max, 0)) != VITX_OK) return rc;
+  }
+
+  // shared buffers
+  const int64_t crow_max = cait ? round_up(B * (1 + e->np_max), 256) : e->mp;
+  const int64_t rmax = std::max(e->mp, crow_max);
+  DALLOC(e->img_dev, (size_t)B * c.image_h * c.image_w * c.channels * 4, false);
+  DALLOC(e->patches, (size_t)e->mpp * e->pd_k * esz, true);
+  DALLOC(e->pooled, (size_t)e->bp * d * 4, false);
+  DALLOC(e->yh, (size_t)e->bp * d * esz, true);
+  DALLOC(e->mean_h, (size_t)e->bp * 4, false);
+  DALLOC(e->rstd_h, (size_t)e->bp * 4, false);
+  DALLOC(e->logits, (size_t)e->bp * e->nc_k * 4, false);
+  DALLOC(e->dlogits, (size_t)e->bp * e->nc_k * 4, false);
+  DALLOC(e->dl_lp, (size_t)e->bp * e->nc_k * esz, true);
+  DALLOC(e->dyh, (size_t)e->bp * d * esz, true);
+  DALLOC(e->dpooled, (size_t)e->bp * d * 4, false);
+  DALLOC(e->loss_rows, (size_t)e->bp * 4, false);
+  DALLOC(e->g, (size_t)rmax * d * 4, false);
+  if (e->bf16) DALLOC(e->g_lp, (size_t)rmax * d * esz, true);
+  if (cait) DALLOC(e->g_ctx, (size_t)e->mpp * d * 4, false);
+  DALLOC(e->d_h, (size_t)rmax * m * esz, true);
+  DALLOC(e->d_y, (size_t)rmax * d * esz, true);
+  DALLOC(e->d_o, (size_t)rmax * inner * esz, true);
+  DALLOC(e->d_qkv, (size_t)(rmax + 256) * 3 * inner * esz + (size_t)crow_max * 2 * inner * esz, true);
+  DALLOC(e->d_ctx, (size_t)crow_max * d * esz, true);
+  DALLOC(e->d_br, (size_t)rmax * d * esz, true);
+  DALLOC(e->dsum, (size_t)B * c.heads * e->ntok_max * 4 + 16, false);
+  DALLOC(e->tmp_f32, (size_t)rmax * std::max<int64_t>(d, e->pd) * 4, false);
+  const int64_t maxfeat = std::max<int64_t>({(int64_t)d, 3LL * inner, (int64_t)m, (int64_t)e->pd_k, (int64_t)e->nc_k});
+  if (e->bf16) {
+    e->t_rows = round_up(maxfeat, 256);
+    DALLOC(e->xt, (size_t)e->t_rows * rmax * 2, false);
+    DALLOC(e->dyt, (size_t)e->t_rows * rmax * 2, false);
+    const int64_t max_w = std::max<int64_t>({(int64_t)d * 3 * inner, (int64_t)d * m, (int64_t)e->pd * d, (int64_t)d * c.num_classes, (int64_t)inner * d});
+    e->partial_elems = 512LL * 256 * 256 + 2 * max_w;
+    DALLOC(e->partial_ws, (size_t)e->partial_elems * 4, false);
+  }
+  e->red_elems = std::max<int64_t>({layernorm_bwd_ws_elems(d), colsum_ws_elems((int)maxfeat), headmix_ws_elems((int)B, c.heads, 1, 1),
+                                    (int64_t)256 * 2 * 32, (int64_t)64 * d});
+  DALLOC(e->red_ws, (size_t)e->red_elems * 4, false);
+  HIPCHK(hipStreamSynchronize(e->stream));
+  *out = e;
+  return VITX_OK;
+}
+
+void engine_destroy(vitx_engine* e) {
+  if (!e) return;
+  (void)hipStreamSynchronize(e->stream);
+  for (void* p : e->allocs) (void)hipFree(p);
+  if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
+  delete e;
+}
+
+// rows >= M of every T buffer must be zero (they are K-padding of the wgrad GEMMs): re-zero when the geometry changes
+static void ensure_geometry(vitx_engine* e, int b, int ntok) {
+  const int64_t geom = ((int64_t)b << 32) | (uint32_t)ntok;
+  if (geom == e->zero_geom) return;
+  if (e->zero_geom >= 0 && e->bf16)
+    for (auto& tb : e->t_buffers) (void)hipMemsetAsync(tb.first, 0, tb.second, e->stream);
+  e->zero_geom = geom;
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------
+static int head_forward(vitx_engine* e, const float* x_last, int b, int ntok, float* logits_dev, std::string& err) {
+  const vitx_config& c = e->cfg;
+  const int d = c.dim, T = e->bf16;
+  const float* src = x_last;
+  int64_t ldsrc = (int64_t)ntok * d;               // cls pooling: row 0 of every image (vit.py:173, cait.py:192)
+  if (c.variant != VITX_VARIANT_CAIT && c.pool == VITX_POOL_MEAN) {   // vit.py:170-171
+    Prof pr(e, "pool", 0, 0);
+    launch_mean_pool(x_last, b, ntok, d, e->pooled, e->stream);
+    src = e->pooled;
+    ldsrc = d;
+  }
+  {
+    Prof pr(e, "layernorm_fwd", 0, 0);
+    launch_layernorm_fwd(src, ldsrc, e->params + e->head_g, e->params + e->head_b, e->yh, T, d, e->mean_h, e->rstd_h, b, d, c.ln_eps, e->stream);
+  }
+  EpiParams ep; ep.out = e->logits; ep.ldo = e->nc_k;
+  dense_fwd(e, e->yh, d, b, e->head, EPI_STORE_F32, ep);                       // vit.py:156
+  if (logits_dev)
+    HIPCHK(hipMemcpy2DAsync(logits_dev, (size_t)c.num_classes * 4, e->logits, (size_t)e->nc_k * 4, (size_t)c.num_classes * 4, b,
+                            hipMemcpyDeviceToDevice, e->stream));
+  return VITX_OK;
+}
+
+int engine_forward(vitx_engine* e, const float* img_dev, int b, int H, int W, int training, uint64_t seed, float* logits_dev,
+                   std::string& err) {
+  const vitx_config& c = e->cfg;
+  if (b <= 0 || b > c.max_batch) { err = "batch must be in [1, max_batch]"; return VITX_ERR_INVALID; }
+  if (H <= 0 || W <= 0 || H > c.image_h || W > c.image_w || H % c.patch_h || W % c.patch_w) {
+    err = "Image dimensions must be divisible by the patch size.";            // and fit the configured pos_embedding (vit.py:165)
+    return VITX_ERR_INVALID;
+  }
+  if (training && (c.dropout > 0.f || c.emb_dropout > 0.f || c.layer_dropout > 0.f)) {
+    err = "dropout > 0 in training mode is not implemented yet (use training=False or rate 0)";
+    return VITX_ERR_UNSUPPORTED;
+  }
+  const bool cait = c.variant == VITX_VARIANT_CAIT;
+  const int np = (H / c.patch_h) * (W / c.patch_w);
+  const int ntok = cait ? np : np + 1;
+  const int d = c.dim, T = e->bf16;
+  ensure_geometry(e, b, ntok);
+  if (e->params_dirty) engine_refresh_weights(e);
+  Stage& s0 = e->stages[0];
+  float* x0 = s0.depth > 0 ? s0.ba[0].x_in : e->tmp_f32;
+  {
+    Prof pr(e, "patch_unfold", 0, (double)b * H * W * c.channels * 4 + (double)b * np * e->pd_k * e->esz);
+    launch_unfold(img_dev, e->patches, T, b, H, W, c.channels, c.patch_h, c.patch_w, e->pd_k, e->stream);   // vit.py:142
+  }
+  if (!cait) {
+    Prof pr(e, "cls_pos_row", 0, 0);
+    launch_cls_pos_row(x0, e->params + e->cls, e->params + e->pos, b, ntok, d, d, e->stream);              // vit.py:163-165
+  }
+  {
+    EpiParams ep;
+    ep.out = x0; ep.ldo = d; ep.pos = e->params + e->pos; ep.ldr = d;
+    ep.np = np; ep.ntok = ntok; ep.tok_off = cait ? 0 : 1;
+    dense_fwd(e, e->patches, e->pd_k, b * np, e->patch, EPI_PATCH, ep);                                     // vit.py:143 (+164-165)
+  }
+  int rc;
+  for (int l = 0; l < s0.depth; ++l)
+    if ((rc = block_forward(e, s0, l, b, ntok, 0, nullptr, err)) != VITX_OK) return rc;
+  const float* x_last = s0.depth > 0 ? s0.ba[s0.depth - 1].x_out : x0;
+  int head_tok = ntok;
+  if (cait) {
+    Stage& s1 = e->stages[1];
+    float* xc = s1.depth > 0 ? s1.ba[0].x_in : e->pooled;
+    {
+      Prof pr(e, "cls_broadcast", 0, 0);
+      launch_broadcast_rows(e->params + e->cls, d, xc, b, e->stream);                                        // cait.py:189
+    }
+    for (int l = 0; l < s1.depth; ++l)
+      if ((rc = block_forward(e, s1, l, b, 1, np, x_last, err)) != VITX_OK) return rc;                       // cait.py:190
+    x_last = s1.depth > 0 ? s1.ba[s1.depth - 1].x_out : xc;
+    head_tok = 1;
+  }
+  if ((rc = head_forward(e, x_last, b, head_tok, logits_dev, err)) != VITX_OK) return rc;
+  e->have_fwd = true;
+  e->last_b = b; e->last_np = np; e->last_ntok = ntok; e->last_H = H; e->last_W = W; e->last_training = training; e->last_seed = seed;
+  return VITX_OK;
+}
+
+int engine_transformer_forward(vitx_engine* e, const float* tokens_dev, int b, int n, float* out_dev, std::string& err) {
+  const vitx_config& c = e->cfg;
+  if (c.variant == VITX_VARIANT_CAIT) { err = "transformer_forward: ViT / DeepViT only"; return VITX_ERR_UNSUPPORTED; }
+  if (b <= 0 || b > c.max_batch || n <= 0 || n > e->ntok_max) { err = "transformer_forward: b or n out of range"; return VITX_ERR_INVALID; }
+  ensure_geometry(e, b, n);
+  if (e->params_dirty) engine_refresh_weights(e);
+  Stage& s0 = e->stages[0];
+  const size_t bytes = (size_t)b * n * c.dim * 4;
+  if (s0.depth == 0) { HIPCHK(hipMemcpyAsync(out_dev, tokens_dev, bytes, hipMemcpyDeviceToDevice, e->stream)); return VITX_OK; }
+  HIPCHK(hipMemcpyAsync(s0.ba[0].x_in, tokens_dev, bytes, hipMemcpyDeviceToDevice, e->stream));
+  int rc;
+  for (int l = 0; l < s0.depth; ++l)
+    if ((rc = block_forward(e, s0, l, b, n, 0, nullptr, err)) != VITX_OK) return rc;
+  HIPCHK(hipMemcpyAsync(out_dev, s0.ba[s0.depth - 1].x_out, bytes, hipMemcpyDeviceToDevice, e->stream));
+  e->have_fwd = false;   // saved activations no longer describe a full model forward
+  return VITX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward
+// ------------------------------------------------------------------------------------------------
+int engine_backward(vitx_engine* e, const float* dlogits_dev, float* dimg_dev, std::string& err) {
+  const vitx_config& c = e->cfg;
+  if (!e->have_fwd) { err = "backward requires a preceding forward"; return VITX_ERR_STATE; }
+  const bool cait = c.variant == VITX_VARIANT_CAIT;
+  const int b = e->last_b, np = e->last_np, ntok = e->last_ntok, d = c.dim, T = e->bf16;
+  const int nc = c.num_classes;
+  HIPCHK(hipMemsetAsync(e->grads, 0, (size_t)e->n_arena * 4, e->stream));
+  if (dlogits_dev)
+    HIPCHK(hipMemcpy2DAsync(e->dlogits, (size_t)e->nc_k * 4, dlogits_dev, (size_t)nc * 4, (size_t)nc * 4, b, hipMemcpyDeviceToDevice, e->stream));
+
+  // ---- head: logits = LN(pooled) @ W + b   (vit.py:154-157)
+  Stage& s_last = e->stages.back();
+  Stage& s0 = e->stages[0];
+  const float* x_last;
+  int head_tok;
+  if (cait) {
+    Stage& s1 = e->stages[1];
+    x_last = s1.depth > 0 ? s1.ba[s1.depth - 1].x_out : e->pooled;
+    head_tok = 1;
+  } else {
+    x_last = s0.depth > 0 ? s0.ba[s0.depth - 1].x_out : e->tmp_f32;
+    head_tok = ntok;
+  }
+  (void)s_last;
+  {
+    Prof pr(e, "head_prep", 0, 0);
+    launch_colsum(e->dlogits, 0, e->nc_k, b, nc, e->red_ws, e->grads + e->head.b, e->stream);
+    if (T) launch_convert(e->dlogits, e->nc_k, e->dl_lp, 1, e->nc_k, b, nc, e->nc_k, e->stream);
+  }
+  const void* dlT = T ? e->dl_lp : (const void*)e->dlogits;
+  {
+    EpiParams ep; ep.out = e->dyh; ep.ldo = d;
+    dense_dgrad(e, dlT, e->nc_k, b, e->head, EPI_STORE, ep);
+  }
+  dense_wgrad(e, e->yh, d, dlT, e->nc_k, b, e->head);
+  const bool mean_pool = !cait && c.pool == VITX_POOL_MEAN;
+  const int head_rows = b * head_tok;
+  HIPCHK(hipMemsetAsync(e->g, 0, (size_t)round_up(head_rows, 256) * d * 4, e->stream));
+  {
+    Prof pr(e, "layernorm_bwd", 0, 0);
+    if (mean_pool) {
+      launch_layernorm_bwd(e->dyh, T, d, e->pooled, d, e->mean_h, e->rstd_h, e->params + e->head_g, nullptr, 0, e->dpooled, d, nullptr, 0,
+                           e->red_ws, e->grads + e->head_g, e->grads + e->head_b, b, d, e->stream);
+      launch_mean_pool_bwd(e->dpooled, b, head_tok, d, e->g, e->stream);
+    } else {
+      const int64_t ldrow = (int64_t)head_tok * d;
+      launch_layernorm_bwd(e->dyh, T, d, x_last, ldrow, e->mean_h, e->rstd_h, e->params + e->head_g, nullptr, 0, e->g, ldrow, nullptr, 0,
+                           e->red_ws, e->grads + e->head_g, e->grads + e->head_b, b, d, e->stream);
+    }
+    if (T) launch_convert(e->g, d, e->g_lp, 1, d, head_rows, d, d, e->stream);
+  }
+  if (e->grad_cb) e->grad_cb(e->grad_cb_user, e->head_g, e->n_arena - e->head_g);
+
+  int rc;
+  if (cait) {
+    Stage& s1 = e->stages[1];
+    HIPCHK(hipMemsetAsync(e->g_ctx, 0, (size_t)b * np * d * 4, e->stream));
+    for (int l = s1.depth - 1; l >= 0; --l)
+      if ((rc = block_backward(e, s1, l, b, 1, np, err)) != VITX_OK) return rc;
+    {
+      Prof pr(e, "embed_bwd", 0, 0);
+      launch_batch_reduce(e->g, b, 1, d, 0, 1, e->grads + e->cls, e->stream);          // dcls = sum_b g (cait.py:189 VJP)
+      // the patch stage's output gradient is what flowed back through every cls layer's context
+      HIPCHK(hipMemcpyAsync(e->g, e->g_ctx, (size_t)b * np * d * 4, hipMemcpyDeviceToDevice, e->stream));
+      if (T) launch_convert(e->g, d, e->g_lp, 1, d, b * np, d, d, e->stream);
+    }
+  }
+  for (int l = s0.depth - 1; l >= 0; --l)
+    if ((rc = block_backward(e, s0, l, b, ntok, 0, err)) != VITX_OK) return rc;
+
+  // ---- embedding: x0 = [cls | patches @ W + b] + pos   (vit.py:160-165; cait.py:181-184)
+  {
+    Prof pr(e, "embed_bwd", 0, (double)b * ntok * d * 4);
+    launch_batch_reduce(e->g, b, ntok, d, 0, ntok, e->grads + e->pos, e->stream);      // dpos[j] = sum_b g[b,j]
+    const int tok_off = cait ? 0 : 1;
+    if (!cait) launch_batch_reduce(e->g, b, ntok, d, 0, 1, e->grads + e->cls, e->stream);   // dcls = sum_b g[b,0]
+    launch_sum_rows(e->grads + e->pos + (int64_t)tok_off * d, np, d, e->grads + e->patch.b, e->stream);   // db = sum over patch rows
+    launch_extract_rows(e->g, b, ntok, tok_off, np, d, e->d_y, T, d, e->stream);        // dE = g[:, tok_off:, :]
+  }
+  dense_wgrad(e, e->patches, e->pd_k, e->d_y, d, b * np, e->patch);
+  if (dimg_dev) {
+    EpiParams ep; ep.out = e->tmp_f32; ep.ldo = e->pd;
+    dense_dgrad(e, e->d_y, d, b * np, e->patch, EPI_STORE_F32, ep);
+    Prof pr(e, "patch_fold", 0, 0);
+    launch_fold_add(e->tmp_f32, e->pd, dimg_dev, b, e->last_H, e->last_W, c.channels, c.patch_h, c.patch_w, e->stream);
+  }
+  if (e->grad_cb) e->grad_cb(e->grad_cb_user, 0, e->stages[0].depth > 0 ? e->stages[0].bp[0].p_begin : e->head_g);
+  return VITX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// raw GEMM micro-benchmark (random bf16 operands), checked against the generic fp32-FMA kernel
+// ------------------------------------------------------------------------------------------------
+int engine_bench_gemm(vitx_engine* e, int M, int N, int K, int kernel, int epilogue, int iters, float* avg_ms, float* max_err,
+                      std::string& err) {
+  if (K % 64 || M <= 0 || N <= 0) { err = "bench_gemm: K must be a multiple of 64"; return VITX_ERR_INVALID; }
+  const int64_t Mp = round_up(M, 256), Np = round_up(N, 256);
+  bf16_t *A, *B; float *C, *R, *bias; bf16_t* C2;
+  HIPCHK(hipMalloc((void**)&A, (size_t)Mp * K * 2));
+  HIPCHK(hipMalloc((void**)&B, (size_t)Np * K * 2));
+  HIPCHK(hipMalloc((void**)&C, (size_t)Mp * Np * 4));
+  HIPCHK(hipMalloc((void**)&R, (size_t)Mp * Np * 4));
+  HIPCHK(hipMalloc((void**)&C2, (size_t)Mp * Np * 2 * 2));
+  HIPCHK(hipMalloc((void**)&bias, (size_t)Np * 4));
+  launch_fill_random_bf16(A, Mp * K, 1u, 1.0f, e->stream);
+  launch_fill_random_bf16(B, Np * K, 2u, 1.0f, e->stream);
+  HIPCHK(hipMemsetAsync(R, 0, (size_t)Mp * Np * 4, e->stream));
+  HIPCHK(hipMemsetAsync(bias, 0, (size_t)Np * 4, e->stream));
+  Bf16GemmArgs g;
+  g.A = A; g.lda = K; g.B = B; g.ldb = K; g.M = M; g.N = N; g.K = K; g.kernel = kernel;
+  EpiParams ep;
+  ep.M = M; ep.N = N; ep.zero_pad = 1;
+  int mode = EPI_STORE_F32;
+  if (epilogue == 1) {            // bias + fp32 residual (to_out / fc2 shape of epilogue)
+    mode = EPI_BIAS_RESID; ep.out = C; ep.ldo = Np; ep.resid = R; ep.ldr = Np; ep.bias = bias;
+  } else if (epilogue == 2) {     // bias + GELU, two bf16 outputs (fc1)
+    mode = EPI_BIAS_GELU; ep.out = C2; ep.ldo = Np; ep.out2 = C2 + Mp * Np; ep.ldo2 = Np; ep.bias = bias;
+  } else if (epilogue == 3) {     // plain bf16 store (QKV / dgrads)
+    mode = EPI_STORE; ep.out = C2; ep.ldo = Np;
+  } else {
+    ep.out = C; ep.ldo = Np;
+  }
+  finalize_epi(ep);
+  launch_gemm_bf16(g, ep, mode, e->stream);   // warm-up (+ attribute setup)
+  hipEvent_t e0, e1;
+  HIPCHK(hipEventCreate(&e0));
+  HIPCHK(hipEventCreate(&e1));
+  HIPCHK(hipEventRecord(e0, e->stream));
+  for (int i = 0; i < iters; ++i) launch_gemm_bf16(g, ep, mode, e->stream);
+  HIPCHK(hipEventRecord(e1, e->stream));
+  HIPCHK(hipEventSynchronize(e1));
+  float ms = 0.f;
+  HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+  *avg_ms = ms / std::max(1, iters);
+  *max_err = -1.f;
+  if (max_err && (epilogue == 0 || epilogue == 1) && (int64_t)M * N <= (1 << 22)) {
+    // reference: generic kernel on the same operands, compared on the host
+    float* C3;
+    HIPCHK(hipMalloc((void**)&C3, (size_t)Mp * Np * 4));
+    GenericGemmArgs gg;
+    gg.A = A; gg.B = B; gg.M = M; gg.N = N; gg.K = K; gg.sam = K; gg.sak = 1; gg.sbk = 1; gg.sbn = K;
+    EpiParams e2; e2.out = C3; e2.ldo = Np; e2.M = M; e2.N = N;
+    finalize_epi(e2);
+    launch_gemm_generic(gg, e2, EPI_STORE_F32, 1, 1, 0, e->stream);
+    std::vector<float> h1((size_t)Mp * Np), h2((size_t)Mp * Np);
+    HIPCHK(hipMemcpyAsync(h1.data(), C, h1.size() * 4, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync(h2.data(), C3, h2.size() * 4, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    float me = 0.f;
+    for (int i = 0; i < M; ++i)
+      for (int j = 0; j < N; ++j) me = std::max(me, std::fabs(h1[(size_t)i * Np + j] - h2[(size_t)i * Np + j]));
+    *max_err = me;
+    (void)hipFree(C3);
+  }
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  (void)hipFree(A); (void)hipFree(B); (void)hipFree(C); (void)hipFree(R); (void)hipFree(C2); (void)hipFree(bias);
+  return VITX_OK;
+}

@@ -1,0 +1,116 @@
+// GEMM epilogues shared by the generic (fp32-FMA) and the MFMA bf16 GEMM kernels.
+// Each epilogue consumes 4 consecutive output columns of one row (float4 of fp32 accumulators).
+#pragma once
+#include "common.h"
+
+enum EpiMode {
+  EPI_STORE = 0,      // out[T] = alpha*acc (+bias)                                  QKV, dgrads
+  EPI_STORE_F32 = 1,  // out[f32] = alpha*acc (+bias)                                logits, scores
+  EPI_BIAS_GELU = 2,  // h = acc+bias; out[T] = h; out2[T] = gelu(h)                 fc1 (vit.py:39,34)
+  EPI_BIAS_RESID = 3, // f = acc+bias; out2[T] = f (iff scale); out[f32] = resid + f*scale   to_out / fc2 + residual (vit.py:101-102, cait.py:47-48)
+  EPI_PATCH = 4,      // out[f32][img*ntok + tok_off + t] = acc + bias + pos[tok_off+t]   patch embed (vit.py:143,164-165)
+  EPI_GELU_BWD = 5,   // out[T] = acc * gelu'(aux[T])                                 fc2 dgrad
+  EPI_PARTIAL = 6,    // out[f32][z][row][col] = acc                                  split-K partial sums
+};
+
+struct EpiParams {
+  void* out = nullptr;
+  void* out2 = nullptr;
+  const float* bias = nullptr;
+  const float* resid = nullptr;
+  const float* scale = nullptr;
+  const void* aux = nullptr;
+  const float* pos = nullptr;
+  int64_t ldo = 0, ldo2 = 0, ldr = 0, ldaux = 0;
+  int64_t out_batch_stride = 0, out_head_stride = 0;  // generic batched kernel only
+  int64_t partial_stride = 0;                         // EPI_PARTIAL: elements per split slice
+  int M = 0, N = 0;        // valid extents (rows >= M are written as zero for T outputs, skipped for f32)
+  int np = 1, ntok = 1, tok_off = 0;
+  int vec_ok = 1;          // 0: some pointer / leading dimension is not 16-B friendly -> scalar accesses
+  int zero_pad = 0;        // 1: rows in [M, tile end) of T outputs are written as zeros (buffers are row-padded)
+  float alpha = 1.0f;
+};
+
+// T = storage type of "T" outputs / aux.  (row, col) are global tile coordinates; v holds columns col..col+3.
+// All leading dimensions are multiples of 4 and col is a multiple of 4, so vector accesses are aligned.
+template <int MODE, typename T>
+__device__ __forceinline__ void epilogue_apply4(const EpiParams& p, int row, int col, float4 v, int64_t out_off = 0) {
+  if (col >= p.N) return;
+  const bool full = (col + 3 < p.N) && p.vec_ok;
+  float a[4] = {v.x * p.alpha, v.y * p.alpha, v.z * p.alpha, v.w * p.alpha};
+  const bool row_ok = row < p.M;
+  if (!row_ok && !p.zero_pad) return;
+
+  if (MODE == EPI_PARTIAL) {
+    if (!row_ok) return;
+    float* o = (float*)p.out + out_off + (int64_t)row * p.ldo + col;
+    if (full) *(float4*)o = make_float4(a[0], a[1], a[2], a[3]);
+    else for (int i = 0; i < 4 && col + i < p.N; ++i) o[i] = a[i];
+    return;
+  }
+  if (p.bias != nullptr && MODE != EPI_GELU_BWD) {
+    if (full) { float4 b = *(const float4*)(p.bias + col); a[0] += b.x; a[1] += b.y; a[2] += b.z; a[3] += b.w; }
+    else for (int i = 0; i < 4 && col + i < p.N; ++i) a[i] += p.bias[col + i];
+  }
+  if (MODE == EPI_STORE) {
+    T* o = (T*)p.out + out_off + (int64_t)row * p.ldo + col;
+    if (!row_ok) { a[0] = a[1] = a[2] = a[3] = 0.f; }
+    if (full) st4<T>(o, make_float4(a[0], a[1], a[2], a[3]));
+    else for (int i = 0; i < 4 && col + i < p.N; ++i) stf<T>(o + i, a[i]);
+  } else if (MODE == EPI_STORE_F32) {
+    if (!row_ok) return;
+    float* o = (float*)p.out + out_off + (int64_t)row * p.ldo + col;
+    if (full) *(float4*)o = make_float4(a[0], a[1], a[2], a[3]);
+    else for (int i = 0; i < 4 && col + i < p.N; ++i) o[i] = a[i];
+  } else if (MODE == EPI_BIAS_GELU) {
+    T* o = (T*)p.out + (int64_t)row * p.ldo + col;
+    T* o2 = (T*)p.out2 + (int64_t)row * p.ldo2 + col;
+    float g[4];
+    for (int i = 0; i < 4; ++i) {
+      if (!row_ok) a[i] = 0.f;
+      // GELU is evaluated on the value as stored (T-rounded) so that backward's gelu'(hpre) matches
+      float hs = (float)(T)a[i];
+      g[i] = row_ok ? gelu_f(hs) : 0.f;
+    }
+    if (full) { st4<T>(o, make_float4(a[0], a[1], a[2], a[3])); st4<T>(o2, make_float4(g[0], g[1], g[2], g[3])); }
+    else for (int i = 0; i < 4 && col + i < p.N; ++i) { stf<T>(o + i, a[i]); stf<T>(o2 + i, g[i]); }
+  } else if (MODE == EPI_BIAS_RESID) {
+    if (p.scale != nullptr && p.out2 != nullptr) {   // LayerScale: keep f(x) for dscale = sum g*f(x)
+      T* o2 = (T*)p.out2 + (int64_t)row * p.ldo2 + col;
+      float z[4] = {row_ok ? a[0] : 0.f, row_ok ? a[1] : 0.f, row_ok ? a[2] : 0.f, row_ok ? a[3] : 0.f};
+      if (full) st4<T>(o2, make_float4(z[0], z[1], z[2], z[3]));
+      else for (int i = 0; i < 4 && col + i < p.N; ++i) stf<T>(o2 + i, z[i]);
+    }
+    if (!row_ok) return;
+    float* o = (float*)p.out + (int64_t)row * p.ldo + col;
+    const float* r = p.resid + (int64_t)row * p.ldr + col;
+    if (full) {
+      float4 rv = *(const float4*)r;
+      float4 s = p.scale ? *(const float4*)(p.scale + col) : make_float4(1.f, 1.f, 1.f, 1.f);
+      *(float4*)o = make_float4(rv.x + a[0] * s.x, rv.y + a[1] * s.y, rv.z + a[2] * s.z, rv.w + a[3] * s.w);
+    } else {
+      for (int i = 0; i < 4 && col + i < p.N; ++i) o[i] = r[i] + a[i] * (p.scale ? p.scale[col + i] : 1.f);
+    }
+  } else if (MODE == EPI_PATCH) {
+    if (!row_ok) return;
+    const int img = row / p.np, t = row - img * p.np;
+    const int64_t orow = (int64_t)img * p.ntok + p.tok_off + t;
+    float* o = (float*)p.out + orow * p.ldo + col;
+    const float* ps = p.pos + (int64_t)(p.tok_off + t) * p.ldr + col;
+    if (full) { float4 q = *(const float4*)ps; *(float4*)o = make_float4(a[0] + q.x, a[1] + q.y, a[2] + q.z, a[3] + q.w); }
+    else for (int i = 0; i < 4 && col + i < p.N; ++i) o[i] = a[i] + ps[i];
+  } else if (MODE == EPI_GELU_BWD) {
+    T* o = (T*)p.out + (int64_t)row * p.ldo + col;
+    const T* h = (const T*)p.aux + (int64_t)row * p.ldaux + col;
+    float g[4];
+    if (full) {
+      float4 hv = ld4<T>(h);
+      g[0] = a[0] * gelu_grad_f(hv.x); g[1] = a[1] * gelu_grad_f(hv.y);
+      g[2] = a[2] * gelu_grad_f(hv.z); g[3] = a[3] * gelu_grad_f(hv.w);
+      if (!row_ok) g[0] = g[1] = g[2] = g[3] = 0.f;
+      st4<T>(o, make_float4(g[0], g[1], g[2], g[3]));
+    } else {
+      for (int i = 0; i < 4 && col + i < p.N; ++i) stf<T>(o + i, row_ok ? a[i] * gelu_grad_f(ldf<T>(h + i)) : 0.f);
+    }
+  }
+}

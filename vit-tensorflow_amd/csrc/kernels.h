@@ -1,0 +1,95 @@
+// Host-callable launchers of every HIP kernel in libvitx (one translation unit per kernel family).
+#pragma once
+#include "common.h"
+#include "epilogue.h"
+
+// ---------------------------------------------------------------- gemm_generic.hip
+struct GenericGemmArgs {
+  const void* A = nullptr;
+  const void* B = nullptr;
+  int M = 0, N = 0, K = 0;
+  int64_t sam = 0, sak = 1, sbk = 0, sbn = 1;
+  int nb = 1, nh = 1;
+  int64_t sAb = 0, sAh = 0, sBb = 0, sBh = 0;
+};
+void launch_gemm_generic(const GenericGemmArgs& g, const EpiParams& ep, int mode, int ta, int tb, int to, hipStream_t s);
+
+// ---------------------------------------------------------------- gemm_bf16.hip
+// C[M,N] = A[M,K] * B[N,K]^T, bf16 operands (K contiguous), fp32 MFMA accumulation.
+struct Bf16GemmArgs {
+  const bf16_t* A = nullptr;
+  const bf16_t* B = nullptr;
+  int64_t lda = 0, ldb = 0;
+  int M = 0, N = 0, K = 0;   // K multiple of 64; A has >= round_up(M,tile) rows, B >= round_up(N,tile) rows
+  int split_k = 1;           // >1: EPI_PARTIAL slices of K/split_k (each a multiple of 64)
+  int kernel = 0;            // tile variant: 0 auto, 1 = 128x128 (4 waves), 2 = 256x256 (8 waves), 3 = 256x128
+};
+void launch_gemm_bf16(const Bf16GemmArgs& g, const EpiParams& ep, int mode, hipStream_t s);
+int gemm_bf16_tile_m(int kernel, int M, int N);
+int gemm_bf16_tile_n(int kernel, int M, int N);
+int gemm_bf16_num_slices(int K, int split_k);
+
+// ---------------------------------------------------------------- attn_bf16.hip
+// fused multi-head self-attention (vit.py:73-82) on packed qkv [b, n, 3, h, 64] bf16.
+bool attn_bf16_supported(int n, int dim_head);
+void launch_attn_bf16_fwd(const bf16_t* qkv, bf16_t* o, float* lse, int b, int n, int h, float scale, hipStream_t s);
+void launch_attn_bf16_bwd(const bf16_t* qkv, const bf16_t* o, const bf16_t* d_o, const float* lse, float* dsum_ws,
+                          bf16_t* dqkv, int b, int n, int h, float scale, hipStream_t s);
+
+// ---------------------------------------------------------------- elementwise.hip
+void launch_unfold(const float* img, void* out, int out_bf16, int b, int H, int W, int C, int ph, int pw,
+                   int64_t ldo, hipStream_t s);
+void launch_fold_add(const float* dpatches, int64_t ld, float* dimg, int b, int H, int W, int C, int ph, int pw, hipStream_t s);
+void launch_cls_pos_row(float* x, const float* cls, const float* pos, int b, int ntok, int d, int64_t ldx, hipStream_t s);
+void launch_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, void* y, int y_bf16,
+                          int64_t ldy, float* mean, float* rstd, int rows, int d, float eps, hipStream_t s);
+// g_out = (g_in ? g_in : 0) + LN_bwd(dy); optional low-precision copy of g_out; dgamma/dbeta via partial_ws
+void launch_layernorm_bwd(const void* dy, int dy_bf16, int64_t lddy, const float* x, int64_t ldx, const float* mean,
+                          const float* rstd, const float* gamma, const float* g_in, int64_t ldgi, float* g_out, int64_t ldgo,
+                          void* g_lp, int64_t ldglp, float* partial_ws, float* dgamma, float* dbeta, int rows, int d,
+                          hipStream_t s);
+int64_t layernorm_bwd_ws_elems(int d);
+void launch_colsum(const void* x, int is_bf16, int64_t ld, int rows, int cols, float* partial_ws, float* out, hipStream_t s);
+int64_t colsum_ws_elems(int cols);
+void launch_reduce_partials(const float* partial, int nparts, int64_t stride, int64_t n, float* out, float alpha, hipStream_t s);
+void launch_convert_weight(const float* w, int in, int out, bf16_t* wn, int64_t ldwn, bf16_t* wt, int64_t ldwt, hipStream_t s);
+void launch_transpose_bf16(const bf16_t* in, int64_t ldi, int rows, int cols, bf16_t* out, int64_t ldo, hipStream_t s);
+void launch_convert(const float* in, int64_t ldi, void* out, int out_bf16, int64_t ldo, int rows, int cols, int64_t out_cols_zero_to,
+                    hipStream_t s);
+void launch_to_f32(const void* in, int in_bf16, int64_t ldi, float* out, int64_t ldo, int rows, int cols, hipStream_t s);
+void launch_mean_pool(const float* x, int b, int ntok, int d, float* out, hipStream_t s);
+void launch_mean_pool_bwd(const float* dp, int b, int ntok, int d, float* g, hipStream_t s);
+void launch_batch_reduce(const float* g, int b, int ntok, int d, int j0, int nj, float* out, hipStream_t s);  // out[j][c] = sum_b g[b][j0+j][c]
+void launch_extract_rows(const float* g, int b, int ntok, int tok_off, int np, int d, void* out, int out_bf16, int64_t ldo, hipStream_t s);
+void launch_sum_rows(const float* in, int rows, int d, float* out, hipStream_t s);  // out[c] = sum_r in[r][c] (small)
+void launch_ce_grad(const float* logits, int64_t ld, const int32_t* labels, int b, int nc, float inv_batch, float* dlogits,
+                    float* loss, hipStream_t s);
+void launch_fill_random_bf16(bf16_t* p, int64_t n, uint32_t seed, float scale, hipStream_t s);
+void launch_dropout(float* x, int64_t n, float rate, uint64_t seed, uint32_t site, hipStream_t s);
+void launch_resid_add(const float* resid, const void* t, int t_bf16, float* out, int64_t n, hipStream_t s);  // out = resid + t
+
+// ---------------------------------------------------------------- attn_generic.hip (materialised attention pieces)
+void launch_softmax_rows(float* sc, int64_t rows, int n, int64_t ld, hipStream_t s);
+void launch_softmax_bwd_rows(const float* p, float* dp_inout, int64_t rows, int n, int64_t ld, hipStream_t s);
+// talking-heads style mix over the head axis of [b, h, nq, ld]: out[b,g,i,j] = sum_h in[b,h,i,j] * W[h,g]
+void launch_headmix_fwd(const float* in, const float* w, float* out, int b, int h, int nq, int nk, int64_t ld, hipStream_t s);
+// din[b,h,i,j] = sum_g dout[b,g,i,j] W[h,g];  dW[h,g] = sum_{b,i,j} in[b,h,i,j] dout[b,g,i,j]
+void launch_headmix_bwd(const float* in, const float* dout, const float* w, float* din, float* dw_partial_ws, float* dw,
+                        int b, int h, int nq, int nk, int64_t ld, hipStream_t s);
+int64_t headmix_ws_elems(int b, int h, int nq, int nk);
+// LayerNorm over the head axis at every (b,i,j)  (deepvit.py:59-63)
+void launch_headnorm_fwd(const float* in, const float* gamma, const float* beta, float* out, int b, int h, int nq, int nk,
+                         int64_t ld, float eps, hipStream_t s);
+void launch_headnorm_bwd(const float* in, const float* dout, const float* gamma, float* din, float* partial_ws, float* dgamma,
+                         float* dbeta, int b, int h, int nq, int nk, int64_t ld, float eps, hipStream_t s);
+// ctx[b, 0:nq] = y[b]; ctx[b, nq:nq+nc] = context[b]   (cait.py:109-112), T-typed output
+void launch_concat_ctx(const void* y, int y_bf16, const float* context, void* ctx, int ctx_bf16, int b, int nq, int nc, int d,
+                       hipStream_t s);
+// split d(ctx) [b, nq+nc, d] (T) back: dy_add[b, 0:nq] (T, overwritten) and dcontext[b, 0:nc] += (fp32 accumulate)
+void launch_split_ctx_bwd(const void* dctx, int is_bf16, void* dy, float* dcontext, int b, int nq, int nc, int d, hipStream_t s);
+void launch_add_T(void* a_inout, const void* b_in, int is_bf16, int64_t n, hipStream_t s);
+void launch_scale_grad(const void* fx, int is_bf16, int64_t ldf, const float* g, int64_t ldg, int rows, int d, float* partial_ws,
+                       float* dscale, hipStream_t s);  // dscale[c] = sum_r g[r][c]*fx[r][c]   (cait.py:47-48 VJP)
+void launch_mul_scale(const float* g, int64_t ldg, const float* scale, void* out, int out_bf16, int64_t ldo, int rows, int d,
+                      hipStream_t s);          // out[T] = g * scale[col]
+void launch_broadcast_rows(const float* src, int d, float* dst, int rows, hipStream_t s);  // dst[r][:] = src[:]

@@ -1,0 +1,11 @@
+"""vit_tensorflow -- MI355X-native engine behind the reference's import surface.
+
+The reference ships no __init__.py although its README does `from vit_tensorflow import ViT`
+(README.md:47); this package supplies it, plus `vit_tensorflow.deepvit.DeepViT` (README.md:148) and
+`vit_tensorflow.cait.CaiT` (README.md:177).
+"""
+from .vit import ViT
+from .deepvit import DeepViT
+from .cait import CaiT
+
+__all__ = ["ViT", "DeepViT", "CaiT"]

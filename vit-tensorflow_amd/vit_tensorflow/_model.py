@@ -1,0 +1,270 @@
+"""Host-side mirror of the reference's model objects (tf.keras.Model subclasses in
+vit_tensorflow/vit.py:106, deepvit.py:112, cait.py:155): same constructor kwargs, same call
+signature, same assertion texts.  All arithmetic is delegated to libvitx (HIP) through ctypes."""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+
+from . import _native as N
+
+
+def pair(t):
+    """vit.py:11-12"""
+    return t if isinstance(t, tuple) else (t, t)
+
+
+def layer_scale_init(depth_1based: int) -> float:
+    """cait.py:36-41"""
+    if depth_1based <= 18:
+        return 0.1
+    if depth_1based <= 24:
+        return 1e-5
+    return 1e-6
+
+
+class _Weight:
+    """Minimal stand-in for a tf.Variable: `.name`, `.shape`, `.numpy()`, `.assign()`."""
+
+    def __init__(self, owner: "VitxModel", name: str, shape, offset: int):
+        self._owner, self.name, self.shape, self._offset = owner, name, tuple(shape), offset
+
+    def numpy(self) -> np.ndarray:
+        self._owner._pull_params()
+        n = int(np.prod(self.shape))
+        return self._owner._blob[self._offset:self._offset + n].reshape(self.shape).copy()
+
+    def assign(self, value) -> None:
+        v = np.asarray(value, dtype=np.float32)
+        assert v.shape == self.shape, f"shape mismatch for {self.name}: {v.shape} vs {self.shape}"
+        self._owner._pull_params()
+        self._owner._blob[self._offset:self._offset + v.size] = v.reshape(-1)
+        self._owner._push_params()
+
+    def __array__(self, dtype=None):
+        a = self.numpy()
+        return a.astype(dtype) if dtype is not None else a
+
+
+class _TransformerProxy:
+    """`model.transformer(tokens, training=...)` as used by mae.py:69, simmim.py:116, mpp.py:212."""
+
+    def __init__(self, owner: "VitxModel"):
+        self._owner = owner
+
+    def __call__(self, tokens, training=True, **_):
+        return self._owner._transformer_call(tokens, training)
+
+
+class VitxModel:
+    _variant = N.VARIANT_VIT
+
+    def _init_common(self, *, image_size, patch_size, num_classes, dim, depth, heads, mlp_dim, pool, dim_head, dropout,
+                     emb_dropout, layer_dropout=0.0, cls_depth=0, compute="fp32", max_batch=None, device=0, seed=None):
+        ih, iw = pair(image_size)
+        ph, pw = pair(patch_size)
+        assert ih % ph == 0 and iw % pw == 0, 'Image dimensions must be divisible by the patch size.'
+        if self._variant != N.VARIANT_CAIT:
+            assert pool in {'cls', 'mean'}, 'pool type must be either cls (cls token) or mean (mean pooling)'
+        self.pool = pool
+        self.heads, self.dim, self.depth, self.mlp_dim, self.dim_head = heads, dim, depth, mlp_dim, dim_head
+        self.num_classes = num_classes
+        cfg = N.Config()
+        cfg.variant = self._variant
+        cfg.image_h, cfg.image_w, cfg.patch_h, cfg.patch_w, cfg.channels = ih, iw, ph, pw, 3
+        cfg.num_classes, cfg.dim, cfg.depth, cfg.cls_depth = num_classes, dim, depth, cls_depth
+        cfg.heads, cfg.dim_head, cfg.mlp_dim = heads, dim_head, mlp_dim
+        cfg.pool = N.POOL_MEAN if pool == 'mean' else N.POOL_CLS
+        cfg.dropout, cfg.emb_dropout, cfg.layer_dropout = float(dropout), float(emb_dropout), float(layer_dropout)
+        cfg.ln_eps = 1e-3  # Keras LayerNormalization default
+        assert compute in ("fp32", "bf16"), "compute must be 'fp32' (parity) or 'bf16' (throughput)"
+        cfg.compute = N.COMPUTE_BF16 if compute == "bf16" else N.COMPUTE_FP32
+        cfg.max_batch = int(max_batch or 0)
+        cfg.device_id = int(device)
+        self._cfg = cfg
+        self.compute = compute
+        self._handle: Optional[C.c_void_p] = None
+        self._table, self._n = N.param_table(cfg)      # C library is the single source of the order
+        self._blob = np.zeros(self._n, dtype=np.float32)
+        self._device_newer = False
+        self._init_weights(np.random.default_rng(seed))
+        self.transformer = _TransformerProxy(self)
+        self._cb_keepalive = None
+
+    # ---- initialisers: tf.random.normal (vit.py:146-147), Keras Dense glorot_uniform / zeros,
+    #      LayerNormalization ones / zeros, LayerScale tf.fill (cait.py:43)
+    def _init_weights(self, rng: np.random.Generator) -> None:
+        for name, shape, off in self._table:
+            n = int(np.prod(shape))
+            leaf = name.split(".")[-1]
+            if name in ("pos_embedding", "cls_token") or leaf in ("reattn_weights", "mix_heads_pre_attn", "mix_heads_post_attn"):
+                v = rng.standard_normal(n)
+            elif leaf == "kernel":
+                lim = math.sqrt(6.0 / (shape[0] + shape[1]))
+                v = rng.uniform(-lim, lim, n)
+            elif leaf == "gamma":
+                v = np.ones(n)
+            elif leaf == "scale":
+                ind = int(name.split(".")[1])
+                v = np.full(n, layer_scale_init(ind + 1))
+            else:  # bias / beta
+                v = np.zeros(n)
+            self._blob[off:off + n] = v.astype(np.float32)
+
+    # ---- handle management
+    def _ensure_handle(self, batch: int):
+        l = N.lib()
+        if self._handle is not None and batch <= self._cfg.max_batch:
+            return self._handle
+        if self._handle is not None:   # grow: keep the weights, rebuild the device plan
+            self._pull_params()
+            N.check(l.vitx_destroy(self._handle))
+            self._handle = None
+        self._cfg.max_batch = max(int(batch), int(self._cfg.max_batch))
+        h = C.c_void_p()
+        N.check(l.vitx_create(C.byref(self._cfg), C.byref(h)))
+        self._handle = h
+        self._push_params()
+        return h
+
+    def _push_params(self):
+        if self._handle is not None:
+            N.check(N.lib().vitx_set_params(self._handle, self._blob.ctypes.data_as(C.c_void_p), self._n))
+        self._device_newer = False
+
+    def _pull_params(self):
+        if self._handle is not None and self._device_newer:
+            N.check(N.lib().vitx_get_params(self._handle, self._blob.ctypes.data_as(C.c_void_p), self._n))
+            self._device_newer = False
+
+    def __del__(self):
+        try:
+            if getattr(self, "_handle", None) is not None:
+                N.lib().vitx_destroy(self._handle)
+                self._handle = None
+        except Exception:
+            pass
+
+    # ---- Keras-like surface
+    def build(self, input_shape=None):
+        """tf.keras.Model.build(input_shape) as called by mae.py:32: creates the device plan."""
+        b = 1
+        if input_shape is not None and input_shape[0]:
+            b = int(input_shape[0])
+        self._ensure_handle(b)
+        return self
+
+    @property
+    def weights(self) -> List[_Weight]:
+        return [_Weight(self, n, s, o) for n, s, o in self._table]
+
+    trainable_variables = weights
+    trainable_weights = weights
+
+    def get_weights(self) -> List[np.ndarray]:
+        self._pull_params()
+        return [self._blob[o:o + int(np.prod(s))].reshape(s).copy() for _, s, o in self._table]
+
+    def set_weights(self, weights: Sequence[np.ndarray]) -> None:
+        assert len(weights) == len(self._table), f"expected {len(self._table)} arrays, got {len(weights)}"
+        for w, (n, s, o) in zip(weights, self._table):
+            a = np.asarray(w, dtype=np.float32)
+            assert a.shape == tuple(s), f"{n}: expected shape {tuple(s)}, got {a.shape}"
+            self._blob[o:o + a.size] = a.reshape(-1)
+        self._push_params()
+
+    def state_dict(self) -> Dict[str, np.ndarray]:
+        return {n: w for (n, _, _), w in zip(self._table, self.get_weights())}
+
+    def load_state_dict(self, sd: Dict[str, np.ndarray]) -> None:
+        self.set_weights([sd[n] for n, _, _ in self._table])
+
+    def save_weights(self, path: str) -> None:
+        np.savez(path, **self.state_dict())
+
+    def load_weights(self, path: str) -> None:
+        with np.load(path) as z:
+            self.load_state_dict({k: z[k] for k in z.files})
+
+    @property
+    def pos_embedding(self):
+        return self.weights[0]
+
+    @property
+    def cls_token(self):
+        return self.weights[1]
+
+    def count_params(self) -> int:
+        return int(self._n)
+
+    # ---- tensors in / out: numpy, torch (CPU or ROCm) -- TensorFlow is what the reference used (vit.py:193)
+    @staticmethod
+    def _as_host(x):
+        is_torch = type(x).__module__.startswith("torch")
+        if is_torch:
+            return np.ascontiguousarray(x.detach().to("cpu").float().numpy()), x
+        return np.ascontiguousarray(np.asarray(x, dtype=np.float32)), None
+
+    @staticmethod
+    def _like(out: np.ndarray, proto):
+        if proto is None:
+            return out
+        import torch
+        return torch.from_numpy(out).to(proto.device)
+
+    def __call__(self, img, training=True, **kwargs):
+        """ViT.call(img, training=True)  (vit.py:159; `training=True` is the reference's default)."""
+        x, proto = self._as_host(img)
+        assert x.ndim == 4, "expected NHWC images [b, H, W, C]"
+        b, H, W, Cc = x.shape
+        assert Cc == self._cfg.channels, f"expected {self._cfg.channels} channels"
+        assert H % self._cfg.patch_h == 0 and W % self._cfg.patch_w == 0, 'Image dimensions must be divisible by the patch size.'
+        h = self._ensure_handle(b)
+        self._img_shape = (b, H, W, Cc)
+        out = np.empty((b, self.num_classes), dtype=np.float32)
+        seed = int(kwargs.get("seed", np.random.randint(0, 2 ** 31 - 1)))
+        N.check(N.lib().vitx_forward(h, x.ctypes.data_as(C.c_void_p), b, H, W, 1 if training else 0, seed,
+                                     out.ctypes.data_as(C.c_void_p)))
+        return self._like(out, proto)
+
+    call = __call__
+    predict = lambda self, img, **kw: self(img, training=False, **kw)
+
+    def backward(self, dlogits, want_dimg: bool = False):
+        """VJP for the last forward (what tf.GradientTape.gradient would return, README.md:746-749).
+        Returns ({name: grad}, dimg|None)."""
+        if self._handle is None:
+            raise N.VitxError(N.ERR_STATE, "backward requires a preceding forward")
+        d, _ = self._as_host(dlogits)
+        dimg = None
+        dimg_p = None
+        if want_dimg:
+            dimg = np.empty(self._last_img_shape(), dtype=np.float32)
+            dimg_p = dimg.ctypes.data_as(C.c_void_p)
+        N.check(N.lib().vitx_backward(self._handle, d.ctypes.data_as(C.c_void_p), dimg_p))
+        g = np.empty(self._n, dtype=np.float32)
+        N.check(N.lib().vitx_get_grads(self._handle, g.ctypes.data_as(C.c_void_p), self._n))
+        grads = {n: g[o:o + int(np.prod(s))].reshape(s) for n, s, o in self._table}
+        return grads, dimg
+
+    def _last_img_shape(self):
+        return self._img_shape
+
+    def _transformer_call(self, tokens, training=True):
+        x, proto = self._as_host(tokens)
+        assert x.ndim == 3 and x.shape[2] == self.dim, "expected tokens [b, n, dim]"
+        b, n, _ = x.shape
+        h = self._ensure_handle(b)
+        out = np.empty_like(x)
+        N.check(N.lib().vitx_transformer_forward(h, x.ctypes.data_as(C.c_void_p), b, n, out.ctypes.data_as(C.c_void_p)))
+        return self._like(out, proto)
+
+    def debug_read(self, which: str, layer: int = 0) -> np.ndarray:
+        n = C.c_int64()
+        N.check(N.lib().vitx_debug_read(self._handle, which.encode(), layer, None, 0, C.byref(n)))
+        out = np.empty(n.value, dtype=np.float32)
+        N.check(N.lib().vitx_debug_read(self._handle, which.encode(), layer, out.ctypes.data_as(C.c_void_p), n.value, C.byref(n)))
+        return out
