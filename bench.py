@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""Headline benchmark (BASELINE.json): images/sec, forward+backward, ViT-B/16 224 px, bf16 operands,
+batch 256 per GPU, synthetic images resident in HBM, one process per GPU (weak scaling).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = re-derive the bf16 operand copies of the (possibly updated) fp32 weights -> forward ->
+softmax-CE gradient -> backward of every parameter [-> bucketed RCCL all-reduce of the gradients].
+Prints ONE JSON line on rank 0 (contract in the task statement) carrying `roofline` for the dominant
+kernel class (the bf16 MFMA GEMM, timed with HIP events on the engine's stream) and `cpu_baseline`
+(the oracle's torch-CPU fp32 restatement of vit.py, timed on this box's host cores; rank 0, N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "vit-tensorflow_amd")]
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+MFMA_BF16_PEAK = 2516.6e12   # 256 CU x 4096 FLOP/clk/CU x 2.4 GHz (MI355X_MICROARCH.md: ~2.5 PF dense bf16)
+HBM_PEAK = 8.0e12
+
+WORKLOADS = {
+    # BASELINE.json configs[1]: the configuration the metric is quoted on
+    "vit_b16_224": dict(image_size=224, patch_size=16, num_classes=1000, dim=768, depth=12, heads=12, mlp_dim=3072),
+    # configs[2] per-GPU shape (ViT-L/16)
+    "vit_l16_224": dict(image_size=224, patch_size=16, num_classes=1000, dim=1024, depth=24, heads=16, mlp_dim=4096),
+    # configs[0] (README example; plumbing-sized)
+    "vit_readme_256": dict(image_size=256, patch_size=32, num_classes=1000, dim=1024, depth=6, heads=16, mlp_dim=2048),
+}
+
+
+def flops_per_image(kw) -> float:
+    from oracle import spec   # FLOP model only; no oracle compute in the timed path
+    return spec.flops_per_image(spec.make_config("vit", **kw))
+
+
+def cpu_baseline(kw, seconds: float, batch: int = 8):
+    """Reference-restatement CPU baseline (torch-CPU fp32, NOT TensorFlow: TF is absent from the image)."""
+    from oracle import ref_torch, spec
+    cfg = spec.make_config("vit", **kw)
+    ncores = os.cpu_count() or 1
+    torch.set_num_threads(ncores)
+    P = {k: torch.tensor(v, dtype=torch.float32, requires_grad=True) for k, v in spec.init_params(cfg, 1).items()}
+    img = torch.randn(batch, *cfg["image_size"], 3)
+    labels = torch.randint(0, cfg["num_classes"], (batch,))
+
+    def step():
+        for p in P.values():
+            p.grad = None
+        logits = ref_torch.forward(cfg, P, img)
+        torch.nn.functional.cross_entropy(logits, labels).backward()
+
+    step()   # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        step()
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= seconds or n >= 50:
+            break
+    return {"value": round(batch * n / el, 3), "unit": "images/sec", "cores": ncores, "kind": "port",
+            "sample": f"oracle/ref_torch.py (unfused torch-CPU fp32 restatement of vit.py, autograd backward), ViT-B/16 224 "
+                      f"batch {batch}, {n} fwd+bwd steps in {el:.1f} s; TensorFlow itself is not installable here"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=256, help="images per GPU")
+    ap.add_argument("--workload", default="vit_b16_224", choices=sorted(WORKLOADS))
+    ap.add_argument("--compute", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--bucket-mb", type=float, default=48.0)
+    args = ap.parse_args()
+
+    from vit_tensorflow import ViT, _native as N
+    from vit_tensorflow.parallel import GradSync, broadcast_params, init_from_env
+    import torch.distributed as dist
+
+    rank, local, world = init_from_env()
+    if world != args.gpus and rank == 0:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path is HIP-only (no CPU fallback)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    kw = WORKLOADS[args.workload]
+    b = args.batch
+    lib = N.lib()
+
+    model = ViT(**kw, compute=args.compute, max_batch=b, device=local, seed=1)
+    model.build((b,))
+    h = model._handle
+    H, W = (kw["image_size"],) * 2
+    # synthetic inputs, resident in HBM before the timed region (tf.random.normal analogue, README.md:61)
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    img = torch.randn(b, H, W, 3, device=dev, generator=g)
+    labels = torch.randint(0, kw["num_classes"], (b,), device=dev, generator=g, dtype=torch.int32)
+    torch.cuda.synchronize()
+
+    sync = None
+    cb = None
+    if world > 1:
+        n = C.c_int64()
+        p = C.c_void_p()
+        N.check(lib.vitx_params_dev(h, C.byref(p), C.byref(n)))
+        params_t = torch.empty(n.value, device=dev, dtype=torch.float32)
+        grads_t = torch.zeros(n.value, device=dev, dtype=torch.float32)
+        N.check(lib.vitx_bind_arenas(h, C.c_void_p(params_t.data_ptr()), C.c_void_p(grads_t.data_ptr())))
+        # engine work must be ordered with RCCL through torch's current stream
+        N.check(lib.vitx_set_stream(h, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        broadcast_params(params_t, 0)
+        N.check(lib.vitx_params_changed(h))
+        sync = GradSync(grads_t, bucket_elems=int(args.bucket_mb * (1 << 20) / 4), average=False)
+        cb = N.GRAD_READY_FN(lambda _u, off, cnt: sync.on_ready(int(off), int(cnt)))
+        N.check(lib.vitx_set_grad_ready_callback(h, cb, None))
+    inv_global = 1.0 / float(b * world)   # dlogits carry 1/global_batch, so the all-reduce is a plain sum
+
+    def step():
+        N.check(lib.vitx_params_changed(h))    # a training step sees updated fp32 weights: re-derive bf16 operands
+        if sync:
+            sync.begin()
+        N.check(lib.vitx_forward_dev(h, C.c_void_p(img.data_ptr()), b, H, W, 0, 0, None))
+        N.check(lib.vitx_ce_loss_grad_dev(h, C.c_void_p(labels.data_ptr()), inv_global, None))
+        N.check(lib.vitx_backward_dev(h, None, None))
+        if sync:
+            sync.finish()
+
+    def full_sync():
+        N.check(lib.vitx_sync(h))
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    full_sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    full_sync()
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+
+    fpi = flops_per_image(kw)
+    value = b * world * args.steps / el
+    out = {
+        "metric": "images/sec (fwd+bwd) ViT-B/16 224px bf16" if args.workload == "vit_b16_224" else f"images/sec (fwd+bwd) {args.workload}",
+        "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1e3 * el / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16" if args.compute == "bf16" else "f32", "data": "synthetic",
+        "config": {"workload": f"{args.workload} fwd+bwd, batch {b}/GPU, N(0,1) NHWC images resident in HBM, random-init weights, "
+                               f"softmax-CE cotangent, dropout 0", "global_batch": b * world,
+                   "parallelism": f"dp{world}", "compute": args.compute},
+        "path_mfma_frac": round(value / world * fpi / MFMA_BF16_PEAK, 4),
+        "flops_per_image": fpi,
+    }
+
+    if rank == 0 and not args.no_profile:
+        try:   # per-kernel-class HIP-event timing of two more steps (outside the timed region)
+            if sync:
+                N.check(lib.vitx_set_grad_ready_callback(h, C.cast(None, N.GRAD_READY_FN), None))
+            psteps = 2
+            N.check(lib.vitx_profile_begin(h))
+            for _ in range(psteps):
+                N.check(lib.vitx_params_changed(h))
+                N.check(lib.vitx_forward_dev(h, C.c_void_p(img.data_ptr()), b, H, W, 0, 0, None))
+                N.check(lib.vitx_ce_loss_grad_dev(h, C.c_void_p(labels.data_ptr()), inv_global, None))
+                N.check(lib.vitx_backward_dev(h, None, None))
+            stats = (N.KernelStat * 64)()
+            ns = C.c_int32()
+            N.check(lib.vitx_profile_end(h, stats, 64, C.byref(ns)))
+            classes = {}
+            for i in range(ns.value):
+                s = stats[i]
+                classes[s.name.decode()] = {"launches_per_step": s.launches // psteps, "ms_per_step": round(s.total_ms / psteps, 4),
+                                            "tflops": round(s.flops / max(s.total_ms, 1e-9) / 1e9, 1) if s.flops else None,
+                                            "gbps": round(s.bytes / max(s.total_ms, 1e-9) / 1e6, 1) if s.bytes else None}
+            out["kernel_classes"] = classes
+            dom = "gemm_bf16_mfma" if "gemm_bf16_mfma" in classes else "gemm_generic_fma"
+            for i in range(ns.value):
+                s = stats[i]
+                if s.name.decode() == dom:
+                    ach = s.flops / (s.total_ms * 1e-3)
+                    peak = MFMA_BF16_PEAK if dom == "gemm_bf16_mfma" else 157.3e12
+                    out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": round(ach / 1e12, 2), "peak": round(peak / 1e12, 1),
+                                       "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+                                       "launches_per_step": int(s.launches // psteps),
+                                       "avg_launch_ms": round(s.total_ms / s.launches, 5),
+                                       "algorithmic_tflop_per_step": round(s.flops / psteps / 1e12, 4)}
+        except Exception as ex:   # never lose the headline line to a diagnostics problem
+            out["roofline_error"] = repr(ex)
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            out["cpu_baseline"] = cpu_baseline(WORKLOADS["vit_b16_224"], args.cpu_seconds)
+        except Exception as ex:
+            out["cpu_baseline_error"] = repr(ex)
+
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
