@@ -45,11 +45,16 @@ def flops_per_image(kw) -> float:
     return spec.flops_per_image(spec.make_config("vit", **kw))
 
 
-def cpu_baseline(kw, seconds: float, batch: int = 8):
+def cpu_baseline(kw, seconds: float, batch: int = 4):
     """Reference-restatement CPU baseline (torch-CPU fp32, NOT TensorFlow: TF is absent from the image)."""
     from oracle import ref_torch, spec
     cfg = spec.make_config("vit", **kw)
-    ncores = os.cpu_count() or 1
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except Exception:
+        avail = os.cpu_count() or 1
+    # a bounded thread count: torch-CPU with hundreds of threads on a shared host oversubscribes badly
+    ncores = max(1, min(avail, int(os.environ.get("VITX_CPU_BASELINE_THREADS", "16"))))
     torch.set_num_threads(ncores)
     P = {k: torch.tensor(v, dtype=torch.float32, requires_grad=True) for k, v in spec.init_params(cfg, 1).items()}
     img = torch.randn(batch, *cfg["image_size"], 3)
@@ -69,7 +74,7 @@ def cpu_baseline(kw, seconds: float, batch: int = 8):
         el = time.perf_counter() - t0
         if el >= seconds or n >= 50:
             break
-    return {"value": round(batch * n / el, 3), "unit": "images/sec", "cores": ncores, "kind": "port",
+    return {"value": round(batch * n / el, 3), "unit": "images/sec", "cores": ncores, "host_cpus": avail, "kind": "port",
             "sample": f"oracle/ref_torch.py (unfused torch-CPU fp32 restatement of vit.py, autograd backward), ViT-B/16 224 "
                       f"batch {batch}, {n} fwd+bwd steps in {el:.1f} s; TensorFlow itself is not installable here"}
 

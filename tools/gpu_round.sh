@@ -13,7 +13,7 @@ for s in $STAGES; do
     probe) timeout 60 tools/probe_tr > $OUT/probe.log 2>&1; tail -4 $OUT/probe.log | tee -a $OUT/summary.log ;;
     pytest) timeout 1500 python -m pytest tests -m gpu -q -rA --timeout 600 -p no:cacheprovider > $OUT/pytest.log 2>&1; tail -40 $OUT/pytest.log | tee -a $OUT/summary.log ;;
     bench) timeout 600 python bench.py --steps 10 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err; cat $OUT/bench.json | tee -a $OUT/summary.log; tail -5 $OUT/bench.err ;;
-    rocprof) (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $OLDPWD/$OUT/prof -o vitb16 -- python $OLDPWD/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-profile > $OLDPWD/$OUT/rocprof_bench.json 2> $OLDPWD/$OUT/rocprof.err); ls -R $OUT/prof | head -20; find $OUT/prof -name "*kernel_stats*" | head -1 | xargs -r head -40 | tee -a $OUT/summary.log ;;
+    rocprof) (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$OUT/prof -o vitb16 -- python $OLDPWD/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-profile > $OLDPWD/$OUT/rocprof_bench.json 2> $OLDPWD/$OUT/rocprof.err); ls -R $OUT/prof | head -20; find $OUT/prof -name "*kernel_stats*" | head -1 | xargs -r head -40 | tee -a $OUT/summary.log ;;
     *) timeout 900 python tools/gpu_diag.py $s > $OUT/$s.log 2>&1; tail -60 $OUT/$s.log ;;
   esac
 done

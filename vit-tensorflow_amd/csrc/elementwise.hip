@@ -369,13 +369,41 @@ __global__ void fill_random_bf16_kernel(bf16_t* p, int64_t n, uint32_t seed, flo
     p[e] = (bf16_t)(((float)(h >> 8) * (1.0f / 8388608.0f) - 1.0f) * scale);  // uniform [-scale, scale)
   }
 }
-// inverted dropout (vit.py:41,43,64,148), counter-based mask keyed by (seed, site, element): x *= m/(1-rate)
-__global__ void dropout_kernel(float* x, int64_t n, float rate, uint32_t seed_lo, uint32_t seed_hi, uint32_t site) {
+// inverted dropout (vit.py:41,43,64,148; Keras Dropout: y = x*m/(1-rate), m ~ Bernoulli(1-rate)), counter-based
+// mask keyed by (seed, site, element) so that backward regenerates it instead of storing it
+__device__ __forceinline__ bool dropout_keep(int64_t e, float rate, uint32_t seed_lo, uint32_t seed_hi, uint32_t site) {
+  const uint32_t h = hash32(hash32((uint32_t)e ^ seed_lo) + hash32((uint32_t)(e >> 32) ^ seed_hi ^ (site * 0x9e3779b9U)));
+  return (float)(h >> 8) * (1.0f / 16777216.0f) >= rate;
+}
+template <typename T>
+__global__ void dropout_kernel(T* x, int64_t n, float rate, uint32_t seed_lo, uint32_t seed_hi, uint32_t site) {
   const float keep_scale = 1.0f / (1.0f - rate);
-  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
-    const uint32_t h = hash32(hash32((uint32_t)e ^ seed_lo) + hash32((uint32_t)(e >> 32) ^ seed_hi ^ (site * 0x9e3779b9U)));
-    const float u = (float)(h >> 8) * (1.0f / 16777216.0f);
-    x[e] = u < rate ? 0.f : x[e] * keep_scale;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x)
+    stf<T>(x + e, dropout_keep(e, rate, seed_lo, seed_hi, site) ? ldf<T>(x + e) * keep_scale : 0.f);
+}
+// x_out = resid + f * scale[col]; optionally keeps f (post-dropout) in T for the LayerScale VJP
+template <typename T>
+__global__ void axpy_resid_kernel(const float* __restrict__ resid, const float* __restrict__ f, const float* __restrict__ scale,
+                                  float* __restrict__ out, T* __restrict__ keep, int64_t rows, int d) {
+  const int64_t total = rows * d;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(e % d);
+    const float v = f[e];
+    out[e] = resid[e] + v * (scale ? scale[c] : 1.f);
+    if (keep) stf<T>(keep + e, v);
+  }
+}
+// out[T] = dropout_mask(g * scale[col])  -- gradient entering a residual branch (LayerScale and/or dropout VJP)
+template <typename T>
+__global__ void branch_grad_kernel(const float* __restrict__ g, const float* __restrict__ scale, T* __restrict__ out, int64_t rows, int d,
+                                   float rate, uint32_t seed_lo, uint32_t seed_hi, uint32_t site) {
+  const int64_t total = rows * d;
+  const float keep_scale = rate > 0.f ? 1.0f / (1.0f - rate) : 1.f;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(e % d);
+    float v = g[e] * (scale ? scale[c] : 1.f);
+    if (rate > 0.f) v = dropout_keep(e, rate, seed_lo, seed_hi, site) ? v * keep_scale : 0.f;
+    stf<T>(out + e, v);
   }
 }
 
@@ -510,9 +538,22 @@ void launch_ce_grad(const float* logits, int64_t ld, const int32_t* labels, int 
 void launch_fill_random_bf16(bf16_t* p, int64_t n, uint32_t seed, float scale, hipStream_t s) {
   hipLaunchKernelGGL(fill_random_bf16_kernel, dim3(grid_for(n)), dim3(256), 0, s, p, n, seed, scale);
 }
-void launch_dropout(float* x, int64_t n, float rate, uint64_t seed, uint32_t site, hipStream_t s) {
+void launch_dropout(void* x, int is_bf16, int64_t n, float rate, uint64_t seed, uint32_t site, hipStream_t s) {
   if (n == 0 || rate <= 0.f) return;
-  hipLaunchKernelGGL(dropout_kernel, dim3(grid_for(n)), dim3(256), 0, s, x, n, rate, (uint32_t)seed, (uint32_t)(seed >> 32), site);
+  if (is_bf16) hipLaunchKernelGGL(dropout_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, s, (bf16_t*)x, n, rate, (uint32_t)seed, (uint32_t)(seed >> 32), site);
+  else hipLaunchKernelGGL(dropout_kernel<float>, dim3(grid_for(n)), dim3(256), 0, s, (float*)x, n, rate, (uint32_t)seed, (uint32_t)(seed >> 32), site);
+}
+void launch_axpy_resid(const float* resid, const float* f, const float* scale, float* out, void* keep, int keep_bf16, int64_t rows, int d,
+                       hipStream_t s) {
+  if (rows == 0) return;
+  if (keep_bf16) hipLaunchKernelGGL(axpy_resid_kernel<bf16_t>, dim3(grid_for(rows * d)), dim3(256), 0, s, resid, f, scale, out, (bf16_t*)keep, rows, d);
+  else hipLaunchKernelGGL(axpy_resid_kernel<float>, dim3(grid_for(rows * d)), dim3(256), 0, s, resid, f, scale, out, (float*)keep, rows, d);
+}
+void launch_branch_grad(const float* g, const float* scale, void* out, int out_bf16, int64_t rows, int d, float rate, uint64_t seed,
+                        uint32_t site, hipStream_t s) {
+  if (rows == 0) return;
+  if (out_bf16) hipLaunchKernelGGL(branch_grad_kernel<bf16_t>, dim3(grid_for(rows * d)), dim3(256), 0, s, g, scale, (bf16_t*)out, rows, d, rate, (uint32_t)seed, (uint32_t)(seed >> 32), site);
+  else hipLaunchKernelGGL(branch_grad_kernel<float>, dim3(grid_for(rows * d)), dim3(256), 0, s, g, scale, (float*)out, rows, d, rate, (uint32_t)seed, (uint32_t)(seed >> 32), site);
 }
 void launch_resid_add(const float* resid, const void* t, int t_bf16, float* out, int64_t n, hipStream_t s) {
   if (n == 0) return;

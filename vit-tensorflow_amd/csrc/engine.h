@@ -106,6 +106,7 @@ struct vitx_engine {
   bool have_fwd = false;
   int last_b = 0, last_np = 0, last_ntok = 0, last_H = 0, last_W = 0, last_training = 0;
   uint64_t last_seed = 0;
+  std::vector<std::vector<bool>> layer_kept;   // per stage: blocks that survived CaiT layer dropout in the last forward
   int64_t zero_geom = -1;
 
   // env switches

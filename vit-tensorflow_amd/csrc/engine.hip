@@ -416,7 +416,9 @@ static bool use_fused_attn(const vitx_engine* e, int n) {
 // one transformer block: x = attn(LN(x)) [*scale] + x ; x = mlp(LN(x)) [*scale] + x
 //   (vit.py:99-104, deepvit.py:106-110, cait.py:146-153)
 // ------------------------------------------------------------------------------------------------
-static int block_forward(vitx_engine* e, Stage& st, int l, int b, int nq, int nc, const float* context, std::string& err) {
+static int block_forward(vitx_engine* e, Stage& st, int si, int l, int b, int nq, int nc, const float* context, float drop, uint64_t seed,
+                         std::string& err) {
+  const uint32_t site0 = (uint32_t)((si * 1000 + l) * 4);
   const BlockParams& bp = st.bp[l];
   BlockActs& ba = st.ba[l];
   const vitx_config& c = e->cfg;
@@ -460,7 +462,15 @@ static int block_forward(vitx_engine* e, Stage& st, int l, int b, int nq, int nc
     if (rc != VITX_OK) return rc;
     attn_generic_fwd(e, bp, av, b);
   }
-  if (bp.has_out) {
+  if (bp.has_out && drop > 0.f) {
+    // Dense -> Dropout -> (LayerScale) -> + residual, unfused (vit.py:61-69,83,101)
+    EpiParams ep; ep.out = e->tmp_f32; ep.ldo = d;
+    dense_fwd(e, ba.o, inner, rows, bp.out, EPI_STORE_F32, ep);
+    Prof pr(e, "dropout", 0, 0);
+    launch_dropout(e->tmp_f32, 0, (int64_t)rows * d, drop, seed, site0 + 1, e->stream);
+    launch_axpy_resid(ba.x_in, e->tmp_f32, bp.a_scale >= 0 ? e->params + bp.a_scale : nullptr, ba.x_mid, bp.a_scale >= 0 ? ba.fa : nullptr, T,
+                      rows, d, e->stream);
+  } else if (bp.has_out) {
     EpiParams ep;
     ep.out = ba.x_mid; ep.ldo = d; ep.resid = ba.x_in; ep.ldr = d;
     if (bp.a_scale >= 0) { ep.scale = e->params + bp.a_scale; ep.out2 = ba.fa; ep.ldo2 = d; }
@@ -477,7 +487,18 @@ static int block_forward(vitx_engine* e, Stage& st, int l, int b, int nq, int nc
     EpiParams ep; ep.out = ba.hpre; ep.ldo = m; ep.out2 = ba.act; ep.ldo2 = m;
     dense_fwd(e, ba.y2, d, rows, bp.fc1, EPI_BIAS_GELU, ep);                  // vit.py:39,34
   }
-  {
+  if (drop > 0.f) {
+    {
+      Prof pr(e, "dropout", 0, 0);
+      launch_dropout(ba.act, T, (int64_t)rows * m, drop, seed, site0 + 2, e->stream);     // vit.py:41
+    }
+    EpiParams ep; ep.out = e->tmp_f32; ep.ldo = d;
+    dense_fwd(e, ba.act, m, rows, bp.fc2, EPI_STORE_F32, ep);
+    Prof pr(e, "dropout", 0, 0);
+    launch_dropout(e->tmp_f32, 0, (int64_t)rows * d, drop, seed, site0 + 3, e->stream);   // vit.py:43
+    launch_axpy_resid(ba.x_mid, e->tmp_f32, bp.m_scale >= 0 ? e->params + bp.m_scale : nullptr, ba.x_out, bp.m_scale >= 0 ? ba.fm : nullptr, T,
+                      rows, d, e->stream);
+  } else {
     EpiParams ep;
     ep.out = ba.x_out; ep.ldo = d; ep.resid = ba.x_mid; ep.ldr = d;
     if (bp.m_scale >= 0) { ep.scale = e->params + bp.m_scale; ep.out2 = ba.fm; ep.ldo2 = d; }
@@ -487,7 +508,8 @@ static int block_forward(vitx_engine* e, Stage& st, int l, int b, int nq, int nc
 }
 
 // g (fp32 [rows,d]) holds dL/dx_out on entry and dL/dx_in on exit; g_lp is its T copy (bf16 mode).
-static int block_backward(vitx_engine* e, Stage& st, int l, int b, int nq, int nc, std::string& err) {
+static int block_backward(vitx_engine* e, Stage& st, int si, int l, int b, int nq, int nc, float drop, uint64_t seed, std::string& err) {
+  const uint32_t site0 = (uint32_t)((si * 1000 + l) * 4);
   const BlockParams& bp = st.bp[l];
   BlockActs& ba = st.ba[l];
   const vitx_config& c = e->cfg;
@@ -498,18 +520,22 @@ static int block_backward(vitx_engine* e, Stage& st, int l, int b, int nq, int n
 
   // ---- MLP branch: x_out = x_mid + scale * fc2(gelu(fc1(LN(x_mid))))
   const void* dbranch = gT;
-  if (bp.m_scale >= 0) {            // LayerScale VJP (cait.py:47-48): dscale = sum g*f(x), d f = g*scale
-    Prof pr(e, "layerscale_bwd", 0, 0);
-    launch_scale_grad(ba.fm, T, d, e->g, d, rows, d, e->red_ws, e->grads + bp.m_scale, e->stream);
-    launch_mul_scale(e->g, d, e->params + bp.m_scale, e->d_br, T, d, rows, d, e->stream);
+  if (bp.m_scale >= 0 || drop > 0.f) {   // LayerScale VJP (cait.py:47-48): dscale = sum g*f(x), d f = g*scale; Dropout VJP: same mask
+    Prof pr(e, "branch_grad", 0, 0);
+    if (bp.m_scale >= 0) launch_scale_grad(ba.fm, T, d, e->g, d, rows, d, e->red_ws, e->grads + bp.m_scale, e->stream);
+    launch_branch_grad(e->g, bp.m_scale >= 0 ? e->params + bp.m_scale : nullptr, e->d_br, T, rows, d, drop, seed, site0 + 3, e->stream);
     dbranch = e->d_br;
   }
   {
     EpiParams ep; ep.out = e->d_h; ep.ldo = m; ep.aux = ba.hpre; ep.ldaux = m;
     dense_dgrad(e, dbranch, d, rows, bp.fc2, EPI_GELU_BWD, ep);             // d hpre = (d act) * gelu'(hpre)
+    if (drop > 0.f) {
+      Prof pr(e, "dropout", 0, 0);
+      launch_dropout(e->d_h, T, (int64_t)rows * m, drop, seed, site0 + 2, e->stream);   // mask of the post-GELU dropout (commutes)
+    }
   }
   dense_wgrad(e, ba.act, m, dbranch, d, rows, bp.fc2);
-  if (bp.m_scale >= 0) bias_grad(e, e->d_br, T, d, rows, bp.fc2); else bias_grad(e, e->g, 0, d, rows, bp.fc2);
+  if (dbranch == e->d_br) bias_grad(e, e->d_br, T, d, rows, bp.fc2); else bias_grad(e, e->g, 0, d, rows, bp.fc2);
   {
     EpiParams ep; ep.out = e->d_y; ep.ldo = d;
     dense_dgrad(e, e->d_h, m, rows, bp.fc1, EPI_STORE, ep);
@@ -524,10 +550,11 @@ static int block_backward(vitx_engine* e, Stage& st, int l, int b, int nq, int n
 
   // ---- attention branch: x_mid = x_in + scale * to_out(attn(LN(x_in)))
   dbranch = gT;
-  if (bp.a_scale >= 0) {
-    Prof pr(e, "layerscale_bwd", 0, 0);
-    launch_scale_grad(ba.fa, T, d, e->g, d, rows, d, e->red_ws, e->grads + bp.a_scale, e->stream);
-    launch_mul_scale(e->g, d, e->params + bp.a_scale, e->d_br, T, d, rows, d, e->stream);
+  if (bp.a_scale >= 0 || (drop > 0.f && bp.has_out)) {
+    Prof pr(e, "branch_grad", 0, 0);
+    if (bp.a_scale >= 0) launch_scale_grad(ba.fa, T, d, e->g, d, rows, d, e->red_ws, e->grads + bp.a_scale, e->stream);
+    launch_branch_grad(e->g, bp.a_scale >= 0 ? e->params + bp.a_scale : nullptr, e->d_br, T, rows, d, bp.has_out ? drop : 0.f, seed, site0 + 1,
+                       e->stream);
     dbranch = e->d_br;
   }
   const void* d_o = dbranch;   // when to_out is the identity (vit.py:53) the branch gradient IS d(attn_out)
@@ -535,7 +562,7 @@ static int block_backward(vitx_engine* e, Stage& st, int l, int b, int nq, int n
     EpiParams ep; ep.out = e->d_o; ep.ldo = inner;
     dense_dgrad(e, dbranch, d, rows, bp.out, EPI_STORE, ep);
     dense_wgrad(e, ba.o, inner, dbranch, d, rows, bp.out);
-    if (bp.a_scale >= 0) bias_grad(e, e->d_br, T, d, rows, bp.out); else bias_grad(e, e->g, 0, d, rows, bp.out);
+    if (dbranch == e->d_br) bias_grad(e, e->d_br, T, d, rows, bp.out); else bias_grad(e, e->g, 0, d, rows, bp.out);
     d_o = e->d_o;
   }
   AttnView av;
@@ -791,6 +818,33 @@ static void ensure_geometry(vitx_engine* e, int b, int ntok) {
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
+// cait.py:17-31: python-level random skipping of whole blocks (numpy RNG in the reference; NOT gated by `training`,
+// cait.py:147).  Host-side, seeded by the call's seed; at least one layer survives per stage.
+static void draw_layer_dropout(vitx_engine* e, uint64_t seed) {
+  e->layer_kept.assign(e->stages.size(), {});
+  uint64_t st = seed * 0x9E3779B97F4A7C15ULL + 0xD1B54A32D192ED03ULL;
+  auto next = [&]() {
+    st += 0x9E3779B97F4A7C15ULL;
+    uint64_t z = st;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+  };
+  for (size_t si = 0; si < e->stages.size(); ++si) {
+    const int n = e->stages[si].depth;
+    auto& kept = e->layer_kept[si];
+    kept.assign((size_t)n, true);
+    const float p = e->cfg.variant == VITX_VARIANT_CAIT ? e->cfg.layer_dropout : 0.f;
+    if (p <= 0.f || n == 0) continue;
+    int alive = 0;
+    for (int i = 0; i < n; ++i) {
+      kept[(size_t)i] = !((double)(next() >> 11) * (1.0 / 9007199254740992.0) < (double)p);
+      alive += kept[(size_t)i];
+    }
+    if (alive == 0) kept[(size_t)(next() % (uint64_t)n)] = true;   // "make sure at least one layer makes it"
+  }
+}
+
 static int head_forward(vitx_engine* e, const float* x_last, int b, int ntok, float* logits_dev, std::string& err) {
   const vitx_config& c = e->cfg;
   const int d = c.dim, T = e->bf16;
@@ -822,10 +876,6 @@ int engine_forward(vitx_engine* e, const float* img_dev, int b, int H, int W, in
     err = "Image dimensions must be divisible by the patch size.";            // and fit the configured pos_embedding (vit.py:165)
     return VITX_ERR_INVALID;
   }
-  if (training && (c.dropout > 0.f || c.emb_dropout > 0.f || c.layer_dropout > 0.f)) {
-    err = "dropout > 0 in training mode is not implemented yet (use training=False or rate 0)";
-    return VITX_ERR_UNSUPPORTED;
-  }
   const bool cait = c.variant == VITX_VARIANT_CAIT;
   const int np = (H / c.patch_h) * (W / c.patch_w);
   const int ntok = cait ? np : np + 1;
@@ -848,9 +898,20 @@ int engine_forward(vitx_engine* e, const float* img_dev, int b, int H, int W, in
     ep.np = np; ep.ntok = ntok; ep.tok_off = cait ? 0 : 1;
     dense_fwd(e, e->patches, e->pd_k, b * np, e->patch, EPI_PATCH, ep);                                     // vit.py:143 (+164-165)
   }
+  const float drop = training ? c.dropout : 0.f, emb_drop = training ? c.emb_dropout : 0.f;
+  if (emb_drop > 0.f) {
+    Prof pr(e, "dropout", 0, 0);
+    launch_dropout(x0, 0, (int64_t)b * ntok * d, emb_drop, seed, 0u, e->stream);                           // vit.py:166
+  }
+  draw_layer_dropout(e, seed);
   int rc;
-  for (int l = 0; l < s0.depth; ++l)
-    if ((rc = block_forward(e, s0, l, b, ntok, 0, nullptr, err)) != VITX_OK) return rc;
+  for (int l = 0; l < s0.depth; ++l) {
+    if (!e->layer_kept[0][(size_t)l]) {   // cait.py:17-31,147: the whole block is skipped
+      HIPCHK(hipMemcpyAsync(s0.ba[l].x_out, s0.ba[l].x_in, (size_t)b * ntok * d * 4, hipMemcpyDeviceToDevice, e->stream));
+      continue;
+    }
+    if ((rc = block_forward(e, s0, 0, l, b, ntok, 0, nullptr, drop, seed, err)) != VITX_OK) return rc;
+  }
   const float* x_last = s0.depth > 0 ? s0.ba[s0.depth - 1].x_out : x0;
   int head_tok = ntok;
   if (cait) {
@@ -860,8 +921,13 @@ int engine_forward(vitx_engine* e, const float* img_dev, int b, int H, int W, in
       Prof pr(e, "cls_broadcast", 0, 0);
       launch_broadcast_rows(e->params + e->cls, d, xc, b, e->stream);                                        // cait.py:189
     }
-    for (int l = 0; l < s1.depth; ++l)
-      if ((rc = block_forward(e, s1, l, b, 1, np, x_last, err)) != VITX_OK) return rc;                       // cait.py:190
+    for (int l = 0; l < s1.depth; ++l) {
+      if (!e->layer_kept[1][(size_t)l]) {
+        HIPCHK(hipMemcpyAsync(s1.ba[l].x_out, s1.ba[l].x_in, (size_t)b * d * 4, hipMemcpyDeviceToDevice, e->stream));
+        continue;
+      }
+      if ((rc = block_forward(e, s1, 1, l, b, 1, np, x_last, drop, seed, err)) != VITX_OK) return rc;       // cait.py:190
+    }
     x_last = s1.depth > 0 ? s1.ba[s1.depth - 1].x_out : xc;
     head_tok = 1;
   }
@@ -883,7 +949,7 @@ int engine_transformer_forward(vitx_engine* e, const float* tokens_dev, int b, i
   HIPCHK(hipMemcpyAsync(s0.ba[0].x_in, tokens_dev, bytes, hipMemcpyDeviceToDevice, e->stream));
   int rc;
   for (int l = 0; l < s0.depth; ++l)
-    if ((rc = block_forward(e, s0, l, b, n, 0, nullptr, err)) != VITX_OK) return rc;
+    if ((rc = block_forward(e, s0, 0, l, b, n, 0, nullptr, 0.f, 0, err)) != VITX_OK) return rc;
   HIPCHK(hipMemcpyAsync(out_dev, s0.ba[s0.depth - 1].x_out, bytes, hipMemcpyDeviceToDevice, e->stream));
   e->have_fwd = false;   // saved activations no longer describe a full model forward
   return VITX_OK;
@@ -898,6 +964,7 @@ int engine_backward(vitx_engine* e, const float* dlogits_dev, float* dimg_dev, s
   const bool cait = c.variant == VITX_VARIANT_CAIT;
   const int b = e->last_b, np = e->last_np, ntok = e->last_ntok, d = c.dim, T = e->bf16;
   const int nc = c.num_classes;
+  const float drop = e->last_training ? c.dropout : 0.f;
   HIPCHK(hipMemsetAsync(e->grads, 0, (size_t)e->n_arena * 4, e->stream));
   if (dlogits_dev)
     HIPCHK(hipMemcpy2DAsync(e->dlogits, (size_t)e->nc_k * 4, dlogits_dev, (size_t)nc * 4, (size_t)nc * 4, b, hipMemcpyDeviceToDevice, e->stream));
@@ -950,7 +1017,7 @@ int engine_backward(vitx_engine* e, const float* dlogits_dev, float* dimg_dev, s
     Stage& s1 = e->stages[1];
     HIPCHK(hipMemsetAsync(e->g_ctx, 0, (size_t)b * np * d * 4, e->stream));
     for (int l = s1.depth - 1; l >= 0; --l)
-      if ((rc = block_backward(e, s1, l, b, 1, np, err)) != VITX_OK) return rc;
+      if (e->layer_kept[1][(size_t)l] && (rc = block_backward(e, s1, 1, l, b, 1, np, drop, e->last_seed, err)) != VITX_OK) return rc;
     {
       Prof pr(e, "embed_bwd", 0, 0);
       launch_batch_reduce(e->g, b, 1, d, 0, 1, e->grads + e->cls, e->stream);          // dcls = sum_b g (cait.py:189 VJP)
@@ -960,7 +1027,11 @@ int engine_backward(vitx_engine* e, const float* dlogits_dev, float* dimg_dev, s
     }
   }
   for (int l = s0.depth - 1; l >= 0; --l)
-    if ((rc = block_backward(e, s0, l, b, ntok, 0, err)) != VITX_OK) return rc;
+    if (e->layer_kept[0][(size_t)l] && (rc = block_backward(e, s0, 0, l, b, ntok, 0, drop, e->last_seed, err)) != VITX_OK) return rc;
+  if (e->last_training && c.emb_dropout > 0.f) {
+    Prof pr(e, "dropout", 0, 0);
+    launch_dropout(e->g, 0, (int64_t)b * ntok * d, c.emb_dropout, e->last_seed, 0u, e->stream);   // same mask as the forward (vit.py:166)
+  }
 
   // ---- embedding: x0 = [cls | patches @ W + b] + pos   (vit.py:160-165; cait.py:181-184)
   {

@@ -65,7 +65,11 @@ void launch_sum_rows(const float* in, int rows, int d, float* out, hipStream_t s
 void launch_ce_grad(const float* logits, int64_t ld, const int32_t* labels, int b, int nc, float inv_batch, float* dlogits,
                     float* loss, hipStream_t s);
 void launch_fill_random_bf16(bf16_t* p, int64_t n, uint32_t seed, float scale, hipStream_t s);
-void launch_dropout(float* x, int64_t n, float rate, uint64_t seed, uint32_t site, hipStream_t s);
+void launch_dropout(void* x, int is_bf16, int64_t n, float rate, uint64_t seed, uint32_t site, hipStream_t s);
+void launch_axpy_resid(const float* resid, const float* f, const float* scale, float* out, void* keep, int keep_bf16, int64_t rows, int d,
+                       hipStream_t s);   // out = resid + f*scale[col]; keep[T] = f
+void launch_branch_grad(const float* g, const float* scale, void* out, int out_bf16, int64_t rows, int d, float rate, uint64_t seed,
+                        uint32_t site, hipStream_t s);   // out[T] = dropout_mask(g*scale[col])
 void launch_resid_add(const float* resid, const void* t, int t_bf16, float* out, int64_t n, hipStream_t s);  // out = resid + t
 
 // ---------------------------------------------------------------- attn_generic.hip (materialised attention pieces)
