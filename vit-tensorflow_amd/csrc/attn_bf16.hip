@@ -20,6 +20,9 @@ namespace {
 
 constexpr int DH = 64;
 constexpr int ROWB = DH * 2;  // 128-byte rows
+constexpr int ATT_THREADS = 512;  // 8 waves share one head's LDS image: 2 waves per SIMD hide LDS / MFMA / exp latency
+
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }  // raw v_exp_f32 (inputs are <= 0 or masked)
 
 __device__ __forceinline__ int swz_chunk(int row, int chunk) { return (chunk ^ ((row >> 1) & 7)) << 4; }
 
@@ -50,7 +53,24 @@ __device__ __forceinline__ void stage_head(const bf16_t* src, int64_t stride, in
 __device__ __forceinline__ bf16x8 frag_rm(const char* rm, int row, int chunk) {
   return *(const bf16x8*)(rm + row * ROWB + swz_chunk(row, chunk));
 }
-// transposed-image operand: row dh, k-slots (g,e): e<4 -> col 32u+4g+e, e>=4 -> col 32u+16+4g+(e-4)
+// Transposed operand straight from the row-major swizzled image via the LDS hardware transpose read
+// (ds_read_b64_tr_b16): fragment row = feature 16c + (lane&15), k-slots (g,e): e<4 -> row 32u+4g+e, e>=4 -> row 32u+16+4g+(e-4)
+// of the image.  Within a 16-lane group, lanes 4j..4j+3 address 16 consecutive features of image row (base + j) and lane q
+// receives feature q of rows base..base+3.
+__device__ __forceinline__ bf16x8 frag_trr(const char* rm, int c, int u, int lane) {
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  const int q = lane & 15, g = lane >> 4;
+  const int row0 = 32 * u + 4 * g + (q >> 2), row1 = row0 + 16;
+  const int b = 32 * c + 8 * (q & 3);
+  const int a0 = row0 * ROWB + ((((b >> 4) ^ ((row0 >> 1) & 7)) << 4) | (b & 15));
+  const int a1 = row1 * ROWB + ((((b >> 4) ^ ((row1 >> 1) & 7)) << 4) | (b & 15));
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(rm + a0));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(rm + a1));
+  union { struct { s16x4 a, b; } s; bf16x8 v; } uu;
+  uu.s.a = lo; uu.s.b = hi;
+  return uu.v;
+}
+// (legacy) transposed-image operand: row dh, k-slots (g,e): e<4 -> col 32u+4g+e, e>=4 -> col 32u+16+4g+(e-4)
 __device__ __forceinline__ bf16x8 frag_tr(const bf16_t* tr, int vs, int dh, int u, int g) {
   const bf16x4 lo = *(const bf16x4*)(tr + dh * vs + 32 * u + 4 * g);
   const bf16x4 hi = *(const bf16x4*)(tr + dh * vs + 32 * u + 16 + 4 * g);
@@ -72,19 +92,19 @@ __device__ __forceinline__ f32x4 mfma16(const bf16x8& a, const bf16x8& b, const 
 // ------------------------------------------------------------------------------------------ forward
 // NTP = number of 16-key tiles (even); keys padded to 16*NTP.
 template <int NTP>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o, float* __restrict__ lse,
+__global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o, float* __restrict__ lse,
                                                        int n, int h, float scale) {
-  constexpr int NKP = 16 * NTP, VS = NKP + 4;
+  constexpr int NKP = 16 * NTP;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* k_rm = smem;                                   // [NKP][128 B]
-  bf16_t* v_tr = (bf16_t*)(smem + NKP * ROWB);         // [64][VS]
+  char* k_rm = smem;                                   // [NKP][128 B] swizzled
+  char* v_rm = smem + NKP * ROWB;                      // [NKP][128 B] swizzled (read through the hardware transpose)
   const int bh = blockIdx.x, bi = bh / h, hi = bh - bi * h;
   const int inner = h * DH;
   const int64_t tok_stride = 3 * (int64_t)inner;
   const bf16_t* qbase = qkv + (int64_t)bi * n * tok_stride + hi * DH;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
   stage_head<true, false>(qbase + inner, tok_stride, n, NKP, k_rm, nullptr, 0, tid, blockDim.x);
-  stage_head<false, true>(qbase + 2 * inner, tok_stride, n, NKP, nullptr, v_tr, VS, tid, blockDim.x);
+  stage_head<true, false>(qbase + 2 * inner, tok_stride, n, NKP, v_rm, nullptr, 0, tid, blockDim.x);
   __syncthreads();
 
   const int qi = lane & 15, g = lane >> 4;
@@ -96,41 +116,48 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
     bf16x8 qf[2];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) qf[ks] = *(const bf16x8*)(qbase + (int64_t)qc * tok_stride + (g + 4 * ks) * 8);
-    f32x4 s[NTP];
+    // pass 1: row maxima of the (log2-domain) scores.  S^T tile t: lane holds S[query qi][key 16t + 4g + r].
     float m = -INFINITY;
-#pragma unroll
+#pragma unroll 2
     for (int t = 0; t < NTP; ++t) {
       f32x4 a = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) a = mfma16(frag_rm(k_rm, t * 16 + qi, g + 4 * ks), qf[ks], a);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int key = t * 16 + 4 * g + r;
-        a[r] = key < n ? a[r] * sl2 : -INFINITY;   // log2-domain scores
-        m = fmaxf(m, a[r]);
-      }
-      s[t] = a;
+      for (int r = 0; r < 4; ++r) m = fmaxf(m, (t * 16 + 4 * g + r) < n ? a[r] : -INFINITY);
     }
     m = fmaxf(m, __shfl_xor(m, 16, 64));
     m = fmaxf(m, __shfl_xor(m, 32, 64));
+    m *= sl2;
+    // pass 2: recompute the tile pair, p = 2^(s - m), accumulate the row sum and O^T += V^T P^T (unnormalised)
     float l = 0.f;
+    f32x4 oacc[4];
 #pragma unroll
-    for (int t = 0; t < NTP; ++t)
+    for (int c = 0; c < 4; ++c) oacc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int u = 0; u < NTP / 2; ++u) {
+      f32x4 p[2];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { const float p = exp2f(s[t][r] - m); s[t][r] = p; l += p; }
+      for (int tt = 0; tt < 2; ++tt) {
+        const int t = 2 * u + tt;
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) a = mfma16(frag_rm(k_rm, t * 16 + qi, g + 4 * ks), qf[ks], a);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float e = (t * 16 + 4 * g + r) < n ? fast_exp2(a[r] * sl2 - m) : 0.f;
+          p[tt][r] = e;
+          l += e;
+        }
+      }
+      const bf16x8 pf = pack8(p[0], p[1]);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) oacc[c] = mfma16(frag_trr(v_rm, c, u, lane), pf, oacc[c]);
+    }
     l += __shfl_xor(l, 16, 64);
     l += __shfl_xor(l, 32, 64);
     const float inv_l = 1.0f / l;
     if (g == 0 && q < n) lse[(int64_t)bh * n + q] = (m + log2f(l)) * 0.69314718055994530942f;  // natural-log LSE of scaled scores
-    f32x4 oacc[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) oacc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int u = 0; u < NTP / 2; ++u) {
-      const bf16x8 pf = pack8(s[2 * u], s[2 * u + 1]);
-#pragma unroll
-      for (int c = 0; c < 4; ++c) oacc[c] = mfma16(frag_tr(v_tr, VS, 16 * c + qi, u, g), pf, oacc[c]);
-    }
     if (q < n) {
       bf16_t* op = o + ((int64_t)bi * n + q) * inner + hi * DH;
 #pragma unroll
@@ -146,20 +173,19 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
 
 // ------------------------------------------------------------------------------------------ backward: dQ (+ row sums D)
 template <int NTP>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
+__global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
                                                           const bf16_t* __restrict__ d_o, const float* __restrict__ lse,
                                                           float* __restrict__ dsum, bf16_t* __restrict__ dqkv, int n, int h, float scale) {
-  constexpr int NKP = 16 * NTP, VS = NKP + 4;
+  constexpr int NKP = 16 * NTP;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* k_rm = smem;
   char* v_rm = smem + NKP * ROWB;
-  bf16_t* k_tr = (bf16_t*)(smem + 2 * NKP * ROWB);
   const int bh = blockIdx.x, bi = bh / h, hi = bh - bi * h;
   const int inner = h * DH;
   const int64_t tok_stride = 3 * (int64_t)inner;
   const bf16_t* qbase = qkv + (int64_t)bi * n * tok_stride + hi * DH;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
-  stage_head<true, true>(qbase + inner, tok_stride, n, NKP, k_rm, k_tr, VS, tid, blockDim.x);
+  stage_head<true, false>(qbase + inner, tok_stride, n, NKP, k_rm, nullptr, 0, tid, blockDim.x);
   stage_head<true, false>(qbase + 2 * inner, tok_stride, n, NKP, v_rm, nullptr, 0, tid, blockDim.x);
   __syncthreads();
 
@@ -202,13 +228,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int key = t * 16 + 4 * g + r;
-          const float p = (key < n && q < n) ? exp2f(sa[r] * sl2 - l2) : 0.f;
+          const float p = (key < n && q < n) ? fast_exp2(sa[r] * sl2 - l2) : 0.f;
           ds[tt][r] = p * (dp[r] - dpart) * scale;
         }
       }
       const bf16x8 dsf = pack8(ds[0], ds[1]);
 #pragma unroll
-      for (int c = 0; c < 4; ++c) dq[c] = mfma16(frag_tr(k_tr, VS, 16 * c + qi, u, g), dsf, dq[c]);
+      for (int c = 0; c < 4; ++c) dq[c] = mfma16(frag_trr(k_rm, c, u, lane), dsf, dq[c]);
     }
     if (q < n) {
       bf16_t* dp_out = dqkv + ((int64_t)bi * n + q) * tok_stride + hi * DH;
@@ -225,24 +251,22 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
 
 // ------------------------------------------------------------------------------------------ backward: dK, dV
 template <int NTP>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ d_o,
+__global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ d_o,
                                                            const float* __restrict__ lse, const float* __restrict__ dsum,
                                                            bf16_t* __restrict__ dqkv, int n, int h, float scale) {
-  constexpr int NQP = 16 * NTP, VS = NQP + 4;
+  constexpr int NQP = 16 * NTP;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* q_rm = smem;
   char* do_rm = smem + NQP * ROWB;
-  bf16_t* q_tr = (bf16_t*)(smem + 2 * NQP * ROWB);
-  bf16_t* do_tr = q_tr + DH * VS;
-  float* lse_s = (float*)(do_tr + DH * VS);   // [NQP] (log2 domain)
+  float* lse_s = (float*)(smem + 2 * NQP * ROWB);   // [NQP] (log2 domain)
   float* d_s = lse_s + NQP;                   // [NQP]
   const int bh = blockIdx.x, bi = bh / h, hi = bh - bi * h;
   const int inner = h * DH;
   const int64_t tok_stride = 3 * (int64_t)inner;
   const bf16_t* qbase = qkv + (int64_t)bi * n * tok_stride + hi * DH;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
-  stage_head<true, true>(qbase, tok_stride, n, NQP, q_rm, q_tr, VS, tid, blockDim.x);
-  stage_head<true, true>(d_o + (int64_t)bi * n * inner + hi * DH, inner, n, NQP, do_rm, do_tr, VS, tid, blockDim.x);
+  stage_head<true, false>(qbase, tok_stride, n, NQP, q_rm, nullptr, 0, tid, blockDim.x);
+  stage_head<true, false>(d_o + (int64_t)bi * n * inner + hi * DH, inner, n, NQP, do_rm, nullptr, 0, tid, blockDim.x);
   for (int i = tid; i < NQP; i += blockDim.x) {
     lse_s[i] = i < n ? lse[(int64_t)bh * n + i] * 1.44269504088896340736f : 0.f;
     d_s[i] = i < n ? dsum[(int64_t)bh * n + i] : 0.f;
@@ -279,7 +303,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int qq = t * 16 + 4 * g + r;
-          const float p = (qq < n && key < n) ? exp2f(sa[r] * sl2 - lse_s[qq]) : 0.f;
+          const float p = (qq < n && key < n) ? fast_exp2(sa[r] * sl2 - lse_s[qq]) : 0.f;
           pp[tt][r] = p;
           ds[tt][r] = p * (dp[r] - d_s[qq]) * scale;
         }
@@ -287,8 +311,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
       const bf16x8 pf = pack8(pp[0], pp[1]), dsf = pack8(ds[0], ds[1]);
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        dv[c] = mfma16(frag_tr(do_tr, VS, 16 * c + ki, u, g), pf, dv[c]);
-        dk[c] = mfma16(frag_tr(q_tr, VS, 16 * c + ki, u, g), dsf, dk[c]);
+        dv[c] = mfma16(frag_trr(do_rm, c, u, lane), pf, dv[c]);
+        dk[c] = mfma16(frag_trr(q_rm, c, u, lane), dsf, dk[c]);
       }
     }
     if (key < n) {
@@ -327,8 +351,8 @@ bool attn_bf16_supported(int n, int dim_head) { return dim_head == DH && n >= 1 
 void launch_attn_bf16_fwd(const bf16_t* qkv, bf16_t* o, float* lse, int b, int n, int h, float scale, hipStream_t s) {
   const int ntp = pick_ntp(n);
   const int nkp = 16 * ntp;
-  const int smem = nkp * ROWB + DH * (nkp + 4) * 2;
-#define CALL(NTP) { set_smem(attn_fwd_kernel<NTP>, smem); hipLaunchKernelGGL(attn_fwd_kernel<NTP>, dim3(b * h), dim3(256), smem, s, qkv, o, lse, n, h, scale); }
+  const int smem = 2 * nkp * ROWB;
+#define CALL(NTP) { set_smem(attn_fwd_kernel<NTP>, smem); hipLaunchKernelGGL(attn_fwd_kernel<NTP>, dim3(b * h), dim3(ATT_THREADS), smem, s, qkv, o, lse, n, h, scale); }
   VITX_NTP_DISPATCH(ntp, CALL);
 #undef CALL
 }
@@ -337,14 +361,14 @@ void launch_attn_bf16_bwd(const bf16_t* qkv, const bf16_t* o, const bf16_t* d_o,
                           int n, int h, float scale, hipStream_t s) {
   const int ntp = pick_ntp(n);
   const int np = 16 * ntp;
-  const int smem_dq = 2 * np * ROWB + DH * (np + 4) * 2;
-  const int smem_dkv = 2 * np * ROWB + 2 * DH * (np + 4) * 2 + 2 * np * 4;
+  const int smem_dq = 2 * np * ROWB;
+  const int smem_dkv = 2 * np * ROWB + 2 * np * 4;
 #define CALL(NTP)                                                                                                                  \
   {                                                                                                                                \
     set_smem(attn_bwd_dq_kernel<NTP>, smem_dq);                                                                                    \
     set_smem(attn_bwd_dkv_kernel<NTP>, smem_dkv);                                                                                  \
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<NTP>, dim3(b * h), dim3(256), smem_dq, s, qkv, o, d_o, lse, dsum_ws, dqkv, n, h, scale);   \
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel<NTP>, dim3(b * h), dim3(256), smem_dkv, s, qkv, d_o, lse, dsum_ws, dqkv, n, h, scale);    \
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<NTP>, dim3(b * h), dim3(ATT_THREADS), smem_dq, s, qkv, o, d_o, lse, dsum_ws, dqkv, n, h, scale);   \
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<NTP>, dim3(b * h), dim3(ATT_THREADS), smem_dkv, s, qkv, d_o, lse, dsum_ws, dqkv, n, h, scale);    \
   }
   VITX_NTP_DISPATCH(ntp, CALL);
 #undef CALL

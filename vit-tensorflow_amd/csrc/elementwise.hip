@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
   }
 }
 
-constexpr int LNB_BLOCKS = 512;
+constexpr int LNB_BLOCKS = 1024;
 
 // dx = r * (g*gamma - mean_d(g*gamma) - xhat * mean_d(g*gamma*xhat));  dgamma += g*xhat; dbeta += g
 template <typename TD, typename TL, int VPL>
@@ -113,15 +113,16 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TD* __restrict
                                                             int64_t ldx, const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             const float* __restrict__ gamma, const float* g_in, int64_t ldgi,
                                                             float* g_out, int64_t ldgo, TL* g_lp, int64_t ldglp,
-                                                            float* __restrict__ partial, int rows, int d) {
+                                                            float* __restrict__ partial, int rows, int d, int want_gsum) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int wib = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int nw = blockDim.x >> 6;
-  float4 ag[VPL], ab[VPL], gm[VPL];
+  float4 ag[VPL], ab[VPL], gm[VPL], as[VPL];   // as: column sums of g_in (= bias gradient of the branch's last Dense)
 #pragma unroll
   for (int i = 0; i < VPL; ++i) {
     ag[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     ab[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    as[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     const int c = (lane + 64 * i) * 4;
     gm[i] = (c < d) ? *(const float4*)(gamma + c) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
@@ -156,6 +157,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TD* __restrict
                                 rs * (gg[i].z - s1 - xh[i].z * s2), rs * (gg[i].w - s1 - xh[i].w * s2));
         if (g_in) {
           const float4 gi = *(const float4*)(g_in + (int64_t)row * ldgi + c);
+          as[i].x += gi.x; as[i].y += gi.y; as[i].z += gi.z; as[i].w += gi.w;
           dx.x += gi.x; dx.y += gi.y; dx.z += gi.z; dx.w += gi.w;
         }
         *(float4*)(g_out + (int64_t)row * ldgo + c) = dx;
@@ -163,19 +165,20 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TD* __restrict
       }
     }
   }
-  // fixed-order combine of the block's waves: dgamma then dbeta, through LDS [nw][d]
-  for (int pass = 0; pass < 2; ++pass) {
+  // fixed-order combine of the block's waves: dgamma, dbeta (, column sums of g_in), through LDS [nw][d]
+  const int npass = want_gsum ? 3 : 2;
+  for (int pass = 0; pass < npass; ++pass) {
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
       const int c = (lane + 64 * i) * 4;
-      if (c < d) *(float4*)(lds + (int64_t)wib * d + c) = pass == 0 ? ag[i] : ab[i];
+      if (c < d) *(float4*)(lds + (int64_t)wib * d + c) = pass == 0 ? ag[i] : (pass == 1 ? ab[i] : as[i]);
     }
     __syncthreads();
     for (int c = threadIdx.x; c < d; c += blockDim.x) {
       float a = 0.f;
       for (int w = 0; w < nw; ++w) a += lds[(int64_t)w * d + c];
-      partial[((int64_t)blockIdx.x * 2 + pass) * d + c] = a;
+      partial[((int64_t)blockIdx.x * 3 + pass) * d + c] = a;
     }
   }
 }
@@ -195,34 +198,47 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
 }
 
 // ------------------------------------------------------------------ column sums (Dense bias gradients: db = sum_rows dY)
-constexpr int CS_CHUNKS = 64;
+constexpr int CS_CHUNKS = 128;
+// block = 4 waves; a wave owns 64 x 8 = 512 consecutive columns of its rows (16-B bf16 / 2 x 16-B fp32 loads); the 4 waves
+// of a block take rows r0+w, r0+w+4, ... of the block's row chunk; 4 rows are in flight per wave.
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, int64_t ld, int rows, int cols, float* __restrict__ partial) {
-  __shared__ float4 red[4][64];
+  __shared__ float red[4][512];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int c = (blockIdx.x * 64 + lane) * 4;
+  const int c = blockIdx.x * 512 + lane * 8;
   const int rows_per = (rows + gridDim.y - 1) / gridDim.y;
   const int r0 = blockIdx.y * rows_per, r1 = min(rows, r0 + rows_per);
-  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (c < cols) {
-    for (int r = r0 + w; r < r1; r += 4) {
-      if (c + 3 < cols) {
-        const float4 v = ld4<T>(x + (int64_t)r * ld + c);
-        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
-      } else {
-        float* ap = (float*)&a;
-        for (int i = 0; i < 4 && c + i < cols; ++i) ap[i] += ldf<T>(x + (int64_t)r * ld + c + i);
+  float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (c + 7 < cols) {
+    int r = r0 + w;
+    for (; r + 12 < r1; r += 16) {
+      float4 v[4][2];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const T* p = x + (int64_t)(r + 4 * u) * ld + c;
+        v[u][0] = ld4<T>(p); v[u][1] = ld4<T>(p + 4);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        a[0] += v[u][0].x; a[1] += v[u][0].y; a[2] += v[u][0].z; a[3] += v[u][0].w;
+        a[4] += v[u][1].x; a[5] += v[u][1].y; a[6] += v[u][1].z; a[7] += v[u][1].w;
       }
     }
+    for (; r < r1; r += 4) {
+      const T* p = x + (int64_t)r * ld + c;
+      const float4 v0 = ld4<T>(p), v1 = ld4<T>(p + 4);
+      a[0] += v0.x; a[1] += v0.y; a[2] += v0.z; a[3] += v0.w; a[4] += v1.x; a[5] += v1.y; a[6] += v1.z; a[7] += v1.w;
+    }
+  } else if (c < cols) {
+    for (int r = r0 + w; r < r1; r += 4)
+      for (int i = 0; i < 8 && c + i < cols; ++i) a[i] += ldf<T>(x + (int64_t)r * ld + c + i);
   }
-  red[w][lane] = a;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) red[w][lane * 8 + i] = a[i];
   __syncthreads();
-  if (w == 0 && c < cols) {
-    float4 t = red[0][lane];
-    for (int k = 1; k < 4; ++k) { t.x += red[k][lane].x; t.y += red[k][lane].y; t.z += red[k][lane].z; t.w += red[k][lane].w; }
-    float* o = partial + (int64_t)blockIdx.y * cols + c;
-    const float tv[4] = {t.x, t.y, t.z, t.w};
-    for (int i = 0; i < 4 && c + i < cols; ++i) o[i] = tv[i];
+  for (int i = threadIdx.x; i < 512; i += 256) {
+    const int cc = blockIdx.x * 512 + i;
+    if (cc < cols) partial[(int64_t)blockIdx.y * cols + cc] = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
   }
 }
 
@@ -456,25 +472,27 @@ void launch_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, const
 #undef CALL
 }
 
-int64_t layernorm_bwd_ws_elems(int d) { return (int64_t)LNB_BLOCKS * 2 * d; }
+int64_t layernorm_bwd_ws_elems(int d) { return (int64_t)LNB_BLOCKS * 3 * d; }
 
 void launch_layernorm_bwd(const void* dy, int dy_bf16, int64_t lddy, const float* x, int64_t ldx, const float* mean, const float* rstd,
                           const float* gamma, const float* g_in, int64_t ldgi, float* g_out, int64_t ldgo, void* g_lp, int64_t ldglp,
-                          float* partial_ws, float* dgamma, float* dbeta, int rows, int d, hipStream_t s) {
+                          float* partial_ws, float* dgamma, float* dbeta, float* gsum, int rows, int d, hipStream_t s) {
   if (rows == 0) return;
-  const int nblk = (int)std::min<int64_t>(LNB_BLOCKS, ceil_div(rows, 4));
+  const int want_gsum = (gsum != nullptr && g_in != nullptr) ? 1 : 0;
+  const int nblk = (int)std::min<int64_t>(LNB_BLOCKS, ceil_div(rows, 8));
   dim3 grid(nblk), block(256);
   const size_t shm = (size_t)4 * d * sizeof(float);
 #define CALL(V)                                                                                                                  \
   if (dy_bf16) hipLaunchKernelGGL((layernorm_bwd_kernel<bf16_t, bf16_t, V>), grid, block, shm, s, (const bf16_t*)dy, lddy, x, ldx, \
-                                  mean, rstd, gamma, g_in, ldgi, g_out, ldgo, (bf16_t*)g_lp, ldglp, partial_ws, rows, d);          \
+                                  mean, rstd, gamma, g_in, ldgi, g_out, ldgo, (bf16_t*)g_lp, ldglp, partial_ws, rows, d, want_gsum); \
   else hipLaunchKernelGGL((layernorm_bwd_kernel<float, float, V>), grid, block, shm, s, (const float*)dy, lddy, x, ldx, mean, rstd, \
-                          gamma, g_in, ldgi, g_out, ldgo, (float*)g_lp, ldglp, partial_ws, rows, d)
+                          gamma, g_in, ldgi, g_out, ldgo, (float*)g_lp, ldglp, partial_ws, rows, d, want_gsum)
   VITX_VPL_DISPATCH(d, CALL);
 #undef CALL
-  // partial layout [blk][2][d]: dgamma = sum_blk partial[blk][0], dbeta = sum_blk partial[blk][1]
-  launch_reduce_partials(partial_ws, nblk, (int64_t)2 * d, d, dgamma, 1.0f, s);
-  launch_reduce_partials(partial_ws + d, nblk, (int64_t)2 * d, d, dbeta, 1.0f, s);
+  // partial layout [blk][3][d]: dgamma = sum_blk partial[blk][0], dbeta = sum_blk partial[blk][1]
+  launch_reduce_partials(partial_ws, nblk, (int64_t)3 * d, d, dgamma, 1.0f, s);
+  launch_reduce_partials(partial_ws + d, nblk, (int64_t)3 * d, d, dbeta, 1.0f, s);
+  if (want_gsum) launch_reduce_partials(partial_ws + 2 * d, nblk, (int64_t)3 * d, d, gsum, 1.0f, s);
 }
 
 void launch_reduce_partials(const float* partial, int nparts, int64_t stride, int64_t n, float* out, float alpha, hipStream_t s) {
@@ -484,8 +502,10 @@ void launch_reduce_partials(const float* partial, int nparts, int64_t stride, in
 
 int64_t colsum_ws_elems(int cols) { return (int64_t)CS_CHUNKS * cols; }
 void launch_colsum(const void* x, int is_bf16, int64_t ld, int rows, int cols, float* partial_ws, float* out, hipStream_t s) {
-  const int chunks = (int)std::max<int64_t>(1, std::min<int64_t>(CS_CHUNKS, ceil_div(rows, 16)));
-  dim3 grid((unsigned)ceil_div(cols, 256), chunks), block(256);
+  // ~2048 blocks when the matrix is large; ld and the base pointer are 16-B aligned for every internal buffer
+  const int cblocks = (int)ceil_div(cols, 512);
+  const int chunks = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)CS_CHUNKS, ceil_div(rows, 16), ceil_div(2048, cblocks)}));
+  dim3 grid((unsigned)cblocks, chunks), block(256);
   if (is_bf16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)x, ld, rows, cols, partial_ws);
   else hipLaunchKernelGGL(colsum_kernel<float>, grid, block, 0, s, (const float*)x, ld, rows, cols, partial_ws);
   launch_reduce_partials(partial_ws, chunks, cols, cols, out, 1.0f, s);

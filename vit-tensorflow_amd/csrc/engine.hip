@@ -137,7 +137,7 @@ static void finalize_epi(EpiParams& ep) {
 
 static int dalloc(vitx_engine* e, void** p, size_t bytes, bool t_buffer, std::string& err) {
   if (bytes == 0) bytes = 16;
-  bytes = (size_t)round_up((int64_t)bytes, 256);
+  bytes = (size_t)round_up((int64_t)bytes, 256) + 8192;   // slack: GEMM tiles may read (never use) a little past a buffer's last row
   HIPCHK(hipMalloc(p, bytes));
   HIPCHK(hipMemsetAsync(*p, 0, bytes, e->stream));
   e->allocs.push_back(*p);
@@ -249,20 +249,26 @@ static void dense_wgrad(vitx_engine* e, const void* X, int64_t ldx, const void* 
   const double flops = 2.0 * rows * (double)w.out * w.in;
   const double bytes = (double)rows * w.in * e->esz + (double)rows * w.out * e->esz + (double)w.in * w.out * 4;
   if (e->bf16 && !e->force_generic_gemm) {
-    const int kext = (int)round_up(rows, 64);
-    {
+    const int kext = (int)round_up(rows, 64);   // rows >= `rows` of both operands are zero (row-padding invariant)
+    Bf16GemmArgs g;
+    g.M = w.in; g.N = w.out; g.K = kext; g.kernel = e->gemm_kernel;
+    int tm, tn;
+    if (e->wgrad_via_transpose) {
       Prof pr(e, "transpose_bf16", 0, 2.0 * ((double)kext * w.in + (double)kext * w.out) * 2);
       launch_transpose_bf16((const bf16_t*)X, ldx, kext, w.in, e->xt, kext, e->stream);
       launch_transpose_bf16((const bf16_t*)dY, ldy, kext, w.out, e->dyt, kext, e->stream);
+      g.A = e->xt; g.lda = kext;
+      g.B = e->dyt; g.ldb = kext;
+      tm = gemm_bf16_tile_m(g.kernel, g.M, g.N); tn = gemm_bf16_tile_n(g.kernel, g.M, g.N);
+    } else {
+      g.A = (const bf16_t*)X; g.lda = ldx;
+      g.B = (const bf16_t*)dY; g.ldb = ldy;
+      tm = tn = gemm_bf16_tn_tile(g.kernel, g.M, g.N);
     }
-    Bf16GemmArgs g;
-    g.A = e->xt; g.lda = kext;
-    g.B = e->dyt; g.ldb = kext;
-    g.M = w.in; g.N = w.out; g.K = kext; g.kernel = e->gemm_kernel;
-    const int tm = gemm_bf16_tile_m(g.kernel, g.M, g.N), tn = gemm_bf16_tile_n(g.kernel, g.M, g.N);
     const int64_t tiles = ceil_div(w.in, tm) * ceil_div(w.out, tn);
     const int nk = kext / 64;
-    int split = (int)std::max<int64_t>(1, std::min<int64_t>(ceil_div(nk, 4), ceil_div(512, tiles)));
+    // one wave of workgroups (these kernels run 1 WG/CU): split-K so that tiles*split ~ 256, fewer slices = less partial traffic
+    int split = (int)std::max<int64_t>(1, std::min<int64_t>(ceil_div(nk, 4), std::max<int64_t>(1, 256 / tiles)));
     while (split > 1 && (int64_t)split * w.in * w.out > e->partial_elems) --split;
     g.split_k = split;
     const int slices = gemm_bf16_num_slices(kext, split);
@@ -271,8 +277,9 @@ static void dense_wgrad(vitx_engine* e, const void* X, int64_t ldx, const void* 
     ep.M = w.in; ep.N = w.out;
     finalize_epi(ep);
     {
-      Prof pr(e, "gemm_bf16_mfma", flops, bytes);
-      launch_gemm_bf16(g, ep, EPI_PARTIAL, e->stream);
+      Prof pr(e, e->wgrad_via_transpose ? "gemm_bf16_mfma" : "gemm_bf16_mfma_tn", flops, bytes);
+      if (e->wgrad_via_transpose) launch_gemm_bf16(g, ep, EPI_PARTIAL, e->stream);
+      else launch_gemm_bf16_tn(g, ep, e->stream);
     }
     Prof pr(e, "reduce_partials", 0, (double)(slices + 1) * w.in * w.out * 4);
     launch_reduce_partials(e->partial_ws, slices, (int64_t)w.in * w.out, (int64_t)w.in * w.out, dW, 1.0f, e->stream);
@@ -535,7 +542,8 @@ static int block_backward(vitx_engine* e, Stage& st, int si, int l, int b, int n
     }
   }
   dense_wgrad(e, ba.act, m, dbranch, d, rows, bp.fc2);
-  if (dbranch == e->d_br) bias_grad(e, e->d_br, T, d, rows, bp.fc2); else bias_grad(e, e->g, 0, d, rows, bp.fc2);
+  const bool fc2_bias_in_ln = dbranch != e->d_br;   // db_fc2 = column sums of g: fused into the LayerNorm backward pass below
+  if (!fc2_bias_in_ln) bias_grad(e, e->d_br, T, d, rows, bp.fc2);
   {
     EpiParams ep; ep.out = e->d_y; ep.ldo = d;
     dense_dgrad(e, e->d_h, m, rows, bp.fc1, EPI_STORE, ep);
@@ -545,7 +553,7 @@ static int block_backward(vitx_engine* e, Stage& st, int si, int l, int b, int n
   {
     Prof pr(e, "layernorm_bwd", 0, lnb);
     launch_layernorm_bwd(e->d_y, T, d, ba.x_mid, d, ba.mean2, ba.rstd2, e->params + bp.ln2_g, e->g, d, e->g, d, T ? e->g_lp : nullptr, d,
-                         e->red_ws, e->grads + bp.ln2_g, e->grads + bp.ln2_b, rows, d, e->stream);
+                         e->red_ws, e->grads + bp.ln2_g, e->grads + bp.ln2_b, fc2_bias_in_ln ? e->grads + bp.fc2.b : nullptr, rows, d, e->stream);
   }
 
   // ---- attention branch: x_mid = x_in + scale * to_out(attn(LN(x_in)))
@@ -557,12 +565,14 @@ static int block_backward(vitx_engine* e, Stage& st, int si, int l, int b, int n
                        e->stream);
     dbranch = e->d_br;
   }
+  bool out_bias_in_ln = false;
   const void* d_o = dbranch;   // when to_out is the identity (vit.py:53) the branch gradient IS d(attn_out)
   if (bp.has_out) {
     EpiParams ep; ep.out = e->d_o; ep.ldo = inner;
     dense_dgrad(e, dbranch, d, rows, bp.out, EPI_STORE, ep);
     dense_wgrad(e, ba.o, inner, dbranch, d, rows, bp.out);
-    if (dbranch == e->d_br) bias_grad(e, e->d_br, T, d, rows, bp.out); else bias_grad(e, e->g, 0, d, rows, bp.out);
+    out_bias_in_ln = dbranch != e->d_br;
+    if (!out_bias_in_ln) bias_grad(e, e->d_br, T, d, rows, bp.out);
     d_o = e->d_o;
   }
   AttnView av;
@@ -621,7 +631,7 @@ static int block_backward(vitx_engine* e, Stage& st, int si, int l, int b, int n
   {
     Prof pr(e, "layernorm_bwd", 0, lnb);
     launch_layernorm_bwd(e->d_y, T, d, ba.x_in, d, ba.mean1, ba.rstd1, e->params + bp.ln1_g, e->g, d, e->g, d, T ? e->g_lp : nullptr, d,
-                         e->red_ws, e->grads + bp.ln1_g, e->grads + bp.ln1_b, rows, d, e->stream);
+                         e->red_ws, e->grads + bp.ln1_g, e->grads + bp.ln1_b, out_bias_in_ln ? e->grads + bp.out.b : nullptr, rows, d, e->stream);
   }
   if (e->grad_cb) e->grad_cb(e->grad_cb_user, bp.p_begin, bp.p_end - bp.p_begin);
   return VITX_OK;
@@ -662,6 +672,7 @@ int engine_create(const vitx_config& cfg, vitx_engine** out, std::string& err) {
   e->force_generic_gemm = env_flag("VITX_GENERIC_GEMM");
   e->force_generic_attn = env_flag("VITX_GENERIC_ATTN");
   if (const char* k = getenv("VITX_GEMM_KERNEL")) e->gemm_kernel = atoi(k);
+  e->wgrad_via_transpose = env_flag("VITX_WGRAD_TRANSPOSE");
 
   HIPCHK(hipSetDevice(c.device_id));
   HIPCHK(hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking));
@@ -784,8 +795,10 @@ int engine_create(const vitx_config& cfg, vitx_engine** out, std::string& err) {
   const int64_t maxfeat = std::max<int64_t>({(int64_t)d, 3LL * inner, (int64_t)m, (int64_t)e->pd_k, (int64_t)e->nc_k});
   if (e->bf16) {
     e->t_rows = round_up(maxfeat, 256);
-    DALLOC(e->xt, (size_t)e->t_rows * rmax * 2, false);
-    DALLOC(e->dyt, (size_t)e->t_rows * rmax * 2, false);
+    if (e->wgrad_via_transpose) {
+      DALLOC(e->xt, (size_t)e->t_rows * rmax * 2, false);
+      DALLOC(e->dyt, (size_t)e->t_rows * rmax * 2, false);
+    }
     const int64_t max_w = std::max<int64_t>({(int64_t)d * 3 * inner, (int64_t)d * m, (int64_t)e->pd * d, (int64_t)d * c.num_classes, (int64_t)inner * d});
     e->partial_elems = 512LL * 256 * 256 + 2 * max_w;
     DALLOC(e->partial_ws, (size_t)e->partial_elems * 4, false);
@@ -1001,12 +1014,12 @@ int engine_backward(vitx_engine* e, const float* dlogits_dev, float* dimg_dev, s
     Prof pr(e, "layernorm_bwd", 0, 0);
     if (mean_pool) {
       launch_layernorm_bwd(e->dyh, T, d, e->pooled, d, e->mean_h, e->rstd_h, e->params + e->head_g, nullptr, 0, e->dpooled, d, nullptr, 0,
-                           e->red_ws, e->grads + e->head_g, e->grads + e->head_b, b, d, e->stream);
+                           e->red_ws, e->grads + e->head_g, e->grads + e->head_b, nullptr, b, d, e->stream);
       launch_mean_pool_bwd(e->dpooled, b, head_tok, d, e->g, e->stream);
     } else {
       const int64_t ldrow = (int64_t)head_tok * d;
       launch_layernorm_bwd(e->dyh, T, d, x_last, ldrow, e->mean_h, e->rstd_h, e->params + e->head_g, nullptr, 0, e->g, ldrow, nullptr, 0,
-                           e->red_ws, e->grads + e->head_g, e->grads + e->head_b, b, d, e->stream);
+                           e->red_ws, e->grads + e->head_g, e->grads + e->head_b, nullptr, b, d, e->stream);
     }
     if (T) launch_convert(e->g, d, e->g_lp, 1, d, head_rows, d, d, e->stream);
   }

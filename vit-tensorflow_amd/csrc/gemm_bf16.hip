@@ -144,6 +144,155 @@ void launch_variant(const Bf16GemmArgs& g, const EpiParams& ep, hipStream_t s) {
   hipLaunchKernelGGL(kern, grid, block, SMEM, s, g, ep, tiles_m, tiles_n, per);
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// "TN" GEMM for the weight gradients:  C[i][j] = sum_m A[m][i] * B[m][j]   (dW = X^T dY, reduction over token rows)
+// Both operands are read in their natural row-major layout ([token][feature], feature contiguous); the
+// transposition the MFMA needs (8 consecutive reduction indices per lane) is done by the LDS hardware
+// transpose read ds_read_b64_tr_b16 (gfx950): within a 16-lane group, lanes 4j..4j+3 address 16 consecutive
+// features of token row j, and lane q receives feature q of rows 0..3.  LDS tile = [64 tokens][BM features],
+// filled by global_load_lds (lane-linear image), 32-B granules XOR-swizzled by 2*(token&3) on the DMA source and
+// on the read address so that the 8 (row, granule) segments a half-wave touches fall in 8 distinct bank groups.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bf16x8 tr_frag(const char* p0, const char* p1) {
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p0);
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p1);
+  union { struct { s16x4 a, b; } s; bf16x8 v; } u;
+  u.s.a = lo; u.s.b = hi;
+  return u.v;
+}
+
+template <int BT, int WM, int WN, int MODE>   // BT = tile extent in both feature dimensions
+__global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_tn_kernel(Bf16GemmArgs g, EpiParams ep, int tiles_m, int tiles_n,
+                                                                    int kt_per_split) {
+  constexpr int NW = WM * WN;
+  constexpr int WTM = BT / WM, WTN = BT / WN;
+  constexpr int MT = WTM / 32, NT = WTN / 32;
+  constexpr int ROWB = BT * 2;                 // bytes per token row of a tile
+  constexpr int LPR = ROWB / 16;               // lanes (16-B chunks) per row
+  constexpr int RPI = 64 / LPR;                // token rows per wave DMA instruction
+  constexpr int OP_BYTES = BK * ROWB, STAGE = 2 * OP_BYTES;
+  constexpr int INSTR = BK / RPI / NW;         // DMA instructions per wave per operand per stage
+  static_assert(BK % (RPI * NW) == 0, "token rows must split evenly over the waves");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
+  const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int tile_m = logical / tiles_n, tile_n = logical - tile_m * tiles_n;
+  const int z = blockIdx.y;
+  const int nk_total = g.K / BK;
+  const int kt0 = z * kt_per_split;
+  const int nk = min(kt_per_split, nk_total - kt0);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave - wm * WN;
+
+  // DMA: instruction i of this wave covers token rows (i*NW + wave)*RPI .. +RPI-1; lane -> (row, physical chunk)
+  const bf16_t* Ag = g.A + (int64_t)kt0 * BK * g.lda + (int64_t)tile_m * BT;
+  const bf16_t* Bg = g.B + (int64_t)kt0 * BK * g.ldb + (int64_t)tile_n * BT;
+  int64_t offA[INSTR], offB[INSTR];
+#pragma unroll
+  for (int i = 0; i < INSTR; ++i) {
+    const int row = (i * NW + wave) * RPI + lane / LPR;
+    const int pc = lane % LPR;
+    const int c = ((((pc >> 1) ^ (2 * (row & 3))) << 1) | (pc & 1));   // logical 16-B chunk stored at physical chunk pc
+    offA[i] = (int64_t)row * g.lda + c * 8;
+    offB[i] = (int64_t)row * g.ldb + c * 8;
+  }
+  auto stage = [&](int buf, int kt) {
+    char* base = smem + buf * STAGE;
+#pragma unroll
+    for (int i = 0; i < INSTR; ++i) {
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(Ag + offA[i] + (int64_t)kt * BK * g.lda),
+                                       (lds_void_t*)(base + (i * NW + wave) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(Bg + offB[i] + (int64_t)kt * BK * g.ldb),
+                                       (lds_void_t*)(base + OP_BYTES + (i * NW + wave) * 1024), 16, 0, 0);
+    }
+  };
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // transpose-read addressing: lane = 16*G + q; G&1 -> 16-feature sub-block, G>>1 -> k-half; q>>2 -> token row, q&3 -> 8-B piece
+  const int q = lane & 15, G = lane >> 4, khalf = lane >> 5;
+  const int trow = q >> 2;                                  // token row within the group of 4
+  // byte offset inside a token row of this lane's 8-B piece, before swizzle, for feature block fb (32 features = 64 B)
+  const int piece = (G & 1) * 32 + (q & 3) * 8;             // bytes within the 64-B span of a 32-feature block
+  auto row_addr = [&](int m, int feat_byte) {               // swizzle the 32-B granule index by 2*(m&3)
+    const int gran = (feat_byte >> 5) ^ (2 * (m & 3));
+    return m * ROWB + (gran << 5) + (feat_byte & 31);
+  };
+
+  if (nk > 0) stage(0, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
+    const char* base = smem + (kt & 1) * STAGE;
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+      const int m0 = 16 * ks + 8 * khalf + trow, m1 = m0 + 4;
+      bf16x8 af[MT], bfr[NT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const int fb = (wm * WTM + i * 32) * 2 + piece;
+        af[i] = tr_frag(base + row_addr(m0, fb), base + row_addr(m1, fb));
+      }
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int fb = (wn * WTN + j * 32) * 2 + piece;
+        bfr[j] = tr_frag(base + OP_BYTES + row_addr(m0, fb), base + OP_BYTES + row_addr(m1, fb));
+      }
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+    }
+  }
+
+  const int64_t out_off = (int64_t)z * ep.partial_stride;
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int row = tile_m * BT + wm * WTM + i * 32 + (lane & 31);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int col0 = tile_n * BT + wn * WTN + j * 32 + 4 * khalf;
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq)
+        epilogue_apply4<MODE, bf16_t>(ep, row, col0 + 8 * qq,
+                                      make_float4(acc[i][j][4 * qq], acc[i][j][4 * qq + 1], acc[i][j][4 * qq + 2], acc[i][j][4 * qq + 3]),
+                                      out_off);
+    }
+  }
+}
+
+template <int BT, int WM, int WN>
+void launch_tn_variant(const Bf16GemmArgs& g, const EpiParams& ep, hipStream_t s) {
+  constexpr int SMEM = 2 * 2 * BK * BT * 2;
+  auto kern = gemm_bf16_tn_kernel<BT, WM, WN, EPI_PARTIAL>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    attr_set = true;
+  }
+  const int tiles_m = (int)ceil_div(g.M, BT), tiles_n = (int)ceil_div(g.N, BT);
+  const int nk = g.K / BK;
+  const int split = g.split_k > 1 ? g.split_k : 1;
+  const int per = (int)ceil_div(nk, split);
+  const int zs = (int)ceil_div(nk, per);
+  dim3 grid((unsigned)(tiles_m * tiles_n), (unsigned)zs), block(WM * WN * 64);
+  hipLaunchKernelGGL(kern, grid, block, SMEM, s, g, ep, tiles_m, tiles_n, per);
+}
+
 template <int MODE>
 void launch_mode(const Bf16GemmArgs& g, const EpiParams& ep, hipStream_t s) {
   int k = g.kernel;
@@ -183,4 +332,11 @@ void launch_gemm_bf16(const Bf16GemmArgs& g, const EpiParams& ep, int mode, hipS
     case EPI_PARTIAL: launch_mode<EPI_PARTIAL>(g, ep, s); break;
     default: break;
   }
+}
+
+// C[M=in][N=out] (split-K partials) = A[K=tokens][in]^T * B[K=tokens][out]; kernel: 1 = 128x128 tile, else 256x256
+int gemm_bf16_tn_tile(int kernel, int M, int N) { return (kernel == 1 || (M <= 128 && N <= 128)) ? 128 : 256; }
+void launch_gemm_bf16_tn(const Bf16GemmArgs& g, const EpiParams& ep, hipStream_t s) {
+  if (gemm_bf16_tn_tile(g.kernel, g.M, g.N) == 128) launch_tn_variant<128, 2, 2>(g, ep, s);
+  else launch_tn_variant<256, 2, 4>(g, ep, s);
 }

@@ -28,6 +28,9 @@ void launch_gemm_bf16(const Bf16GemmArgs& g, const EpiParams& ep, int mode, hipS
 int gemm_bf16_tile_m(int kernel, int M, int N);
 int gemm_bf16_tile_n(int kernel, int M, int N);
 int gemm_bf16_num_slices(int K, int split_k);
+// weight-gradient form: C[M,N] partials = A[K,M]^T * B[K,N] (A, B row-major with leading dims lda, ldb; K = token rows, multiple of 64)
+void launch_gemm_bf16_tn(const Bf16GemmArgs& g, const EpiParams& ep, hipStream_t s);
+int gemm_bf16_tn_tile(int kernel, int M, int N);
 
 // ---------------------------------------------------------------- attn_bf16.hip
 // fused multi-head self-attention (vit.py:73-82) on packed qkv [b, n, 3, h, 64] bf16.
@@ -46,8 +49,8 @@ void launch_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, const
 // g_out = (g_in ? g_in : 0) + LN_bwd(dy); optional low-precision copy of g_out; dgamma/dbeta via partial_ws
 void launch_layernorm_bwd(const void* dy, int dy_bf16, int64_t lddy, const float* x, int64_t ldx, const float* mean,
                           const float* rstd, const float* gamma, const float* g_in, int64_t ldgi, float* g_out, int64_t ldgo,
-                          void* g_lp, int64_t ldglp, float* partial_ws, float* dgamma, float* dbeta, int rows, int d,
-                          hipStream_t s);
+                          void* g_lp, int64_t ldglp, float* partial_ws, float* dgamma, float* dbeta, float* gsum, int rows, int d,
+                          hipStream_t s);   // gsum (optional): column sums of g_in
 int64_t layernorm_bwd_ws_elems(int d);
 void launch_colsum(const void* x, int is_bf16, int64_t ld, int rows, int cols, float* partial_ws, float* out, hipStream_t s);
 int64_t colsum_ws_elems(int cols);
