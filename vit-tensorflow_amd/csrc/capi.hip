@@ -426,7 +426,8 @@ int32_t vitx_debug_read(vitx_handle h, const char* which, int32_t layer, float* 
   if (!src) return fail(VITX_ERR_INVALID, "activation not available for this variant");
   const int64_t n = rows * cols;
   if (n_elems) *n_elems = n;
-  if (!out_host || cap < n) return n <= cap ? VITX_OK : fail(VITX_ERR_INVALID, "output buffer too small");
+  if (!out_host) return VITX_OK;   // size query
+  if (cap < n) return fail(VITX_ERR_INVALID, "output buffer too small");
   float* tmp = nullptr;
   CAPI_HIP(hipMalloc((void**)&tmp, (size_t)std::max<int64_t>(n, 1) * 4));
   launch_to_f32(src, is_t && h->bf16, ld, tmp, cols, (int)rows, (int)cols, h->stream);

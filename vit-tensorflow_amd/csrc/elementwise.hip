@@ -105,11 +105,12 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
   }
 }
 
-constexpr int LNB_BLOCKS = 1024;
+constexpr int LNB_BLOCKS = 512;
+constexpr int LNB_THREADS = 512;   // 8 waves per block: 4096 waves in flight with only 512 partial rows to reduce
 
 // dx = r * (g*gamma - mean_d(g*gamma) - xhat * mean_d(g*gamma*xhat));  dgamma += g*xhat; dbeta += g
 template <typename TD, typename TL, int VPL>
-__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TD* __restrict__ dy, int64_t lddy, const float* __restrict__ x,
+__global__ __launch_bounds__(LNB_THREADS) void layernorm_bwd_kernel(const TD* __restrict__ dy, int64_t lddy, const float* __restrict__ x,
                                                             int64_t ldx, const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             const float* __restrict__ gamma, const float* g_in, int64_t ldgi,
                                                             float* g_out, int64_t ldgo, TL* g_lp, int64_t ldglp,
@@ -183,18 +184,31 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TD* __restrict
   }
 }
 
-// out[c] = alpha * sum_p partial[p*stride + c]; 64 columns x 4 part-groups per block, fixed order
+// out[c] = alpha * sum_p partial[p*stride + c]; 64 columns x 4 part-groups per block, fixed order.
+// blockIdx.y selects a chunk of parts (two-level reduction when there are many parts and few columns);
+// columns [0,seg) go to out0, [seg,2seg) to out1, [2seg,3seg) to out2 (seg = n when only out0 is used).
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial, int nparts, int64_t stride, int64_t n,
-                                                              float* __restrict__ out, float alpha) {
+                                                              float* __restrict__ out0, float* __restrict__ out1, float* __restrict__ out2,
+                                                              int64_t seg, int64_t out_chunk_stride, float alpha) {
   __shared__ float red[4][64];
   const int lane = threadIdx.x & 63, pg = threadIdx.x >> 6;
   const int64_t c = (int64_t)blockIdx.x * 64 + lane;
-  float a = 0.f;
-  if (c < n)
-    for (int p = pg; p < nparts; p += 4) a += partial[(int64_t)p * stride + c];
-  red[pg][lane] = a;
+  const int per = (nparts + gridDim.y - 1) / gridDim.y;
+  const int p0 = blockIdx.y * per, p1 = min(nparts, p0 + per);
+  float a0 = 0.f, a1 = 0.f;
+  if (c < n) {
+    int p = p0 + pg;
+    for (; p + 4 < p1; p += 8) { a0 += partial[(int64_t)p * stride + c]; a1 += partial[(int64_t)(p + 4) * stride + c]; }
+    for (; p < p1; p += 4) a0 += partial[(int64_t)p * stride + c];
+  }
+  red[pg][lane] = a0 + a1;
   __syncthreads();
-  if (pg == 0 && c < n) out[c] = alpha * ((red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]));
+  if (pg == 0 && c < n) {
+    const float v = alpha * ((red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]));
+    if (out_chunk_stride) { out0[(int64_t)blockIdx.y * out_chunk_stride + c] = v; return; }
+    const int64_t which = c / seg, cc = c - which * seg;
+    (which == 0 ? out0 : (which == 1 ? out1 : out2))[cc] = v;
+  }
 }
 
 // ------------------------------------------------------------------ column sums (Dense bias gradients: db = sum_rows dY)
@@ -472,7 +486,7 @@ void launch_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, const
 #undef CALL
 }
 
-int64_t layernorm_bwd_ws_elems(int d) { return (int64_t)LNB_BLOCKS * 3 * d; }
+int64_t layernorm_bwd_ws_elems(int d) { return (int64_t)(LNB_BLOCKS + 32) * 3 * d; }
 
 void launch_layernorm_bwd(const void* dy, int dy_bf16, int64_t lddy, const float* x, int64_t ldx, const float* mean, const float* rstd,
                           const float* gamma, const float* g_in, int64_t ldgi, float* g_out, int64_t ldgo, void* g_lp, int64_t ldglp,
@@ -480,8 +494,8 @@ void launch_layernorm_bwd(const void* dy, int dy_bf16, int64_t lddy, const float
   if (rows == 0) return;
   const int want_gsum = (gsum != nullptr && g_in != nullptr) ? 1 : 0;
   const int nblk = (int)std::min<int64_t>(LNB_BLOCKS, ceil_div(rows, 8));
-  dim3 grid(nblk), block(256);
-  const size_t shm = (size_t)4 * d * sizeof(float);
+  dim3 grid(nblk), block(LNB_THREADS);
+  const size_t shm = (size_t)(LNB_THREADS / 64) * d * sizeof(float);
 #define CALL(V)                                                                                                                  \
   if (dy_bf16) hipLaunchKernelGGL((layernorm_bwd_kernel<bf16_t, bf16_t, V>), grid, block, shm, s, (const bf16_t*)dy, lddy, x, ldx, \
                                   mean, rstd, gamma, g_in, ldgi, g_out, ldgo, (bf16_t*)g_lp, ldglp, partial_ws, rows, d, want_gsum); \
@@ -490,17 +504,29 @@ void launch_layernorm_bwd(const void* dy, int dy_bf16, int64_t lddy, const float
   VITX_VPL_DISPATCH(d, CALL);
 #undef CALL
   // partial layout [blk][3][d]: dgamma = sum_blk partial[blk][0], dbeta = sum_blk partial[blk][1]
-  launch_reduce_partials(partial_ws, nblk, (int64_t)3 * d, d, dgamma, 1.0f, s);
-  launch_reduce_partials(partial_ws + d, nblk, (int64_t)3 * d, d, dbeta, 1.0f, s);
-  if (want_gsum) launch_reduce_partials(partial_ws + 2 * d, nblk, (int64_t)3 * d, d, gsum, 1.0f, s);
+  launch_reduce_partials3(partial_ws, nblk, (int64_t)3 * d, d, want_gsum ? 3 : 2, dgamma, dbeta, gsum, partial_ws + (int64_t)LNB_BLOCKS * 3 * d,
+                          1.0f, s);
 }
 
-void launch_reduce_partials(const float* partial, int nparts, int64_t stride, int64_t n, float* out, float alpha, hipStream_t s) {
+// level-2 scratch for the two-level path lives behind the level-1 partials (callers size their workspace with *_ws_elems)
+void launch_reduce_partials3(const float* partial, int nparts, int64_t stride, int64_t seg, int nseg, float* out0, float* out1, float* out2,
+                             float* ws2, float alpha, hipStream_t s) {
+  const int64_t n = seg * nseg;
   if (n == 0) return;
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)ceil_div(n, 64)), dim3(256), 0, s, partial, nparts, stride, n, out, alpha);
+  const unsigned gx = (unsigned)ceil_div(n, 64);
+  if (nparts > 32 && ws2 != nullptr) {
+    const int chunks = (int)std::min<int64_t>(32, ceil_div(nparts, 8));
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(gx, chunks), dim3(256), 0, s, partial, nparts, stride, n, ws2, nullptr, nullptr, seg, n, 1.0f);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(gx, 1), dim3(256), 0, s, ws2, chunks, n, n, out0, out1, out2, seg, (int64_t)0, alpha);
+  } else {
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(gx, 1), dim3(256), 0, s, partial, nparts, stride, n, out0, out1, out2, seg, (int64_t)0, alpha);
+  }
+}
+void launch_reduce_partials(const float* partial, int nparts, int64_t stride, int64_t n, float* out, float alpha, hipStream_t s) {
+  launch_reduce_partials3(partial, nparts, stride, n, 1, out, nullptr, nullptr, nullptr, alpha, s);
 }
 
-int64_t colsum_ws_elems(int cols) { return (int64_t)CS_CHUNKS * cols; }
+int64_t colsum_ws_elems(int cols) { return (int64_t)(CS_CHUNKS + 32) * cols; }
 void launch_colsum(const void* x, int is_bf16, int64_t ld, int rows, int cols, float* partial_ws, float* out, hipStream_t s) {
   // ~2048 blocks when the matrix is large; ld and the base pointer are 16-B aligned for every internal buffer
   const int cblocks = (int)ceil_div(cols, 512);
@@ -508,7 +534,7 @@ void launch_colsum(const void* x, int is_bf16, int64_t ld, int rows, int cols, f
   dim3 grid((unsigned)cblocks, chunks), block(256);
   if (is_bf16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)x, ld, rows, cols, partial_ws);
   else hipLaunchKernelGGL(colsum_kernel<float>, grid, block, 0, s, (const float*)x, ld, rows, cols, partial_ws);
-  launch_reduce_partials(partial_ws, chunks, cols, cols, out, 1.0f, s);
+  launch_reduce_partials3(partial_ws, chunks, cols, cols, 1, out, nullptr, nullptr, partial_ws + (int64_t)CS_CHUNKS * cols, 1.0f, s);
 }
 
 void launch_convert_weight(const float* w, int in, int out, bf16_t* wn, int64_t ldwn, bf16_t* wt, int64_t ldwt, hipStream_t s) {

@@ -55,6 +55,8 @@ int64_t layernorm_bwd_ws_elems(int d);
 void launch_colsum(const void* x, int is_bf16, int64_t ld, int rows, int cols, float* partial_ws, float* out, hipStream_t s);
 int64_t colsum_ws_elems(int cols);
 void launch_reduce_partials(const float* partial, int nparts, int64_t stride, int64_t n, float* out, float alpha, hipStream_t s);
+void launch_reduce_partials3(const float* partial, int nparts, int64_t stride, int64_t seg, int nseg, float* out0, float* out1, float* out2,
+                             float* ws2, float alpha, hipStream_t s);
 void launch_convert_weight(const float* w, int in, int out, bf16_t* wn, int64_t ldwn, bf16_t* wt, int64_t ldwt, hipStream_t s);
 void launch_transpose_bf16(const bf16_t* in, int64_t ldi, int rows, int cols, bf16_t* out, int64_t ldo, hipStream_t s);
 void launch_convert(const float* in, int64_t ldi, void* out, int out_bf16, int64_t ldo, int rows, int cols, int64_t out_cols_zero_to,
