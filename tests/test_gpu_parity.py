@@ -188,7 +188,7 @@ def test_bf16_mfma_gemm_equals_fp32_fma_gemm():
     m = make_engine_model("vit_bf16_small", "bf16", 1)
     m.build((1,))
     avg, err = C.c_float(), C.c_float()
-    for kern in (1, 2, 3):
+    for kern in (1, 2, 3, 1 + 256, 2 + 256, 3 + 256, 2 + 16):   # +256: direct epilogue; +16: phase stagger
         for (M, Nn, K) in [(256, 256, 64), (300, 200, 192), (1000, 768, 768), (197 * 4, 2304, 768)]:
             N.check(N.lib().vitx_bench_gemm(m._handle, M, Nn, K, kern, 0, 1, C.byref(avg), C.byref(err)))
             assert 0 <= err.value <= 2e-3 * np.sqrt(K), (kern, M, Nn, K, err.value)

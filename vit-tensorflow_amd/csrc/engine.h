@@ -112,6 +112,7 @@ struct vitx_engine {
   // env switches
   bool force_generic_gemm = false, force_generic_attn = false, wgrad_via_transpose = true;
   int gemm_kernel = 0;
+  int gemm_stagger = 0;
 
   // profiling
   bool profiling = false;

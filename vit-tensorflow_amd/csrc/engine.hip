@@ -199,6 +199,7 @@ static void dense_fwd(vitx_engine* e, const void* X, int64_t ldx, int rows, cons
     g.A = (const bf16_t*)X; g.lda = ldx;
     g.B = w.wt; g.ldb = w.in_k;
     g.M = rows; g.N = w.out; g.K = w.in_k; g.kernel = e->gemm_kernel;
+    g.stagger = (mode == EPI_BIAS_GELU || mode == EPI_BIAS_RESID || mode == EPI_PATCH) ? e->gemm_stagger : 0;
     ep.zero_pad = 1;
     finalize_epi(ep);
     Prof pr(e, "gemm_bf16_mfma", flops, bytes);
@@ -227,6 +228,7 @@ static void dense_dgrad(vitx_engine* e, const void* dY, int64_t ldy, int rows, c
     g.A = (const bf16_t*)dY; g.lda = ldy;
     g.B = w.wn; g.ldb = w.out_k;
     g.M = rows; g.N = w.in; g.K = w.out_k; g.kernel = e->gemm_kernel;
+    g.stagger = (mode == EPI_GELU_BWD) ? e->gemm_stagger : 0;
     ep.zero_pad = 1;
     finalize_epi(ep);
     Prof pr(e, "gemm_bf16_mfma", flops, bytes);
@@ -673,6 +675,7 @@ int engine_create(const vitx_config& cfg, vitx_engine** out, std::string& err) {
   e->force_generic_attn = env_flag("VITX_GENERIC_ATTN");
   if (const char* k = getenv("VITX_GEMM_KERNEL")) e->gemm_kernel = atoi(k);
   e->wgrad_via_transpose = env_flag("VITX_WGRAD_TRANSPOSE");
+  if (const char* k = getenv("VITX_GEMM_STAGGER")) e->gemm_stagger = atoi(k);
 
   HIPCHK(hipSetDevice(c.device_id));
   HIPCHK(hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking));
@@ -1085,7 +1088,7 @@ int engine_bench_gemm(vitx_engine* e, int M, int N, int K, int kernel, int epilo
   HIPCHK(hipMemsetAsync(R, 0, (size_t)Mp * Np * 4, e->stream));
   HIPCHK(hipMemsetAsync(bias, 0, (size_t)Np * 4, e->stream));
   Bf16GemmArgs g;
-  g.A = A; g.lda = K; g.B = B; g.ldb = K; g.M = M; g.N = N; g.K = K; g.kernel = kernel;
+  g.A = A; g.lda = K; g.B = B; g.ldb = K; g.M = M; g.N = N; g.K = K; g.kernel = kernel & (15 | 256); g.stagger = (kernel >> 4) & 15;
   EpiParams ep;
   ep.M = M; ep.N = N; ep.zero_pad = 1;
   int mode = EPI_STORE_F32;

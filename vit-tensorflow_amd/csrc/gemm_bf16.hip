@@ -19,7 +19,7 @@ typedef const __attribute__((address_space(1))) void gbl_void_t;
 
 constexpr int BK = 64;
 
-template <int BM, int BN, int WM, int WN, int MODE>
+template <int BM, int BN, int WM, int WN, int MODE, bool LDS_EPI>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_kernel(Bf16GemmArgs g, EpiParams ep, int tiles_m, int tiles_n,
                                                                     int kt_per_split) {
   constexpr int NW = WM * WN;
@@ -43,6 +43,14 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_kernel(Bf16GemmArgs
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave - wm * WN;
+
+  // Optional phase stagger: every workgroup runs [K loop (MFMA-bound)] -> [epilogue (HBM-bound)]; launched together
+  // they stay in lockstep and the two resources alternate idling.  Delaying the first wave of workgroups by a quarter
+  // period per CU slot spreads the phases; later workgroups inherit the offset of the CU they land on.
+  if (g.stagger > 0 && bid < 256 && blockIdx.y == 0) {
+    const int ph = (bid >> 3) & 3;
+    for (int i = 0; i < ph * g.stagger; ++i) __builtin_amdgcn_s_sleep(32);
+  }
 
   // ---- per-lane DMA source offsets (elements); LDS destination is wave-uniform base + lane*16
   const bf16_t* Ag = g.A + (int64_t)tile_m * BM * g.lda + (int64_t)kt0 * BK;
@@ -111,25 +119,58 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_kernel(Bf16GemmArgs
 
   // ---- epilogue: lane holds row m = lane&31 and columns 8q + 4*(lane>>5) + {0..3} of each 32x32 tile
   const int64_t out_off = (int64_t)z * ep.partial_stride;
+  if constexpr (LDS_EPI) {
+    // Stage 64 output rows at a time through LDS (fp32, padded rows) and run the fused epilogue on ROW-CONTIGUOUS data:
+    // every wave instruction then reads/writes whole 512-B / 1-KiB row segments (full cache lines) instead of
+    // 32 scattered 16/32-B pieces -- the store phase of these GEMMs is what bounds them (fp32 residual stream, 2x bf16 of fc1).
+    static_assert(MT % 2 == 0, "64-row rounds need an even number of 32-row MFMA blocks per wave");
+    constexpr int SROW = BN + 4;                     // floats; +16 B keeps the 8-lane ds_write_b128 groups conflict-free
+    constexpr int LPRW = BN / 4, RPIW = 64 / LPRW;   // lanes per staged row, rows per wave instruction
+    float* st = (float*)smem;
 #pragma unroll
-  for (int i = 0; i < MT; ++i) {
-    const int row = tile_m * BM + wm * WTM + i * 32 + (lane & 31);
+    for (int R = 0; R < BM / 64; ++R) {
+      const int wm_r = (R * 64) / WTM, i0 = ((R * 64) % WTM) / 32;
+      __syncthreads();
+      if (wm == wm_r) {
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const int col0 = tile_n * BN + wn * WTN + j * 32 + 4 * khalf;
+        for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
-        epilogue_apply4<MODE, bf16_t>(ep, row, col0 + 8 * q,
-                                      make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]),
-                                      out_off);
+          for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              *(float4*)(st + (ii * 32 + (lane & 31)) * SROW + wn * WTN + j * 32 + 8 * q + 4 * khalf) =
+                  make_float4(acc[i0 + ii][j][4 * q], acc[i0 + ii][j][4 * q + 1], acc[i0 + ii][j][4 * q + 2], acc[i0 + ii][j][4 * q + 3]);
+      }
+      __syncthreads();
+      const int col_l = (lane % LPRW) * 4;
+#pragma unroll
+      for (int rr = wave * RPIW + lane / LPRW; rr < 64; rr += NW * RPIW) {
+        const float4 v = *(const float4*)(st + rr * SROW + col_l);
+        epilogue_apply4<MODE, bf16_t>(ep, tile_m * BM + R * 64 + rr, tile_n * BN + col_l, v, out_off);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int row = tile_m * BM + wm * WTM + i * 32 + (lane & 31);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int col0 = tile_n * BN + wn * WTN + j * 32 + 4 * khalf;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          epilogue_apply4<MODE, bf16_t>(ep, row, col0 + 8 * q,
+                                        make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]),
+                                        out_off);
+      }
     }
   }
 }
 
-template <int BM, int BN, int WM, int WN, int MODE>
+template <int BM, int BN, int WM, int WN, int MODE, bool LDS_EPI>
 void launch_variant(const Bf16GemmArgs& g, const EpiParams& ep, hipStream_t s) {
   constexpr int SMEM = 2 * (BM + BN) * BK * 2;
-  auto kern = gemm_bf16_nt_kernel<BM, BN, WM, WN, MODE>;
+  static_assert(64 * (BN + 4) * 4 <= SMEM, "epilogue staging must fit in the pipeline buffers");
+  auto kern = gemm_bf16_nt_kernel<BM, BN, WM, WN, MODE, LDS_EPI>;
   static bool attr_set = false;
   if (!attr_set) {
     hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
@@ -295,20 +336,29 @@ void launch_tn_variant(const Bf16GemmArgs& g, const EpiParams& ep, hipStream_t s
 
 template <int MODE>
 void launch_mode(const Bf16GemmArgs& g, const EpiParams& ep, hipStream_t s) {
-  int k = g.kernel;
+  int k = g.kernel & 15;
+  const bool direct = (g.kernel & 256) != 0;   // bit 8: per-lane direct epilogue instead of the LDS-staged one
   if (k == 0) k = (g.N % 256 == 0 || g.N > 512) ? 2 : 1;
-  if (k == 1) launch_variant<128, 128, 2, 2, MODE>(g, ep, s);
-  else if (k == 3) launch_variant<256, 128, 4, 2, MODE>(g, ep, s);
-  else launch_variant<256, 256, 2, 4, MODE>(g, ep, s);
+  if (direct) {
+    if (k == 1) launch_variant<128, 128, 2, 2, MODE, false>(g, ep, s);
+    else if (k == 3) launch_variant<256, 128, 4, 2, MODE, false>(g, ep, s);
+    else launch_variant<256, 256, 2, 4, MODE, false>(g, ep, s);
+  } else {
+    if (k == 1) launch_variant<128, 128, 2, 2, MODE, true>(g, ep, s);
+    else if (k == 3) launch_variant<256, 128, 4, 2, MODE, true>(g, ep, s);
+    else launch_variant<256, 256, 2, 4, MODE, true>(g, ep, s);
+  }
 }
 
 }  // namespace
 
 int gemm_bf16_tile_m(int kernel, int M, int N) {
+  kernel &= 15;
   if (kernel == 0) kernel = (N % 256 == 0 || N > 512) ? 2 : 1;
   return kernel == 1 ? 128 : 256;
 }
 int gemm_bf16_tile_n(int kernel, int M, int N) {
+  kernel &= 15;
   if (kernel == 0) kernel = (N % 256 == 0 || N > 512) ? 2 : 1;
   return kernel == 2 ? 256 : 128;
 }
@@ -335,7 +385,7 @@ void launch_gemm_bf16(const Bf16GemmArgs& g, const EpiParams& ep, int mode, hipS
 }
 
 // C[M=in][N=out] (split-K partials) = A[K=tokens][in]^T * B[K=tokens][out]; kernel: 1 = 128x128 tile, else 256x256
-int gemm_bf16_tn_tile(int kernel, int M, int N) { return (kernel == 1 || (M <= 128 && N <= 128)) ? 128 : 256; }
+int gemm_bf16_tn_tile(int kernel, int M, int N) { kernel &= 15; return (kernel == 1 || (M <= 128 && N <= 128)) ? 128 : 256; }
 void launch_gemm_bf16_tn(const Bf16GemmArgs& g, const EpiParams& ep, hipStream_t s) {
   if (gemm_bf16_tn_tile(g.kernel, g.M, g.N) == 128) launch_tn_variant<128, 2, 2>(g, ep, s);
   else launch_tn_variant<256, 2, 4>(g, ep, s);

@@ -23,6 +23,7 @@ struct Bf16GemmArgs {
   int M = 0, N = 0, K = 0;   // K multiple of 64; A has >= round_up(M,tile) rows, B >= round_up(N,tile) rows
   int split_k = 1;           // >1: EPI_PARTIAL slices of K/split_k (each a multiple of 64)
   int kernel = 0;            // tile variant: 0 auto, 1 = 128x128 (4 waves), 2 = 256x256 (8 waves), 3 = 256x128
+  int stagger = 0;           // >0: first-wave workgroups start (cu_slot & 3) * stagger * 2048 cycles late (de-phases store-heavy epilogues)
 };
 void launch_gemm_bf16(const Bf16GemmArgs& g, const EpiParams& ep, int mode, hipStream_t s);
 int gemm_bf16_tile_m(int kernel, int M, int N);
