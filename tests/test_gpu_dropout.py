@@ -36,17 +36,21 @@ def test_dropout_is_identity_at_inference_and_active_in_training():
 
 
 def test_dropout_keep_rate_and_scaling():
+    """Post-GELU dropout (vit.py:41): act = gelu(hpre) * m / (1 - rate) with m ~ Bernoulli(1 - rate), on the same forward."""
+    from scipy.special import erf
     rate = 0.4
     m, cfg = _model(dropout=rate, depth=1)
     img = rand_images(cfg, 4)
-    m(img, training=False)
-    act_eval = m.debug_read("act", 0)
     m(img, training=True, seed=5)
-    act_train = m.debug_read("act", 0)
-    kept = act_train != 0
+    hpre = m.debug_read("hpre", 0).astype(np.float64)
+    act = m.debug_read("act", 0)
+    kept = act != 0
     frac = 1.0 - kept.mean()
     assert abs(frac - rate) < 0.03, frac
-    assert np.allclose(act_train[kept], act_eval[kept] / (1 - rate), rtol=1e-5, atol=1e-7)   # inverted dropout
+    gelu = 0.5 * hpre * (1.0 + erf(hpre / np.sqrt(2.0)))
+    assert np.allclose(act[kept], gelu[kept] / (1 - rate), rtol=1e-4, atol=1e-6)   # inverted dropout
+    m(img, training=False)
+    assert np.allclose(m.debug_read("act", 0), 0.5 * (h := m.debug_read("hpre", 0).astype(np.float64)) * (1.0 + erf(h / np.sqrt(2.0))), rtol=1e-4, atol=1e-6)
 
 
 @pytest.mark.parametrize("variant,over", [("vit", dict(dropout=0.25, emb_dropout=0.25)), ("cait", dict(dropout=0.2, emb_dropout=0.1, layer_dropout=0.3))])

@@ -14,6 +14,11 @@ for s in $STAGES; do
     pytest) timeout 1500 python -m pytest tests -m gpu -q -rA --timeout 600 -p no:cacheprovider > $OUT/pytest.log 2>&1; tail -40 $OUT/pytest.log | tee -a $OUT/summary.log ;;
     bench) timeout 600 python bench.py --steps 10 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err; cat $OUT/bench.json | tee -a $OUT/summary.log; tail -5 $OUT/bench.err ;;
     rocprof) (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$OUT/prof -o vitb16 -- python $OLDPWD/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-profile > $OLDPWD/$OUT/rocprof_bench.json 2> $OLDPWD/$OUT/rocprof.err); ls -R $OUT/prof | head -20; find $OUT/prof -name "*kernel_stats*" | head -1 | xargs -r head -40 | tee -a $OUT/summary.log ;;
+    counters) (cd /tmp && rocprofv3 -L > $OLDPWD/$OUT/counters_list.txt 2>&1); grep -c SQ_ $OUT/counters_list.txt ;;
+    pmc_gemm) for pass in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_WAVES" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU" "SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_VMEM SQ_WAIT_INST_ANY SQ_ACTIVE_INST_SCA" "GRBM_GUI_ACTIVE GRBM_COUNT TCC_HIT_sum TCC_MISS_sum" "FETCH_SIZE" "WRITE_SIZE"; do
+        tag=$(echo $pass | tr ' ' '_' | cut -c1-40)
+        (cd /tmp && timeout 300 rocprofv3 --pmc $pass --kernel-trace --output-format csv -d $OLDPWD/$OUT/pmc_$tag -o g -- python $OLDPWD/tools/gemm_bench.py ${PMC_SHAPE:-8192 8192 8192 2 3 3} > $OLDPWD/$OUT/pmc_$tag.log 2>&1); tail -2 $OUT/pmc_$tag.log
+      done ;;
     *) timeout 900 python tools/gpu_diag.py $s > $OUT/$s.log 2>&1; tail -60 $OUT/$s.log ;;
   esac
 done

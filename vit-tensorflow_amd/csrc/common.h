@@ -51,5 +51,28 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
   return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
 }
 
+// Fast variant for the bf16 throughput mode (Abramowitz-Stegun 7.1.26, |erf error| <= 1.5e-7 -- far below bf16 resolution):
+// ~15 VALU ops instead of the ~60 of the branchy library erff, which made the GELU epilogues VALU-bound.
+// Returns Phi(x) = 0.5*(1+erf(x/sqrt2)) and e = exp(-x^2/2).
+__device__ __forceinline__ float gelu_phi_fast(float x, float& e) {
+  const float ax = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752440f, ax, 1.0f));
+  e = __expf(-0.5f * x * x);
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float half_erfc = 0.5f * p * t * e;          // 0.5*(1 - erf(|x|/sqrt2))
+  return x >= 0.f ? 1.0f - half_erfc : half_erfc;
+}
+template <typename T> __device__ __forceinline__ float gelu_t(float x) { return gelu_f(x); }
+template <> __device__ __forceinline__ float gelu_t<bf16_t>(float x) { float e; return x * gelu_phi_fast(x, e); }
+template <typename T> __device__ __forceinline__ float gelu_grad_t(float x) { return gelu_grad_f(x); }
+template <> __device__ __forceinline__ float gelu_grad_t<bf16_t>(float x) {
+  float e;
+  const float phi = gelu_phi_fast(x, e);
+  return fmaf(x * 0.39894228040143267794f, e, phi);
+}
+
 static inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -393,6 +393,9 @@ __device__ __forceinline__ uint32_t hash32(uint32_t x) {
   x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
   return x;
 }
+__global__ void fill_zero_kernel(float4* p, int64_t n16) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n16; e += (int64_t)gridDim.x * blockDim.x) p[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
 __global__ void fill_random_bf16_kernel(bf16_t* p, int64_t n, uint32_t seed, float scale) {
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
     const uint32_t h = hash32((uint32_t)e * 2654435761U + seed);
@@ -580,6 +583,10 @@ void launch_sum_rows(const float* in, int rows, int d, float* out, hipStream_t s
 void launch_ce_grad(const float* logits, int64_t ld, const int32_t* labels, int b, int nc, float inv_batch, float* dlogits, float* loss,
                     hipStream_t s) {
   hipLaunchKernelGGL(ce_grad_kernel, dim3(b), dim3(64), 0, s, logits, ld, labels, b, nc, inv_batch, dlogits, loss);
+}
+void launch_fill_zero(void* p, int64_t bytes, hipStream_t s) {
+  if (bytes <= 0) return;
+  hipLaunchKernelGGL(fill_zero_kernel, dim3(grid_for(bytes / 16)), dim3(256), 0, s, (float4*)p, bytes / 16);
 }
 void launch_fill_random_bf16(bf16_t* p, int64_t n, uint32_t seed, float scale, hipStream_t s) {
   hipLaunchKernelGGL(fill_random_bf16_kernel, dim3(grid_for(n)), dim3(256), 0, s, p, n, seed, scale);

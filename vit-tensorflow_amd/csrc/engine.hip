@@ -981,7 +981,13 @@ int engine_backward(vitx_engine* e, const float* dlogits_dev, float* dimg_dev, s
   const int b = e->last_b, np = e->last_np, ntok = e->last_ntok, d = c.dim, T = e->bf16;
   const int nc = c.num_classes;
   const float drop = e->last_training ? c.dropout : 0.f;
-  HIPCHK(hipMemsetAsync(e->grads, 0, (size_t)e->n_arena * 4, e->stream));
+  {
+    // every gradient tensor is overwritten by its producer; a full clear is only needed when part of the arena will not be
+    // produced this step (pos_embedding rows beyond the image's tokens, blocks skipped by CaiT layer dropout)
+    bool need_clear = ntok < e->ntok_max;
+    for (auto& k : e->layer_kept) for (bool kept : k) need_clear = need_clear || !kept;
+    if (need_clear) { Prof pr(e, "fill_zero", 0, (double)e->n_arena * 4); launch_fill_zero(e->grads, (int64_t)e->n_arena * 4, e->stream); }
+  }
   if (dlogits_dev)
     HIPCHK(hipMemcpy2DAsync(e->dlogits, (size_t)e->nc_k * 4, dlogits_dev, (size_t)nc * 4, (size_t)nc * 4, b, hipMemcpyDeviceToDevice, e->stream));
 
@@ -1012,7 +1018,7 @@ int engine_backward(vitx_engine* e, const float* dlogits_dev, float* dimg_dev, s
   dense_wgrad(e, e->yh, d, dlT, e->nc_k, b, e->head);
   const bool mean_pool = !cait && c.pool == VITX_POOL_MEAN;
   const int head_rows = b * head_tok;
-  HIPCHK(hipMemsetAsync(e->g, 0, (size_t)round_up(head_rows, 256) * d * 4, e->stream));
+  { Prof pr(e, "fill_zero", 0, (double)head_rows * d * 4); launch_fill_zero(e->g, (int64_t)round_up(head_rows, 256) * d * 4, e->stream); }
   {
     Prof pr(e, "layernorm_bwd", 0, 0);
     if (mean_pool) {
@@ -1031,7 +1037,7 @@ int engine_backward(vitx_engine* e, const float* dlogits_dev, float* dimg_dev, s
   int rc;
   if (cait) {
     Stage& s1 = e->stages[1];
-    HIPCHK(hipMemsetAsync(e->g_ctx, 0, (size_t)b * np * d * 4, e->stream));
+    launch_fill_zero(e->g_ctx, (int64_t)b * np * d * 4, e->stream);
     for (int l = s1.depth - 1; l >= 0; --l)
       if (e->layer_kept[1][(size_t)l] && (rc = block_backward(e, s1, 1, l, b, 1, np, drop, e->last_seed, err)) != VITX_OK) return rc;
     {
@@ -1088,7 +1094,7 @@ int engine_bench_gemm(vitx_engine* e, int M, int N, int K, int kernel, int epilo
   HIPCHK(hipMemsetAsync(R, 0, (size_t)Mp * Np * 4, e->stream));
   HIPCHK(hipMemsetAsync(bias, 0, (size_t)Np * 4, e->stream));
   Bf16GemmArgs g;
-  g.A = A; g.lda = K; g.B = B; g.ldb = K; g.M = M; g.N = N; g.K = K; g.kernel = kernel & (15 | 256); g.stagger = (kernel >> 4) & 15;
+  g.A = A; g.lda = K; g.B = B; g.ldb = K; g.M = M; g.N = N; g.K = K; g.kernel = kernel & (15 | 256 | 512); g.stagger = (kernel >> 4) & 15;
   EpiParams ep;
   ep.M = M; ep.N = N; ep.zero_pad = 1;
   int mode = EPI_STORE_F32;

@@ -70,7 +70,7 @@ __device__ __forceinline__ void epilogue_apply4(const EpiParams& p, int row, int
       if (!row_ok) a[i] = 0.f;
       // GELU is evaluated on the value as stored (T-rounded) so that backward's gelu'(hpre) matches
       float hs = (float)(T)a[i];
-      g[i] = row_ok ? gelu_f(hs) : 0.f;
+      g[i] = row_ok ? gelu_t<T>(hs) : 0.f;
     }
     if (full) { st4<T>(o, make_float4(a[0], a[1], a[2], a[3])); st4<T>(o2, make_float4(g[0], g[1], g[2], g[3])); }
     else for (int i = 0; i < 4 && col + i < p.N; ++i) { stf<T>(o + i, a[i]); stf<T>(o2 + i, g[i]); }
@@ -105,12 +105,12 @@ __device__ __forceinline__ void epilogue_apply4(const EpiParams& p, int row, int
     float g[4];
     if (full) {
       float4 hv = ld4<T>(h);
-      g[0] = a[0] * gelu_grad_f(hv.x); g[1] = a[1] * gelu_grad_f(hv.y);
-      g[2] = a[2] * gelu_grad_f(hv.z); g[3] = a[3] * gelu_grad_f(hv.w);
+      g[0] = a[0] * gelu_grad_t<T>(hv.x); g[1] = a[1] * gelu_grad_t<T>(hv.y);
+      g[2] = a[2] * gelu_grad_t<T>(hv.z); g[3] = a[3] * gelu_grad_t<T>(hv.w);
       if (!row_ok) g[0] = g[1] = g[2] = g[3] = 0.f;
       st4<T>(o, make_float4(g[0], g[1], g[2], g[3]));
     } else {
-      for (int i = 0; i < 4 && col + i < p.N; ++i) stf<T>(o + i, row_ok ? a[i] * gelu_grad_f(ldf<T>(h + i)) : 0.f);
+      for (int i = 0; i < 4 && col + i < p.N; ++i) stf<T>(o + i, row_ok ? a[i] * gelu_grad_t<T>(ldf<T>(h + i)) : 0.f);
     }
   }
 }

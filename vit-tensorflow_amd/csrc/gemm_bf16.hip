@@ -337,7 +337,10 @@ void launch_tn_variant(const Bf16GemmArgs& g, const EpiParams& ep, hipStream_t s
 template <int MODE>
 void launch_mode(const Bf16GemmArgs& g, const EpiParams& ep, hipStream_t s) {
   int k = g.kernel & 15;
-  const bool direct = (g.kernel & 256) != 0;   // bit 8: per-lane direct epilogue instead of the LDS-staged one
+  // epilogue form: bit 8 forces the per-lane direct form, bit 9 forces the LDS-staged form; by default bf16-output epilogues
+  // (8-B per-lane pieces) are staged through LDS into whole-row stores, fp32-output ones (16-B pieces) go out directly (measured).
+  const bool bf16_out = (MODE == EPI_STORE || MODE == EPI_BIAS_GELU || MODE == EPI_GELU_BWD);
+  const bool direct = (g.kernel & 256) ? true : ((g.kernel & 512) ? false : !bf16_out);
   if (k == 0) k = (g.N % 256 == 0 || g.N > 512) ? 2 : 1;
   if (direct) {
     if (k == 1) launch_variant<128, 128, 2, 2, MODE, false>(g, ep, s);

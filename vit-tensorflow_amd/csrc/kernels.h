@@ -70,6 +70,7 @@ void launch_extract_rows(const float* g, int b, int ntok, int tok_off, int np, i
 void launch_sum_rows(const float* in, int rows, int d, float* out, hipStream_t s);  // out[c] = sum_r in[r][c] (small)
 void launch_ce_grad(const float* logits, int64_t ld, const int32_t* labels, int b, int nc, float inv_batch, float* dlogits,
                     float* loss, hipStream_t s);
+void launch_fill_zero(void* p, int64_t bytes, hipStream_t s);   // bytes multiple of 16
 void launch_fill_random_bf16(bf16_t* p, int64_t n, uint32_t seed, float scale, hipStream_t s);
 void launch_dropout(void* x, int is_bf16, int64_t n, float rate, uint64_t seed, uint32_t site, hipStream_t s);
 void launch_axpy_resid(const float* resid, const float* f, const float* scale, float* out, void* keep, int keep_bf16, int64_t rows, int d,
