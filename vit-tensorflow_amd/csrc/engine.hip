@@ -587,7 +587,7 @@ static int block_backward(vitx_engine* e, Stage& st, int si, int l, int b, int n
     av.v = boff(ba.kv, inner, esz); av.ldv = 2 * inner; av.vb = av.kb;
     // d_qkv buffer reused as [dq | dkv]: dq [rows, inner], then dkv [b*nk, 2*inner]
     void* dq = e->d_qkv;
-    void* dkv = boff(e->d_qkv, round_up((int64_t)rows, 256) * inner, esz);
+    void* dkv = boff(e->d_qkv, (round_up((int64_t)rows, 256) + 320) * inner, esz);
     ag.dq = dq; ag.lddq = inner; ag.dqb = (int64_t)nq * inner;
     ag.dk = dkv; ag.lddk = 2 * inner; ag.dkb = (int64_t)nk * 2 * inner;
     ag.dv = boff(dkv, inner, esz); ag.lddv = 2 * inner; ag.dvb = ag.dkb;
@@ -683,9 +683,10 @@ int engine_create(const vitx_config& cfg, vitx_engine** out, std::string& err) {
 
   const int d = c.dim, inner = e->inner, m = c.mlp_dim, esz = e->esz;
   const int64_t B = c.max_batch;
-  e->mp = round_up(B * e->ntok_max, 256);
-  e->mpp = round_up(B * e->np_max, 256);
-  e->bp = round_up(B, 256);
+  // row padding: a multiple of 256 plus 320 spare rows (the 320-row GEMM tile may cover up to 319 rows past M)
+  e->mp = round_up(B * e->ntok_max, 256) + 320;
+  e->mpp = round_up(B * e->np_max, 256) + 320;
+  e->bp = round_up(B, 256) + 320;
 
   DALLOC(e->params, (size_t)e->n_arena * 4, false);
   DALLOC(e->grads, (size_t)e->n_arena * 4, false);
@@ -704,7 +705,7 @@ int engine_create(const vitx_config& cfg, vitx_engine** out, std::string& err) {
     st.prefix = prefix; st.depth = depth; st.nq_max = nq; st.nc_max = nc;
     st.bp.resize(depth);
     st.ba.resize(depth);
-    const int64_t rows = round_up(B * nq, 256), crow = round_up(B * (nq + nc), 256);
+    const int64_t rows = round_up(B * nq, 256) + 320, crow = round_up(B * (nq + nc), 256) + 320;
     float* x_prev = nullptr;
     for (int l = 0; l < depth; ++l) {
       BlockParams& bp = st.bp[l];
@@ -770,7 +771,7 @@ int engine_create(const vitx_config& cfg, vitx_engine** out, std::string& err) {
   }
 
   // shared buffers
-  const int64_t crow_max = cait ? round_up(B * (1 + e->np_max), 256) : e->mp;
+  const int64_t crow_max = cait ? round_up(B * (1 + e->np_max), 256) + 320 : e->mp;
   const int64_t rmax = std::max(e->mp, crow_max);
   DALLOC(e->img_dev, (size_t)B * c.image_h * c.image_w * c.channels * 4, false);
   DALLOC(e->patches, (size_t)e->mpp * e->pd_k * esz, true);
@@ -1081,7 +1082,7 @@ int engine_backward(vitx_engine* e, const float* dlogits_dev, float* dimg_dev, s
 int engine_bench_gemm(vitx_engine* e, int M, int N, int K, int kernel, int epilogue, int iters, float* avg_ms, float* max_err,
                       std::string& err) {
   if (K % 64 || M <= 0 || N <= 0) { err = "bench_gemm: K must be a multiple of 64"; return VITX_ERR_INVALID; }
-  const int64_t Mp = round_up(M, 256), Np = round_up(N, 256);
+  const int64_t Mp = round_up(M, 1280), Np = round_up(N, 256);
   bf16_t *A, *B; float *C, *R, *bias; bf16_t* C2;
   HIPCHK(hipMalloc((void**)&A, (size_t)Mp * K * 2));
   HIPCHK(hipMalloc((void**)&B, (size_t)Np * K * 2));
@@ -1089,8 +1090,9 @@ int engine_bench_gemm(vitx_engine* e, int M, int N, int K, int kernel, int epilo
   HIPCHK(hipMalloc((void**)&R, (size_t)Mp * Np * 4));
   HIPCHK(hipMalloc((void**)&C2, (size_t)Mp * Np * 2 * 2));
   HIPCHK(hipMalloc((void**)&bias, (size_t)Np * 4));
-  launch_fill_random_bf16(A, Mp * K, 1u, 1.0f, e->stream);
-  launch_fill_random_bf16(B, Np * K, 2u, 1.0f, e->stream);
+  const float fill_scale = getenv("VITX_BENCH_ZERO") ? 0.0f : 1.0f;   // zero operands: DVFS / power-limit experiment only
+  launch_fill_random_bf16(A, Mp * K, 1u, fill_scale, e->stream);
+  launch_fill_random_bf16(B, Np * K, 2u, fill_scale, e->stream);
   HIPCHK(hipMemsetAsync(R, 0, (size_t)Mp * Np * 4, e->stream));
   HIPCHK(hipMemsetAsync(bias, 0, (size_t)Np * 4, e->stream));
   Bf16GemmArgs g;

@@ -12,6 +12,9 @@
 //     panel) run on the same XCD and hit its private L2.
 #include "kernels.h"
 
+static int g_allow_320 = 1;
+int gemm_bf16_pick(int M, int N);
+
 namespace {
 
 typedef __attribute__((address_space(3))) void lds_void_t;
@@ -19,7 +22,7 @@ typedef const __attribute__((address_space(1))) void gbl_void_t;
 
 constexpr int BK = 64;
 
-template <int BM, int BN, int WM, int WN, int MODE, bool LDS_EPI>
+template <int BM, int BN, int WM, int WN, int MODE, bool LDS_EPI, int SCHED>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_kernel(Bf16GemmArgs g, EpiParams ep, int tiles_m, int tiles_n,
                                                                     int kt_per_split) {
   constexpr int NW = WM * WN;
@@ -95,35 +98,108 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_kernel(Bf16GemmArgs
   const int b_row_byte = A_BYTES + (wn * WTN + (lane & 31)) * 128;
   const int khalf = lane >> 5;
 
-  if (nk > 0) stage(0, 0);
-  for (int kt = 0; kt < nk; ++kt) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
-    const char* base = smem + (kt & 1) * STAGE;
+  if constexpr (SCHED == 0) {
+    // ---- lockstep schedule: one barrier per K-tile, next tile's DMA in flight during the MFMAs
+    if (nk > 0) stage(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
+      const char* base = smem + (kt & 1) * STAGE;
 #pragma unroll
-    for (int ks = 0; ks < BK / 16; ++ks) {
-      const int cb = ((ks * 2 + khalf) ^ sw) << 4;
-      bf16x8 af[MT], bfr[NT];
+      for (int ks = 0; ks < BK / 16; ++ks) {
+        const int cb = ((ks * 2 + khalf) ^ sw) << 4;
+        bf16x8 af[MT], bfr[NT];
 #pragma unroll
-      for (int i = 0; i < MT; ++i) af[i] = *(const bf16x8*)(base + a_row_byte + i * 32 * 128 + cb);
+        for (int i = 0; i < MT; ++i) af[i] = *(const bf16x8*)(base + a_row_byte + i * 32 * 128 + cb);
 #pragma unroll
-      for (int j = 0; j < NT; ++j) bfr[j] = *(const bf16x8*)(base + b_row_byte + j * 32 * 128 + cb);
+        for (int j = 0; j < NT; ++j) bfr[j] = *(const bf16x8*)(base + b_row_byte + j * 32 * 128 + cb);
 #pragma unroll
-      for (int i = 0; i < MT; ++i)
+        for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < NT; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < NT; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+      }
     }
+  } else {
+    // ---- ping-pong schedule (8 waves = 2 per SIMD).  A K-tile is processed as two halves (k 0..31, k 32..63), each half as a
+    // LOAD phase (ds_read the fragments, issue DMA) and an MFMA phase (16 MFMAs), separated by workgroup barriers.  The second
+    // wave of every SIMD (waves NW/2..NW-1, "group B") runs the same sequence ONE PHASE LATE, so at any time one wave of a SIMD is
+    // in its MFMA phase while its partner reads LDS / issues DMA / waits: the matrix pipe is no longer idle around the barriers.
+    //   epoch:      4t        4t+1      4t+2      4t+3      4t+4
+    //   group A:  L(t,H0)   M(t,H0)   L(t,H1)   M(t,H1)   L(t+1,H0)      A issues its DMA share of tile t+1 at L(t,H0)
+    //   group B:  M(t-1,H1) L(t,H0)   M(t,H0)   L(t,H1)   M(t,H1)        B issues its DMA share of tile t+1 at M(t-1,H1)
+    // Buffer (t+1)&1 was last read in epoch 4t-1 (B's L(t-1,H1)), so both DMA issues (epoch 4t) are WAR-safe; tile t+1 is first
+    // read in epoch 4t+4, and every wave drains its own DMA (vmcnt(0)) before the barrier that ends epoch 4t+3.
+    static_assert(NW == 8, "ping-pong needs two waves per SIMD");
+    const bool grpB = wave >= NW / 2;
+    bf16x8 af[2][MT], bfr[2][NT];
+    auto load_half = [&](const char* base, int h) {
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const int cb = (((2 * h + kk) * 2 + khalf) ^ sw) << 4;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) af[kk][i] = *(const bf16x8*)(base + a_row_byte + i * 32 * 128 + cb);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) bfr[kk][j] = *(const bf16x8*)(base + b_row_byte + j * 32 * 128 + cb);
+      }
+    };
+    auto mma_half = [&]() {
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[kk][j], af[kk][i], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+    };
+#define VITX_BAR()                                  \
+  do {                                              \
+    asm volatile("" ::: "memory");                  \
+    __builtin_amdgcn_s_barrier();                   \
+    asm volatile("" ::: "memory");                  \
+    __builtin_amdgcn_sched_barrier(0);              \
+  } while (0)
+    if (nk > 0) stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    VITX_BAR();                                           // tile 0 visible to every wave
+    if (grpB) {
+      if (nk > 1) stage(1, 1);                            // B's share of tile 1 (its "M(-1,H1)" slot)
+      VITX_BAR();                                         // B starts one epoch late
+    }
+    for (int t = 0; t < nk; ++t) {
+      const char* base = smem + (t & 1) * STAGE;
+      // ---- L(t,H0)
+      if (!grpB && t + 1 < nk) stage((t + 1) & 1, t + 1);
+      load_half(base, 0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      VITX_BAR();
+      // ---- M(t,H0)
+      mma_half();
+      VITX_BAR();
+      // ---- L(t,H1)
+      load_half(base, 1);
+      if (grpB) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      VITX_BAR();
+      // ---- M(t,H1)
+      if (grpB && t + 2 < nk) stage(t & 1, t + 2);
+      mma_half();
+      if (!grpB) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      VITX_BAR();
+    }
+    if (!grpB) VITX_BAR();                                // balance B's extra barrier
+#undef VITX_BAR
   }
 
   // ---- epilogue: lane holds row m = lane&31 and columns 8q + 4*(lane>>5) + {0..3} of each 32x32 tile
   const int64_t out_off = (int64_t)z * ep.partial_stride;
-  if constexpr (LDS_EPI) {
+  if constexpr (LDS_EPI && (MT % 2 == 0)) {
     // Stage 64 output rows at a time through LDS (fp32, padded rows) and run the fused epilogue on ROW-CONTIGUOUS data:
     // every wave instruction then reads/writes whole 512-B / 1-KiB row segments (full cache lines) instead of
     // 32 scattered 16/32-B pieces -- the store phase of these GEMMs is what bounds them (fp32 residual stream, 2x bf16 of fc1).
-    static_assert(MT % 2 == 0, "64-row rounds need an even number of 32-row MFMA blocks per wave");
     constexpr int SROW = BN + 4;                     // floats; +16 B keeps the 8-lane ds_write_b128 groups conflict-free
     constexpr int LPRW = BN / 4, RPIW = 64 / LPRW;   // lanes per staged row, rows per wave instruction
     float* st = (float*)smem;
@@ -144,7 +220,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_kernel(Bf16GemmArgs
       __syncthreads();
       const int col_l = (lane % LPRW) * 4;
 #pragma unroll
-      for (int rr = wave * RPIW + lane / LPRW; rr < 64; rr += NW * RPIW) {
+      for (int k = 0; k < 64 / (NW * RPIW); ++k) {
+        const int rr = (k * NW + wave) * RPIW + lane / LPRW;
         const float4 v = *(const float4*)(st + rr * SROW + col_l);
         epilogue_apply4<MODE, bf16_t>(ep, tile_m * BM + R * 64 + rr, tile_n * BN + col_l, v, out_off);
       }
@@ -166,11 +243,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_kernel(Bf16GemmArgs
   }
 }
 
-template <int BM, int BN, int WM, int WN, int MODE, bool LDS_EPI>
+template <int BM, int BN, int WM, int WN, int MODE, bool LDS_EPI, int SCHED = 0>
 void launch_variant(const Bf16GemmArgs& g, const EpiParams& ep, hipStream_t s) {
   constexpr int SMEM = 2 * (BM + BN) * BK * 2;
   static_assert(64 * (BN + 4) * 4 <= SMEM, "epilogue staging must fit in the pipeline buffers");
-  auto kern = gemm_bf16_nt_kernel<BM, BN, WM, WN, MODE, LDS_EPI>;
+  auto kern = gemm_bf16_nt_kernel<BM, BN, WM, WN, MODE, LDS_EPI, SCHED>;
   static bool attr_set = false;
   if (!attr_set) {
     hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
@@ -337,34 +414,49 @@ void launch_tn_variant(const Bf16GemmArgs& g, const EpiParams& ep, hipStream_t s
 template <int MODE>
 void launch_mode(const Bf16GemmArgs& g, const EpiParams& ep, hipStream_t s) {
   int k = g.kernel & 15;
+  if (k == 0) k = gemm_bf16_pick(g.M, g.N);
   // epilogue form: bit 8 forces the per-lane direct form, bit 9 forces the LDS-staged form; by default bf16-output epilogues
   // (8-B per-lane pieces) are staged through LDS into whole-row stores, fp32-output ones (16-B pieces) go out directly (measured).
   const bool bf16_out = (MODE == EPI_STORE || MODE == EPI_BIAS_GELU || MODE == EPI_GELU_BWD);
   const bool direct = (g.kernel & 256) ? true : ((g.kernel & 512) ? false : !bf16_out);
-  if (k == 0) k = (g.N % 256 == 0 || g.N > 512) ? 2 : 1;
   if (direct) {
     if (k == 1) launch_variant<128, 128, 2, 2, MODE, false>(g, ep, s);
     else if (k == 3) launch_variant<256, 128, 4, 2, MODE, false>(g, ep, s);
+    else if (k == 4) launch_variant<256, 256, 2, 4, MODE, false, 1>(g, ep, s);
+    else if (k == 5) launch_variant<320, 256, 2, 4, MODE, false>(g, ep, s);
     else launch_variant<256, 256, 2, 4, MODE, false>(g, ep, s);
   } else {
     if (k == 1) launch_variant<128, 128, 2, 2, MODE, true>(g, ep, s);
     else if (k == 3) launch_variant<256, 128, 4, 2, MODE, true>(g, ep, s);
+    else if (k == 4) launch_variant<256, 256, 2, 4, MODE, true, 1>(g, ep, s);
+    else if (k == 5) launch_variant<320, 256, 2, 4, MODE, false>(g, ep, s);   // MT = 5: direct epilogue only
     else launch_variant<256, 256, 2, 4, MODE, true>(g, ep, s);
   }
 }
 
 }  // namespace
 
+// automatic tile choice: 128x128 for small N; otherwise 256x256, or 320x256 when that fills the 256 CUs' rounds better
+// (M = 50432, N = 768: 591 tiles = 2.31 rounds (77 %) vs 474 tiles = 1.85 rounds (93 %)).
+int gemm_bf16_pick(int M, int N) {
+  if (!(N % 256 == 0 || N > 512)) return 1;
+  const int64_t tn = ceil_div(N, 256);
+  const int64_t t256 = ceil_div(M, 256) * tn, t320 = ceil_div(M, 320) * tn;
+  const double e256 = (double)M * N / ((double)ceil_div(t256, 256) * 256 * 256 * 256);
+  const double e320 = (double)M * N / ((double)ceil_div(t320, 256) * 256 * 320 * 256);
+  return (g_allow_320 && e320 > e256 * 1.08) ? 5 : 2;
+}
 int gemm_bf16_tile_m(int kernel, int M, int N) {
   kernel &= 15;
-  if (kernel == 0) kernel = (N % 256 == 0 || N > 512) ? 2 : 1;
-  return kernel == 1 ? 128 : 256;
+  if (kernel == 0) kernel = gemm_bf16_pick(M, N);
+  return kernel == 1 ? 128 : (kernel == 5 ? 320 : 256);
 }
 int gemm_bf16_tile_n(int kernel, int M, int N) {
   kernel &= 15;
-  if (kernel == 0) kernel = (N % 256 == 0 || N > 512) ? 2 : 1;
-  return kernel == 2 ? 256 : 128;
+  if (kernel == 0) kernel = gemm_bf16_pick(M, N);
+  return (kernel == 1 || kernel == 3) ? 128 : 256;
 }
+void gemm_bf16_allow_320(int on) { g_allow_320 = on; }
 
 // Number of K slices a split-K launch actually produces (matches launch_variant)
 int gemm_bf16_num_slices(int K, int split_k) {
