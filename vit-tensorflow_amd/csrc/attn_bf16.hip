@@ -50,6 +50,22 @@ __device__ __forceinline__ void stage_head(const bf16_t* src, int64_t stride, in
   }
 }
 
+// Asynchronous staging of one head's [npad][64] bf16 matrix into the swizzled row-major LDS image with direct-to-LDS loads
+// (global_load_lds_dwordx4: 1 KiB = 8 rows per wave instruction, no VGPR round trip, every load of the workgroup in flight at
+// once).  The LDS image is lane-linear, so the swizzle goes on the per-lane SOURCE address; rows >= nvalid read a zero page.
+// Caller: s_waitcnt vmcnt(0) + barrier before the first ds_read.
+__device__ __forceinline__ void stage_head_dma(const bf16_t* src, int64_t stride, int nvalid, int npad, char* rm, const bf16_t* zero_page,
+                                               int wave, int lane, int nwaves) {
+  typedef __attribute__((address_space(3))) void lds_void_t;
+  typedef const __attribute__((address_space(1))) void gbl_void_t;
+  for (int i = wave; i < npad / 8; i += nwaves) {
+    const int row = i * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((row >> 1) & 7);
+    const bf16_t* p = row < nvalid ? src + (int64_t)row * stride + c * 8 : zero_page + (lane & 7) * 8;
+    __builtin_amdgcn_global_load_lds((gbl_void_t*)p, (lds_void_t*)(rm + i * 1024), 16, 0, 0);
+  }
+}
+
 __device__ __forceinline__ bf16x8 frag_rm(const char* rm, int row, int chunk) {
   return *(const bf16x8*)(rm + row * ROWB + swz_chunk(row, chunk));
 }
@@ -93,7 +109,7 @@ __device__ __forceinline__ f32x4 mfma16(const bf16x8& a, const bf16x8& b, const 
 // NTP = number of 16-key tiles (even); keys padded to 16*NTP.
 template <int NTP>
 __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o, float* __restrict__ lse,
-                                                       int n, int h, float scale) {
+                                                       int n, int h, float scale, const bf16_t* __restrict__ zero_page) {
   constexpr int NKP = 16 * NTP;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* k_rm = smem;                                   // [NKP][128 B] swizzled
@@ -102,9 +118,11 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(const bf16_t* __r
   const int inner = h * DH;
   const int64_t tok_stride = 3 * (int64_t)inner;
   const bf16_t* qbase = qkv + (int64_t)bi * n * tok_stride + hi * DH;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
-  stage_head<true, false>(qbase + inner, tok_stride, n, NKP, k_rm, nullptr, 0, tid, blockDim.x);
-  stage_head<true, false>(qbase + 2 * inner, tok_stride, n, NKP, v_rm, nullptr, 0, tid, blockDim.x);
+  const int tid = threadIdx.x, lane = tid & 63, nwaves = blockDim.x >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  stage_head_dma(qbase + inner, tok_stride, n, NKP, k_rm, zero_page, wave, lane, nwaves);
+  stage_head_dma(qbase + 2 * inner, tok_stride, n, NKP, v_rm, zero_page, wave, lane, nwaves);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
   const int qi = lane & 15, g = lane >> 4;
@@ -175,7 +193,8 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(const bf16_t* __r
 template <int NTP>
 __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
                                                           const bf16_t* __restrict__ d_o, const float* __restrict__ lse,
-                                                          float* __restrict__ dsum, bf16_t* __restrict__ dqkv, int n, int h, float scale) {
+                                                          float* __restrict__ dsum, bf16_t* __restrict__ dqkv, int n, int h, float scale,
+                                                          const bf16_t* __restrict__ zero_page) {
   constexpr int NKP = 16 * NTP;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* k_rm = smem;
@@ -184,9 +203,11 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dq_kernel(const bf16_t* 
   const int inner = h * DH;
   const int64_t tok_stride = 3 * (int64_t)inner;
   const bf16_t* qbase = qkv + (int64_t)bi * n * tok_stride + hi * DH;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
-  stage_head<true, false>(qbase + inner, tok_stride, n, NKP, k_rm, nullptr, 0, tid, blockDim.x);
-  stage_head<true, false>(qbase + 2 * inner, tok_stride, n, NKP, v_rm, nullptr, 0, tid, blockDim.x);
+  const int tid = threadIdx.x, lane = tid & 63, nwaves = blockDim.x >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  stage_head_dma(qbase + inner, tok_stride, n, NKP, k_rm, zero_page, wave, lane, nwaves);
+  stage_head_dma(qbase + 2 * inner, tok_stride, n, NKP, v_rm, zero_page, wave, lane, nwaves);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
   const int qi = lane & 15, g = lane >> 4;
@@ -253,7 +274,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dq_kernel(const bf16_t* 
 template <int NTP>
 __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ d_o,
                                                            const float* __restrict__ lse, const float* __restrict__ dsum,
-                                                           bf16_t* __restrict__ dqkv, int n, int h, float scale) {
+                                                           bf16_t* __restrict__ dqkv, int n, int h, float scale, const bf16_t* __restrict__ zero_page) {
   constexpr int NQP = 16 * NTP;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* q_rm = smem;
@@ -264,13 +285,15 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dkv_kernel(const bf16_t*
   const int inner = h * DH;
   const int64_t tok_stride = 3 * (int64_t)inner;
   const bf16_t* qbase = qkv + (int64_t)bi * n * tok_stride + hi * DH;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
-  stage_head<true, false>(qbase, tok_stride, n, NQP, q_rm, nullptr, 0, tid, blockDim.x);
-  stage_head<true, false>(d_o + (int64_t)bi * n * inner + hi * DH, inner, n, NQP, do_rm, nullptr, 0, tid, blockDim.x);
+  const int tid = threadIdx.x, lane = tid & 63, nwaves = blockDim.x >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  stage_head_dma(qbase, tok_stride, n, NQP, q_rm, zero_page, wave, lane, nwaves);
+  stage_head_dma(d_o + (int64_t)bi * n * inner + hi * DH, inner, n, NQP, do_rm, zero_page, wave, lane, nwaves);
   for (int i = tid; i < NQP; i += blockDim.x) {
     lse_s[i] = i < n ? lse[(int64_t)bh * n + i] * 1.44269504088896340736f : 0.f;
     d_s[i] = i < n ? dsum[(int64_t)bh * n + i] : 0.f;
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
   const int ki = lane & 15, g = lane >> 4;
@@ -348,17 +371,17 @@ bool attn_bf16_supported(int n, int dim_head) { return dim_head == DH && n >= 1 
 #define VITX_NTP_DISPATCH(ntp, CALL) \
   do { if ((ntp) == 4) { CALL(4); } else if ((ntp) == 6) { CALL(6); } else if ((ntp) == 14) { CALL(14); } else { CALL(18); } } while (0)
 
-void launch_attn_bf16_fwd(const bf16_t* qkv, bf16_t* o, float* lse, int b, int n, int h, float scale, hipStream_t s) {
+void launch_attn_bf16_fwd(const bf16_t* qkv, bf16_t* o, float* lse, int b, int n, int h, float scale, const bf16_t* zero_page, hipStream_t s) {
   const int ntp = pick_ntp(n);
   const int nkp = 16 * ntp;
   const int smem = 2 * nkp * ROWB;
-#define CALL(NTP) { set_smem(attn_fwd_kernel<NTP>, smem); hipLaunchKernelGGL(attn_fwd_kernel<NTP>, dim3(b * h), dim3(ATT_THREADS), smem, s, qkv, o, lse, n, h, scale); }
+#define CALL(NTP) { set_smem(attn_fwd_kernel<NTP>, smem); hipLaunchKernelGGL(attn_fwd_kernel<NTP>, dim3(b * h), dim3(ATT_THREADS), smem, s, qkv, o, lse, n, h, scale, zero_page); }
   VITX_NTP_DISPATCH(ntp, CALL);
 #undef CALL
 }
 
 void launch_attn_bf16_bwd(const bf16_t* qkv, const bf16_t* o, const bf16_t* d_o, const float* lse, float* dsum_ws, bf16_t* dqkv, int b,
-                          int n, int h, float scale, hipStream_t s) {
+                          int n, int h, float scale, const bf16_t* zero_page, hipStream_t s) {
   const int ntp = pick_ntp(n);
   const int np = 16 * ntp;
   const int smem_dq = 2 * np * ROWB;
@@ -367,8 +390,8 @@ void launch_attn_bf16_bwd(const bf16_t* qkv, const bf16_t* o, const bf16_t* d_o,
   {                                                                                                                                \
     set_smem(attn_bwd_dq_kernel<NTP>, smem_dq);                                                                                    \
     set_smem(attn_bwd_dkv_kernel<NTP>, smem_dkv);                                                                                  \
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<NTP>, dim3(b * h), dim3(ATT_THREADS), smem_dq, s, qkv, o, d_o, lse, dsum_ws, dqkv, n, h, scale);   \
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel<NTP>, dim3(b * h), dim3(ATT_THREADS), smem_dkv, s, qkv, d_o, lse, dsum_ws, dqkv, n, h, scale);    \
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<NTP>, dim3(b * h), dim3(ATT_THREADS), smem_dq, s, qkv, o, d_o, lse, dsum_ws, dqkv, n, h, scale, zero_page);   \
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<NTP>, dim3(b * h), dim3(ATT_THREADS), smem_dkv, s, qkv, d_o, lse, dsum_ws, dqkv, n, h, scale, zero_page);    \
   }
   VITX_NTP_DISPATCH(ntp, CALL);
 #undef CALL

@@ -98,6 +98,7 @@ struct vitx_engine {
   float* red_ws = nullptr; int64_t red_elems = 0;
   float* sc[4] = {nullptr, nullptr, nullptr, nullptr}; int64_t sc_elems = 0;
   float* dsum = nullptr;
+  void* zero_page = nullptr;         // 256 B of zeros (source of the padded rows in the attention DMA staging)
   float* tmp_f32 = nullptr;          // [mp, max(d, pd)] fp32 scratch (dropout / dimg paths)
   float* loss_rows = nullptr;
   bf16_t *bench_a = nullptr, *bench_b = nullptr; float* bench_c = nullptr; int64_t bench_elems = 0;

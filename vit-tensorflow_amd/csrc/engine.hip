@@ -464,7 +464,7 @@ static int block_forward(vitx_engine* e, Stage& st, int si, int l, int b, int nq
   }
   if (use_fused_attn(e, nq)) {
     Prof pr(e, "attn_bf16_fwd", 4.0 * b * c.heads * (double)nq * nq * c.dim_head, (double)rows * inner * 4 * esz);
-    launch_attn_bf16_fwd((const bf16_t*)ba.qkv, (bf16_t*)ba.o, ba.lse, b, nq, c.heads, 1.0f / std::sqrt((float)c.dim_head), e->stream);
+    launch_attn_bf16_fwd((const bf16_t*)ba.qkv, (bf16_t*)ba.o, ba.lse, b, nq, c.heads, 1.0f / std::sqrt((float)c.dim_head), (const bf16_t*)e->zero_page, e->stream);
   } else {
     const int need = c.variant == VITX_VARIANT_VIT ? 1 : 3;
     int rc = ensure_scores(e, need, (int64_t)b * c.heads * nq * round_up(nk, 4), err);
@@ -620,7 +620,7 @@ static int block_backward(vitx_engine* e, Stage& st, int si, int l, int b, int n
     if (use_fused_attn(e, nq)) {
       Prof pr(e, "attn_bf16_bwd", 14.0 * b * c.heads * (double)nq * nq * c.dim_head, (double)rows * inner * 8 * esz);
       launch_attn_bf16_bwd((const bf16_t*)ba.qkv, (const bf16_t*)ba.o, (const bf16_t*)d_o, ba.lse, e->dsum, (bf16_t*)e->d_qkv, b, nq,
-                           c.heads, 1.0f / std::sqrt((float)c.dim_head), e->stream);
+                           c.heads, 1.0f / std::sqrt((float)c.dim_head), (const bf16_t*)e->zero_page, e->stream);
     } else {
       int rc = ensure_scores(e, 4, (int64_t)b * c.heads * nq * round_up(nk, 4), err);
       if (rc != VITX_OK) return rc;
@@ -795,6 +795,7 @@ int engine_create(const vitx_config& cfg, vitx_engine** out, std::string& err) {
   DALLOC(e->d_ctx, (size_t)crow_max * d * esz, true);
   DALLOC(e->d_br, (size_t)rmax * d * esz, true);
   DALLOC(e->dsum, (size_t)B * c.heads * e->ntok_max * 4 + 16, false);
+  DALLOC(e->zero_page, 256, false);
   DALLOC(e->tmp_f32, (size_t)rmax * std::max<int64_t>(d, e->pd) * 4, false);
   const int64_t maxfeat = std::max<int64_t>({(int64_t)d, 3LL * inner, (int64_t)m, (int64_t)e->pd_k, (int64_t)e->nc_k});
   if (e->bf16) {

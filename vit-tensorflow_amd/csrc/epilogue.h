@@ -114,3 +114,41 @@ __device__ __forceinline__ void epilogue_apply4(const EpiParams& p, int row, int
     }
   }
 }
+
+// Branch-free form for INTERIOR tiles (every row < M, every column < N, vector-friendly pointers, alpha == 1): the caller has
+// hoisted all those wave-uniform tests out of the per-element code, so the compiler can batch the loads and stores of a
+// whole tile (the generic form above waits for each load before issuing the next: one memory operation in flight per wave).
+// b4 / s4 = bias / LayerScale values of columns col..col+3 (loaded once per column group by the caller).
+// The global READ an epilogue needs (fp32 residual / saved pre-activation) is split from the rest so that callers can issue
+// a batch of them before the first store (the compiler cannot hoist loads over stores to possibly-aliasing pointers).
+template <int MODE, typename T>
+__device__ __forceinline__ float4 epilogue_fast_load(const EpiParams& p, int row, int col) {
+  if (MODE == EPI_BIAS_RESID) return *(const float4*)(p.resid + (int64_t)row * p.ldr + col);
+  if (MODE == EPI_GELU_BWD) return ld4<T>((const T*)p.aux + (int64_t)row * p.ldaux + col);
+  return make_float4(0.f, 0.f, 0.f, 0.f);
+}
+template <int MODE, typename T, bool HAS_BIAS, bool HAS_SCALE>
+__device__ __forceinline__ void epilogue_fast4(const EpiParams& p, int row, int col, float4 v, float4 b4, float4 s4, float4 x, int64_t out_off) {
+  if (HAS_BIAS && MODE != EPI_GELU_BWD && MODE != EPI_PARTIAL) { v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w; }
+  if (MODE == EPI_STORE) {
+    st4<T>((T*)p.out + out_off + (int64_t)row * p.ldo + col, v);
+  } else if (MODE == EPI_STORE_F32 || MODE == EPI_PARTIAL) {
+    *(float4*)((float*)p.out + out_off + (int64_t)row * p.ldo + col) = v;
+  } else if (MODE == EPI_BIAS_GELU) {
+    st4<T>((T*)p.out + (int64_t)row * p.ldo + col, v);
+    const float4 g = make_float4(gelu_t<T>((float)(T)v.x), gelu_t<T>((float)(T)v.y), gelu_t<T>((float)(T)v.z), gelu_t<T>((float)(T)v.w));
+    st4<T>((T*)p.out2 + (int64_t)row * p.ldo2 + col, g);
+  } else if (MODE == EPI_BIAS_RESID) {
+    if (HAS_SCALE) {
+      if (p.out2) st4<T>((T*)p.out2 + (int64_t)row * p.ldo2 + col, v);
+      v.x *= s4.x; v.y *= s4.y; v.z *= s4.z; v.w *= s4.w;
+    }
+    *(float4*)((float*)p.out + (int64_t)row * p.ldo + col) = make_float4(x.x + v.x, x.y + v.y, x.z + v.z, x.w + v.w);
+  } else if (MODE == EPI_GELU_BWD) {
+    st4<T>((T*)p.out + (int64_t)row * p.ldo + col,
+           make_float4(v.x * gelu_grad_t<T>(x.x), v.y * gelu_grad_t<T>(x.y), v.z * gelu_grad_t<T>(x.z), v.w * gelu_grad_t<T>(x.w)));
+  }
+}
+__device__ __forceinline__ bool epilogue_fast_ok(const EpiParams& p, int mode) {
+  return p.vec_ok && p.alpha == 1.0f && mode != EPI_PATCH;
+}

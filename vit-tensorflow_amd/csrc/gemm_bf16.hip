@@ -10,6 +10,8 @@
 //     128-B row) -- conflict-free for the 16-lane groups ds_read_b128 is serviced in.
 //   * XCD-aware tile order: the grid is walked so that consecutive logical tiles (sharing an A row
 //     panel) run on the same XCD and hit its private L2.
+#include <type_traits>
+
 #include "kernels.h"
 
 static int g_allow_320 = 1;
@@ -196,13 +198,22 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_kernel(Bf16GemmArgs
 
   // ---- epilogue: lane holds row m = lane&31 and columns 8q + 4*(lane>>5) + {0..3} of each 32x32 tile
   const int64_t out_off = (int64_t)z * ep.partial_stride;
+  // interior tiles (all but the ragged edge) take the branch-free epilogue: every wave-uniform test is made once, here
+  const bool interior = epilogue_fast_ok(ep, MODE) && (tile_m + 1) * BM <= ep.M && (tile_n + 1) * BN <= ep.N;
+  const bool has_bias = ep.bias != nullptr, has_scale = ep.scale != nullptr;
   if constexpr (LDS_EPI && (MT % 2 == 0)) {
     // Stage 64 output rows at a time through LDS (fp32, padded rows) and run the fused epilogue on ROW-CONTIGUOUS data:
     // every wave instruction then reads/writes whole 512-B / 1-KiB row segments (full cache lines) instead of
-    // 32 scattered 16/32-B pieces -- the store phase of these GEMMs is what bounds them (fp32 residual stream, 2x bf16 of fc1).
+    // 32 scattered 16/32-B pieces.
     constexpr int SROW = BN + 4;                     // floats; +16 B keeps the 8-lane ds_write_b128 groups conflict-free
     constexpr int LPRW = BN / 4, RPIW = 64 / LPRW;   // lanes per staged row, rows per wave instruction
+    constexpr int RPW = 64 / (NW * RPIW);            // rows handled per wave per round
     float* st = (float*)smem;
+    const int col_l = (lane % LPRW) * 4;
+    const int gcol = tile_n * BN + col_l;
+    float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f), s4 = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (interior && has_bias) b4 = *(const float4*)(ep.bias + gcol);
+    if (interior && has_scale) s4 = *(const float4*)(ep.scale + gcol);
 #pragma unroll
     for (int R = 0; R < BM / 64; ++R) {
       const int wm_r = (R * 64) / WTM, i0 = ((R * 64) % WTM) / 32;
@@ -218,26 +229,71 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_kernel(Bf16GemmArgs
                   make_float4(acc[i0 + ii][j][4 * q], acc[i0 + ii][j][4 * q + 1], acc[i0 + ii][j][4 * q + 2], acc[i0 + ii][j][4 * q + 3]);
       }
       __syncthreads();
-      const int col_l = (lane % LPRW) * 4;
+      float4 v[RPW];
 #pragma unroll
-      for (int k = 0; k < 64 / (NW * RPIW); ++k) {
-        const int rr = (k * NW + wave) * RPIW + lane / LPRW;
-        const float4 v = *(const float4*)(st + rr * SROW + col_l);
-        epilogue_apply4<MODE, bf16_t>(ep, tile_m * BM + R * 64 + rr, tile_n * BN + col_l, v, out_off);
+      for (int k = 0; k < RPW; ++k) v[k] = *(const float4*)(st + ((k * NW + wave) * RPIW + lane / LPRW) * SROW + col_l);
+      const int grow0 = tile_m * BM + R * 64 + lane / LPRW;
+      if (interior) {
+        float4 x[RPW];
+#pragma unroll
+        for (int k = 0; k < RPW; ++k) x[k] = epilogue_fast_load<MODE, bf16_t>(ep, grow0 + (k * NW + wave) * RPIW, gcol);
+        if (has_bias) {
+#pragma unroll
+          for (int k = 0; k < RPW; ++k) epilogue_fast4<MODE, bf16_t, true, false>(ep, grow0 + (k * NW + wave) * RPIW, gcol, v[k], b4, s4, x[k], out_off);
+        } else {
+#pragma unroll
+          for (int k = 0; k < RPW; ++k) epilogue_fast4<MODE, bf16_t, false, false>(ep, grow0 + (k * NW + wave) * RPIW, gcol, v[k], b4, s4, x[k], out_off);
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < RPW; ++k) epilogue_apply4<MODE, bf16_t>(ep, grow0 + (k * NW + wave) * RPIW, gcol, v[k], out_off);
       }
     }
   } else {
+    const int row0 = tile_m * BM + wm * WTM + (lane & 31);
+    const int col00 = tile_n * BN + wn * WTN + 4 * khalf;
+    if (interior) {
+      auto run = [&](auto hb, auto hs) {
+        constexpr bool HB = decltype(hb)::value, HS = decltype(hs)::value;
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
-      const int row = tile_m * BM + wm * WTM + i * 32 + (lane & 31);
+        for (int j = 0; j < NT; ++j)
 #pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        const int col0 = tile_n * BN + wn * WTN + j * 32 + 4 * khalf;
+          for (int qp = 0; qp < 2; ++qp) {       // two column groups at a time: 2*MT global reads in flight before the stores
+            float4 b4[2], s4[2], x[2][MT];
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-          epilogue_apply4<MODE, bf16_t>(ep, row, col0 + 8 * q,
-                                        make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]),
-                                        out_off);
+            for (int qq = 0; qq < 2; ++qq) {
+              const int col = col00 + j * 32 + 8 * (2 * qp + qq);
+              b4[qq] = HB ? *(const float4*)(ep.bias + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+              s4[qq] = HS ? *(const float4*)(ep.scale + col) : make_float4(1.f, 1.f, 1.f, 1.f);
+#pragma unroll
+              for (int i = 0; i < MT; ++i) x[qq][i] = epilogue_fast_load<MODE, bf16_t>(ep, row0 + i * 32, col);
+            }
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq) {
+              const int q = 2 * qp + qq;
+              const int col = col00 + j * 32 + 8 * q;
+#pragma unroll
+              for (int i = 0; i < MT; ++i)
+                epilogue_fast4<MODE, bf16_t, HB, HS>(ep, row0 + i * 32, col,
+                                                     make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]),
+                                                     b4[qq], s4[qq], x[qq][i], out_off);
+            }
+          }
+      };
+      if (has_bias && has_scale) run(std::true_type{}, std::true_type{});
+      else if (has_bias) run(std::true_type{}, std::false_type{});
+      else run(std::false_type{}, std::false_type{});
+    } else {
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            epilogue_apply4<MODE, bf16_t>(ep, row0 + i * 32, col00 + j * 32 + 8 * q,
+                                          make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]),
+                                          out_off);
+        }
       }
     }
   }
@@ -378,6 +434,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_tn_kernel(Bf16GemmArgs
   }
 
   const int64_t out_off = (int64_t)z * ep.partial_stride;
+  const bool interior = epilogue_fast_ok(ep, MODE) && (tile_m + 1) * BT <= ep.M && (tile_n + 1) * BT <= ep.N;
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
     const int row = tile_m * BT + wm * WTM + i * 32 + (lane & 31);
@@ -385,10 +443,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_tn_kernel(Bf16GemmArgs
     for (int j = 0; j < NT; ++j) {
       const int col0 = tile_n * BT + wn * WTN + j * 32 + 4 * khalf;
 #pragma unroll
-      for (int qq = 0; qq < 4; ++qq)
-        epilogue_apply4<MODE, bf16_t>(ep, row, col0 + 8 * qq,
-                                      make_float4(acc[i][j][4 * qq], acc[i][j][4 * qq + 1], acc[i][j][4 * qq + 2], acc[i][j][4 * qq + 3]),
-                                      out_off);
+      for (int qq = 0; qq < 4; ++qq) {
+        const float4 v = make_float4(acc[i][j][4 * qq], acc[i][j][4 * qq + 1], acc[i][j][4 * qq + 2], acc[i][j][4 * qq + 3]);
+        if (interior) epilogue_fast4<MODE, bf16_t, false, false>(ep, row, col0 + 8 * qq, v, z4, z4, z4, out_off);
+        else epilogue_apply4<MODE, bf16_t>(ep, row, col0 + 8 * qq, v, out_off);
+      }
     }
   }
 }

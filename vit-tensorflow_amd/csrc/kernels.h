@@ -37,9 +37,9 @@ int gemm_bf16_tn_tile(int kernel, int M, int N);
 // ---------------------------------------------------------------- attn_bf16.hip
 // fused multi-head self-attention (vit.py:73-82) on packed qkv [b, n, 3, h, 64] bf16.
 bool attn_bf16_supported(int n, int dim_head);
-void launch_attn_bf16_fwd(const bf16_t* qkv, bf16_t* o, float* lse, int b, int n, int h, float scale, hipStream_t s);
+void launch_attn_bf16_fwd(const bf16_t* qkv, bf16_t* o, float* lse, int b, int n, int h, float scale, const bf16_t* zero_page, hipStream_t s);   // zero_page: >= 128 B of zeros
 void launch_attn_bf16_bwd(const bf16_t* qkv, const bf16_t* o, const bf16_t* d_o, const float* lse, float* dsum_ws,
-                          bf16_t* dqkv, int b, int n, int h, float scale, hipStream_t s);
+                          bf16_t* dqkv, int b, int n, int h, float scale, const bf16_t* zero_page, hipStream_t s);
 
 // ---------------------------------------------------------------- elementwise.hip
 void launch_unfold(const float* img, void* out, int out_bf16, int b, int H, int W, int C, int ph, int pw,
