@@ -93,11 +93,17 @@ def main():
     ap.add_argument("--bucket-mb", type=float, default=48.0)
     args = ap.parse_args()
 
+    # The contract is ONE JSON line on stdout.  Native libraries (RCCL prints a version banner through C stdio, flushed at exit)
+    # would add lines of their own, so fd 1 is pointed at stderr for the whole run and the result is written to the saved fd.
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     from vit_tensorflow import ViT, _native as N
     from vit_tensorflow.parallel import GradSync, broadcast_params, init_from_env
     import torch.distributed as dist
 
-    rank, local, world = init_from_env()
+    force_dp = bool(os.environ.get("VITX_FORCE_DP"))   # exercise the whole DP path (RCCL group of 1) on a single GPU
+    rank, local, world = init_from_env(force=force_dp)
     if world != args.gpus and rank == 0:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
     if not torch.cuda.is_available():
@@ -120,7 +126,12 @@ def main():
 
     sync = None
     cb = None
-    if world > 1:
+    dp = world > 1 or force_dp
+    if dp:
+        # The engine must run on the stream RCCL orders itself against.  torch's default stream has handle 0, which the C ABI
+        # reads as "use the library's own stream", so the data-parallel path runs under an explicit side stream.
+        dp_stream = torch.cuda.Stream(device=dev)
+        torch.cuda.set_stream(dp_stream)
         n = C.c_int64()
         p = C.c_void_p()
         N.check(lib.vitx_params_dev(h, C.byref(p), C.byref(n)))
@@ -131,7 +142,7 @@ def main():
         N.check(lib.vitx_set_stream(h, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
         broadcast_params(params_t, 0)
         N.check(lib.vitx_params_changed(h))
-        sync = GradSync(grads_t, bucket_elems=int(args.bucket_mb * (1 << 20) / 4), average=False)
+        sync = GradSync(grads_t, bucket_elems=int(args.bucket_mb * (1 << 20) / 4), average=False, always_reduce=force_dp)
         cb = N.GRAD_READY_FN(lambda _u, off, cnt: sync.on_ready(int(off), int(cnt)))
         N.check(lib.vitx_set_grad_ready_callback(h, cb, None))
     inv_global = 1.0 / float(b * world)   # dlogits carry 1/global_batch, so the all-reduce is a plain sum
@@ -149,7 +160,7 @@ def main():
     def full_sync():
         N.check(lib.vitx_sync(h))
         torch.cuda.synchronize()
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
 
     for _ in range(args.warmup):
@@ -160,7 +171,7 @@ def main():
         step()
     full_sync()
     el = time.perf_counter() - t0
-    if world > 1:
+    if dist.is_initialized():
         t = torch.tensor([el], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
@@ -223,8 +234,8 @@ def main():
             out["cpu_baseline_error"] = repr(ex)
 
     if rank == 0:
-        print(json.dumps(out), flush=True)
-    if world > 1:
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

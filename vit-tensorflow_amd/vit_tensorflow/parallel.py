@@ -20,7 +20,7 @@ import torch.distributed as dist
 
 
 class GradSync:
-    def __init__(self, grads: torch.Tensor, bucket_elems: int = 8 << 20, group=None, average: bool = True):
+    def __init__(self, grads: torch.Tensor, bucket_elems: int = 8 << 20, group=None, average: bool = True, always_reduce: bool = False):
         assert grads.dim() == 1 and grads.is_contiguous()
         self.grads = grads
         self.n = grads.numel()
@@ -29,6 +29,7 @@ class GradSync:
         self.group = group
         self.average = average
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.always_reduce = always_reduce and dist.is_initialized()   # issue the collective even for a group of one (plumbing tests)
         self._covered = [0] * self.nb
         self._launched = [False] * self.nb
         self._works: List = []
@@ -40,7 +41,7 @@ class GradSync:
         if self._launched[i]:
             return
         self._launched[i] = True
-        if self.world == 1:
+        if self.world == 1 and not self.always_reduce:
             return
         sl = self.grads[i * self.bucket: i * self.bucket + self._size(i)]
         self._works.append(dist.all_reduce(sl, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
@@ -72,14 +73,14 @@ class GradSync:
             self.grads.mul_(1.0 / self.world)
 
 
-def init_from_env(backend: Optional[str] = None) -> tuple:
+def init_from_env(backend: Optional[str] = None, force: bool = False) -> tuple:
     """(rank, local_rank, world) from the torchrun environment; initialises the default process group
-    when WORLD_SIZE > 1."""
+    when WORLD_SIZE > 1 (or when `force` asks for a group of one)."""
     import os
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         be = backend or ("nccl" if torch.cuda.is_available() else "gloo")
