@@ -20,7 +20,7 @@ namespace {
 
 constexpr int DH = 64;
 constexpr int ROWB = DH * 2;  // 128-byte rows
-constexpr int ATT_THREADS = 512;  // 8 waves share one head's LDS image: 2 waves per SIMD hide LDS / MFMA / exp latency
+constexpr int ATT_THREADS = 512;   // 8 waves share one head's LDS image (2 per SIMD)
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }  // raw v_exp_f32 (inputs are <= 0 or masked)
 
@@ -106,11 +106,15 @@ __device__ __forceinline__ f32x4 mfma16(const bf16x8& a, const bf16x8& b, const 
 }
 
 // ------------------------------------------------------------------------------------------ forward
-// NTP = number of 16-key tiles (even); keys padded to 16*NTP.
+// NTP = number of 16-key tiles (even); keys padded to 16*NTP.  A wave owns QB = 2 blocks of 16 queries at a time, so every
+// K / V^T fragment read from LDS feeds two MFMAs (LDS bandwidth, not the matrix pipe, bounds these kernels).
+constexpr int QB_FWD = 2;   // forward: 114 VGPRs, still two workgroups per CU
+constexpr int QB_BWD = 1;   // backward: QB = 2 costs a workgroup of occupancy (146 / 212 VGPRs) and measured slower
+
 template <int NTP>
 __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o, float* __restrict__ lse,
                                                        int n, int h, float scale, const bf16_t* __restrict__ zero_page) {
-  constexpr int NKP = 16 * NTP;
+  constexpr int NKP = 16 * NTP, QB = QB_FWD;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* k_rm = smem;                                   // [NKP][128 B] swizzled
   char* v_rm = smem + NKP * ROWB;                      // [NKP][128 B] swizzled (read through the hardware transpose)
@@ -126,64 +130,95 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(const bf16_t* __r
   __syncthreads();
 
   const int qi = lane & 15, g = lane >> 4;
-  const int nqb = (n + 15) >> 4;
+  const int nqb = (n + 16 * QB - 1) / (16 * QB);
   const float sl2 = scale * 1.44269504088896340736f;
   for (int qb = wave; qb < nqb; qb += nwaves) {
-    const int q = qb * 16 + qi;
-    const int qc = min(q, n - 1);
-    bf16x8 qf[2];
+    int q[QB];
+    bf16x8 qf[QB][2];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) qf[ks] = *(const bf16x8*)(qbase + (int64_t)qc * tok_stride + (g + 4 * ks) * 8);
-    // pass 1: row maxima of the (log2-domain) scores.  S^T tile t: lane holds S[query qi][key 16t + 4g + r].
-    float m = -INFINITY;
+    for (int s = 0; s < QB; ++s) {
+      q[s] = (qb * QB + s) * 16 + qi;
+      const int qc = min(q[s], n - 1);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) qf[s][ks] = *(const bf16x8*)(qbase + (int64_t)qc * tok_stride + (g + 4 * ks) * 8);
+    }
+    // pass 1: row maxima of the scores.  S^T tile t: lane holds S[query qi][key 16t + 4g + r].
+    float m[QB];
+#pragma unroll
+    for (int s = 0; s < QB; ++s) m[s] = -INFINITY;
 #pragma unroll 2
     for (int t = 0; t < NTP; ++t) {
-      f32x4 a = {0.f, 0.f, 0.f, 0.f};
+      const bf16x8 kf0 = frag_rm(k_rm, t * 16 + qi, g), kf1 = frag_rm(k_rm, t * 16 + qi, g + 4);
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) a = mfma16(frag_rm(k_rm, t * 16 + qi, g + 4 * ks), qf[ks], a);
+      for (int s = 0; s < QB; ++s) {
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+        a = mfma16(kf0, qf[s][0], a);
+        a = mfma16(kf1, qf[s][1], a);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) m = fmaxf(m, (t * 16 + 4 * g + r) < n ? a[r] : -INFINITY);
+        for (int r = 0; r < 4; ++r) m[s] = fmaxf(m[s], (t * 16 + 4 * g + r) < n ? a[r] : -INFINITY);
+      }
     }
-    m = fmaxf(m, __shfl_xor(m, 16, 64));
-    m = fmaxf(m, __shfl_xor(m, 32, 64));
-    m *= sl2;
-    // pass 2: recompute the tile pair, p = 2^(s - m), accumulate the row sum and O^T += V^T P^T (unnormalised)
-    float l = 0.f;
-    f32x4 oacc[4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) oacc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < QB; ++s) {
+      m[s] = fmaxf(m[s], __shfl_xor(m[s], 16, 64));
+      m[s] = fmaxf(m[s], __shfl_xor(m[s], 32, 64));
+      m[s] *= sl2;
+    }
+    // pass 2: recompute the tile pair, p = 2^(s - m), accumulate the row sum and O^T += V^T P^T (unnormalised)
+    float l[QB];
+    f32x4 oacc[QB][4];
+#pragma unroll
+    for (int s = 0; s < QB; ++s) {
+      l[s] = 0.f;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) oacc[s][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 #pragma unroll 1
     for (int u = 0; u < NTP / 2; ++u) {
-      f32x4 p[2];
+      f32x4 p[QB][2];
 #pragma unroll
       for (int tt = 0; tt < 2; ++tt) {
         const int t = 2 * u + tt;
-        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+        const bf16x8 kf0 = frag_rm(k_rm, t * 16 + qi, g), kf1 = frag_rm(k_rm, t * 16 + qi, g + 4);
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) a = mfma16(frag_rm(k_rm, t * 16 + qi, g + 4 * ks), qf[ks], a);
+        for (int s = 0; s < QB; ++s) {
+          f32x4 a = {0.f, 0.f, 0.f, 0.f};
+          a = mfma16(kf0, qf[s][0], a);
+          a = mfma16(kf1, qf[s][1], a);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float e = (t * 16 + 4 * g + r) < n ? fast_exp2(a[r] * sl2 - m) : 0.f;
-          p[tt][r] = e;
-          l += e;
+          for (int r = 0; r < 4; ++r) {
+            const float e = (t * 16 + 4 * g + r) < n ? fast_exp2(a[r] * sl2 - m[s]) : 0.f;
+            p[s][tt][r] = e;
+            l[s] += e;
+          }
         }
       }
-      const bf16x8 pf = pack8(p[0], p[1]);
+      bf16x8 pf[QB];
 #pragma unroll
-      for (int c = 0; c < 4; ++c) oacc[c] = mfma16(frag_trr(v_rm, c, u, lane), pf, oacc[c]);
-    }
-    l += __shfl_xor(l, 16, 64);
-    l += __shfl_xor(l, 32, 64);
-    const float inv_l = 1.0f / l;
-    if (g == 0 && q < n) lse[(int64_t)bh * n + q] = (m + log2f(l)) * 0.69314718055994530942f;  // natural-log LSE of scaled scores
-    if (q < n) {
-      bf16_t* op = o + ((int64_t)bi * n + q) * inner + hi * DH;
+      for (int s = 0; s < QB; ++s) pf[s] = pack8(p[s][0], p[s][1]);
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        bf16x4 ov;
+        const bf16x8 vf = frag_trr(v_rm, c, u, lane);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) ov[r] = (bf16_t)(oacc[c][r] * inv_l);
-        *(bf16x4*)(op + 16 * c + 4 * g) = ov;
+        for (int s = 0; s < QB; ++s) oacc[s][c] = mfma16(vf, pf[s], oacc[s][c]);
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < QB; ++s) {
+      float ls = l[s];
+      ls += __shfl_xor(ls, 16, 64);
+      ls += __shfl_xor(ls, 32, 64);
+      const float inv_l = 1.0f / ls;
+      if (g == 0 && q[s] < n) lse[(int64_t)bh * n + q[s]] = (m[s] + log2f(ls)) * 0.69314718055994530942f;  // natural-log LSE
+      if (q[s] < n) {
+        bf16_t* op = o + ((int64_t)bi * n + q[s]) * inner + hi * DH;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          bf16x4 ov;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) ov[r] = (bf16_t)(oacc[s][c][r] * inv_l);
+          *(bf16x4*)(op + 16 * c + 4 * g) = ov;
+        }
       }
     }
   }
@@ -195,7 +230,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dq_kernel(const bf16_t* 
                                                           const bf16_t* __restrict__ d_o, const float* __restrict__ lse,
                                                           float* __restrict__ dsum, bf16_t* __restrict__ dqkv, int n, int h, float scale,
                                                           const bf16_t* __restrict__ zero_page) {
-  constexpr int NKP = 16 * NTP;
+  constexpr int NKP = 16 * NTP, QB = QB_BWD;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* k_rm = smem;
   char* v_rm = smem + NKP * ROWB;
@@ -211,60 +246,79 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dq_kernel(const bf16_t* 
   __syncthreads();
 
   const int qi = lane & 15, g = lane >> 4;
-  const int nqb = (n + 15) >> 4;
+  const int nqb = (n + 16 * QB - 1) / (16 * QB);
   const float sl2 = scale * 1.44269504088896340736f;
   for (int qb = wave; qb < nqb; qb += nwaves) {
-    const int q = qb * 16 + qi;
-    const int qc = min(q, n - 1);
-    const int64_t orow = ((int64_t)bi * n + qc) * inner + hi * DH;
-    bf16x8 qf[2], dof[2];
-    float dpart = 0.f;
+    int q[QB];
+    bf16x8 qf[QB][2], dof[QB][2];
+    float dpart[QB], l2[QB];
+    f32x4 dq[QB][4];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      qf[ks] = *(const bf16x8*)(qbase + (int64_t)qc * tok_stride + (g + 4 * ks) * 8);
-      dof[ks] = *(const bf16x8*)(d_o + orow + (g + 4 * ks) * 8);
-      const bf16x8 of = *(const bf16x8*)(o + orow + (g + 4 * ks) * 8);
+    for (int s = 0; s < QB; ++s) {
+      q[s] = (qb * QB + s) * 16 + qi;
+      const int qc = min(q[s], n - 1);
+      const int64_t orow = ((int64_t)bi * n + qc) * inner + hi * DH;
+      float dp_ = 0.f;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) dpart += (float)dof[ks][e] * (float)of[e];
+      for (int ks = 0; ks < 2; ++ks) {
+        qf[s][ks] = *(const bf16x8*)(qbase + (int64_t)qc * tok_stride + (g + 4 * ks) * 8);
+        dof[s][ks] = *(const bf16x8*)(d_o + orow + (g + 4 * ks) * 8);
+        const bf16x8 of = *(const bf16x8*)(o + orow + (g + 4 * ks) * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dp_ += (float)dof[s][ks][e] * (float)of[e];
+      }
+      dp_ += __shfl_xor(dp_, 16, 64);
+      dp_ += __shfl_xor(dp_, 32, 64);   // D[q] = sum_d dO*O
+      if (g == 0 && q[s] < n) dsum[(int64_t)bh * n + q[s]] = dp_;
+      dpart[s] = dp_;
+      l2[s] = lse[(int64_t)bh * n + qc] * 1.44269504088896340736f;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) dq[s][c] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    dpart += __shfl_xor(dpart, 16, 64);
-    dpart += __shfl_xor(dpart, 32, 64);   // D[q] = sum_d dO*O
-    if (g == 0 && q < n) dsum[(int64_t)bh * n + q] = dpart;
-    const float l2 = lse[(int64_t)bh * n + qc] * 1.44269504088896340736f;
-    f32x4 dq[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) dq[c] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
     for (int u = 0; u < NTP / 2; ++u) {
-      f32x4 ds[2];
+      f32x4 ds[QB][2];
 #pragma unroll
       for (int tt = 0; tt < 2; ++tt) {
         const int t = 2 * u + tt;
-        f32x4 sa = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+        const bf16x8 kf0 = frag_rm(k_rm, t * 16 + qi, g), kf1 = frag_rm(k_rm, t * 16 + qi, g + 4);
+        const bf16x8 vf0 = frag_rm(v_rm, t * 16 + qi, g), vf1 = frag_rm(v_rm, t * 16 + qi, g + 4);
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          sa = mfma16(frag_rm(k_rm, t * 16 + qi, g + 4 * ks), qf[ks], sa);
-          dp = mfma16(frag_rm(v_rm, t * 16 + qi, g + 4 * ks), dof[ks], dp);
-        }
+        for (int s = 0; s < QB; ++s) {
+          f32x4 sa = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+          sa = mfma16(kf0, qf[s][0], sa);
+          sa = mfma16(kf1, qf[s][1], sa);
+          dp = mfma16(vf0, dof[s][0], dp);
+          dp = mfma16(vf1, dof[s][1], dp);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int key = t * 16 + 4 * g + r;
-          const float p = (key < n && q < n) ? fast_exp2(sa[r] * sl2 - l2) : 0.f;
-          ds[tt][r] = p * (dp[r] - dpart) * scale;
+          for (int r = 0; r < 4; ++r) {
+            const int key = t * 16 + 4 * g + r;
+            const float p = (key < n && q[s] < n) ? fast_exp2(sa[r] * sl2 - l2[s]) : 0.f;
+            ds[s][tt][r] = p * (dp[r] - dpart[s]) * scale;
+          }
         }
       }
-      const bf16x8 dsf = pack8(ds[0], ds[1]);
+      bf16x8 dsf[QB];
 #pragma unroll
-      for (int c = 0; c < 4; ++c) dq[c] = mfma16(frag_trr(k_rm, c, u, lane), dsf, dq[c]);
-    }
-    if (q < n) {
-      bf16_t* dp_out = dqkv + ((int64_t)bi * n + q) * tok_stride + hi * DH;
+      for (int s = 0; s < QB; ++s) dsf[s] = pack8(ds[s][0], ds[s][1]);
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        bf16x4 ov;
+        const bf16x8 kt = frag_trr(k_rm, c, u, lane);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) ov[r] = (bf16_t)dq[c][r];
-        *(bf16x4*)(dp_out + 16 * c + 4 * g) = ov;
+        for (int s = 0; s < QB; ++s) dq[s][c] = mfma16(kt, dsf[s], dq[s][c]);
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < QB; ++s) {
+      if (q[s] < n) {
+        bf16_t* dp_out = dqkv + ((int64_t)bi * n + q[s]) * tok_stride + hi * DH;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          bf16x4 ov;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) ov[r] = (bf16_t)dq[s][c][r];
+          *(bf16x4*)(dp_out + 16 * c + 4 * g) = ov;
+        }
       }
     }
   }
@@ -275,7 +329,7 @@ template <int NTP>
 __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ d_o,
                                                            const float* __restrict__ lse, const float* __restrict__ dsum,
                                                            bf16_t* __restrict__ dqkv, int n, int h, float scale, const bf16_t* __restrict__ zero_page) {
-  constexpr int NQP = 16 * NTP;
+  constexpr int NQP = 16 * NTP, QB = QB_BWD;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* q_rm = smem;
   char* do_rm = smem + NQP * ROWB;
@@ -297,57 +351,77 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dkv_kernel(const bf16_t*
   __syncthreads();
 
   const int ki = lane & 15, g = lane >> 4;
-  const int nkb = (n + 15) >> 4;
+  const int nkb = (n + 16 * QB - 1) / (16 * QB);
   const float sl2 = scale * 1.44269504088896340736f;
   for (int kb = wave; kb < nkb; kb += nwaves) {
-    const int key = kb * 16 + ki;
-    const int kc = min(key, n - 1);
-    bf16x8 kf[2], vf[2];
+    int key[QB];
+    bf16x8 kf[QB][2], vf[QB][2];
+    f32x4 dk[QB][4], dv[QB][4];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      kf[ks] = *(const bf16x8*)(qbase + inner + (int64_t)kc * tok_stride + (g + 4 * ks) * 8);
-      vf[ks] = *(const bf16x8*)(qbase + 2 * inner + (int64_t)kc * tok_stride + (g + 4 * ks) * 8);
+    for (int s = 0; s < QB; ++s) {
+      key[s] = (kb * QB + s) * 16 + ki;
+      const int kc = min(key[s], n - 1);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        kf[s][ks] = *(const bf16x8*)(qbase + inner + (int64_t)kc * tok_stride + (g + 4 * ks) * 8);
+        vf[s][ks] = *(const bf16x8*)(qbase + 2 * inner + (int64_t)kc * tok_stride + (g + 4 * ks) * 8);
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) { dk[s][c] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[s][c] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     }
-    f32x4 dk[4], dv[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) { dk[c] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[c] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll 1
     for (int u = 0; u < NTP / 2; ++u) {
-      f32x4 pp[2], ds[2];
+      f32x4 pp[QB][2], ds[QB][2];
 #pragma unroll
       for (int tt = 0; tt < 2; ++tt) {
         const int t = 2 * u + tt;
-        f32x4 sa = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+        const bf16x8 qa0 = frag_rm(q_rm, t * 16 + ki, g), qa1 = frag_rm(q_rm, t * 16 + ki, g + 4);
+        const bf16x8 da0 = frag_rm(do_rm, t * 16 + ki, g), da1 = frag_rm(do_rm, t * 16 + ki, g + 4);
+        float lq[4], dd[4];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          sa = mfma16(frag_rm(q_rm, t * 16 + ki, g + 4 * ks), kf[ks], sa);    // S[query 16t+4g+r][key ki]
-          dp = mfma16(frag_rm(do_rm, t * 16 + ki, g + 4 * ks), vf[ks], dp);   // dP same layout
-        }
+        for (int r = 0; r < 4; ++r) { lq[r] = lse_s[t * 16 + 4 * g + r]; dd[r] = d_s[t * 16 + 4 * g + r]; }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int qq = t * 16 + 4 * g + r;
-          const float p = (qq < n && key < n) ? fast_exp2(sa[r] * sl2 - lse_s[qq]) : 0.f;
-          pp[tt][r] = p;
-          ds[tt][r] = p * (dp[r] - d_s[qq]) * scale;
+        for (int s = 0; s < QB; ++s) {
+          f32x4 sa = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+          sa = mfma16(qa0, kf[s][0], sa);     // S[query 16t+4g+r][key ki]
+          sa = mfma16(qa1, kf[s][1], sa);
+          dp = mfma16(da0, vf[s][0], dp);     // dP same layout
+          dp = mfma16(da1, vf[s][1], dp);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int qq = t * 16 + 4 * g + r;
+            const float p = (qq < n && key[s] < n) ? fast_exp2(sa[r] * sl2 - lq[r]) : 0.f;
+            pp[s][tt][r] = p;
+            ds[s][tt][r] = p * (dp[r] - dd[r]) * scale;
+          }
         }
       }
-      const bf16x8 pf = pack8(pp[0], pp[1]), dsf = pack8(ds[0], ds[1]);
+      bf16x8 pf[QB], dsf[QB];
+#pragma unroll
+      for (int s = 0; s < QB; ++s) { pf[s] = pack8(pp[s][0], pp[s][1]); dsf[s] = pack8(ds[s][0], ds[s][1]); }
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        dv[c] = mfma16(frag_trr(do_rm, c, u, lane), pf, dv[c]);
-        dk[c] = mfma16(frag_trr(q_rm, c, u, lane), dsf, dk[c]);
+        const bf16x8 a1 = frag_trr(do_rm, c, u, lane), a2 = frag_trr(q_rm, c, u, lane);
+#pragma unroll
+        for (int s = 0; s < QB; ++s) {
+          dv[s][c] = mfma16(a1, pf[s], dv[s][c]);
+          dk[s][c] = mfma16(a2, dsf[s], dk[s][c]);
+        }
       }
     }
-    if (key < n) {
-      bf16_t* dkp = dqkv + ((int64_t)bi * n + key) * tok_stride + inner + hi * DH;
-      bf16_t* dvp = dkp + inner;
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        bf16x4 a, b2;
+    for (int s = 0; s < QB; ++s) {
+      if (key[s] < n) {
+        bf16_t* dkp = dqkv + ((int64_t)bi * n + key[s]) * tok_stride + inner + hi * DH;
+        bf16_t* dvp = dkp + inner;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { a[r] = (bf16_t)dk[c][r]; b2[r] = (bf16_t)dv[c][r]; }
-        *(bf16x4*)(dkp + 16 * c + 4 * g) = a;
-        *(bf16x4*)(dvp + 16 * c + 4 * g) = b2;
+        for (int c = 0; c < 4; ++c) {
+          bf16x4 a, b2;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { a[r] = (bf16_t)dk[s][c][r]; b2[r] = (bf16_t)dv[s][c][r]; }
+          *(bf16x4*)(dkp + 16 * c + 4 * g) = a;
+          *(bf16x4*)(dvp + 16 * c + 4 * g) = b2;
+        }
       }
     }
   }
@@ -362,6 +436,7 @@ void set_smem(K kern, int bytes) {   // one attribute call per distinct kernel (
   if (ndone < 32) done[ndone++] = (const void*)kern;
 }
 
+inline int att_threads(int n) { (void)n; return 512; }   // 8 waves measured best (13 one-block waves: bwd 16 % slower)
 inline int pick_ntp(int n) { return n <= 64 ? 4 : n <= 96 ? 6 : n <= 224 ? 14 : 18; }
 
 }  // namespace
@@ -375,7 +450,7 @@ void launch_attn_bf16_fwd(const bf16_t* qkv, bf16_t* o, float* lse, int b, int n
   const int ntp = pick_ntp(n);
   const int nkp = 16 * ntp;
   const int smem = 2 * nkp * ROWB;
-#define CALL(NTP) { set_smem(attn_fwd_kernel<NTP>, smem); hipLaunchKernelGGL(attn_fwd_kernel<NTP>, dim3(b * h), dim3(ATT_THREADS), smem, s, qkv, o, lse, n, h, scale, zero_page); }
+#define CALL(NTP) { set_smem(attn_fwd_kernel<NTP>, smem); hipLaunchKernelGGL(attn_fwd_kernel<NTP>, dim3(b * h), dim3(att_threads(n)), smem, s, qkv, o, lse, n, h, scale, zero_page); }
   VITX_NTP_DISPATCH(ntp, CALL);
 #undef CALL
 }
@@ -390,8 +465,8 @@ void launch_attn_bf16_bwd(const bf16_t* qkv, const bf16_t* o, const bf16_t* d_o,
   {                                                                                                                                \
     set_smem(attn_bwd_dq_kernel<NTP>, smem_dq);                                                                                    \
     set_smem(attn_bwd_dkv_kernel<NTP>, smem_dkv);                                                                                  \
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<NTP>, dim3(b * h), dim3(ATT_THREADS), smem_dq, s, qkv, o, d_o, lse, dsum_ws, dqkv, n, h, scale, zero_page);   \
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel<NTP>, dim3(b * h), dim3(ATT_THREADS), smem_dkv, s, qkv, d_o, lse, dsum_ws, dqkv, n, h, scale, zero_page);    \
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<NTP>, dim3(b * h), dim3(att_threads(n)), smem_dq, s, qkv, o, d_o, lse, dsum_ws, dqkv, n, h, scale, zero_page);   \
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<NTP>, dim3(b * h), dim3(att_threads(n)), smem_dkv, s, qkv, d_o, lse, dsum_ws, dqkv, n, h, scale, zero_page);    \
   }
   VITX_NTP_DISPATCH(ntp, CALL);
 #undef CALL
