@@ -37,12 +37,16 @@ WORKLOADS = {
     "vit_l16_224": dict(image_size=224, patch_size=16, num_classes=1000, dim=1024, depth=24, heads=16, mlp_dim=4096),
     # configs[0] (README example; plumbing-sized)
     "vit_readme_256": dict(image_size=256, patch_size=32, num_classes=1000, dim=1024, depth=6, heads=16, mlp_dim=2048),
+    # configs[3]: DeepViT with Re-attention; configs[4]: CaiT (LayerScale + talking heads + class attention)
+    "deepvit_256": dict(variant="deepvit", image_size=256, patch_size=32, num_classes=1000, dim=1024, depth=12, heads=16, mlp_dim=2048),
+    "cait_256": dict(variant="cait", image_size=256, patch_size=32, num_classes=1000, dim=1024, depth=24, cls_depth=2, heads=16, mlp_dim=2048),
 }
 
 
 def flops_per_image(kw) -> float:
     from oracle import spec   # FLOP model only; no oracle compute in the timed path
-    return spec.flops_per_image(spec.make_config("vit", **kw))
+    kw = dict(kw)
+    return spec.flops_per_image(spec.make_config(kw.pop("variant", "vit"), **kw))
 
 
 def cpu_baseline(kw, seconds: float, batch: int = 4):
@@ -110,11 +114,17 @@ def main():
         raise SystemExit("bench.py needs a GPU: the product path is HIP-only (no CPU fallback)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    kw = WORKLOADS[args.workload]
+    kw = dict(WORKLOADS[args.workload])
+    variant = kw.pop("variant", "vit")
     b = args.batch
     lib = N.lib()
-
-    model = ViT(**kw, compute=args.compute, max_batch=b, device=local, seed=1)
+    if variant == "deepvit":
+        from vit_tensorflow.deepvit import DeepViT as Model
+    elif variant == "cait":
+        from vit_tensorflow.cait import CaiT as Model
+    else:
+        Model = ViT
+    model = Model(**kw, compute=args.compute, max_batch=b, device=local, seed=1)
     model.build((b,))
     h = model._handle
     H, W = (kw["image_size"],) * 2
@@ -176,7 +186,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
 
-    fpi = flops_per_image(kw)
+    fpi = flops_per_image(WORKLOADS[args.workload])
     value = b * world * args.steps / el
     out = {
         "metric": "images/sec (fwd+bwd) ViT-B/16 224px bf16" if args.workload == "vit_b16_224" else f"images/sec (fwd+bwd) {args.workload}",

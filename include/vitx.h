@@ -134,6 +134,11 @@ int32_t vitx_patch_unfold(const float* img_host, int32_t b, int32_t H, int32_t W
 int32_t vitx_ce_loss_grad_dev(vitx_handle h, const int32_t* labels_dev, float inv_global_batch,
                               float* loss_dev_or_null);
 
+/* ---- optimizer step on the device arenas ("next" row f1 of SURVEY.md section 8: the reference has no optimizer or trainer at
+ * all; this turns forward+backward into a training step).  Uses the gradients of the last backward (all-reduced or not). */
+int32_t vitx_adamw_step(vitx_handle h, float lr, float beta1, float beta2, float eps, float weight_decay);
+int32_t vitx_sgd_step(vitx_handle h, float lr, float momentum, float weight_decay);
+
 /* ---- streams / sync */
 int32_t vitx_set_stream(vitx_handle h, void* hip_stream); /* NULL = the handle's own stream */
 int32_t vitx_sync(vitx_handle h);

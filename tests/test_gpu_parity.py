@@ -220,3 +220,34 @@ def test_full_size_properties_vit_b16_bf16():
         acc = gh if acc is None else {k: acc[k] + gh[k] for k in gh}
     for k in ("transformer.0.attn.to_qkv.kernel", "transformer.5.mlp.fc1.bias", "cls_token", "mlp_head.bias"):
         assert rel_max_err(acc[k], g1[k].astype(np.float64)) <= 3e-2, k
+
+
+def test_optimizer_steps_match_numpy():
+    """Row f1 ("next"): fused AdamW / SGD-momentum step on the device arenas vs the textbook update in numpy."""
+    cfg = oracle_cfg("vit_small")
+    P = spec.init_params(cfg, 1, randomize_all=True)
+    for opt in ("adamw", "sgd"):
+        m = make_engine_model("vit_small", "fp32", 2, P)
+        img = rand_images(cfg, 2)
+        dl = (np.random.default_rng(5).standard_normal((2, cfg["num_classes"])) / 2).astype(np.float32)
+        w = {k: v.astype(np.float64) for k, v in m.state_dict().items()}
+        mom = {k: np.zeros_like(v) for k, v in w.items()}
+        var = {k: np.zeros_like(v) for k, v in w.items()}
+        for step in (1, 2, 3):
+            m(img, training=False)
+            grads, _ = m.backward(dl)
+            if opt == "adamw":
+                m.apply_gradients("adamw", lr=1e-2, beta1=0.9, beta2=0.99, eps=1e-7, weight_decay=0.01)
+                for k in w:
+                    g = grads[k].astype(np.float64)
+                    mom[k] = 0.9 * mom[k] + 0.1 * g
+                    var[k] = 0.99 * var[k] + 0.01 * g * g
+                    w[k] = w[k] - 1e-2 * ((mom[k] / (1 - 0.9 ** step)) / (np.sqrt(var[k] / (1 - 0.99 ** step)) + 1e-7) + 0.01 * w[k])
+            else:
+                m.apply_gradients("sgd", lr=1e-2, momentum=0.9, weight_decay=0.01)
+                for k in w:
+                    mom[k] = 0.9 * mom[k] + grads[k].astype(np.float64) + 0.01 * w[k]
+                    w[k] = w[k] - 1e-2 * mom[k]
+            got = m.state_dict()
+            for k in w:
+                assert np.abs(got[k] - w[k]).max() <= 2e-5 * max(1.0, np.abs(w[k]).max()), (opt, step, k)

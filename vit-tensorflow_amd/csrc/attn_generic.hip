@@ -39,9 +39,11 @@ __global__ __launch_bounds__(256) void softmax_bwd_rows_kernel(const float* __re
 }
 
 // out[b,g,i,j] = sum_h in[b,h,i,j] W[h,g]    -- one thread per (b,i,j)
+template <int HT>
 __global__ __launch_bounds__(256) void headmix_fwd_kernel(const float* __restrict__ in, const float* __restrict__ w,
-                                                          float* __restrict__ out, int b, int h, int64_t plane, int64_t nvalid_per_row,
+                                                          float* __restrict__ out, int b, int h_rt, int64_t plane, int64_t nvalid_per_row,
                                                           int64_t ld) {
+  const int h = HT ? HT : h_rt;   // compile-time head count keeps the per-point arrays in registers
   __shared__ float ws[MAXH * MAXH];
   for (int i = threadIdx.x; i < h * h; i += blockDim.x) ws[i] = w[i];
   __syncthreads();
@@ -52,21 +54,22 @@ __global__ __launch_bounds__(256) void headmix_fwd_kernel(const float* __restric
     const float* ip = in + bi * h * plane + ij;
     float* op = out + bi * h * plane + ij;
     float v[MAXH];
-#pragma unroll 4
-    for (int hh = 0; hh < h; ++hh) v[hh] = ip[(int64_t)hh * plane];
-    for (int gg = 0; gg < h; ++gg) {
+    _Pragma("unroll") for (int hh = 0; hh < h; ++hh) v[hh] = ip[(int64_t)hh * plane];
+    _Pragma("unroll") for (int gg = 0; gg < h; ++gg) {
       float a = 0.f;
-      for (int hh = 0; hh < h; ++hh) a = fmaf(v[hh], ws[hh * h + gg], a);
+      _Pragma("unroll") for (int hh = 0; hh < h; ++hh) a = fmaf(v[hh], ws[hh * h + gg], a);
       op[(int64_t)gg * plane] = a;
     }
   }
 }
 
 // din[b,h,i,j] = sum_g dout[b,g,i,j] W[h,g];  per-block partial of dW[h,g] = sum in[h]*dout[g]
+template <int HT>
 __global__ __launch_bounds__(256) void headmix_bwd_kernel(const float* __restrict__ in, const float* __restrict__ dout,
                                                           const float* __restrict__ w, float* __restrict__ din,
-                                                          float* __restrict__ dw_partial, int b, int h, int64_t plane,
+                                                          float* __restrict__ dw_partial, int b, int h_rt, int64_t plane,
                                                           int64_t nvalid_per_row, int64_t ld) {
+  const int h = HT ? HT : h_rt;
   __shared__ float ws[MAXH * MAXH];
   extern __shared__ float pts[];   // [256][2h]: in[h], dout[h] of each point handled by this block iteration
   for (int i = threadIdx.x; i < h * h; i += blockDim.x) ws[i] = w[i];
@@ -83,26 +86,60 @@ __global__ __launch_bounds__(256) void headmix_bwd_kernel(const float* __restric
     float* mine = pts + (int64_t)threadIdx.x * 2 * h;
     if (valid) {
       float dv[MAXH];
-      for (int gg = 0; gg < h; ++gg) { dv[gg] = dout[(bi * h + gg) * plane + ij]; mine[h + gg] = dv[gg]; }
-      for (int hh = 0; hh < h; ++hh) {
+      _Pragma("unroll") for (int gg = 0; gg < h; ++gg) { dv[gg] = dout[(bi * h + gg) * plane + ij]; mine[h + gg] = dv[gg]; }
+      _Pragma("unroll") for (int hh = 0; hh < h; ++hh) {
         mine[hh] = in[(bi * h + hh) * plane + ij];
         float a = 0.f;
-        for (int gg = 0; gg < h; ++gg) a = fmaf(dv[gg], ws[hh * h + gg], a);
+        _Pragma("unroll") for (int gg = 0; gg < h; ++gg) a = fmaf(dv[gg], ws[hh * h + gg], a);
         din[(bi * h + hh) * plane + ij] = a;
       }
     } else {
       for (int k = 0; k < 2 * h; ++k) mine[k] = 0.f;
     }
     __syncthreads();
-    for (int k = 0; k < 4; ++k) {
-      const int pair = threadIdx.x + 256 * k;
-      if (pair < h * h) {
-        const int hh = pair / h, gg = pair - hh * h;
-        float a = dwacc[k];
-        for (int p = 0; p < 256; ++p) a = fmaf(pts[p * 2 * h + hh], pts[p * 2 * h + h + gg], a);
-        dwacc[k] = a;
+    if (HT >= 4 && HT * HT <= 256) {
+      // thread = (pg, hh, g4): 64 threads cover the HT*HT/4 float4 column groups ... each thread owns 4 consecutive g of one hh
+      // and a quarter of the points; one scalar + one 16-B LDS read per 4 FMAs
+      constexpr int GROUPS = (HT * HT) / 4;            // float4 groups of dW
+      constexpr int PG = 256 / (GROUPS > 0 ? GROUPS : 1);   // point groups (>= 4 for HT <= 16)
+      const int grp = threadIdx.x % GROUPS, pg = threadIdx.x / GROUPS;
+      const int hh = (grp * 4) / HT, g0 = (grp * 4) % HT;
+      float4 a4 = make_float4(dwacc[0], dwacc[1], dwacc[2], dwacc[3]);
+      for (int p = pg; p < 256; p += PG) {
+        const float x = pts[p * 2 * HT + hh];
+        const float4 d4 = *(const float4*)(pts + p * 2 * HT + HT + g0);
+        a4.x = fmaf(x, d4.x, a4.x); a4.y = fmaf(x, d4.y, a4.y); a4.z = fmaf(x, d4.z, a4.z); a4.w = fmaf(x, d4.w, a4.w);
+      }
+      dwacc[0] = a4.x; dwacc[1] = a4.y; dwacc[2] = a4.z; dwacc[3] = a4.w;
+    } else {
+      for (int k = 0; k < 4; ++k) {
+        const int pair = threadIdx.x + 256 * k;
+        if (pair < h * h) {
+          const int hh = pair / h, gg = pair - hh * h;
+          float a = dwacc[k];
+          for (int p = 0; p < 256; ++p) a = fmaf(pts[p * 2 * h + hh], pts[p * 2 * h + h + gg], a);
+          dwacc[k] = a;
+        }
       }
     }
+  }
+  if (HT >= 4 && HT * HT <= 256) {
+    // combine the point groups in fixed order: partial[blk][hh][g] = sum_pg
+    constexpr int GROUPS = (HT * HT) / 4;
+    constexpr int PG = 256 / (GROUPS > 0 ? GROUPS : 1);
+    __syncthreads();
+    float4* red = (float4*)pts;                       // [PG][GROUPS]
+    red[threadIdx.x] = make_float4(dwacc[0], dwacc[1], dwacc[2], dwacc[3]);
+    __syncthreads();
+    if (threadIdx.x < GROUPS) {
+      float4 t = red[threadIdx.x];
+      for (int k = 1; k < PG; ++k) {
+        const float4 u = red[k * GROUPS + threadIdx.x];
+        t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+      }
+      *(float4*)(dw_partial + (int64_t)blockIdx.x * HT * HT + threadIdx.x * 4) = t;
+    }
+    return;
   }
   for (int k = 0; k < 4; ++k) {
     const int pair = threadIdx.x + 256 * k;
@@ -111,43 +148,47 @@ __global__ __launch_bounds__(256) void headmix_bwd_kernel(const float* __restric
 }
 
 // LayerNorm over heads at every (b,i,j)  (deepvit.py:59-63)
+template <int HT>
 __global__ __launch_bounds__(256) void headnorm_fwd_kernel(const float* __restrict__ in, const float* __restrict__ gamma,
-                                                           const float* __restrict__ beta, float* __restrict__ out, int b, int h,
+                                                           const float* __restrict__ beta, float* __restrict__ out, int b, int h_rt,
                                                            int64_t plane, int64_t nvalid_per_row, int64_t ld, float eps) {
+  const int h = HT ? HT : h_rt;
   const int64_t total = (int64_t)b * plane;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
     const int64_t bi = e / plane, ij = e - bi * plane;
     if ((ij % ld) >= nvalid_per_row) continue;
     float v[MAXH];
     float mu = 0.f;
-    for (int hh = 0; hh < h; ++hh) { v[hh] = in[(bi * h + hh) * plane + ij]; mu += v[hh]; }
+    _Pragma("unroll") for (int hh = 0; hh < h; ++hh) { v[hh] = in[(bi * h + hh) * plane + ij]; mu += v[hh]; }
     mu /= (float)h;
     float var = 0.f;
-    for (int hh = 0; hh < h; ++hh) var += (v[hh] - mu) * (v[hh] - mu);
+    _Pragma("unroll") for (int hh = 0; hh < h; ++hh) var += (v[hh] - mu) * (v[hh] - mu);
     const float rs = rsqrtf(var / (float)h + eps);
-    for (int hh = 0; hh < h; ++hh) out[(bi * h + hh) * plane + ij] = (v[hh] - mu) * rs * gamma[hh] + beta[hh];
+    _Pragma("unroll") for (int hh = 0; hh < h; ++hh) out[(bi * h + hh) * plane + ij] = (v[hh] - mu) * rs * gamma[hh] + beta[hh];
   }
 }
+template <int HT>
 __global__ __launch_bounds__(256) void headnorm_bwd_kernel(const float* __restrict__ in, const float* __restrict__ dout,
                                                            const float* __restrict__ gamma, float* __restrict__ din,
-                                                           float* __restrict__ partial, int b, int h, int64_t plane,
+                                                           float* __restrict__ partial, int b, int h_rt, int64_t plane,
                                                            int64_t nvalid_per_row, int64_t ld, float eps) {
+  const int h = HT ? HT : h_rt;
   __shared__ float red[256];
   float ag[MAXH], ab[MAXH];
-  for (int hh = 0; hh < h; ++hh) { ag[hh] = 0.f; ab[hh] = 0.f; }
+  _Pragma("unroll") for (int hh = 0; hh < h; ++hh) { ag[hh] = 0.f; ab[hh] = 0.f; }
   const int64_t total = (int64_t)b * plane;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
     const int64_t bi = e / plane, ij = e - bi * plane;
     if ((ij % ld) >= nvalid_per_row) continue;
     float xh[MAXH], gg[MAXH];
     float mu = 0.f;
-    for (int hh = 0; hh < h; ++hh) { xh[hh] = in[(bi * h + hh) * plane + ij]; mu += xh[hh]; }
+    _Pragma("unroll") for (int hh = 0; hh < h; ++hh) { xh[hh] = in[(bi * h + hh) * plane + ij]; mu += xh[hh]; }
     mu /= (float)h;
     float var = 0.f;
-    for (int hh = 0; hh < h; ++hh) { xh[hh] -= mu; var += xh[hh] * xh[hh]; }
+    _Pragma("unroll") for (int hh = 0; hh < h; ++hh) { xh[hh] -= mu; var += xh[hh] * xh[hh]; }
     const float rs = rsqrtf(var / (float)h + eps);
     float s1 = 0.f, s2 = 0.f;
-    for (int hh = 0; hh < h; ++hh) {
+    _Pragma("unroll") for (int hh = 0; hh < h; ++hh) {
       xh[hh] *= rs;
       const float d = dout[(bi * h + hh) * plane + ij];
       ab[hh] += d;
@@ -158,10 +199,10 @@ __global__ __launch_bounds__(256) void headnorm_bwd_kernel(const float* __restri
     }
     s1 /= (float)h;
     s2 /= (float)h;
-    for (int hh = 0; hh < h; ++hh) din[(bi * h + hh) * plane + ij] = rs * (gg[hh] - s1 - xh[hh] * s2);
+    _Pragma("unroll") for (int hh = 0; hh < h; ++hh) din[(bi * h + hh) * plane + ij] = rs * (gg[hh] - s1 - xh[hh] * s2);
   }
   // fixed-order block reduction of the 2h accumulators
-  for (int k = 0; k < 2 * h; ++k) {
+  _Pragma("unroll") for (int k = 0; k < 2 * h; ++k) {
     __syncthreads();
     red[threadIdx.x] = k < h ? ag[k] : ab[k - h];
     __syncthreads();
@@ -205,17 +246,38 @@ __global__ void add_T_kernel(T* __restrict__ a, const T* __restrict__ b2, int64_
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x)
     stf<T>(a + e, ldf<T>(a + e) + ldf<T>(b2 + e));
 }
-// partial[chunk][c] = sum_{rows in chunk} g[r][c] * fx[r][c]
+// partial[chunk][c] = sum_{rows in chunk} g[r][c] * fx[r][c]; a wave owns 64 x 4 consecutive columns, the 4 waves of a block
+// take interleaved rows (same shape as the bias column sums)
 template <typename T>
 __global__ __launch_bounds__(256) void scale_grad_kernel(const T* __restrict__ fx, int64_t ldf_, const float* __restrict__ g, int64_t ldg,
                                                          int rows, int d, float* __restrict__ partial) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= d) return;
+  __shared__ float red[4][256];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int c = blockIdx.x * 256 + lane * 4;
   const int rows_per = (rows + gridDim.y - 1) / gridDim.y;
   const int r0 = blockIdx.y * rows_per, r1 = min(rows, r0 + rows_per);
-  float a = 0.f;
-  for (int r = r0; r < r1; ++r) a = fmaf(g[(int64_t)r * ldg + c], ldf<T>(fx + (int64_t)r * ldf_ + c), a);
-  partial[(int64_t)blockIdx.y * d + c] = a;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (c + 3 < d) {
+    int r = r0 + w;
+    for (; r + 4 < r1; r += 8) {
+      const float4 g0 = *(const float4*)(g + (int64_t)r * ldg + c), g1 = *(const float4*)(g + (int64_t)(r + 4) * ldg + c);
+      const float4 f0 = ld4<T>(fx + (int64_t)r * ldf_ + c), f1 = ld4<T>(fx + (int64_t)(r + 4) * ldf_ + c);
+      a.x += g0.x * f0.x + g1.x * f1.x; a.y += g0.y * f0.y + g1.y * f1.y; a.z += g0.z * f0.z + g1.z * f1.z; a.w += g0.w * f0.w + g1.w * f1.w;
+    }
+    for (; r < r1; r += 4) {
+      const float4 g0 = *(const float4*)(g + (int64_t)r * ldg + c);
+      const float4 f0 = ld4<T>(fx + (int64_t)r * ldf_ + c);
+      a.x += g0.x * f0.x; a.y += g0.y * f0.y; a.z += g0.z * f0.z; a.w += g0.w * f0.w;
+    }
+  } else if (c < d) {
+    float* ap = (float*)&a;
+    for (int r = r0 + w; r < r1; r += 4)
+      for (int i = 0; i < 4 && c + i < d; ++i) ap[i] += g[(int64_t)r * ldg + c + i] * ldf<T>(fx + (int64_t)r * ldf_ + c + i);
+  }
+  *(float4*)&red[w][lane * 4] = a;
+  __syncthreads();
+  const int cc = blockIdx.x * 256 + threadIdx.x;
+  if (cc < d) partial[(int64_t)blockIdx.y * d + cc] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 template <typename TO>
 __global__ void mul_scale_kernel(const float* __restrict__ g, int64_t ldg, const float* __restrict__ scale, TO* __restrict__ out,
@@ -233,9 +295,15 @@ __global__ void broadcast_rows_kernel(const float* __restrict__ src, int d, floa
     dst[e] = src[e % d];
 }
 
+#define VITX_H_DISPATCH(h, CALL)                                                              \
+  do {                                                                                       \
+    if ((h) == 16) { CALL(16); } else if ((h) == 12) { CALL(12); } else if ((h) == 8) { CALL(8); } \
+    else if ((h) == 4) { CALL(4); } else { CALL(0); }                                         \
+  } while (0)
+
 inline int grid_for(int64_t total, int block = 256) { return (int)std::max<int64_t>(1, std::min<int64_t>(ceil_div(total, block), 256 * 8)); }
 constexpr int HM_BLOCKS = 256;
-constexpr int SG_CHUNKS = 64;
+constexpr int SG_CHUNKS = 512;
 
 }  // namespace
 
@@ -249,7 +317,9 @@ void launch_softmax_bwd_rows(const float* p, float* dp, int64_t rows, int n, int
 }
 void launch_headmix_fwd(const float* in, const float* w, float* out, int b, int h, int nq, int nk, int64_t ld, hipStream_t s) {
   const int64_t plane = (int64_t)nq * ld;
-  hipLaunchKernelGGL(headmix_fwd_kernel, dim3(grid_for((int64_t)b * plane)), dim3(256), 0, s, in, w, out, b, h, plane, (int64_t)nk, ld);
+#define CALL(HT) hipLaunchKernelGGL(headmix_fwd_kernel<HT>, dim3(grid_for((int64_t)b * plane)), dim3(256), 0, s, in, w, out, b, h, plane, (int64_t)nk, ld)
+  VITX_H_DISPATCH(h, CALL);
+#undef CALL
 }
 int64_t headmix_ws_elems(int b, int h, int nq, int nk) { return (int64_t)HM_BLOCKS * h * h; }
 void launch_headmix_bwd(const float* in, const float* dout, const float* w, float* din, float* dw_partial_ws, float* dw, int b, int h,
@@ -257,20 +327,25 @@ void launch_headmix_bwd(const float* in, const float* dout, const float* w, floa
   const int64_t plane = (int64_t)nq * ld;
   const int nblk = (int)std::max<int64_t>(1, std::min<int64_t>(HM_BLOCKS, ceil_div((int64_t)b * plane, 256)));
   const size_t shm = (size_t)256 * 2 * h * sizeof(float);
-  hipLaunchKernelGGL(headmix_bwd_kernel, dim3(nblk), dim3(256), shm, s, in, dout, w, din, dw_partial_ws, b, h, plane, (int64_t)nk, ld);
+#define CALL(HT) hipLaunchKernelGGL(headmix_bwd_kernel<HT>, dim3(nblk), dim3(256), shm, s, in, dout, w, din, dw_partial_ws, b, h, plane, (int64_t)nk, ld)
+  VITX_H_DISPATCH(h, CALL);
+#undef CALL
   launch_reduce_partials(dw_partial_ws, nblk, (int64_t)h * h, (int64_t)h * h, dw, 1.0f, s);
 }
 void launch_headnorm_fwd(const float* in, const float* gamma, const float* beta, float* out, int b, int h, int nq, int nk, int64_t ld,
                          float eps, hipStream_t s) {
   const int64_t plane = (int64_t)nq * ld;
-  hipLaunchKernelGGL(headnorm_fwd_kernel, dim3(grid_for((int64_t)b * plane)), dim3(256), 0, s, in, gamma, beta, out, b, h, plane,
-                     (int64_t)nk, ld, eps);
+#define CALL(HT) hipLaunchKernelGGL(headnorm_fwd_kernel<HT>, dim3(grid_for((int64_t)b * plane)), dim3(256), 0, s, in, gamma, beta, out, b, h, plane, (int64_t)nk, ld, eps)
+  VITX_H_DISPATCH(h, CALL);
+#undef CALL
 }
 void launch_headnorm_bwd(const float* in, const float* dout, const float* gamma, float* din, float* partial_ws, float* dgamma, float* dbeta,
                          int b, int h, int nq, int nk, int64_t ld, float eps, hipStream_t s) {
   const int64_t plane = (int64_t)nq * ld;
   const int nblk = (int)std::max<int64_t>(1, std::min<int64_t>(HM_BLOCKS, ceil_div((int64_t)b * plane, 256)));
-  hipLaunchKernelGGL(headnorm_bwd_kernel, dim3(nblk), dim3(256), 0, s, in, dout, gamma, din, partial_ws, b, h, plane, (int64_t)nk, ld, eps);
+#define CALL(HT) hipLaunchKernelGGL(headnorm_bwd_kernel<HT>, dim3(nblk), dim3(256), 0, s, in, dout, gamma, din, partial_ws, b, h, plane, (int64_t)nk, ld, eps)
+  VITX_H_DISPATCH(h, CALL);
+#undef CALL
   launch_reduce_partials(partial_ws, nblk, (int64_t)2 * h, h, dgamma, 1.0f, s);
   launch_reduce_partials(partial_ws + h, nblk, (int64_t)2 * h, h, dbeta, 1.0f, s);
 }
@@ -291,11 +366,12 @@ void launch_add_T(void* a, const void* b2, int is_bf16, int64_t n, hipStream_t s
 }
 void launch_scale_grad(const void* fx, int is_bf16, int64_t ldf_, const float* g, int64_t ldg, int rows, int d, float* partial_ws,
                        float* dscale, hipStream_t s) {
-  const int chunks = (int)std::max<int64_t>(1, std::min<int64_t>(SG_CHUNKS, ceil_div(rows, 8)));
-  dim3 grid((unsigned)ceil_div(d, 256), chunks), block(256);
+  const int cblocks = (int)ceil_div(d, 256);
+  const int chunks = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)SG_CHUNKS, ceil_div(rows, 16), ceil_div(2048, cblocks)}));
+  dim3 grid((unsigned)cblocks, chunks), block(256);
   if (is_bf16) hipLaunchKernelGGL(scale_grad_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)fx, ldf_, g, ldg, rows, d, partial_ws);
   else hipLaunchKernelGGL(scale_grad_kernel<float>, grid, block, 0, s, (const float*)fx, ldf_, g, ldg, rows, d, partial_ws);
-  launch_reduce_partials(partial_ws, chunks, d, d, dscale, 1.0f, s);
+  launch_reduce_partials3(partial_ws, chunks, d, d, 1, dscale, nullptr, nullptr, partial_ws + (int64_t)SG_CHUNKS * d, 1.0f, s);
 }
 void launch_mul_scale(const float* g, int64_t ldg, const float* scale, void* out, int out_bf16, int64_t ldo, int rows, int d, hipStream_t s) {
   const int64_t total = (int64_t)rows * d;

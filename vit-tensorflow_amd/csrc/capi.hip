@@ -262,6 +262,42 @@ int32_t vitx_ce_loss_grad_dev(vitx_handle h, const int32_t* labels_dev, float in
   CAPI_CATCH
 }
 
+static int ensure_opt_state(vitx_engine* e, bool need_v) {
+  if (!e->opt_m) {
+    CAPI_HIP(hipMalloc((void**)&e->opt_m, (size_t)e->n_arena * 4));
+    CAPI_HIP(hipMemsetAsync(e->opt_m, 0, (size_t)e->n_arena * 4, e->stream));
+    e->allocs.push_back(e->opt_m);
+  }
+  if (need_v && !e->opt_v) {
+    CAPI_HIP(hipMalloc((void**)&e->opt_v, (size_t)e->n_arena * 4));
+    CAPI_HIP(hipMemsetAsync(e->opt_v, 0, (size_t)e->n_arena * 4, e->stream));
+    e->allocs.push_back(e->opt_v);
+  }
+  return VITX_OK;
+}
+
+int32_t vitx_adamw_step(vitx_handle h, float lr, float beta1, float beta2, float eps, float weight_decay) {
+  CAPI_TRY
+  if (!h) return fail(VITX_ERR_INVALID, "null handle");
+  int rc = ensure_opt_state(h, true);
+  if (rc != VITX_OK) return rc;
+  h->opt_step += 1;
+  launch_adamw(h->params, h->grads, h->opt_m, h->opt_v, h->n_arena, lr, beta1, beta2, eps, weight_decay, h->opt_step, h->stream);
+  h->params_dirty = true;
+  return VITX_OK;
+  CAPI_CATCH
+}
+
+int32_t vitx_sgd_step(vitx_handle h, float lr, float momentum, float weight_decay) {
+  CAPI_TRY
+  if (!h) return fail(VITX_ERR_INVALID, "null handle");
+  if (momentum != 0.f) { int rc = ensure_opt_state(h, false); if (rc != VITX_OK) return rc; }
+  launch_sgd(h->params, h->grads, momentum != 0.f ? h->opt_m : nullptr, h->n_arena, lr, momentum, weight_decay, h->stream);
+  h->params_dirty = true;
+  return VITX_OK;
+  CAPI_CATCH
+}
+
 int32_t vitx_set_stream(vitx_handle h, void* s) {
   if (!h) return fail(VITX_ERR_INVALID, "null handle");
   (void)hipStreamSynchronize(h->stream);

@@ -393,6 +393,35 @@ __device__ __forceinline__ uint32_t hash32(uint32_t x) {
   x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
   return x;
 }
+// decoupled-weight-decay Adam (AdamW) / SGD-momentum on the flat fp32 arenas; one fused pass, 16-B accesses
+__global__ void adamw_kernel(float4* __restrict__ p, const float4* __restrict__ g, float4* __restrict__ m, float4* __restrict__ v, int64_t n4,
+                             float lr, float b1, float b2, float eps, float wd, float c1, float c2) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (int64_t)gridDim.x * blockDim.x) {
+    float4 pp = p[e], gg = g[e], mm = m[e], vv = v[e];
+    float* P = (float*)&pp; const float* G = (const float*)&gg; float* M = (float*)&mm; float* V = (float*)&vv;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      M[i] = b1 * M[i] + (1.f - b1) * G[i];
+      V[i] = b2 * V[i] + (1.f - b2) * G[i] * G[i];
+      P[i] = P[i] - lr * ((M[i] * c1) / (sqrtf(V[i] * c2) + eps) + wd * P[i]);
+    }
+    p[e] = pp; m[e] = mm; v[e] = vv;
+  }
+}
+__global__ void sgd_kernel(float4* __restrict__ p, const float4* __restrict__ g, float4* __restrict__ m, int64_t n4, float lr, float mom, float wd) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (int64_t)gridDim.x * blockDim.x) {
+    float4 pp = p[e], gg = g[e], mm = m ? m[e] : make_float4(0.f, 0.f, 0.f, 0.f);
+    float* P = (float*)&pp; const float* G = (const float*)&gg; float* M = (float*)&mm;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float d = G[i] + wd * P[i];
+      M[i] = mom * M[i] + d;
+      P[i] -= lr * (m ? M[i] : d);
+    }
+    p[e] = pp;
+    if (m) m[e] = mm;
+  }
+}
 __global__ void fill_zero_kernel(float4* p, int64_t n16) {
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n16; e += (int64_t)gridDim.x * blockDim.x) p[e] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
@@ -583,6 +612,15 @@ void launch_sum_rows(const float* in, int rows, int d, float* out, hipStream_t s
 void launch_ce_grad(const float* logits, int64_t ld, const int32_t* labels, int b, int nc, float inv_batch, float* dlogits, float* loss,
                     hipStream_t s) {
   hipLaunchKernelGGL(ce_grad_kernel, dim3(b), dim3(64), 0, s, logits, ld, labels, b, nc, inv_batch, dlogits, loss);
+}
+void launch_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps, float wd, int step, hipStream_t s) {
+  if (n == 0) return;
+  const float c1 = 1.0f / (1.0f - powf(b1, (float)step)), c2 = 1.0f / (1.0f - powf(b2, (float)step));
+  hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n / 4)), dim3(256), 0, s, (float4*)p, (const float4*)g, (float4*)m, (float4*)v, n / 4, lr, b1, b2, eps, wd, c1, c2);
+}
+void launch_sgd(float* p, const float* g, float* m, int64_t n, float lr, float mom, float wd, hipStream_t s) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(n / 4)), dim3(256), 0, s, (float4*)p, (const float4*)g, (float4*)m, n / 4, lr, mom, wd);
 }
 void launch_fill_zero(void* p, int64_t bytes, hipStream_t s) {
   if (bytes <= 0) return;

@@ -101,6 +101,7 @@ struct vitx_engine {
   void* zero_page = nullptr;         // 256 B of zeros (source of the padded rows in the attention DMA staging)
   float* tmp_f32 = nullptr;          // [mp, max(d, pd)] fp32 scratch (dropout / dimg paths)
   float* loss_rows = nullptr;
+  float *opt_m = nullptr, *opt_v = nullptr; int opt_step = 0;   // optimizer state (allocated on first use)
   bf16_t *bench_a = nullptr, *bench_b = nullptr; float* bench_c = nullptr; int64_t bench_elems = 0;
 
   // state of the last forward

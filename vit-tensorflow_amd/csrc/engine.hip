@@ -809,7 +809,7 @@ int engine_create(const vitx_config& cfg, vitx_engine** out, std::string& err) {
     DALLOC(e->partial_ws, (size_t)e->partial_elems * 4, false);
   }
   e->red_elems = std::max<int64_t>({layernorm_bwd_ws_elems(d), colsum_ws_elems((int)maxfeat), headmix_ws_elems((int)B, c.heads, 1, 1),
-                                    (int64_t)256 * 2 * 32, (int64_t)64 * d});
+                                    (int64_t)256 * 2 * 32, (int64_t)(512 + 32) * d});
   DALLOC(e->red_ws, (size_t)e->red_elems * 4, false);
   HIPCHK(hipStreamSynchronize(e->stream));
   *out = e;

@@ -71,6 +71,8 @@ void launch_extract_rows(const float* g, int b, int ntok, int tok_off, int np, i
 void launch_sum_rows(const float* in, int rows, int d, float* out, hipStream_t s);  // out[c] = sum_r in[r][c] (small)
 void launch_ce_grad(const float* logits, int64_t ld, const int32_t* labels, int b, int nc, float inv_batch, float* dlogits,
                     float* loss, hipStream_t s);
+void launch_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps, float wd, int step, hipStream_t s);
+void launch_sgd(float* p, const float* g, float* m, int64_t n, float lr, float mom, float wd, hipStream_t s);   // m may be null (plain SGD)
 void launch_fill_zero(void* p, int64_t bytes, hipStream_t s);   // bytes multiple of 16
 void launch_fill_random_bf16(bf16_t* p, int64_t n, uint32_t seed, float scale, hipStream_t s);
 void launch_dropout(void* x, int is_bf16, int64_t n, float rate, uint64_t seed, uint32_t site, hipStream_t s);

@@ -250,6 +250,20 @@ class VitxModel:
         grads = {n: g[o:o + int(np.prod(s))].reshape(s) for n, s, o in self._table}
         return grads, dimg
 
+    def apply_gradients(self, optimizer: str = "adamw", lr: float = 1e-3, beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-7,
+                        weight_decay: float = 0.0, momentum: float = 0.0) -> None:
+        """One optimizer step on the device with the gradients of the last backward (the reference ships no optimizer;
+        eps defaults to Keras' 1e-7)."""
+        if self._handle is None:
+            raise N.VitxError(N.ERR_STATE, "apply_gradients requires forward + backward first")
+        if optimizer == "adamw":
+            N.check(N.lib().vitx_adamw_step(self._handle, lr, beta1, beta2, eps, weight_decay))
+        elif optimizer == "sgd":
+            N.check(N.lib().vitx_sgd_step(self._handle, lr, momentum, weight_decay))
+        else:
+            raise ValueError("optimizer must be 'adamw' or 'sgd'")
+        self._device_newer = True
+
     def _last_img_shape(self):
         return self._img_shape
 

@@ -71,6 +71,8 @@ SYMBOLS: List[Tuple[str, object, list]] = [
     ("vitx_transformer_forward", C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     ("vitx_patch_unfold", C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     ("vitx_ce_loss_grad_dev", C.c_int32, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]),
+    ("vitx_adamw_step", C.c_int32, [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float]),
+    ("vitx_sgd_step", C.c_int32, [C.c_void_p, C.c_float, C.c_float, C.c_float]),
     ("vitx_set_stream", C.c_int32, [C.c_void_p, C.c_void_p]),
     ("vitx_sync", C.c_int32, [C.c_void_p]),
     ("vitx_set_grad_ready_callback", C.c_int32, [C.c_void_p, GRAD_READY_FN, C.c_void_p]),
