@@ -46,24 +46,41 @@ def stage_gemm():
     lib = N.lib()
     avg, err = C.c_float(), C.c_float()
     print("== correctness (vs fp32-FMA generic kernel on the same bf16 operands)")
-    for kern in (1, 2, 3, 4, 5, 0):
-        for (M, Nn, K) in [(256, 256, 64), (256, 256, 128), (256, 256, 192), (300, 200, 192), (1000, 768, 768), (2048, 1024, 4096)]:
+    for kern in (1, 2, 3, 5, 6, 7, 9, 10, 13, 14, 15, 0):
+        for (M, Nn, K) in [(256, 256, 64), (256, 256, 128), (256, 256, 192), (300, 200, 192), (3000, 2304, 64), (50432, 768, 128), (1000, 768, 768), (2048, 1024, 4096)]:
             rc = lib.vitx_bench_gemm(m._handle, M, Nn, K, kern, 0, 1, C.byref(avg), C.byref(err))
             print(f"kernel {kern} M{M} N{Nn} K{K}: rc {rc} max_abs_err {err.value:.4g}")
     print("== throughput (random bf16 operands), epilogue 0=f32 store 1=bias+resid f32 2=bias+gelu 2xbf16 3=bf16 store")
-    print("   kernel code = variant(1=128x128, 2=256x256, 3=256x128) + 16*stagger_units + 256*(direct per-lane epilogue instead of LDS-staged)")
+    print("   kernel code: 1=128^2 2=256^2 3=256x128 5=320x256 | persistent: 6/7 lockstep 256^2/320x256, 9/10 software-pipelined, 13/14/15 + DMA pieces spread | 0 = measured choice; +256 direct epilogue, +512 LDS-staged")
     shapes = [(50432, 768, 768), (50432, 2304, 768), (50432, 3072, 768), (50432, 768, 3072), (8192, 8192, 8192), (4096, 4096, 4096)]
     for (M, Nn, K) in shapes:
-        for kern in (2, 5, 0):
+        for kern in (2, 6, 13, 14, 5, 7, 15, 0):
             for epi in (0, 1, 2, 3):
                 big = (M, Nn, K) in [(8192, 8192, 8192), (4096, 4096, 4096)]
                 if big and (epi not in (0, 3) or kern >= 16 and kern < 256):
                     continue
                 if (kern & 255) >= 16 and epi in (0, 3):
                     continue
-                rc = lib.vitx_bench_gemm(m._handle, M, Nn, K, kern, epi, 5, C.byref(avg), C.byref(err))
+                rc = lib.vitx_bench_gemm(m._handle, M, Nn, K, kern, epi, 20, C.byref(avg), C.byref(err))
                 tf = 2.0 * M * Nn * K / (avg.value * 1e-3) / 1e12 if rc == 0 else float("nan")
                 print(f"M{M} N{Nn} K{K} kernel {kern} epi {epi}: {avg.value:.4f} ms  {tf:.1f} TFLOP/s  rc {rc}", flush=True)
+
+
+def stage_gemmx():
+    """timing experiments on the software-pipelined kernel: +16 = no DMA wait, +32 = no DMA issue (results wrong, time only)"""
+    from vit_tensorflow import _native as N
+    m = _model("vit_bf16_small", "bf16", 1)
+    m.build((1,))
+    lib = N.lib()
+    avg, err = C.c_float(), C.c_float()
+    for zero in (0, 1):
+        if zero:
+            os.environ["VITX_BENCH_ZERO"] = "1"
+        for (M, Nn, K) in [(8192, 8192, 8192), (50432, 768, 3072), (50432, 3072, 768)]:
+            for kern in (9, 9 + 16, 9 + 32, 14, 14 + 32):
+                rc = lib.vitx_bench_gemm(m._handle, M, Nn, K, kern, 3, 20, C.byref(avg), C.byref(err))
+                tf = 2.0 * M * Nn * K / (avg.value * 1e-3) / 1e12 if rc == 0 else float("nan")
+                print(f"zero={zero} M{M} N{Nn} K{K} kernel {kern}: {avg.value:.4f} ms  {tf:.1f} TFLOP/s  rc {rc}", flush=True)
 
 
 def _bisect(m, cfg, P, img, variant_prefixes):

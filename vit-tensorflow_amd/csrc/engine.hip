@@ -1094,8 +1094,21 @@ int engine_bench_gemm(vitx_engine* e, int M, int N, int K, int kernel, int epilo
   const float fill_scale = getenv("VITX_BENCH_ZERO") ? 0.0f : 1.0f;   // zero operands: DVFS / power-limit experiment only
   launch_fill_random_bf16(A, Mp * K, 1u, fill_scale, e->stream);
   launch_fill_random_bf16(B, Np * K, 2u, fill_scale, e->stream);
+  // small problems are checked against the generic kernel: give the fused epilogues non-trivial bias / residual operands
+  const bool check = max_err && (int64_t)M * N <= (1 << 25);
+  std::vector<float> hbias((size_t)Np, 0.f), hres;
   HIPCHK(hipMemsetAsync(R, 0, (size_t)Mp * Np * 4, e->stream));
   HIPCHK(hipMemsetAsync(bias, 0, (size_t)Np * 4, e->stream));
+  if (check && epilogue != 0) {
+    for (int64_t j = 0; j < Np; ++j) hbias[j] = 0.25f * (float)(j % 7) - 0.75f;
+    HIPCHK(hipMemcpyAsync(bias, hbias.data(), (size_t)Np * 4, hipMemcpyHostToDevice, e->stream));
+    if (epilogue == 1) {
+      hres.resize((size_t)Mp * Np);
+      for (size_t i = 0; i < hres.size(); ++i) hres[i] = 0.125f * (float)((i * 2654435761u >> 7) % 33) - 2.0f;
+      HIPCHK(hipMemcpyAsync(R, hres.data(), hres.size() * 4, hipMemcpyHostToDevice, e->stream));
+    }
+    HIPCHK(hipStreamSynchronize(e->stream));
+  }
   Bf16GemmArgs g;
   g.A = A; g.lda = K; g.B = B; g.ldb = K; g.M = M; g.N = N; g.K = K; g.kernel = kernel & (15 | 256 | 512); g.stagger = (kernel >> 4) & 15;
   EpiParams ep;
@@ -1123,8 +1136,8 @@ int engine_bench_gemm(vitx_engine* e, int M, int N, int K, int kernel, int epilo
   HIPCHK(hipEventElapsedTime(&ms, e0, e1));
   *avg_ms = ms / std::max(1, iters);
   *max_err = -1.f;
-  if (max_err && (epilogue == 0 || epilogue == 1) && (int64_t)M * N <= (1 << 22)) {
-    // reference: generic kernel on the same operands, compared on the host
+  if (check) {
+    // reference: generic fp32-FMA kernel on the same operands; the fused epilogue is re-stated on the host
     float* C3;
     HIPCHK(hipMalloc((void**)&C3, (size_t)Mp * Np * 4));
     GenericGemmArgs gg;
@@ -1132,13 +1145,40 @@ int engine_bench_gemm(vitx_engine* e, int M, int N, int K, int kernel, int epilo
     EpiParams e2; e2.out = C3; e2.ldo = Np; e2.M = M; e2.N = N;
     finalize_epi(e2);
     launch_gemm_generic(gg, e2, EPI_STORE_F32, 1, 1, 0, e->stream);
-    std::vector<float> h1((size_t)Mp * Np), h2((size_t)Mp * Np);
-    HIPCHK(hipMemcpyAsync(h1.data(), C, h1.size() * 4, hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipMemcpyAsync(h2.data(), C3, h2.size() * 4, hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipStreamSynchronize(e->stream));
+    std::vector<float> ref((size_t)Mp * Np), got, got2;
+    HIPCHK(hipMemcpyAsync(ref.data(), C3, ref.size() * 4, hipMemcpyDeviceToHost, e->stream));
+    auto fetch_bf16 = [&](const bf16_t* src, std::vector<float>& dst) -> int {
+      std::vector<uint16_t> raw((size_t)Mp * Np);
+      HIPCHK(hipMemcpyAsync(raw.data(), src, raw.size() * 2, hipMemcpyDeviceToHost, e->stream));
+      HIPCHK(hipStreamSynchronize(e->stream));
+      dst.resize(raw.size());
+      for (size_t i = 0; i < raw.size(); ++i) { uint32_t u = (uint32_t)raw[i] << 16; float f; memcpy(&f, &u, 4); dst[i] = f; }
+      return VITX_OK;
+    };
+    if (epilogue == 0 || epilogue == 1) {
+      got.resize(ref.size());
+      HIPCHK(hipMemcpyAsync(got.data(), C, got.size() * 4, hipMemcpyDeviceToHost, e->stream));
+      HIPCHK(hipStreamSynchronize(e->stream));
+    } else {
+      if (int rc = fetch_bf16(C2, got)) return rc;
+      if (epilogue == 2) { if (int rc = fetch_bf16(C2 + Mp * Np, got2)) return rc; }
+    }
     float me = 0.f;
     for (int i = 0; i < M; ++i)
-      for (int j = 0; j < N; ++j) me = std::max(me, std::fabs(h1[(size_t)i * Np + j] - h2[(size_t)i * Np + j]));
+      for (int j = 0; j < N; ++j) {
+        const size_t o = (size_t)i * Np + j;
+        float want = ref[o];
+        if (epilogue == 1) want += hbias[j] + hres[o];
+        if (epilogue == 2) want += hbias[j];
+        float tol_scale = 1.f;
+        if (epilogue >= 2) tol_scale = 1.f / (1.f + std::fabs(want));   // bf16 outputs: error relative to magnitude
+        me = std::max(me, std::fabs(got[o] - want) * tol_scale);
+        if (epilogue == 2) {
+          const float h = got[o];   // GELU is evaluated on the stored (rounded) pre-activation
+          const float gl = 0.5f * h * (1.f + std::erf(h * 0.70710678f));
+          me = std::max(me, std::fabs(got2[o] - gl) / (1.f + std::fabs(gl)));
+        }
+      }
     *max_err = me;
     (void)hipFree(C3);
   }

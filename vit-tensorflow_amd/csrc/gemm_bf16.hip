@@ -10,7 +10,14 @@
 //     128-B row) -- conflict-free for the 16-lane groups ds_read_b128 is serviced in.
 //   * XCD-aware tile order: the grid is walked so that consecutive logical tiles (sharing an A row
 //     panel) run on the same XCD and hit its private L2.
+#include <algorithm>
+#include <array>
+#include <cstdio>
+#include <cstdlib>
+#include <map>
+#include <mutex>
 #include <type_traits>
+#include <utility>
 
 #include "kernels.h"
 
@@ -24,9 +31,19 @@ typedef const __attribute__((address_space(1))) void gbl_void_t;
 
 constexpr int BK = 64;
 
+// compile-time loop: f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N-1>{})
+template <typename F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+template <int V> using ic = std::integral_constant<int, V>;
+
 template <int BM, int BN, int WM, int WN, int MODE, bool LDS_EPI, int SCHED>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_kernel(Bf16GemmArgs g, EpiParams ep, int tiles_m, int tiles_n,
                                                                     int kt_per_split) {
+  // SCHED 0: one tile per workgroup, lockstep 2-stage K loop.
+  // SCHED 2: PERSISTENT workgroups (grid = #CUs) walking the tile list; the first K-tile of the NEXT output tile is prefetched
+  //          during the last K-tile of the current one, so the DMA latency and the epilogue's memory phase overlap.
   constexpr int NW = WM * WN;
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int MT = WTM / 32, NT = WTN / 32;
@@ -38,8 +55,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_kernel(Bf16GemmArgs
   // ---- XCD-aware tile mapping (bijective for any grid size)
   const int nwg = gridDim.x, bid = blockIdx.x;
   const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
-  const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-  const int tile_m = logical / tiles_n, tile_n = logical - tile_m * tiles_n;
+  const int logical0 = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int total_tiles = tiles_m * tiles_n;
   const int z = blockIdx.y;
   const int nk_total = g.K / BK;
   const int kt0 = z * kt_per_split;
@@ -49,253 +66,206 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_kernel(Bf16GemmArgs
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave - wm * WN;
 
-  // Optional phase stagger: every workgroup runs [K loop (MFMA-bound)] -> [epilogue (HBM-bound)]; launched together
-  // they stay in lockstep and the two resources alternate idling.  Delaying the first wave of workgroups by a quarter
-  // period per CU slot spreads the phases; later workgroups inherit the offset of the CU they land on.
-  if (g.stagger > 0 && bid < 256 && blockIdx.y == 0) {
+  if (g.stagger > 0 && bid < 256 && blockIdx.y == 0) {   // optional phase stagger of the first wave of workgroups (experiment)
     const int ph = (bid >> 3) & 3;
     for (int i = 0; i < ph * g.stagger; ++i) __builtin_amdgcn_s_sleep(32);
   }
 
   // ---- per-lane DMA source offsets (elements); LDS destination is wave-uniform base + lane*16
-  const bf16_t* Ag = g.A + (int64_t)tile_m * BM * g.lda + (int64_t)kt0 * BK;
-  const bf16_t* Bg = g.B + (int64_t)tile_n * BN * g.ldb + (int64_t)kt0 * BK;
-  int64_t offA[A_INSTR], offB[B_INSTR];
+  int offA[A_INSTR], offB[B_INSTR];   // 32-bit: a tile spans < 2^31 elements of its operand
 #pragma unroll
   for (int i = 0; i < A_INSTR; ++i) {
     const int row = (i * NW + wave) * 8 + (lane >> 3);
     const int c = (lane & 7) ^ ((row >> 1) & 7);
-    offA[i] = (int64_t)row * g.lda + c * 8;
+    offA[i] = row * (int)g.lda + c * 8;
   }
 #pragma unroll
   for (int i = 0; i < B_INSTR; ++i) {
     const int row = (i * NW + wave) * 8 + (lane >> 3);
     const int c = (lane & 7) ^ ((row >> 1) & 7);
-    offB[i] = (int64_t)row * g.ldb + c * 8;
+    offB[i] = row * (int)g.ldb + c * 8;
   }
-
-  auto stage = [&](int buf, int kt) {
+  auto stage_ptr = [&](int buf, const bf16_t* Ap, const bf16_t* Bp, int kt) {
     char* base = smem + buf * STAGE;
 #pragma unroll
     for (int i = 0; i < A_INSTR; ++i)
-      __builtin_amdgcn_global_load_lds((gbl_void_t*)(Ag + offA[i] + (int64_t)kt * BK),
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(Ap + (offA[i] + kt * BK)),
                                        (lds_void_t*)(base + (i * NW + wave) * 1024), 16, 0, 0);
 #pragma unroll
     for (int i = 0; i < B_INSTR; ++i)
-      __builtin_amdgcn_global_load_lds((gbl_void_t*)(Bg + offB[i] + (int64_t)kt * BK),
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(Bp + (offB[i] + kt * BK)),
                                        (lds_void_t*)(base + A_BYTES + (i * NW + wave) * 1024), 16, 0, 0);
   };
-
-  f32x16 acc[MT][NT];
-#pragma unroll
-  for (int i = 0; i < MT; ++i)
-#pragma unroll
-    for (int j = 0; j < NT; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   // fragment read addressing: row = tile row of this lane (lane&31), chunk = (ks*2 + (lane>>5)) ^ swz(row)
   const int sw = ((lane & 31) >> 1) & 7;
   const int a_row_byte = (wm * WTM + (lane & 31)) * 128;
   const int b_row_byte = A_BYTES + (wn * WTN + (lane & 31)) * 128;
   const int khalf = lane >> 5;
-
-  if constexpr (SCHED == 0) {
-    // ---- lockstep schedule: one barrier per K-tile, next tile's DMA in flight during the MFMAs
-    if (nk > 0) stage(0, 0);
-    for (int kt = 0; kt < nk; ++kt) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
-      const char* base = smem + (kt & 1) * STAGE;
-#pragma unroll
-      for (int ks = 0; ks < BK / 16; ++ks) {
-        const int cb = ((ks * 2 + khalf) ^ sw) << 4;
-        bf16x8 af[MT], bfr[NT];
-#pragma unroll
-        for (int i = 0; i < MT; ++i) af[i] = *(const bf16x8*)(base + a_row_byte + i * 32 * 128 + cb);
-#pragma unroll
-        for (int j = 0; j < NT; ++j) bfr[j] = *(const bf16x8*)(base + b_row_byte + j * 32 * 128 + cb);
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-          for (int j = 0; j < NT; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
-      }
-    }
-  } else {
-    // ---- ping-pong schedule (8 waves = 2 per SIMD).  A K-tile is processed as two halves (k 0..31, k 32..63), each half as a
-    // LOAD phase (ds_read the fragments, issue DMA) and an MFMA phase (16 MFMAs), separated by workgroup barriers.  The second
-    // wave of every SIMD (waves NW/2..NW-1, "group B") runs the same sequence ONE PHASE LATE, so at any time one wave of a SIMD is
-    // in its MFMA phase while its partner reads LDS / issues DMA / waits: the matrix pipe is no longer idle around the barriers.
-    //   epoch:      4t        4t+1      4t+2      4t+3      4t+4
-    //   group A:  L(t,H0)   M(t,H0)   L(t,H1)   M(t,H1)   L(t+1,H0)      A issues its DMA share of tile t+1 at L(t,H0)
-    //   group B:  M(t-1,H1) L(t,H0)   M(t,H0)   L(t,H1)   M(t,H1)        B issues its DMA share of tile t+1 at M(t-1,H1)
-    // Buffer (t+1)&1 was last read in epoch 4t-1 (B's L(t-1,H1)), so both DMA issues (epoch 4t) are WAR-safe; tile t+1 is first
-    // read in epoch 4t+4, and every wave drains its own DMA (vmcnt(0)) before the barrier that ends epoch 4t+3.
-    static_assert(NW == 8, "ping-pong needs two waves per SIMD");
-    const bool grpB = wave >= NW / 2;
-    bf16x8 af[2][MT], bfr[2][NT];
-    auto load_half = [&](const char* base, int h) {
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        const int cb = (((2 * h + kk) * 2 + khalf) ^ sw) << 4;
-#pragma unroll
-        for (int i = 0; i < MT; ++i) af[kk][i] = *(const bf16x8*)(base + a_row_byte + i * 32 * 128 + cb);
-#pragma unroll
-        for (int j = 0; j < NT; ++j) bfr[kk][j] = *(const bf16x8*)(base + b_row_byte + j * 32 * 128 + cb);
-      }
-    };
-    auto mma_half = [&]() {
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-          for (int j = 0; j < NT; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[kk][j], af[kk][i], acc[i][j], 0, 0, 0);
-      __builtin_amdgcn_s_setprio(0);
-    };
-#define VITX_BAR()                                  \
-  do {                                              \
-    asm volatile("" ::: "memory");                  \
-    __builtin_amdgcn_s_barrier();                   \
-    asm volatile("" ::: "memory");                  \
-    __builtin_amdgcn_sched_barrier(0);              \
-  } while (0)
-    if (nk > 0) stage(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    VITX_BAR();                                           // tile 0 visible to every wave
-    if (grpB) {
-      if (nk > 1) stage(1, 1);                            // B's share of tile 1 (its "M(-1,H1)" slot)
-      VITX_BAR();                                         // B starts one epoch late
-    }
-    for (int t = 0; t < nk; ++t) {
-      const char* base = smem + (t & 1) * STAGE;
-      // ---- L(t,H0)
-      if (!grpB && t + 1 < nk) stage((t + 1) & 1, t + 1);
-      load_half(base, 0);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      VITX_BAR();
-      // ---- M(t,H0)
-      mma_half();
-      VITX_BAR();
-      // ---- L(t,H1)
-      load_half(base, 1);
-      if (grpB) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      VITX_BAR();
-      // ---- M(t,H1)
-      if (grpB && t + 2 < nk) stage(t & 1, t + 2);
-      mma_half();
-      if (!grpB) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      VITX_BAR();
-    }
-    if (!grpB) VITX_BAR();                                // balance B's extra barrier
-#undef VITX_BAR
-  }
-
-  // ---- epilogue: lane holds row m = lane&31 and columns 8q + 4*(lane>>5) + {0..3} of each 32x32 tile
-  const int64_t out_off = (int64_t)z * ep.partial_stride;
-  // interior tiles (all but the ragged edge) take the branch-free epilogue: every wave-uniform test is made once, here
-  const bool interior = epilogue_fast_ok(ep, MODE) && (tile_m + 1) * BM <= ep.M && (tile_n + 1) * BN <= ep.N;
   const bool has_bias = ep.bias != nullptr, has_scale = ep.scale != nullptr;
-  if constexpr (LDS_EPI && (MT % 2 == 0)) {
-    // Stage 64 output rows at a time through LDS (fp32, padded rows) and run the fused epilogue on ROW-CONTIGUOUS data:
-    // every wave instruction then reads/writes whole 512-B / 1-KiB row segments (full cache lines) instead of
-    // 32 scattered 16/32-B pieces.
-    constexpr int SROW = BN + 4;                     // floats; +16 B keeps the 8-lane ds_write_b128 groups conflict-free
-    constexpr int LPRW = BN / 4, RPIW = 64 / LPRW;   // lanes per staged row, rows per wave instruction
-    constexpr int RPW = 64 / (NW * RPIW);            // rows handled per wave per round
-    float* st = (float*)smem;
-    const int col_l = (lane % LPRW) * 4;
-    const int gcol = tile_n * BN + col_l;
-    float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f), s4 = make_float4(1.f, 1.f, 1.f, 1.f);
-    if (interior && has_bias) b4 = *(const float4*)(ep.bias + gcol);
-    if (interior && has_scale) s4 = *(const float4*)(ep.scale + gcol);
+  const int64_t out_off = (int64_t)z * ep.partial_stride;
+
+  int it = 0;                                   // running K-tile counter: LDS buffer = it & 1 (continues across output tiles)
+  int logical = logical0;
+  if (logical >= total_tiles) return;
+  int tile_m = logical / tiles_n, tile_n = logical - tile_m * tiles_n;
+  const bf16_t* Ag = g.A + (int64_t)tile_m * BM * g.lda + (int64_t)kt0 * BK;
+  const bf16_t* Bg = g.B + (int64_t)tile_n * BN * g.ldb + (int64_t)kt0 * BK;
+  if (SCHED == 2 && nk > 0) stage_ptr(0, Ag, Bg, 0);
+
+  for (;;) {
+    auto stage = [&](int buf, int kt) { stage_ptr(buf, Ag, Bg, kt); };
+    // next output tile of this (persistent) workgroup
+    const int next_logical = logical + nwg;
+    const bool has_next = SCHED == 2 && next_logical < total_tiles;
+    const int ntm = has_next ? next_logical / tiles_n : 0, ntn = has_next ? next_logical - ntm * tiles_n : 0;
+    const bf16_t* Agn = g.A + (int64_t)ntm * BM * g.lda + (int64_t)kt0 * BK;
+    const bf16_t* Bgn = g.B + (int64_t)ntn * BN * g.ldb + (int64_t)kt0 * BK;
+
+    f32x16 acc[MT][NT];
 #pragma unroll
-    for (int R = 0; R < BM / 64; ++R) {
-      const int wm_r = (R * 64) / WTM, i0 = ((R * 64) % WTM) / 32;
-      __syncthreads();
-      if (wm == wm_r) {
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int ii = 0; ii < 2; ++ii)
+      for (int j = 0; j < NT; ++j)
 #pragma unroll
-          for (int j = 0; j < NT; ++j)
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    {
+      // ---- lockstep schedule: one barrier per K-tile, next tile's DMA in flight during the MFMAs
+      if (SCHED != 2 && nk > 0) stage(0, 0);
+      for (int kt = 0; kt < nk; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (kt + 1 < nk) stage((it + 1) & 1, kt + 1);
+        else if (has_next) stage_ptr((it + 1) & 1, Agn, Bgn, 0);
+        const char* base = smem + (it & 1) * STAGE;
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-              *(float4*)(st + (ii * 32 + (lane & 31)) * SROW + wn * WTN + j * 32 + 8 * q + 4 * khalf) =
-                  make_float4(acc[i0 + ii][j][4 * q], acc[i0 + ii][j][4 * q + 1], acc[i0 + ii][j][4 * q + 2], acc[i0 + ii][j][4 * q + 3]);
+        for (int ks = 0; ks < BK / 16; ++ks) {
+          const int cb = ((ks * 2 + khalf) ^ sw) << 4;
+          bf16x8 af[MT], bfr[NT];
+#pragma unroll
+          for (int i = 0; i < MT; ++i) af[i] = *(const bf16x8*)(base + a_row_byte + i * 32 * 128 + cb);
+#pragma unroll
+          for (int j = 0; j < NT; ++j) bfr[j] = *(const bf16x8*)(base + b_row_byte + j * 32 * 128 + cb);
+#pragma unroll
+          for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+        }
+        ++it;
       }
-      __syncthreads();
-      float4 v[RPW];
+    }
+
+    // ---- epilogue: lane holds row m = lane&31 and columns 8q + 4*(lane>>5) + {0..3} of each 32x32 tile.
+    // Interior tiles (all but the ragged edge) take the branch-free form: every wave-uniform test is made once, here.
+    const bool interior = epilogue_fast_ok(ep, MODE) && (tile_m + 1) * BM <= ep.M && (tile_n + 1) * BN <= ep.N;
+    // rows per LDS staging round: 64, or 32 when only one pipeline buffer is free (persistent schedule) or MT is odd
+    constexpr int RR = ((SCHED == 2 && 64 * (BN + 4) * 4 > STAGE) || (MT % 2 != 0)) ? 32 : 64;
+    if constexpr (LDS_EPI) {
+      // Stage RR output rows at a time through LDS (fp32, padded rows) and run the fused epilogue on ROW-CONTIGUOUS data:
+      // every wave instruction then reads/writes whole 512-B / 1-KiB row segments (full cache lines) instead of
+      // 32 scattered 16/32-B pieces.
+      constexpr int SROW = BN + 4;                     // floats; +16 B keeps the 8-lane ds_write_b128 groups conflict-free
+      constexpr int LPRW = BN / 4, RPIW = 64 / LPRW;   // lanes per staged row, rows per wave instruction
+      constexpr int RPW = RR / (NW * RPIW);            // rows handled per wave per round
+      static_assert(RPW >= 1 && RR * SROW * 4 <= (SCHED == 2 ? 1 : 2) * STAGE, "staging round must fit the free pipeline buffer(s)");
+      // SCHED 2: buffer (it & 1) holds the prefetched next tile; the one just consumed is free
+      float* st = (float*)(smem + (SCHED == 2 ? ((it + 1) & 1) * STAGE : 0));
+      const int col_l = (lane % LPRW) * 4;
+      const int gcol = tile_n * BN + col_l;
+      float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f), s4 = make_float4(1.f, 1.f, 1.f, 1.f);
+      if (interior && has_bias) b4 = *(const float4*)(ep.bias + gcol);
+      if (interior && has_scale) s4 = *(const float4*)(ep.scale + gcol);
+#pragma clang loop unroll(full)
+      for (int R = 0; R < BM / RR; ++R) {
+        const int wm_r = (R * RR) / WTM, i0 = ((R * RR) % WTM) / 32;
+        __syncthreads();
+        if (wm == wm_r) {
 #pragma unroll
-      for (int k = 0; k < RPW; ++k) v[k] = *(const float4*)(st + ((k * NW + wave) * RPIW + lane / LPRW) * SROW + col_l);
-      const int grow0 = tile_m * BM + R * 64 + lane / LPRW;
-      if (interior) {
-        float4 x[RPW];
+          for (int ii = 0; ii < RR / 32; ++ii)
 #pragma unroll
-        for (int k = 0; k < RPW; ++k) x[k] = epilogue_fast_load<MODE, bf16_t>(ep, grow0 + (k * NW + wave) * RPIW, gcol);
-        if (has_bias) {
+            for (int j = 0; j < NT; ++j)
 #pragma unroll
-          for (int k = 0; k < RPW; ++k) epilogue_fast4<MODE, bf16_t, true, false>(ep, grow0 + (k * NW + wave) * RPIW, gcol, v[k], b4, s4, x[k], out_off);
+              for (int q = 0; q < 4; ++q)
+                *(float4*)(st + (ii * 32 + (lane & 31)) * SROW + wn * WTN + j * 32 + 8 * q + 4 * khalf) =
+                    make_float4(acc[i0 + ii][j][4 * q], acc[i0 + ii][j][4 * q + 1], acc[i0 + ii][j][4 * q + 2], acc[i0 + ii][j][4 * q + 3]);
+        }
+        __syncthreads();
+        float4 v[RPW];
+#pragma unroll
+        for (int k = 0; k < RPW; ++k) v[k] = *(const float4*)(st + ((k * NW + wave) * RPIW + lane / LPRW) * SROW + col_l);
+        const int grow0 = tile_m * BM + R * RR + lane / LPRW;
+        if (interior) {
+          float4 x[RPW];
+#pragma unroll
+          for (int k = 0; k < RPW; ++k) x[k] = epilogue_fast_load<MODE, bf16_t>(ep, grow0 + (k * NW + wave) * RPIW, gcol);
+          if (has_bias) {
+#pragma unroll
+            for (int k = 0; k < RPW; ++k) epilogue_fast4<MODE, bf16_t, true, false>(ep, grow0 + (k * NW + wave) * RPIW, gcol, v[k], b4, s4, x[k], out_off);
+          } else {
+#pragma unroll
+            for (int k = 0; k < RPW; ++k) epilogue_fast4<MODE, bf16_t, false, false>(ep, grow0 + (k * NW + wave) * RPIW, gcol, v[k], b4, s4, x[k], out_off);
+          }
         } else {
 #pragma unroll
-          for (int k = 0; k < RPW; ++k) epilogue_fast4<MODE, bf16_t, false, false>(ep, grow0 + (k * NW + wave) * RPIW, gcol, v[k], b4, s4, x[k], out_off);
+          for (int k = 0; k < RPW; ++k) epilogue_apply4<MODE, bf16_t>(ep, grow0 + (k * NW + wave) * RPIW, gcol, v[k], out_off);
         }
+      }
+      if (SCHED == 2) __syncthreads();   // the staging buffer becomes the next DMA target at the top of the next K loop
+    } else {
+      const int row0 = tile_m * BM + wm * WTM + (lane & 31);
+      const int col00 = tile_n * BN + wn * WTN + 4 * khalf;
+      if (interior) {
+        auto run = [&](auto hb, auto hs) {
+          constexpr bool HB = decltype(hb)::value, HS = decltype(hs)::value;
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int qp = 0; qp < 2; ++qp) {       // two column groups at a time: 2*MT global reads in flight before the stores
+              float4 b4[2], s4[2], x[2][MT];
+#pragma unroll
+              for (int qq = 0; qq < 2; ++qq) {
+                const int col = col00 + j * 32 + 8 * (2 * qp + qq);
+                b4[qq] = HB ? *(const float4*)(ep.bias + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+                s4[qq] = HS ? *(const float4*)(ep.scale + col) : make_float4(1.f, 1.f, 1.f, 1.f);
+#pragma unroll
+                for (int i = 0; i < MT; ++i) x[qq][i] = epilogue_fast_load<MODE, bf16_t>(ep, row0 + i * 32, col);
+              }
+#pragma unroll
+              for (int qq = 0; qq < 2; ++qq) {
+                const int q = 2 * qp + qq;
+                const int col = col00 + j * 32 + 8 * q;
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+                  epilogue_fast4<MODE, bf16_t, HB, HS>(ep, row0 + i * 32, col,
+                                                       make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]),
+                                                       b4[qq], s4[qq], x[qq][i], out_off);
+              }
+            }
+        };
+        if (has_bias && has_scale) run(std::true_type{}, std::true_type{});
+        else if (has_bias) run(std::true_type{}, std::false_type{});
+        else run(std::false_type{}, std::false_type{});
       } else {
 #pragma unroll
-        for (int k = 0; k < RPW; ++k) epilogue_apply4<MODE, bf16_t>(ep, grow0 + (k * NW + wave) * RPIW, gcol, v[k], out_off);
-      }
-    }
-  } else {
-    const int row0 = tile_m * BM + wm * WTM + (lane & 31);
-    const int col00 = tile_n * BN + wn * WTN + 4 * khalf;
-    if (interior) {
-      auto run = [&](auto hb, auto hs) {
-        constexpr bool HB = decltype(hb)::value, HS = decltype(hs)::value;
+        for (int i = 0; i < MT; ++i) {
 #pragma unroll
-        for (int j = 0; j < NT; ++j)
+          for (int j = 0; j < NT; ++j) {
 #pragma unroll
-          for (int qp = 0; qp < 2; ++qp) {       // two column groups at a time: 2*MT global reads in flight before the stores
-            float4 b4[2], s4[2], x[2][MT];
-#pragma unroll
-            for (int qq = 0; qq < 2; ++qq) {
-              const int col = col00 + j * 32 + 8 * (2 * qp + qq);
-              b4[qq] = HB ? *(const float4*)(ep.bias + col) : make_float4(0.f, 0.f, 0.f, 0.f);
-              s4[qq] = HS ? *(const float4*)(ep.scale + col) : make_float4(1.f, 1.f, 1.f, 1.f);
-#pragma unroll
-              for (int i = 0; i < MT; ++i) x[qq][i] = epilogue_fast_load<MODE, bf16_t>(ep, row0 + i * 32, col);
-            }
-#pragma unroll
-            for (int qq = 0; qq < 2; ++qq) {
-              const int q = 2 * qp + qq;
-              const int col = col00 + j * 32 + 8 * q;
-#pragma unroll
-              for (int i = 0; i < MT; ++i)
-                epilogue_fast4<MODE, bf16_t, HB, HS>(ep, row0 + i * 32, col,
-                                                     make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]),
-                                                     b4[qq], s4[qq], x[qq][i], out_off);
-            }
+            for (int q = 0; q < 4; ++q)
+              epilogue_apply4<MODE, bf16_t>(ep, row0 + i * 32, col00 + j * 32 + 8 * q,
+                                            make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]),
+                                            out_off);
           }
-      };
-      if (has_bias && has_scale) run(std::true_type{}, std::true_type{});
-      else if (has_bias) run(std::true_type{}, std::false_type{});
-      else run(std::false_type{}, std::false_type{});
-    } else {
-#pragma unroll
-      for (int i = 0; i < MT; ++i) {
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-            epilogue_apply4<MODE, bf16_t>(ep, row0 + i * 32, col00 + j * 32 + 8 * q,
-                                          make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]),
-                                          out_off);
         }
       }
     }
+
+    if (!has_next) break;
+    logical = next_logical;
+    tile_m = ntm; tile_n = ntn;
+    Ag = Agn; Bg = Bgn;
   }
 }
 
@@ -314,10 +284,269 @@ void launch_variant(const Bf16GemmArgs& g, const EpiParams& ep, hipStream_t s) {
   const int split = g.split_k > 1 ? g.split_k : 1;
   const int per = (int)ceil_div(nk, split);
   const int zs = (int)ceil_div(nk, per);  // no empty slices
-  dim3 grid((unsigned)(tiles_m * tiles_n), (unsigned)zs), block(WM * WN * 64);
+  const unsigned gx = (SCHED == 2 && zs == 1) ? (unsigned)std::min(tiles_m * tiles_n, 256) : (unsigned)(tiles_m * tiles_n);
+  dim3 grid(gx, (unsigned)zs), block(WM * WN * 64);
   hipLaunchKernelGGL(kern, grid, block, SMEM, s, g, ep, tiles_m, tiles_n, per);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Software-pipelined persistent NT kernel (the default for N >= 256).  Same tile / wave decomposition, LDS image and swizzle as
+// gemm_bf16_nt_kernel, but
+//   * the MFMA fragments are double-buffered in registers: the ds_reads of k-step s+1 are issued before the MFMAs of k-step s,
+//     so the LDS latency (8 exposed lgkmcnt(0) waits per K-tile in the plain loop, taken by both waves of a SIMD at the same time)
+//     disappears from the critical path; PMC on the plain loop: 38 % of wave cycles parked in s_waitcnt, MFMA pipe 54 % busy;
+//   * the K-tile hand-over (vmcnt(0) + barrier + DMA issue for the tile after next + first fragments of the next tile) sits in
+//     front of the LAST k-step's MFMAs instead of between two tiles;
+//   * workgroups are persistent and their K-tile stream runs across output tiles (the next tile's first K-tile is in LDS before
+//     the epilogue of the current one starts).
+template <int BM, int BN, int WM, int WN, int MODE, int PAT>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_pipe_kernel(Bf16GemmArgs g, EpiParams ep, int tiles_m, int tiles_n,
+                                                                         int kt_per_split) {
+  constexpr int NW = WM * WN;
+  constexpr int WTM = BM / WM, WTN = BN / WN;
+  constexpr int MT = WTM / 32, NT = WTN / 32;
+  constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
+  constexpr int A_INSTR = BM / 8 / NW, B_INSTR = BN / 8 / NW;
+  constexpr int SROW = BN + 4;                     // epilogue staging row (floats); +16 B keeps ds_write_b128 groups conflict-free
+  static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile rows must split evenly over the waves");
+  static_assert(BN == 256 && 32 * SROW * 4 <= STAGE, "epilogue staging (32 rows) must fit one pipeline buffer");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
+  const int logical0 = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int total_tiles = tiles_m * tiles_n;
+  if (logical0 >= total_tiles) return;
+  const int z = blockIdx.y;
+  const int kt0 = z * kt_per_split;
+  const int nk = min(kt_per_split, g.K / BK - kt0);
+  const bool persistent = gridDim.y == 1;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave - wm * WN;
+
+  // per-lane DMA source offsets in BYTES, unsigned: address = uniform 64-bit base (SGPR pair) + zero-extended 32-bit lane offset,
+  // which selects the saddr form of global_load_lds (one address dword per lane, no per-piece VALU address arithmetic)
+  uint32_t offA[A_INSTR], offB[B_INSTR];
+#pragma unroll
+  for (int i = 0; i < A_INSTR; ++i) {
+    const int row = (i * NW + wave) * 8 + (lane >> 3);
+    offA[i] = (uint32_t)(row * (int)g.lda + (((lane & 7) ^ ((row >> 1) & 7)) << 3)) * 2u;
+  }
+#pragma unroll
+  for (int i = 0; i < B_INSTR; ++i) {
+    const int row = (i * NW + wave) * 8 + (lane >> 3);
+    offB[i] = (uint32_t)(row * (int)g.ldb + (((lane & 7) ^ ((row >> 1) & 7)) << 3)) * 2u;
+  }
+
+  // ---- issue cursor over this workgroup's K-tile stream (tile, kt); LDS buffer of stream item i = i & 1
+  int i_logical = logical0, i_k = 0, issued = 0;
+  bool i_more = nk > 0;
+  const bf16_t *Ai, *Bi;
+  auto i_set_tile = [&]() {
+    const int tm = i_logical / tiles_n, tn = i_logical - tm * tiles_n;
+    Ai = g.A + (int64_t)tm * BM * g.lda + (int64_t)kt0 * BK;
+    Bi = g.B + (int64_t)tn * BN * g.ldb + (int64_t)kt0 * BK;
+  };
+  i_set_tile();
+  constexpr int P = A_INSTR + B_INSTR;   // DMA pieces (1 KiB each) per K-tile per wave
+  // where the P pieces of K-tile it+2 are issued: k-step 3 of tile it (after the hand-over), k-steps 0 and 1 of tile it+1.
+  // 64 pieces issued by 8 waves at the same moment queue up behind one address unit (~50 cycles each, all waves blocked);
+  // spread over the tile each one costs ~18 cycles and hides under an MFMA.
+  constexpr int N3 = PAT == 0 ? P : (PAT == 1 ? (P + 1) / 2 : (P + 2) / 3);
+  constexpr int N0 = PAT == 0 ? 0 : (PAT == 1 ? P / 2 : (P + 1) / 3);
+  constexpr int N1 = P - N3 - N0;
+  bool pending = false;                  // pieces of the cursor's K-tile still to be issued
+  const int xp = g.stagger;   // timing experiments only (results are wrong): 1 = no DMA wait, 2 = no DMA issue in the K loop
+  auto issue_piece = [&](char* base, auto p_c) {
+    constexpr int p = decltype(p_c)::value;
+    if constexpr (p < A_INSTR)
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)((const char*)(Ai + i_k * BK) + offA[p]), (lds_void_t*)(base + (p * NW + wave) * 1024), 16, 0, 0);
+    else
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)((const char*)(Bi + i_k * BK) + offB[p - A_INSTR]),
+                                       (lds_void_t*)(base + A_BYTES + ((p - A_INSTR) * NW + wave) * 1024), 16, 0, 0);
+  };
+  auto i_advance = [&]() {
+    ++issued;
+    if (++i_k == nk) {
+      i_k = 0;
+      i_logical += nwg;
+      i_more = persistent && i_logical < total_tiles;
+      if (i_more) i_set_tile();
+    }
+  };
+  auto issue = [&]() {
+    if (!i_more) return;
+    char* base = smem + (issued & 1) * STAGE;
+    static_for<P>([&](auto p_c) { issue_piece(base, p_c); });
+    i_advance();
+  };
+
+  // fragment addressing: row = tile row of this lane (lane&31), chunk = (ks*2 + (lane>>5)) ^ swz(row)
+  const int sw = ((lane & 31) >> 1) & 7;
+  const int a_row_byte = (wm * WTM + (lane & 31)) * 128;
+  const int b_row_byte = A_BYTES + (wn * WTN + (lane & 31)) * 128;
+  const int khalf = lane >> 5;
+  bf16x8 fa[2][MT], fb[2][NT];
+  auto load_frags = [&](bf16x8(&af)[MT], bf16x8(&bfr)[NT], const char* base, int ks) {
+    const int cb = ((ks * 2 + khalf) ^ sw) << 4;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) af[i] = *(const bf16x8*)(base + a_row_byte + i * 32 * 128 + cb);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) bfr[j] = *(const bf16x8*)(base + b_row_byte + j * 32 * 128 + cb);
+  };
+  constexpr int Q = MT * NT;             // MFMAs per k-step per wave
+  f32x16 acc[MT][NT];
+  auto mfma_range = [&](auto cur_c, auto first_c, auto last_c) {   // MFMAs [first, last) of a k-step, fragments set `cur`
+    constexpr int CUR = decltype(cur_c)::value, FIRST = decltype(first_c)::value, LAST = decltype(last_c)::value;
+    static_for<(LAST > FIRST ? LAST - FIRST : 0)>([&](auto d) {
+      constexpr int idx = FIRST + decltype(d)::value, i = idx / NT, j = idx % NT;
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[CUR][j], fa[CUR][i], acc[i][j], 0, 0, 0);
+    });
+  };
+  auto handover = [&]() {   // every wave's reads of the older buffer are in registers, the younger buffer has landed
+    if (xp & 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+  const bool has_bias = ep.bias != nullptr, has_scale = ep.scale != nullptr;
+  const int64_t out_off = (int64_t)z * ep.partial_stride;
+
+  issue();      // stream items 0 and 1
+  issue();
+  handover();
+  load_frags(fa[0], fb[0], smem, 0);
+  int it = 0;   // consumed K-tile counter of the stream
+  for (int logical = logical0; logical < total_tiles; logical += nwg) {
+    const int tile_m = logical / tiles_n, tile_n = logical - tile_m * tiles_n;
+    const bool has_next = persistent && logical + nwg < total_tiles;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    for (int kt = 0; kt < nk; ++kt) {
+      const char* base = smem + (it & 1) * STAGE;
+      static_for<BK / 16>([&](auto ks_c) {
+        constexpr int ks = decltype(ks_c)::value, CUR = ks & 1;
+        // Order is pinned with sched_barrier(0): two MFMAs, then the ds_reads of the NEXT k-step, then the remaining MFMAs with
+        // this k-step's share of the DMA pieces between them (the reads are >= Q-2 MFMAs old when their consumer arrives; left
+        // alone, the scheduler sinks them to just before use).
+        constexpr int NP = ks == 3 ? N3 : (ks == 0 ? N0 : (ks == 1 ? N1 : 0));   // DMA pieces issued in this k-step
+        constexpr int FP = ks == 3 ? 0 : (ks == 0 ? N3 : N3 + N0);              // first of them
+        if constexpr (ks + 1 < BK / 16) {
+          mfma_range(ic<CUR>{}, ic<0>{}, ic<2>{});
+          __builtin_amdgcn_sched_barrier(0);
+          load_frags(fa[CUR ^ 1], fb[CUR ^ 1], base, ks + 1);
+        } else {
+          // K-tile hand-over in front of the last k-step's MFMAs (ONE instruction stream for every case -- branching the MFMA
+          // sequence makes the allocator copy accumulators): K-tile it+1 has landed, buffer it&1 is fully read by every wave.
+          handover();
+          mfma_range(ic<CUR>{}, ic<0>{}, ic<2>{});
+          __builtin_amdgcn_sched_barrier(0);
+          load_frags(fa[0], fb[0], smem + ((it + 1) & 1) * STAGE, 0);    // (stale LDS at the very end of the stream: unused)
+          // K-tile it+2 goes into the buffer just released; at the last K-tile of an output tile the refill is deferred until
+          // after the epilogue, which stages through that buffer.
+          pending = i_more && kt + 1 < nk && !(xp & 2);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (NP > 0) {
+          char* ibase = smem + (issued & 1) * STAGE;
+          static_for<NP>([&](auto d_c) {
+            constexpr int d = decltype(d_c)::value;
+            mfma_range(ic<CUR>{}, ic<(2 + d < Q ? 2 + d : Q)>{}, ic<(3 + d < Q ? 3 + d : Q)>{});
+            if (pending) issue_piece(ibase, ic<FP + d>{});
+            __builtin_amdgcn_sched_barrier(0);
+          });
+          mfma_range(ic<CUR>{}, ic<(2 + NP < Q ? 2 + NP : Q)>{}, ic<Q>{});
+          if constexpr (FP + NP == P) {
+            if (pending) i_advance();
+            pending = false;
+          }
+        } else {
+          mfma_range(ic<CUR>{}, ic<2>{}, ic<Q>{});
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      ++it;
+    }
+
+    // ---- epilogue: 32 output rows per round through the buffer of the last K-tile (its refill is deferred until after the epilogue)
+    {
+      const bool interior = epilogue_fast_ok(ep, MODE) && (tile_m + 1) * BM <= ep.M && (tile_n + 1) * BN <= ep.N;
+      float* st = (float*)(smem + ((it + 1) & 1) * STAGE);
+      const int gcol = tile_n * BN + lane * 4;
+      float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f), s4 = make_float4(1.f, 1.f, 1.f, 1.f);
+      if (interior && has_bias) b4 = *(const float4*)(ep.bias + gcol);
+      if (interior && has_scale) s4 = *(const float4*)(ep.scale + gcol);
+      constexpr int RPW = 32 / NW;   // rows per wave per round (one 1-KiB row per wave instruction)
+#pragma clang loop unroll(full)
+      for (int R = 0; R < BM / 32; ++R) {
+        const int wm_r = (R * 32) / WTM, i0 = ((R * 32) % WTM) / 32;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (wm == wm_r) {
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              *(float4*)(st + (lane & 31) * SROW + wn * WTN + j * 32 + 8 * q + 4 * khalf) =
+                  make_float4(acc[i0][j][4 * q], acc[i0][j][4 * q + 1], acc[i0][j][4 * q + 2], acc[i0][j][4 * q + 3]);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        float4 v[RPW];
+#pragma unroll
+        for (int k = 0; k < RPW; ++k) v[k] = *(const float4*)(st + (k * NW + wave) * SROW + lane * 4);
+        const int grow0 = tile_m * BM + R * 32;
+        if (interior) {
+          float4 x[RPW];
+#pragma unroll
+          for (int k = 0; k < RPW; ++k) x[k] = epilogue_fast_load<MODE, bf16_t>(ep, grow0 + k * NW + wave, gcol);
+          if (has_bias) {
+#pragma unroll
+            for (int k = 0; k < RPW; ++k) epilogue_fast4<MODE, bf16_t, true, false>(ep, grow0 + k * NW + wave, gcol, v[k], b4, s4, x[k], out_off);
+          } else {
+#pragma unroll
+            for (int k = 0; k < RPW; ++k) epilogue_fast4<MODE, bf16_t, false, false>(ep, grow0 + k * NW + wave, gcol, v[k], b4, s4, x[k], out_off);
+          }
+        } else {
+#pragma unroll
+          for (int k = 0; k < RPW; ++k) epilogue_apply4<MODE, bf16_t>(ep, grow0 + k * NW + wave, gcol, v[k], out_off);
+        }
+      }
+    }
+    if (has_next) {
+      handover();                                   // staging reads done everywhere
+      issue();                                      // deferred refill of the staging buffer: stream item it+1
+    }
+  }
+}
+
+template <int BM, int BN, int WM, int WN, int MODE, int PAT = 0>
+void launch_pipe(const Bf16GemmArgs& g, const EpiParams& ep, hipStream_t s) {
+  constexpr int SMEM = 2 * (BM + BN) * BK * 2;
+  auto kern = gemm_bf16_nt_pipe_kernel<BM, BN, WM, WN, MODE, PAT>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    attr_set = true;
+  }
+  const int tiles_m = (int)ceil_div(g.M, BM), tiles_n = (int)ceil_div(g.N, BN);
+  const int nk = g.K / BK;
+  const int split = g.split_k > 1 ? g.split_k : 1;
+  const int per = (int)ceil_div(nk, split);
+  const int zs = (int)ceil_div(nk, per);
+  const unsigned gx = zs == 1 ? (unsigned)std::min(tiles_m * tiles_n, 256) : (unsigned)(tiles_m * tiles_n);
+  dim3 grid(gx, (unsigned)zs), block(WM * WN * 64);
+  hipLaunchKernelGGL(kern, grid, block, SMEM, s, g, ep, tiles_m, tiles_n, per);
+}
 
 // ------------------------------------------------------------------------------------------------
 // "TN" GEMM for the weight gradients:  C[i][j] = sum_m A[m][i] * B[m][j]   (dW = X^T dY, reduction over token rows)
@@ -477,18 +706,26 @@ void launch_mode(const Bf16GemmArgs& g, const EpiParams& ep, hipStream_t s) {
   // epilogue form: bit 8 forces the per-lane direct form, bit 9 forces the LDS-staged form; by default bf16-output epilogues
   // (8-B per-lane pieces) are staged through LDS into whole-row stores, fp32-output ones (16-B pieces) go out directly (measured).
   const bool bf16_out = (MODE == EPI_STORE || MODE == EPI_BIAS_GELU || MODE == EPI_GELU_BWD);
-  const bool direct = (g.kernel & 256) ? true : ((g.kernel & 512) ? false : !bf16_out);
+  // (8-B per-lane pieces) are staged; with 32-row staging rounds (variants 5-8) staging wins for fp32 outputs too.
+  const bool direct = (g.kernel & 256) ? true : ((g.kernel & 512) ? false : (!bf16_out && k < 5));
+  if (k == 13) { launch_pipe<256, 256, 2, 4, MODE, 1>(g, ep, s); return; }
+  if (k == 14) { launch_pipe<256, 256, 2, 4, MODE, 2>(g, ep, s); return; }
+  if (k == 15) { launch_pipe<320, 256, 2, 4, MODE, 2>(g, ep, s); return; }
+  if (k == 9) { launch_pipe<256, 256, 2, 4, MODE>(g, ep, s); return; }
+  if (k == 10) { launch_pipe<320, 256, 2, 4, MODE>(g, ep, s); return; }
   if (direct) {
     if (k == 1) launch_variant<128, 128, 2, 2, MODE, false>(g, ep, s);
     else if (k == 3) launch_variant<256, 128, 4, 2, MODE, false>(g, ep, s);
-    else if (k == 4) launch_variant<256, 256, 2, 4, MODE, false, 1>(g, ep, s);
     else if (k == 5) launch_variant<320, 256, 2, 4, MODE, false>(g, ep, s);
+    else if (k == 6) launch_variant<256, 256, 2, 4, MODE, false, 2>(g, ep, s);
+    else if (k == 7) launch_variant<320, 256, 2, 4, MODE, false, 2>(g, ep, s);
     else launch_variant<256, 256, 2, 4, MODE, false>(g, ep, s);
   } else {
     if (k == 1) launch_variant<128, 128, 2, 2, MODE, true>(g, ep, s);
     else if (k == 3) launch_variant<256, 128, 4, 2, MODE, true>(g, ep, s);
-    else if (k == 4) launch_variant<256, 256, 2, 4, MODE, true, 1>(g, ep, s);
-    else if (k == 5) launch_variant<320, 256, 2, 4, MODE, false>(g, ep, s);   // MT = 5: direct epilogue only
+    else if (k == 5) launch_variant<320, 256, 2, 4, MODE, true>(g, ep, s);    // MT = 5: 32-row staging rounds
+    else if (k == 6) launch_variant<256, 256, 2, 4, MODE, true, 2>(g, ep, s);
+    else if (k == 7) launch_variant<320, 256, 2, 4, MODE, true, 2>(g, ep, s);
     else launch_variant<256, 256, 2, 4, MODE, true>(g, ep, s);
   }
 }
@@ -503,12 +740,12 @@ int gemm_bf16_pick(int M, int N) {
   const int64_t t256 = ceil_div(M, 256) * tn, t320 = ceil_div(M, 320) * tn;
   const double e256 = (double)M * N / ((double)ceil_div(t256, 256) * 256 * 256 * 256);
   const double e320 = (double)M * N / ((double)ceil_div(t320, 256) * 256 * 320 * 256);
-  return (g_allow_320 && e320 > e256 * 1.08) ? 5 : 2;
+  return (g_allow_320 && e320 > e256 * 1.08) ? 7 : 6;   // persistent variants
 }
 int gemm_bf16_tile_m(int kernel, int M, int N) {
   kernel &= 15;
   if (kernel == 0) kernel = gemm_bf16_pick(M, N);
-  return kernel == 1 ? 128 : (kernel == 5 ? 320 : 256);
+  return kernel == 1 ? 128 : ((kernel == 5 || kernel == 7 || kernel == 10 || kernel == 15) ? 320 : 256);
 }
 int gemm_bf16_tile_n(int kernel, int M, int N) {
   kernel &= 15;
@@ -525,7 +762,7 @@ int gemm_bf16_num_slices(int K, int split_k) {
   return (int)ceil_div(nk, per);
 }
 
-void launch_gemm_bf16(const Bf16GemmArgs& g, const EpiParams& ep, int mode, hipStream_t s) {
+static void dispatch_gemm_bf16(const Bf16GemmArgs& g, const EpiParams& ep, int mode, hipStream_t s) {
   switch (mode) {
     case EPI_STORE: launch_mode<EPI_STORE>(g, ep, s); break;
     case EPI_STORE_F32: launch_mode<EPI_STORE_F32>(g, ep, s); break;
@@ -536,6 +773,62 @@ void launch_gemm_bf16(const Bf16GemmArgs& g, const EpiParams& ep, int mode, hipS
     case EPI_PARTIAL: launch_mode<EPI_PARTIAL>(g, ep, s); break;
     default: break;
   }
+}
+
+// ---- per-shape variant selection by measurement.  The variants differ by a few percent per (shape, epilogue) and the ranking
+// moves with the board's clocks, so with kernel = 0 (automatic) the first launch of each (mode, M, N, K) times the candidates on
+// the caller's stream with the caller's operands (every fused epilogue is a pure function of its inputs -- the launch is
+// repeatable as long as the output does not alias the residual) and caches the winner for the process.  All variants accumulate
+// every output element in the same K order, so the choice does not change results.  VITX_GEMM_AUTOTUNE=0 falls back to the
+// static rule gemm_bf16_pick().
+static std::mutex g_tune_mu;
+static std::map<std::array<int64_t, 6>, int> g_tuned;
+static int autotune_enabled() {
+  static int on = -1;
+  if (on < 0) { const char* v = getenv("VITX_GEMM_AUTOTUNE"); on = (v && atoi(v) == 0) ? 0 : 1; }
+  return on;
+}
+void launch_gemm_bf16(const Bf16GemmArgs& g0, const EpiParams& ep, int mode, hipStream_t s) {
+  const bool tunable = g0.kernel == 0 && autotune_enabled() && (g0.N % 256 == 0 || g0.N > 512) && (double)g0.M * g0.N * g0.K >= 2.0e9 &&
+                       !(mode == EPI_BIAS_RESID && ep.out == (void*)ep.resid);
+  if (!tunable) { dispatch_gemm_bf16(g0, ep, mode, s); return; }
+  const std::array<int64_t, 6> key = {mode, g0.M, g0.N, g0.K, g0.split_k > 1 ? g0.split_k : 1, ep.scale != nullptr};
+  int best = -1;
+  {
+    std::lock_guard<std::mutex> lk(g_tune_mu);
+    auto it = g_tuned.find(key);
+    if (it != g_tuned.end()) best = it->second;
+  }
+  Bf16GemmArgs g = g0;
+  if (best < 0) {
+    static const int cand[] = {6, 13, 14, 2, 7, 15, 10, 5};   // 256x256 variants first, then 320x256 (only when allowed)
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    float best_ms = 1e30f;
+    best = gemm_bf16_pick(g0.M, g0.N);
+    for (int c : cand) {
+      const bool is320 = c == 5 || c == 7 || c == 10 || c == 15;
+      if (is320 && !g_allow_320) continue;
+      g.kernel = c;
+      dispatch_gemm_bf16(g, ep, mode, s);   // warm-up (first-use attribute setup, instruction cache)
+      (void)hipEventRecord(e0, s);
+      for (int r = 0; r < 3; ++r) dispatch_gemm_bf16(g, ep, mode, s);
+      (void)hipEventRecord(e1, s);
+      if (hipEventSynchronize(e1) != hipSuccess) continue;
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess && ms < best_ms) { best_ms = ms; best = c; }
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (getenv("VITX_GEMM_AUTOTUNE_LOG"))
+      fprintf(stderr, "[vitx] gemm autotune: mode %d M %d N %d K %d split %d -> variant %d (%.4f ms)\n", mode, g0.M, g0.N, g0.K, g0.split_k, best,
+              best_ms / 3.f);
+    std::lock_guard<std::mutex> lk(g_tune_mu);
+    g_tuned[key] = best;
+  }
+  g.kernel = best;
+  dispatch_gemm_bf16(g, ep, mode, s);
 }
 
 // C[M=in][N=out] (split-K partials) = A[K=tokens][in]^T * B[K=tokens][out]; kernel: 1 = 128x128 tile, else 256x256
