@@ -67,7 +67,8 @@ def stage_gemm():
 
 
 def stage_gemmx():
-    """timing experiments on the software-pipelined kernel: +16 = no DMA wait, +32 = no DMA issue (results wrong, time only)"""
+    """timing experiments on the software-pipelined kernel (results wrong, time only): +16 = no DMA wait, +32 = no DMA issue in
+    the K loop; run once with random and once with zero-filled operands (clock / power effect)"""
     from vit_tensorflow import _native as N
     m = _model("vit_bf16_small", "bf16", 1)
     m.build((1,))
@@ -77,7 +78,7 @@ def stage_gemmx():
         if zero:
             os.environ["VITX_BENCH_ZERO"] = "1"
         for (M, Nn, K) in [(8192, 8192, 8192), (50432, 768, 3072), (50432, 3072, 768)]:
-            for kern in (9, 9 + 16, 9 + 32, 14, 14 + 32):
+            for kern in (2 + 512, 6, 9, 9 + 16, 9 + 32, 14, 14 + 32):
                 rc = lib.vitx_bench_gemm(m._handle, M, Nn, K, kern, 3, 20, C.byref(avg), C.byref(err))
                 tf = 2.0 * M * Nn * K / (avg.value * 1e-3) / 1e12 if rc == 0 else float("nan")
                 print(f"zero={zero} M{M} N{Nn} K{K} kernel {kern}: {avg.value:.4f} ms  {tf:.1f} TFLOP/s  rc {rc}", flush=True)

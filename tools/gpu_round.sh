@@ -19,6 +19,12 @@ for s in $STAGES; do
         tag=$(echo $pass | tr ' ' '_' | cut -c1-40)
         (cd /tmp && timeout 300 rocprofv3 --pmc $pass --kernel-trace --output-format csv -d $OLDPWD/$OUT/pmc_$tag -o g -- python $OLDPWD/tools/gemm_bench.py ${PMC_SHAPE:-8192 8192 8192 2 3 3} > $OLDPWD/$OUT/pmc_$tag.log 2>&1); tail -2 $OUT/pmc_$tag.log
       done ;;
+    pmc_bench) for pass in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
+        tag=$(echo $pass | tr ' ' '_' | cut -c1-40)
+        (cd /tmp && timeout 400 rocprofv3 --pmc $pass --kernel-trace --output-format csv -d $OLDPWD/$OUT/pmc_$tag -o b -- python $OLDPWD/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-profile > $OLDPWD/$OUT/pmc_$tag.json 2> $OLDPWD/$OUT/pmc_$tag.err); tail -c 300 $OUT/pmc_$tag.json
+      done
+      find $OUT -name "*kernel_trace.csv" -delete 2>/dev/null
+      python tools/pmc_traffic.py $OUT 0 > $OUT/pmc_traffic_all_steps.json 2>$OUT/pmc_traffic.err; head -c 1500 $OUT/pmc_traffic_all_steps.json ;;
     *) timeout 900 python tools/gpu_diag.py $s > $OUT/$s.log 2>&1; tail -60 $OUT/$s.log ;;
   esac
 done

@@ -535,9 +535,21 @@ static int block_backward(vitx_engine* e, Stage& st, int si, int l, int b, int n
     launch_branch_grad(e->g, bp.m_scale >= 0 ? e->params + bp.m_scale : nullptr, e->d_br, T, rows, d, drop, seed, site0 + 3, e->stream);
     dbranch = e->d_br;
   }
+  // fc1 bias gradient = column sums of d hpre: produced per M-tile by the fc2-dgrad epilogue itself (no second pass over the
+  // 310 MB output) whenever that GEMM runs an LDS-staged bf16 kernel and no dropout mask is applied to d hpre afterwards
+  const bool fc1_bias_fused = e->bf16 && !e->force_generic_gemm && !(e->gemm_kernel & 256) && drop == 0.f && bp.fc1.b >= 0;
+  const int cs_rows = (int)ceil_div(rows, 128);   // >= the M-tile count of every variant (128 / 256 / 320 rows per tile)
   {
     EpiParams ep; ep.out = e->d_h; ep.ldo = m; ep.aux = ba.hpre; ep.ldaux = m;
+    if (fc1_bias_fused) {
+      HIPCHK(hipMemsetAsync(e->red_ws, 0, (size_t)cs_rows * m * 4, e->stream));   // rows the chosen tile shape does not reach stay 0
+      ep.colsum = e->red_ws; ep.ldcs = m;
+    }
     dense_dgrad(e, dbranch, d, rows, bp.fc2, EPI_GELU_BWD, ep);             // d hpre = (d act) * gelu'(hpre)
+    if (fc1_bias_fused) {
+      Prof pr(e, "reduce_partials", 0, (double)(cs_rows + 1) * m * 4);
+      launch_reduce_partials3(e->red_ws, cs_rows, m, m, 1, e->grads + bp.fc1.b, nullptr, nullptr, e->red_ws + (int64_t)cs_rows * m, 1.0f, e->stream);
+    }
     if (drop > 0.f) {
       Prof pr(e, "dropout", 0, 0);
       launch_dropout(e->d_h, T, (int64_t)rows * m, drop, seed, site0 + 2, e->stream);   // mask of the post-GELU dropout (commutes)
@@ -551,7 +563,7 @@ static int block_backward(vitx_engine* e, Stage& st, int si, int l, int b, int n
     dense_dgrad(e, e->d_h, m, rows, bp.fc1, EPI_STORE, ep);
   }
   dense_wgrad(e, ba.y2, d, e->d_h, m, rows, bp.fc1);
-  bias_grad(e, e->d_h, T, m, rows, bp.fc1);
+  if (!fc1_bias_fused) bias_grad(e, e->d_h, T, m, rows, bp.fc1);
   {
     Prof pr(e, "layernorm_bwd", 0, lnb);
     launch_layernorm_bwd(e->d_y, T, d, ba.x_mid, d, ba.mean2, ba.rstd2, e->params + bp.ln2_g, e->g, d, e->g, d, T ? e->g_lp : nullptr, d,
@@ -808,8 +820,9 @@ int engine_create(const vitx_config& cfg, vitx_engine** out, std::string& err) {
     e->partial_elems = 512LL * 256 * 256 + 2 * max_w;
     DALLOC(e->partial_ws, (size_t)e->partial_elems * 4, false);
   }
+  // (+ per-M-tile column sums of the fc2-dgrad epilogue: one row per 256 token rows, 32 second-level rows)
   e->red_elems = std::max<int64_t>({layernorm_bwd_ws_elems(d), colsum_ws_elems((int)maxfeat), headmix_ws_elems((int)B, c.heads, 1, 1),
-                                    (int64_t)256 * 2 * 32, (int64_t)(512 + 32) * d});
+                                    (int64_t)256 * 2 * 32, (int64_t)(512 + 32) * d, (ceil_div(std::max<int64_t>(e->mp, e->mpp), 128) + 40) * (int64_t)m});
   DALLOC(e->red_ws, (size_t)e->red_elems * 4, false);
   HIPCHK(hipStreamSynchronize(e->stream));
   *out = e;

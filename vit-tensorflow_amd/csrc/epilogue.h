@@ -24,6 +24,8 @@ struct EpiParams {
   int64_t ldo = 0, ldo2 = 0, ldr = 0, ldaux = 0;
   int64_t out_batch_stride = 0, out_head_stride = 0;  // generic batched kernel only
   int64_t partial_stride = 0;                         // EPI_PARTIAL: elements per split slice
+  float* colsum = nullptr;                            // EPI_GELU_BWD, LDS-staged bf16 kernels: [tile_m][N] column sums of the output
+  int64_t ldcs = 0;                                   //   (bias gradient without re-reading the output), row = the launch's M-tile index
   int M = 0, N = 0;        // valid extents (rows >= M are written as zero for T outputs, skipped for f32)
   int np = 1, ntok = 1, tok_off = 0;
   int vec_ok = 1;          // 0: some pointer / leading dimension is not 16-B friendly -> scalar accesses
@@ -34,19 +36,20 @@ struct EpiParams {
 // T = storage type of "T" outputs / aux.  (row, col) are global tile coordinates; v holds columns col..col+3.
 // All leading dimensions are multiples of 4 and col is a multiple of 4, so vector accesses are aligned.
 template <int MODE, typename T>
-__device__ __forceinline__ void epilogue_apply4(const EpiParams& p, int row, int col, float4 v, int64_t out_off = 0) {
-  if (col >= p.N) return;
+__device__ __forceinline__ float4 epilogue_apply4(const EpiParams& p, int row, int col, float4 v, int64_t out_off = 0) {
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (col >= p.N) return zero4;
   const bool full = (col + 3 < p.N) && p.vec_ok;
   float a[4] = {v.x * p.alpha, v.y * p.alpha, v.z * p.alpha, v.w * p.alpha};
   const bool row_ok = row < p.M;
-  if (!row_ok && !p.zero_pad) return;
+  if (!row_ok && !p.zero_pad) return zero4;
 
   if (MODE == EPI_PARTIAL) {
-    if (!row_ok) return;
+    if (!row_ok) return zero4;
     float* o = (float*)p.out + out_off + (int64_t)row * p.ldo + col;
     if (full) *(float4*)o = make_float4(a[0], a[1], a[2], a[3]);
     else for (int i = 0; i < 4 && col + i < p.N; ++i) o[i] = a[i];
-    return;
+    return zero4;
   }
   if (p.bias != nullptr && MODE != EPI_GELU_BWD) {
     if (full) { float4 b = *(const float4*)(p.bias + col); a[0] += b.x; a[1] += b.y; a[2] += b.z; a[3] += b.w; }
@@ -58,7 +61,7 @@ __device__ __forceinline__ void epilogue_apply4(const EpiParams& p, int row, int
     if (full) st4<T>(o, make_float4(a[0], a[1], a[2], a[3]));
     else for (int i = 0; i < 4 && col + i < p.N; ++i) stf<T>(o + i, a[i]);
   } else if (MODE == EPI_STORE_F32) {
-    if (!row_ok) return;
+    if (!row_ok) return zero4;
     float* o = (float*)p.out + out_off + (int64_t)row * p.ldo + col;
     if (full) *(float4*)o = make_float4(a[0], a[1], a[2], a[3]);
     else for (int i = 0; i < 4 && col + i < p.N; ++i) o[i] = a[i];
@@ -81,7 +84,7 @@ __device__ __forceinline__ void epilogue_apply4(const EpiParams& p, int row, int
       if (full) st4<T>(o2, make_float4(z[0], z[1], z[2], z[3]));
       else for (int i = 0; i < 4 && col + i < p.N; ++i) stf<T>(o2 + i, z[i]);
     }
-    if (!row_ok) return;
+    if (!row_ok) return zero4;
     float* o = (float*)p.out + (int64_t)row * p.ldo + col;
     const float* r = p.resid + (int64_t)row * p.ldr + col;
     if (full) {
@@ -92,7 +95,7 @@ __device__ __forceinline__ void epilogue_apply4(const EpiParams& p, int row, int
       for (int i = 0; i < 4 && col + i < p.N; ++i) o[i] = r[i] + a[i] * (p.scale ? p.scale[col + i] : 1.f);
     }
   } else if (MODE == EPI_PATCH) {
-    if (!row_ok) return;
+    if (!row_ok) return zero4;
     const int img = row / p.np, t = row - img * p.np;
     const int64_t orow = (int64_t)img * p.ntok + p.tok_off + t;
     float* o = (float*)p.out + orow * p.ldo + col;
@@ -110,9 +113,13 @@ __device__ __forceinline__ void epilogue_apply4(const EpiParams& p, int row, int
       if (!row_ok) g[0] = g[1] = g[2] = g[3] = 0.f;
       st4<T>(o, make_float4(g[0], g[1], g[2], g[3]));
     } else {
-      for (int i = 0; i < 4 && col + i < p.N; ++i) stf<T>(o + i, row_ok ? a[i] * gelu_grad_t<T>(ldf<T>(h + i)) : 0.f);
+      g[0] = g[1] = g[2] = g[3] = 0.f;
+      for (int i = 0; i < 4 && col + i < p.N; ++i) { g[i] = row_ok ? a[i] * gelu_grad_t<T>(ldf<T>(h + i)) : 0.f; stf<T>(o + i, g[i]); }
     }
+    // what was stored (rounded to T): the fused column sums add exactly what a later pass over the output would read
+    return make_float4((float)(T)g[0], (float)(T)g[1], (float)(T)g[2], (float)(T)g[3]);
   }
+  return zero4;
 }
 
 // Branch-free form for INTERIOR tiles (every row < M, every column < N, vector-friendly pointers, alpha == 1): the caller has
@@ -128,7 +135,7 @@ __device__ __forceinline__ float4 epilogue_fast_load(const EpiParams& p, int row
   return make_float4(0.f, 0.f, 0.f, 0.f);
 }
 template <int MODE, typename T, bool HAS_BIAS, bool HAS_SCALE>
-__device__ __forceinline__ void epilogue_fast4(const EpiParams& p, int row, int col, float4 v, float4 b4, float4 s4, float4 x, int64_t out_off) {
+__device__ __forceinline__ float4 epilogue_fast4(const EpiParams& p, int row, int col, float4 v, float4 b4, float4 s4, float4 x, int64_t out_off) {
   if (HAS_BIAS && MODE != EPI_GELU_BWD && MODE != EPI_PARTIAL) { v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w; }
   if (MODE == EPI_STORE) {
     st4<T>((T*)p.out + out_off + (int64_t)row * p.ldo + col, v);
@@ -145,9 +152,11 @@ __device__ __forceinline__ void epilogue_fast4(const EpiParams& p, int row, int 
     }
     *(float4*)((float*)p.out + (int64_t)row * p.ldo + col) = make_float4(x.x + v.x, x.y + v.y, x.z + v.z, x.w + v.w);
   } else if (MODE == EPI_GELU_BWD) {
-    st4<T>((T*)p.out + (int64_t)row * p.ldo + col,
-           make_float4(v.x * gelu_grad_t<T>(x.x), v.y * gelu_grad_t<T>(x.y), v.z * gelu_grad_t<T>(x.z), v.w * gelu_grad_t<T>(x.w)));
+    const float4 gq = make_float4(v.x * gelu_grad_t<T>(x.x), v.y * gelu_grad_t<T>(x.y), v.z * gelu_grad_t<T>(x.z), v.w * gelu_grad_t<T>(x.w));
+    st4<T>((T*)p.out + (int64_t)row * p.ldo + col, gq);
+    return make_float4((float)(T)gq.x, (float)(T)gq.y, (float)(T)gq.z, (float)(T)gq.w);   // as stored (see epilogue_apply4)
   }
+  return v;
 }
 __device__ __forceinline__ bool epilogue_fast_ok(const EpiParams& p, int mode) {
   return p.vec_ok && p.alpha == 1.0f && mode != EPI_PATCH;

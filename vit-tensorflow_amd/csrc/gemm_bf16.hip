@@ -177,6 +177,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_kernel(Bf16GemmArgs
       float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f), s4 = make_float4(1.f, 1.f, 1.f, 1.f);
       if (interior && has_bias) b4 = *(const float4*)(ep.bias + gcol);
       if (interior && has_scale) s4 = *(const float4*)(ep.scale + gcol);
+      float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);   // EPI_GELU_BWD: column sums of what this lane stores (fused bias gradient)
+      auto cs_add = [&](float4 r) { if (MODE == EPI_GELU_BWD) { cs.x += r.x; cs.y += r.y; cs.z += r.z; cs.w += r.w; } };
 #pragma clang loop unroll(full)
       for (int R = 0; R < BM / RR; ++R) {
         const int wm_r = (R * RR) / WTM, i0 = ((R * RR) % WTM) / 32;
@@ -202,14 +204,27 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_kernel(Bf16GemmArgs
           for (int k = 0; k < RPW; ++k) x[k] = epilogue_fast_load<MODE, bf16_t>(ep, grow0 + (k * NW + wave) * RPIW, gcol);
           if (has_bias) {
 #pragma unroll
-            for (int k = 0; k < RPW; ++k) epilogue_fast4<MODE, bf16_t, true, false>(ep, grow0 + (k * NW + wave) * RPIW, gcol, v[k], b4, s4, x[k], out_off);
+            for (int k = 0; k < RPW; ++k) cs_add(epilogue_fast4<MODE, bf16_t, true, false>(ep, grow0 + (k * NW + wave) * RPIW, gcol, v[k], b4, s4, x[k], out_off));
           } else {
 #pragma unroll
-            for (int k = 0; k < RPW; ++k) epilogue_fast4<MODE, bf16_t, false, false>(ep, grow0 + (k * NW + wave) * RPIW, gcol, v[k], b4, s4, x[k], out_off);
+            for (int k = 0; k < RPW; ++k) cs_add(epilogue_fast4<MODE, bf16_t, false, false>(ep, grow0 + (k * NW + wave) * RPIW, gcol, v[k], b4, s4, x[k], out_off));
           }
         } else {
 #pragma unroll
-          for (int k = 0; k < RPW; ++k) epilogue_apply4<MODE, bf16_t>(ep, grow0 + (k * NW + wave) * RPIW, gcol, v[k], out_off);
+          for (int k = 0; k < RPW; ++k) cs_add(epilogue_apply4<MODE, bf16_t>(ep, grow0 + (k * NW + wave) * RPIW, gcol, v[k], out_off));
+        }
+      }
+      if (MODE == EPI_GELU_BWD && ep.colsum != nullptr) {
+        // per-tile column sums: NW*RPIW partial rows through the staging buffer, then one row of [BN] to colsum[tile_m][...]
+        __syncthreads();
+        *(float4*)(st + (wave * RPIW + lane / LPRW) * BN + col_l) = cs;
+        __syncthreads();
+        if (tid < BN) {
+          float a = 0.f;
+#pragma unroll
+          for (int w = 0; w < NW * RPIW; ++w) a += st[w * BN + tid];
+          const int c = tile_n * BN + tid;
+          if (c < ep.N) ep.colsum[(int64_t)tile_m * ep.ldcs + c] = a;
         }
       }
       if (SCHED == 2) __syncthreads();   // the staging buffer becomes the next DMA target at the top of the next K loop
@@ -484,6 +499,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_pipe_kernel(Bf16Gem
       if (interior && has_bias) b4 = *(const float4*)(ep.bias + gcol);
       if (interior && has_scale) s4 = *(const float4*)(ep.scale + gcol);
       constexpr int RPW = 32 / NW;   // rows per wave per round (one 1-KiB row per wave instruction)
+      float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);   // EPI_GELU_BWD: column sums of what this lane stores (fused bias gradient)
+      auto cs_add = [&](float4 r) { if (MODE == EPI_GELU_BWD) { cs.x += r.x; cs.y += r.y; cs.z += r.z; cs.w += r.w; } };
 #pragma clang loop unroll(full)
       for (int R = 0; R < BM / 32; ++R) {
         const int wm_r = (R * 32) / WTM, i0 = ((R * 32) % WTM) / 32;
@@ -511,14 +528,30 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_pipe_kernel(Bf16Gem
           for (int k = 0; k < RPW; ++k) x[k] = epilogue_fast_load<MODE, bf16_t>(ep, grow0 + k * NW + wave, gcol);
           if (has_bias) {
 #pragma unroll
-            for (int k = 0; k < RPW; ++k) epilogue_fast4<MODE, bf16_t, true, false>(ep, grow0 + k * NW + wave, gcol, v[k], b4, s4, x[k], out_off);
+            for (int k = 0; k < RPW; ++k) cs_add(epilogue_fast4<MODE, bf16_t, true, false>(ep, grow0 + k * NW + wave, gcol, v[k], b4, s4, x[k], out_off));
           } else {
 #pragma unroll
-            for (int k = 0; k < RPW; ++k) epilogue_fast4<MODE, bf16_t, false, false>(ep, grow0 + k * NW + wave, gcol, v[k], b4, s4, x[k], out_off);
+            for (int k = 0; k < RPW; ++k) cs_add(epilogue_fast4<MODE, bf16_t, false, false>(ep, grow0 + k * NW + wave, gcol, v[k], b4, s4, x[k], out_off));
           }
         } else {
 #pragma unroll
-          for (int k = 0; k < RPW; ++k) epilogue_apply4<MODE, bf16_t>(ep, grow0 + k * NW + wave, gcol, v[k], out_off);
+          for (int k = 0; k < RPW; ++k) cs_add(epilogue_apply4<MODE, bf16_t>(ep, grow0 + k * NW + wave, gcol, v[k], out_off));
+        }
+      }
+      if (MODE == EPI_GELU_BWD && ep.colsum != nullptr) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        *(float4*)(st + wave * BN + lane * 4) = cs;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (tid < BN) {
+          float a = 0.f;
+#pragma unroll
+          for (int w = 0; w < NW; ++w) a += st[w * BN + tid];
+          const int c = tile_n * BN + tid;
+          if (c < ep.N) ep.colsum[(int64_t)tile_m * ep.ldcs + c] = a;
         }
       }
     }
@@ -582,9 +615,15 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_tn_kernel(Bf16GemmArgs
 
   const int nwg = gridDim.x, bid = blockIdx.x;
   const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
-  const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  // 1-D grid over (K-slice, tile), K-slice major.  Workgroup ids go round-robin to the 8 XCDs, so XCD x is given a CONTIGUOUS
+  // chunk of that list: (almost) all tiles of one K-slice run on one XCD at the same time, and the slice of X / dY they share is
+  // fetched from HBM once into that XCD's L2 instead of once per XCD (PMC: 898 MB fetched per launch for 310 MB of operands
+  // with the slice index on gridDim.y, where the linear id -- hence the XCD -- mixes slices).
+  const int work = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int tiles = tiles_m * tiles_n;
+  const int z = work / tiles;
+  const int logical = work - z * tiles;
   const int tile_m = logical / tiles_n, tile_n = logical - tile_m * tiles_n;
-  const int z = blockIdx.y;
   const int nk_total = g.K / BK;
   const int kt0 = z * kt_per_split;
   const int nk = min(kt_per_split, nk_total - kt0);
@@ -596,25 +635,31 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_tn_kernel(Bf16GemmArgs
   // DMA: instruction i of this wave covers token rows (i*NW + wave)*RPI .. +RPI-1; lane -> (row, physical chunk)
   const bf16_t* Ag = g.A + (int64_t)kt0 * BK * g.lda + (int64_t)tile_m * BT;
   const bf16_t* Bg = g.B + (int64_t)kt0 * BK * g.ldb + (int64_t)tile_n * BT;
-  int64_t offA[INSTR], offB[INSTR];
+  // per-lane DMA source offsets in bytes (unsigned 32-bit: uniform 64-bit base + zero-extended lane offset)
+  uint32_t offA[INSTR], offB[INSTR];
 #pragma unroll
   for (int i = 0; i < INSTR; ++i) {
     const int row = (i * NW + wave) * RPI + lane / LPR;
     const int pc = lane % LPR;
     const int c = ((((pc >> 1) ^ (2 * (row & 3))) << 1) | (pc & 1));   // logical 16-B chunk stored at physical chunk pc
-    offA[i] = (int64_t)row * g.lda + c * 8;
-    offB[i] = (int64_t)row * g.ldb + c * 8;
+    offA[i] = (uint32_t)(row * (int)g.lda + c * 8) * 2u;
+    offB[i] = (uint32_t)(row * (int)g.ldb + c * 8) * 2u;
   }
-  auto stage = [&](int buf, int kt) {
+  constexpr int P = 2 * INSTR;           // DMA pieces (1 KiB) per K-tile per wave: A pieces, then B pieces
+  constexpr int Q = MT * NT;             // MFMAs per k-step per wave
+  // pieces of K-tile kt+2 are issued in k-step 3 of tile kt (after the hand-over) and k-steps 0, 1 of tile kt+1 -- see the NT kernel
+  constexpr int N3 = (P + 2) / 3, N0 = (P + 1) / 3, N1 = P - N3 - N0;
+  auto issue_piece = [&](int buf, int kt, auto p_c) {
+    constexpr int p = decltype(p_c)::value;
     char* base = smem + buf * STAGE;
-#pragma unroll
-    for (int i = 0; i < INSTR; ++i) {
-      __builtin_amdgcn_global_load_lds((gbl_void_t*)(Ag + offA[i] + (int64_t)kt * BK * g.lda),
-                                       (lds_void_t*)(base + (i * NW + wave) * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gbl_void_t*)(Bg + offB[i] + (int64_t)kt * BK * g.ldb),
-                                       (lds_void_t*)(base + OP_BYTES + (i * NW + wave) * 1024), 16, 0, 0);
-    }
+    if constexpr (p < INSTR)
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)((const char*)(Ag + (int64_t)kt * BK * g.lda) + offA[p]),
+                                       (lds_void_t*)(base + (p * NW + wave) * 1024), 16, 0, 0);
+    else
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)((const char*)(Bg + (int64_t)kt * BK * g.ldb) + offB[p - INSTR]),
+                                       (lds_void_t*)(base + OP_BYTES + ((p - INSTR) * NW + wave) * 1024), 16, 0, 0);
   };
+  auto stage = [&](int buf, int kt) { static_for<P>([&](auto p_c) { issue_piece(buf, kt, p_c); }); };
 
   f32x16 acc[MT][NT];
 #pragma unroll
@@ -633,33 +678,75 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_tn_kernel(Bf16GemmArgs
     const int gran = (feat_byte >> 5) ^ (2 * (m & 3));
     return m * ROWB + (gran << 5) + (feat_byte & 31);
   };
+  bf16x8 fa[2][MT], fb[2][NT];                              // register double-buffered fragments (see the NT kernel)
+  auto load_frags = [&](bf16x8(&af)[MT], bf16x8(&bfr)[NT], const char* base, int ks) {
+    const int m0 = 16 * ks + 8 * khalf + trow, m1 = m0 + 4;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int fbyte = (wm * WTM + i * 32) * 2 + piece;
+      af[i] = tr_frag(base + row_addr(m0, fbyte), base + row_addr(m1, fbyte));
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int fbyte = (wn * WTN + j * 32) * 2 + piece;
+      bfr[j] = tr_frag(base + OP_BYTES + row_addr(m0, fbyte), base + OP_BYTES + row_addr(m1, fbyte));
+    }
+  };
+  auto mfma_range = [&](auto cur_c, auto first_c, auto last_c) {
+    constexpr int CUR = decltype(cur_c)::value, FIRST = decltype(first_c)::value, LAST = decltype(last_c)::value;
+    static_for<(LAST > FIRST ? LAST - FIRST : 0)>([&](auto d) {
+      constexpr int idx = FIRST + decltype(d)::value, i = idx / NT, j = idx % NT;
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[CUR][j], fa[CUR][i], acc[i][j], 0, 0, 0);
+    });
+  };
+  auto handover = [&]() {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
 
   if (nk > 0) stage(0, 0);
+  if (nk > 1) stage(1, 1);
+  handover();
+  load_frags(fa[0], fb[0], smem, 0);
+  bool pending = false;
+  constexpr int QH = Q < 2 ? Q : 2;      // MFMAs issued ahead of the prefetch reads
   for (int kt = 0; kt < nk; ++kt) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
     const char* base = smem + (kt & 1) * STAGE;
-#pragma unroll
-    for (int ks = 0; ks < BK / 16; ++ks) {
-      const int m0 = 16 * ks + 8 * khalf + trow, m1 = m0 + 4;
-      bf16x8 af[MT], bfr[NT];
-#pragma unroll
-      for (int i = 0; i < MT; ++i) {
-        const int fb = (wm * WTM + i * 32) * 2 + piece;
-        af[i] = tr_frag(base + row_addr(m0, fb), base + row_addr(m1, fb));
+    static_for<BK / 16>([&](auto ks_c) {
+      constexpr int ks = decltype(ks_c)::value, CUR = ks & 1;
+      constexpr int NP = ks == 3 ? N3 : (ks == 0 ? N0 : (ks == 1 ? N1 : 0));
+      constexpr int FP = ks == 3 ? 0 : (ks == 0 ? N3 : N3 + N0);
+      if constexpr (ks + 1 < BK / 16) {
+        mfma_range(ic<CUR>{}, ic<0>{}, ic<QH>{});
+        __builtin_amdgcn_sched_barrier(0);
+        load_frags(fa[CUR ^ 1], fb[CUR ^ 1], base, ks + 1);
+      } else {
+        handover();                                                   // K-tile kt+1 landed; buffer kt&1 fully read by every wave
+        mfma_range(ic<CUR>{}, ic<0>{}, ic<QH>{});
+        __builtin_amdgcn_sched_barrier(0);
+        load_frags(fa[0], fb[0], smem + ((kt + 1) & 1) * STAGE, 0);    // (stale LDS after the last K-tile: unused)
+        pending = kt + 2 < nk;
       }
-#pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        const int fb = (wn * WTN + j * 32) * 2 + piece;
-        bfr[j] = tr_frag(base + OP_BYTES + row_addr(m0, fb), base + OP_BYTES + row_addr(m1, fb));
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (NP > 0) {
+        // the pending K-tile is kt+2 at k-step 3, and (this tile)+1 at k-steps 0/1 of the following tile; its buffer has the
+        // parity of the tile that was current when the hand-over released it
+        const int ikt = ks == 3 ? kt + 2 : kt + 1;
+        const int ibuf = ikt & 1;
+        static_for<NP>([&](auto d_c) {
+          constexpr int d = decltype(d_c)::value;
+          mfma_range(ic<CUR>{}, ic<(QH + d < Q ? QH + d : Q)>{}, ic<(QH + 1 + d < Q ? QH + 1 + d : Q)>{});
+          if (pending) issue_piece(ibuf, ikt, ic<FP + d>{});
+          __builtin_amdgcn_sched_barrier(0);
+        });
+        mfma_range(ic<CUR>{}, ic<(QH + NP < Q ? QH + NP : Q)>{}, ic<Q>{});
+        if constexpr (FP + NP == P) pending = false;
+      } else {
+        mfma_range(ic<CUR>{}, ic<QH>{}, ic<Q>{});
       }
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
-    }
+      __builtin_amdgcn_sched_barrier(0);
+    });
   }
 
   const int64_t out_off = (int64_t)z * ep.partial_stride;
@@ -695,7 +782,7 @@ void launch_tn_variant(const Bf16GemmArgs& g, const EpiParams& ep, hipStream_t s
   const int split = g.split_k > 1 ? g.split_k : 1;
   const int per = (int)ceil_div(nk, split);
   const int zs = (int)ceil_div(nk, per);
-  dim3 grid((unsigned)(tiles_m * tiles_n), (unsigned)zs), block(WM * WN * 64);
+  dim3 grid((unsigned)(tiles_m * tiles_n * zs)), block(WM * WN * 64);
   hipLaunchKernelGGL(kern, grid, block, SMEM, s, g, ep, tiles_m, tiles_n, per);
 }
 
