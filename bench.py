@@ -230,8 +230,21 @@ def main():
             if fam:
                 fl = sum(s.flops for s in fam); ms = sum(s.total_ms for s in fam); ln = sum(s.launches for s in fam)
                 ach = fl / (ms * 1e-3)
+                # HBM traffic of the family per launch: PMC counters cannot be collected from inside this process; the committed
+                # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE reduction of this very command (tools/pmc_traffic.py) is reported
+                traffic, traffic_src = None, None
+                try:
+                    tp = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")
+                    if args.workload == "vit_b16_224" and b == 256 and os.path.exists(tp):
+                        with open(tp) as f:
+                            traffic = json.load(f).get("gemm_family_hbm_bytes_per_launch")
+                        traffic_src = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this command)"
+                except Exception:
+                    traffic = None
                 out["roofline"] = {"bound": "mfma", "kernel": "+".join(s.name.decode() for s in fam), "achieved": round(ach / 1e12, 2),
-                                   "peak": round(peak / 1e12, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+                                   "peak": round(peak / 1e12, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
+                                   "traffic_unit": "HBM bytes per launch (PMC)", "traffic_source": traffic_src,
+                                   "algorithmic_bytes_per_launch": round(sum(s.bytes for s in fam) / max(ln, 1)),
                                    "launches_per_step": int(ln // psteps), "avg_launch_ms": round(ms / ln, 5),
                                    "algorithmic_tflop_per_step": round(fl / psteps / 1e12, 4)}
         except Exception as ex:   # never lose the headline line to a diagnostics problem

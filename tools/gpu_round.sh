@@ -24,7 +24,7 @@ for s in $STAGES; do
         (cd /tmp && timeout 400 rocprofv3 --pmc $pass --kernel-trace --output-format csv -d $OLDPWD/$OUT/pmc_$tag -o b -- python $OLDPWD/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-profile > $OLDPWD/$OUT/pmc_$tag.json 2> $OLDPWD/$OUT/pmc_$tag.err); tail -c 300 $OUT/pmc_$tag.json
       done
       find $OUT -name "*kernel_trace.csv" -delete 2>/dev/null
-      python tools/pmc_traffic.py $OUT 0 > $OUT/pmc_traffic_all_steps.json 2>$OUT/pmc_traffic.err; head -c 1500 $OUT/pmc_traffic_all_steps.json ;;
+      python tools/pmc_traffic.py $OUT gemm_bf16_mfma=99,gemm_bf16_mfma_tn=50 > $OUT/pmc_traffic.json 2>$OUT/pmc_traffic.err; head -c 1500 $OUT/pmc_traffic.json ;;
     *) timeout 900 python tools/gpu_diag.py $s > $OUT/$s.log 2>&1; tail -60 $OUT/$s.log ;;
   esac
 done

@@ -44,8 +44,15 @@ def load(root: str, counter: str):
 
 
 def main():
-    root, per_step = sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 0
-    out = OrderedDict(source="rocprofv3 --pmc (separate passes) over bench.py, last step only",
+    # usage: pmc_traffic.py <dir> [family=launches_per_step,...]   (families not listed: last half of their dispatches, the
+    # profiled command runs two steps)
+    root = sys.argv[1]
+    last = {}
+    if len(sys.argv) > 2:
+        for kv in sys.argv[2].split(","):
+            k, v = kv.split("=")
+            last[k] = int(v)
+    out = OrderedDict(source="rocprofv3 --pmc (separate passes) over bench.py --steps 1 --warmup 1, LAST step only",
                       corrections="fetch bytes = 2 x FETCH_SIZE x 1024 (gfx950 tallies 128-B requests at 64 B); WRITE_SIZE x 1024 as reported (uncalibrated)")
     fams = defaultdict(lambda: {"launches": 0, "fetch_bytes": 0.0, "write_bytes": 0.0})
     for counter, key, mult in (("FETCH_SIZE", "fetch_bytes", 2.0 * 1024.0), ("WRITE_SIZE", "write_bytes", 1024.0)):
@@ -53,13 +60,16 @@ def main():
         if rows is None:
             out[f"missing_{counter}"] = True
             continue
-        if per_step and len(rows) > per_step:
-            rows = rows[-per_step:]
+        byfam = defaultdict(list)
         for _, name, v in rows:
-            f = fams[family(name)]
-            f[key] += v * mult
+            byfam[family(name)].append(v)
+        for fam, vals in byfam.items():
+            keep = last.get(fam, max(1, len(vals) // 2))
+            vals = vals[-keep:]
+            f = fams[fam]
+            f[key] += sum(vals) * mult
             if counter == "FETCH_SIZE":
-                f["launches"] += 1
+                f["launches"] += len(vals)
     res = OrderedDict()
     for k, f in sorted(fams.items(), key=lambda kv: -(kv[1]["fetch_bytes"] + kv[1]["write_bytes"])):
         n = max(f["launches"], 1)

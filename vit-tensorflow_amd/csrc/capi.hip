@@ -314,6 +314,9 @@ int32_t vitx_set_grad_ready_callback(vitx_handle h, vitx_grad_ready_fn fn, void*
   if (!h) return fail(VITX_ERR_INVALID, "null handle");
   h->grad_cb = fn;
   h->grad_cb_user = user;
+  // a gradient-ready callback means collectives will run beside the backward pass: their workgroups take CUs away, and a
+  // persistent GEMM (grid = #CUs, static tile lists) then waits for its late workgroups -- use one-tile-per-workgroup variants
+  if (fn != nullptr) gemm_bf16_set_shared_gpu(1);   // sticky for the process
   return VITX_OK;
 }
 

@@ -22,6 +22,7 @@
 #include "kernels.h"
 
 static int g_allow_320 = 1;
+static int g_shared_gpu = 0;
 int gemm_bf16_pick(int M, int N);
 
 namespace {
@@ -827,7 +828,8 @@ int gemm_bf16_pick(int M, int N) {
   const int64_t t256 = ceil_div(M, 256) * tn, t320 = ceil_div(M, 320) * tn;
   const double e256 = (double)M * N / ((double)ceil_div(t256, 256) * 256 * 256 * 256);
   const double e320 = (double)M * N / ((double)ceil_div(t320, 256) * 256 * 320 * 256);
-  return (g_allow_320 && e320 > e256 * 1.08) ? 7 : 6;   // persistent variants
+  if (g_shared_gpu) return (g_allow_320 && e320 > e256 * 1.08) ? 5 : 2;   // the hardware dispatcher balances one-tile workgroups
+  return (g_allow_320 && e320 > e256 * 1.08) ? 7 : 6;                      // persistent variants
 }
 int gemm_bf16_tile_m(int kernel, int M, int N) {
   kernel &= 15;
@@ -840,6 +842,7 @@ int gemm_bf16_tile_n(int kernel, int M, int N) {
   return (kernel == 1 || kernel == 3) ? 128 : 256;
 }
 void gemm_bf16_allow_320(int on) { g_allow_320 = on; }
+void gemm_bf16_set_shared_gpu(int on) { g_shared_gpu = on; }
 
 // Number of K slices a split-K launch actually produces (matches launch_variant)
 int gemm_bf16_num_slices(int K, int split_k) {
@@ -879,7 +882,7 @@ void launch_gemm_bf16(const Bf16GemmArgs& g0, const EpiParams& ep, int mode, hip
   const bool tunable = g0.kernel == 0 && autotune_enabled() && (g0.N % 256 == 0 || g0.N > 512) && (double)g0.M * g0.N * g0.K >= 2.0e9 &&
                        !(mode == EPI_BIAS_RESID && ep.out == (void*)ep.resid);
   if (!tunable) { dispatch_gemm_bf16(g0, ep, mode, s); return; }
-  const std::array<int64_t, 6> key = {mode, g0.M, g0.N, g0.K, g0.split_k > 1 ? g0.split_k : 1, ep.scale != nullptr};
+  const std::array<int64_t, 6> key = {mode, g0.M, g0.N, g0.K, g0.split_k > 1 ? g0.split_k : 1, (ep.scale != nullptr) + 2 * g_shared_gpu};
   int best = -1;
   {
     std::lock_guard<std::mutex> lk(g_tune_mu);
@@ -897,6 +900,7 @@ void launch_gemm_bf16(const Bf16GemmArgs& g0, const EpiParams& ep, int mode, hip
     for (int c : cand) {
       const bool is320 = c == 5 || c == 7 || c == 10 || c == 15;
       if (is320 && !g_allow_320) continue;
+      if (g_shared_gpu && c != 2 && c != 5) continue;   // no persistent variants beside collectives (see gemm_bf16_set_shared_gpu)
       g.kernel = c;
       dispatch_gemm_bf16(g, ep, mode, s);   // warm-up (first-use attribute setup, instruction cache)
       (void)hipEventRecord(e0, s);

@@ -29,6 +29,7 @@ void launch_gemm_bf16(const Bf16GemmArgs& g, const EpiParams& ep, int mode, hipS
 int gemm_bf16_tile_m(int kernel, int M, int N);
 int gemm_bf16_tile_n(int kernel, int M, int N);
 int gemm_bf16_num_slices(int K, int split_k);
+void gemm_bf16_set_shared_gpu(int on);   // 1: other kernels (collectives) share the CUs -> no persistent variants
 void gemm_bf16_allow_320(int on);   // the 320-row tile needs operand/output buffers with 320 spare rows
 // weight-gradient form: C[M,N] partials = A[K,M]^T * B[K,N] (A, B row-major with leading dims lda, ldb; K = token rows, multiple of 64)
 void launch_gemm_bf16_tn(const Bf16GemmArgs& g, const EpiParams& ep, hipStream_t s);
