@@ -73,7 +73,19 @@ __global__ __launch_bounds__(256) void headmix_bwd_kernel(const float* __restric
   __shared__ float ws[MAXH * MAXH];
   extern __shared__ float pts[];   // [256][2h]: in[h], dout[h] of each point handled by this block iteration
   for (int i = threadIdx.x; i < h * h; i += blockDim.x) ws[i] = w[i];
-  float dwacc[4] = {0.f, 0.f, 0.f, 0.f};  // thread t owns (h,g) pairs t, t+256, ... (h*h <= 1024)
+  // dW accumulation.  Specialised head counts (multiples of 4): the h x h matrix is cut into 4x4 blocks; a thread owns ONE block
+  // (16 accumulators) and every NB-th... point group: per point it reads 4 inputs + 4 output-gradients from LDS (two 16-B reads)
+  // for 16 FMAs -- the LDS, not HBM, bounds this kernel, and this form moves 2.5x fewer LDS bytes than one float4 per 4 FMAs.
+  // Runtime head counts: thread t owns pairs t, t+256, ... (h*h <= 1024).
+  constexpr int HB = HT / 4;                                   // 4x4 blocks per side
+  constexpr int NBLK = HB * HB > 0 ? HB * HB : 1;              // blocks of dW
+  constexpr int PG = 256 / NBLK;                               // point groups (threads beyond NBLK*PG idle in the dW phase)
+  constexpr bool TILED = HT >= 4 && HT % 4 == 0 && HT <= MAXH;
+  float acc[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) acc[k] = 0.f;
+  const int blk = threadIdx.x % NBLK, pg = threadIdx.x / NBLK;
+  const int hb = (blk / (HB > 0 ? HB : 1)) * 4, gb = (blk % (HB > 0 ? HB : 1)) * 4;
   const int64_t total = (int64_t)b * plane;
   const int64_t span = (int64_t)gridDim.x * blockDim.x;
   const int64_t iters = (total + span - 1) / span;
@@ -97,53 +109,51 @@ __global__ __launch_bounds__(256) void headmix_bwd_kernel(const float* __restric
       for (int k = 0; k < 2 * h; ++k) mine[k] = 0.f;
     }
     __syncthreads();
-    if (HT >= 4 && HT * HT <= 256) {
-      // thread = (pg, hh, g4): 64 threads cover the HT*HT/4 float4 column groups ... each thread owns 4 consecutive g of one hh
-      // and a quarter of the points; one scalar + one 16-B LDS read per 4 FMAs
-      constexpr int GROUPS = (HT * HT) / 4;            // float4 groups of dW
-      constexpr int PG = 256 / (GROUPS > 0 ? GROUPS : 1);   // point groups (>= 4 for HT <= 16)
-      const int grp = threadIdx.x % GROUPS, pg = threadIdx.x / GROUPS;
-      const int hh = (grp * 4) / HT, g0 = (grp * 4) % HT;
-      float4 a4 = make_float4(dwacc[0], dwacc[1], dwacc[2], dwacc[3]);
-      for (int p = pg; p < 256; p += PG) {
-        const float x = pts[p * 2 * HT + hh];
-        const float4 d4 = *(const float4*)(pts + p * 2 * HT + HT + g0);
-        a4.x = fmaf(x, d4.x, a4.x); a4.y = fmaf(x, d4.y, a4.y); a4.z = fmaf(x, d4.z, a4.z); a4.w = fmaf(x, d4.w, a4.w);
+    if (TILED) {
+      if (pg < PG) {
+        for (int p = pg; p < 256; p += PG) {
+          const float4 x4 = *(const float4*)(pts + p * 2 * HT + hb);
+          const float4 d4 = *(const float4*)(pts + p * 2 * HT + HT + gb);
+          const float xs[4] = {x4.x, x4.y, x4.z, x4.w}, ds[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+          for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[a * 4 + c] = fmaf(xs[a], ds[c], acc[a * 4 + c]);
+        }
       }
-      dwacc[0] = a4.x; dwacc[1] = a4.y; dwacc[2] = a4.z; dwacc[3] = a4.w;
     } else {
       for (int k = 0; k < 4; ++k) {
         const int pair = threadIdx.x + 256 * k;
         if (pair < h * h) {
           const int hh = pair / h, gg = pair - hh * h;
-          float a = dwacc[k];
+          float a = acc[k];
           for (int p = 0; p < 256; ++p) a = fmaf(pts[p * 2 * h + hh], pts[p * 2 * h + h + gg], a);
-          dwacc[k] = a;
+          acc[k] = a;
         }
       }
     }
   }
-  if (HT >= 4 && HT * HT <= 256) {
-    // combine the point groups in fixed order: partial[blk][hh][g] = sum_pg
-    constexpr int GROUPS = (HT * HT) / 4;
-    constexpr int PG = 256 / (GROUPS > 0 ? GROUPS : 1);
+  if (TILED) {
+    // combine the point groups in fixed order: partial[blk][hh][g] = sum over pg of this block's accumulators
     __syncthreads();
-    float4* red = (float4*)pts;                       // [PG][GROUPS]
-    red[threadIdx.x] = make_float4(dwacc[0], dwacc[1], dwacc[2], dwacc[3]);
+    float* red = pts;                                 // [PG][NBLK][16]
+    if (pg < PG) {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) red[(pg * NBLK + blk) * 16 + k] = acc[k];
+    }
     __syncthreads();
-    if (threadIdx.x < GROUPS) {
-      float4 t = red[threadIdx.x];
-      for (int k = 1; k < PG; ++k) {
-        const float4 u = red[k * GROUPS + threadIdx.x];
-        t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
-      }
-      *(float4*)(dw_partial + (int64_t)blockIdx.x * HT * HT + threadIdx.x * 4) = t;
+    if (threadIdx.x < NBLK * 16) {
+      const int bq = threadIdx.x / 16, k = threadIdx.x % 16;
+      float t = 0.f;
+      for (int q = 0; q < PG; ++q) t += red[(q * NBLK + bq) * 16 + k];
+      const int hh = (bq / (HB > 0 ? HB : 1)) * 4 + k / 4, gg = (bq % (HB > 0 ? HB : 1)) * 4 + k % 4;
+      dw_partial[(int64_t)blockIdx.x * HT * HT + hh * HT + gg] = t;
     }
     return;
   }
   for (int k = 0; k < 4; ++k) {
     const int pair = threadIdx.x + 256 * k;
-    if (pair < h * h) dw_partial[(int64_t)blockIdx.x * h * h + pair] = dwacc[k];
+    if (pair < h * h) dw_partial[(int64_t)blockIdx.x * h * h + pair] = acc[k];
   }
 }
 
@@ -326,7 +336,7 @@ void launch_headmix_bwd(const float* in, const float* dout, const float* w, floa
                         int nq, int nk, int64_t ld, hipStream_t s) {
   const int64_t plane = (int64_t)nq * ld;
   const int nblk = (int)std::max<int64_t>(1, std::min<int64_t>(HM_BLOCKS, ceil_div((int64_t)b * plane, 256)));
-  const size_t shm = (size_t)256 * 2 * h * sizeof(float);
+  const size_t shm = (size_t)std::max(256 * 2 * h, 4096) * sizeof(float);   // points [256][2h]; later the [PG][blocks][16] combine buffer
 #define CALL(HT) hipLaunchKernelGGL(headmix_bwd_kernel<HT>, dim3(nblk), dim3(256), shm, s, in, dout, w, din, dw_partial_ws, b, h, plane, (int64_t)nk, ld)
   VITX_H_DISPATCH(h, CALL);
 #undef CALL

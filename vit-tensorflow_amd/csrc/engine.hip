@@ -336,6 +336,11 @@ static void bgemm(vitx_engine* e, const void* A, int ta, int64_t sam, int64_t sa
   ep.out = out; ep.ldo = ldo; ep.out_batch_stride = ob; ep.out_head_stride = oh; ep.alpha = alpha;
   ep.M = M; ep.N = N;
   finalize_epi(ep);
+  if (e->bf16 && !e->force_generic_gemm && bgemm_mfma_supported(g, ta, tb, to, mode)) {
+    Prof pr(e, "attn_bgemm_mfma", 2.0 * M * (double)N * K * nb * nh, 0);
+    launch_bgemm_mfma(g, ep, ta, e->stream);
+    return;
+  }
   Prof pr(e, "attn_generic_bgemm", 2.0 * M * (double)N * K * nb * nh, 0);
   launch_gemm_generic(g, ep, mode, ta, tb, to, e->stream);
 }

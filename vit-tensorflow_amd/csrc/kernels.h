@@ -14,6 +14,11 @@ struct GenericGemmArgs {
 };
 void launch_gemm_generic(const GenericGemmArgs& g, const EpiParams& ep, int mode, int ta, int tb, int to, hipStream_t s);
 
+// ---------------------------------------------------------------- attn_bgemm_mfma.hip
+// batched small GEMM (M, N, K <= 128 per (image, head)) on MFMA for the materialised attention path in bf16 mode
+bool bgemm_mfma_supported(const GenericGemmArgs& g, int ta, int tb, int to, int mode);
+void launch_bgemm_mfma(const GenericGemmArgs& g, const EpiParams& ep, int ta, hipStream_t s);
+
 // ---------------------------------------------------------------- gemm_bf16.hip
 // C[M,N] = A[M,K] * B[N,K]^T, bf16 operands (K contiguous), fp32 MFMA accumulation.
 struct Bf16GemmArgs {
