@@ -35,6 +35,8 @@ WORKLOADS = {
     "vit_b16_224": dict(image_size=224, patch_size=16, num_classes=1000, dim=768, depth=12, heads=12, mlp_dim=3072),
     # configs[2] per-GPU shape (ViT-L/16)
     "vit_l16_224": dict(image_size=224, patch_size=16, num_classes=1000, dim=1024, depth=24, heads=16, mlp_dim=4096),
+    # north_star's "256x256x3 synthetic images" wording applied to ViT-B/16: 257 tokens (SURVEY.md section 8 header)
+    "vit_b16_256": dict(image_size=256, patch_size=16, num_classes=1000, dim=768, depth=12, heads=12, mlp_dim=3072),
     # configs[0] (README example; plumbing-sized)
     "vit_readme_256": dict(image_size=256, patch_size=32, num_classes=1000, dim=1024, depth=6, heads=16, mlp_dim=2048),
     # configs[3]: DeepViT with Re-attention; configs[4]: CaiT (LayerScale + talking heads + class attention)

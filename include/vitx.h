@@ -122,6 +122,10 @@ int32_t vitx_backward_dev(vitx_handle h, const float* dlogits_dev, float* dimg_d
  * mpp.py:212).  ViT / DeepViT only. */
 int32_t vitx_transformer_forward(vitx_handle h, const float* tokens_host, int32_t b, int32_t n,
                                  float* out_host);
+/* VJP of the call above (what GradientTape gives the wrappers that train through encoder.transformer: mae.py:69 + README.md:746-749):
+ * d(out) [b,n,dim] -> d(tokens) [b,n,dim] (may be NULL); the gradient arena holds the transformer's parameter gradients, every
+ * other entry is zero.  Requires a preceding vitx_transformer_forward (same handle, no full forward in between). */
+int32_t vitx_transformer_backward(vitx_handle h, const float* dout_host, float* dtokens_host_or_null);
 
 /* ---- stand-alone patch unfold: Rearrange('b (h p1) (w p2) c -> b (h w) (p1 p2 c)') (vit.py:142,
  * deepvit.py:122, cait.py:164).  Pure index arithmetic: bit-exact. */

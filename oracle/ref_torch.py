@@ -144,3 +144,15 @@ def ce_dlogits(logits: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
     p = torch.softmax(logits, dim=-1)
     p[torch.arange(logits.shape[0]), labels] -= 1.0
     return p / logits.shape[0]
+
+
+def transformer_forward_backward(cfg, params, tokens, dout, dtype=torch.float64, q=None):
+    """encoder.transformer(tokens) (mae.py:69 / vit.py:92-104) and its VJP for the cotangent `dout`:
+    returns (out, {name: grad for the transformer's parameters}, dtokens)."""
+    q = q or _ident
+    P = to_torch(params, dtype, requires_grad=True)
+    x = torch.tensor(tokens, dtype=dtype, requires_grad=True)
+    out = _transformer(x, P, cfg, "transformer", cfg["depth"], q)
+    out.backward(torch.tensor(dout, dtype=dtype))
+    grads = {k: (v.grad.detach().numpy() if v.grad is not None else None) for k, v in P.items()}
+    return out.detach().numpy(), grads, x.grad.detach().numpy()

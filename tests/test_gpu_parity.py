@@ -129,10 +129,43 @@ def test_transformer_entry_point():
     assert np.abs(out - ref).max() <= 1e-4
 
 
+BF16_GRAD_RTOL = 6e-2
+
+
+@pytest.mark.parametrize("name,compute,b,n", [("vit_small", "fp32", 2, 5), ("vit_noproj", "fp32", 1, 9), ("deepvit_small", "fp32", 2, 7),
+                                              ("vit_bf16_small", "bf16", 3, 11)])
+def test_transformer_backward_entry_point(name, compute, b, n):
+    """VJP of encoder.transformer(tokens) on an arbitrary token count (mae.py:69 trained through GradientTape): d(tokens) and the
+    transformer's parameter gradients against the autograd twin; parameters outside the transformer get exactly zero."""
+    cfg = oracle_cfg(name)
+    P = spec.init_params(cfg, 1, randomize_all=True)
+    m = make_engine_model(name, compute, b, P)
+    rng = np.random.default_rng(3)
+    tok = rng.standard_normal((b, n, cfg["dim"])).astype(np.float32)
+    dout = rng.standard_normal((b, n, cfg["dim"])).astype(np.float32)
+    out = m.transformer(tok, training=False)
+    grads, dtok = m.transformer.backward(dout)
+    qf = ref_torch.bf16_round if compute == "bf16" else None
+    ref_out, ref_g, ref_dtok = ref_torch.transformer_forward_backward(cfg, P, tok, dout, q=qf)
+    tol = 1e-4 if compute == "fp32" else BF16_GRAD_RTOL
+    assert np.abs(out - ref_out).max() <= tol * max(1.0, np.abs(ref_out).max())
+    assert np.abs(dtok - ref_dtok).max() <= tol * max(1.0, np.abs(ref_dtok).max())
+    for k, g in grads.items():
+        if k.startswith("transformer."):
+            r = ref_g[k]
+            assert np.abs(g - r).max() <= tol * max(1e-6, np.abs(r).max()) + 1e-6, k
+        else:
+            assert not g.any(), k
+    # state machine: a full forward invalidates the saved transformer activations
+    with pytest.raises(N.VitxError):
+        img = rng.standard_normal((b,) + tuple(cfg["image_size"]) + (3,)).astype(np.float32)
+        m(img, training=False)
+        m.transformer.backward(dout)
+
+
 # ------------------------------------------------------------------------------------------------ bf16 throughput mode
 BF16_LOGIT_TOL_VS_EMULATED = 2e-2   # same rounding points, different accumulation order / exp2 / bf16 P in attention
 BF16_LOGIT_TOL_VS_EXACT = 8e-2      # documented loose bound (SURVEY.md 7.2 #1: bf16 operands cost ~1.5e-2 on logits of std ~1)
-BF16_GRAD_RTOL = 6e-2
 
 
 @pytest.mark.parametrize("name,b", [("vit_bf16_small", 3), ("cfg1_readme", 2), ("cfg2_vit_b16", 2), ("deepvit_bf16_small", 2),

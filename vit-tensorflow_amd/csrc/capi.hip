@@ -231,6 +231,22 @@ int32_t vitx_transformer_forward(vitx_handle h, const float* tokens_host, int32_
   CAPI_CATCH
 }
 
+int32_t vitx_transformer_backward(vitx_handle h, const float* dout_host, float* dtokens_host_or_null) {
+  CAPI_TRY
+  if (!h || !dout_host) return fail(VITX_ERR_INVALID, "null argument");
+  if (!h->have_tf) return fail(VITX_ERR_STATE, "transformer_backward requires a preceding transformer_forward");
+  const size_t bytes = (size_t)h->tf_b * h->tf_n * h->cfg.dim * 4;
+  float* tmp = h->tmp_f32;   // [>= mp, max(d, pd)] fp32 scratch; block_backward overwrites it only after d(out) has been consumed
+  CAPI_HIP(hipMemcpyAsync(tmp, dout_host, bytes, hipMemcpyHostToDevice, h->stream));
+  std::string err;
+  int rc = engine_transformer_backward(h, tmp, dtokens_host_or_null ? tmp : nullptr, err);
+  if (rc != VITX_OK) return fail(rc, err);
+  if (dtokens_host_or_null) CAPI_HIP(hipMemcpyAsync(dtokens_host_or_null, tmp, bytes, hipMemcpyDeviceToHost, h->stream));
+  CAPI_HIP(hipStreamSynchronize(h->stream));
+  return VITX_OK;
+  CAPI_CATCH
+}
+
 int32_t vitx_patch_unfold(const float* img_host, int32_t b, int32_t H, int32_t W, int32_t C, int32_t ph, int32_t pw, float* out_host) {
   CAPI_TRY
   if (!img_host || !out_host) return fail(VITX_ERR_INVALID, "null argument");

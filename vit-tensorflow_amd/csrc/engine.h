@@ -106,6 +106,8 @@ struct vitx_engine {
 
   // state of the last forward
   bool have_fwd = false;
+  bool have_tf = false;              // saved activations describe a transformer_forward(tokens) of [tf_b, tf_n, dim]
+  int tf_b = 0, tf_n = 0;
   int last_b = 0, last_np = 0, last_ntok = 0, last_H = 0, last_W = 0, last_training = 0;
   uint64_t last_seed = 0;
   std::vector<std::vector<bool>> layer_kept;   // per stage: blocks that survived CaiT layer dropout in the last forward
@@ -132,6 +134,7 @@ int engine_forward(vitx_engine* e, const float* img_dev, int b, int H, int W, in
                    std::string& err);
 int engine_backward(vitx_engine* e, const float* dlogits_dev, float* dimg_dev, std::string& err);
 int engine_transformer_forward(vitx_engine* e, const float* tokens_dev, int b, int n, float* out_dev, std::string& err);
+int engine_transformer_backward(vitx_engine* e, const float* dout_dev, float* dtokens_dev, std::string& err);
 void engine_refresh_weights(vitx_engine* e);
 int engine_bench_gemm(vitx_engine* e, int M, int N, int K, int kernel, int epilogue, int iters, float* avg_ms, float* max_err,
                       std::string& err);

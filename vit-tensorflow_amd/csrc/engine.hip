@@ -969,6 +969,7 @@ int engine_forward(vitx_engine* e, const float* img_dev, int b, int H, int W, in
   }
   if ((rc = head_forward(e, x_last, b, head_tok, logits_dev, err)) != VITX_OK) return rc;
   e->have_fwd = true;
+  e->have_tf = false;
   e->last_b = b; e->last_np = np; e->last_ntok = ntok; e->last_H = H; e->last_W = W; e->last_training = training; e->last_seed = seed;
   return VITX_OK;
 }
@@ -988,6 +989,28 @@ int engine_transformer_forward(vitx_engine* e, const float* tokens_dev, int b, i
     if ((rc = block_forward(e, s0, 0, l, b, n, 0, nullptr, 0.f, 0, err)) != VITX_OK) return rc;
   HIPCHK(hipMemcpyAsync(out_dev, s0.ba[s0.depth - 1].x_out, bytes, hipMemcpyDeviceToDevice, e->stream));
   e->have_fwd = false;   // saved activations no longer describe a full model forward
+  e->have_tf = true; e->tf_b = b; e->tf_n = n;
+  e->last_training = 0;
+  return VITX_OK;
+}
+
+// VJP of engine_transformer_forward: d(out) [b,n,dim] -> d(tokens) [b,n,dim] and the gradients of the transformer's parameters
+// (every other entry of the gradient arena is zero).  This is what lets the wrappers that call encoder.transformer(tokens)
+// on a subset of the patches (mae.py:69, simmim.py:116) train the encoder.
+int engine_transformer_backward(vitx_engine* e, const float* dout_dev, float* dtokens_dev, std::string& err) {
+  const vitx_config& c = e->cfg;
+  if (!e->have_tf) { err = "transformer_backward requires a preceding transformer_forward"; return VITX_ERR_STATE; }
+  const int b = e->tf_b, n = e->tf_n, d = c.dim, T = e->bf16;
+  Stage& s0 = e->stages[0];
+  const size_t bytes = (size_t)b * n * d * 4;
+  { Prof pr(e, "fill_zero", 0, (double)e->n_arena * 4); launch_fill_zero(e->grads, (int64_t)e->n_arena * 4, e->stream); }
+  launch_fill_zero(e->g, (int64_t)round_up((int64_t)b * n, 256) * d * 4, e->stream);
+  HIPCHK(hipMemcpyAsync(e->g, dout_dev, bytes, hipMemcpyDeviceToDevice, e->stream));
+  if (T) launch_convert(e->g, d, e->g_lp, 1, d, b * n, d, d, e->stream);
+  int rc;
+  for (int l = s0.depth - 1; l >= 0; --l)
+    if ((rc = block_backward(e, s0, 0, l, b, n, 0, 0.f, 0, err)) != VITX_OK) return rc;
+  if (dtokens_dev) HIPCHK(hipMemcpyAsync(dtokens_dev, e->g, bytes, hipMemcpyDeviceToDevice, e->stream));
   return VITX_OK;
 }
 

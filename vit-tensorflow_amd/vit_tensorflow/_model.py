@@ -58,6 +58,11 @@ class _TransformerProxy:
     def __call__(self, tokens, training=True, **_):
         return self._owner._transformer_call(tokens, training)
 
+    def backward(self, dout, want_dtokens: bool = True):
+        """VJP of the last `transformer(tokens)` call: returns ({name: grad}, dtokens|None); gradients of parameters outside the
+        transformer are zero."""
+        return self._owner._transformer_backward(dout, want_dtokens)
+
 
 class VitxModel:
     _variant = N.VARIANT_VIT
@@ -275,6 +280,19 @@ class VitxModel:
         out = np.empty_like(x)
         N.check(N.lib().vitx_transformer_forward(h, x.ctypes.data_as(C.c_void_p), b, n, out.ctypes.data_as(C.c_void_p)))
         return self._like(out, proto)
+
+    def _transformer_backward(self, dout, want_dtokens=True):
+        if self._handle is None:
+            raise N.VitxError(N.ERR_STATE, "transformer.backward requires a preceding transformer(tokens) call")
+        d, proto = self._as_host(dout)
+        assert d.ndim == 3 and d.shape[2] == self.dim, "expected d(out) [b, n, dim]"
+        dtok = np.empty_like(d) if want_dtokens else None
+        N.check(N.lib().vitx_transformer_backward(self._handle, d.ctypes.data_as(C.c_void_p),
+                                                  dtok.ctypes.data_as(C.c_void_p) if want_dtokens else None))
+        g = np.empty(self._n, dtype=np.float32)
+        N.check(N.lib().vitx_get_grads(self._handle, g.ctypes.data_as(C.c_void_p), self._n))
+        grads = {n: g[o:o + int(np.prod(s))].reshape(s) for n, s, o in self._table}
+        return grads, (self._like(dtok, proto) if want_dtokens else None)
 
     def debug_read(self, which: str, layer: int = 0) -> np.ndarray:
         n = C.c_int64()

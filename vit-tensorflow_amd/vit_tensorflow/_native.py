@@ -69,6 +69,7 @@ SYMBOLS: List[Tuple[str, object, list]] = [
     ("vitx_backward", C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p]),
     ("vitx_backward_dev", C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p]),
     ("vitx_transformer_forward", C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    ("vitx_transformer_backward", C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p]),
     ("vitx_patch_unfold", C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     ("vitx_ce_loss_grad_dev", C.c_int32, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]),
     ("vitx_adamw_step", C.c_int32, [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float]),
