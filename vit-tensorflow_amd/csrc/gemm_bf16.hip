@@ -359,11 +359,16 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_pipe_kernel(Bf16Gem
   // ---- issue cursor over this workgroup's K-tile stream (tile, kt); LDS buffer of stream item i = i & 1
   int i_logical = logical0, i_k = 0, issued = 0;
   bool i_more = nk > 0;
-  const bf16_t *Ai, *Bi;
+  // DMA addressing: buffer_load ... lds with one resource per operand (SGPRs), the tile / K offset in the scalar offset and a
+  // loop-invariant 32-bit lane offset -- no per-piece VALU address arithmetic and one address dword per lane instead of two
+  // (the flat global_load_lds form needs a 64-bit address per lane).  Operands are < 4 GiB (checked by the launcher).
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)g.A, 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)g.B, 0, 0x7fffffff, 0x00020000);
+  uint32_t a_soff = 0, b_soff = 0;       // byte offset of the cursor tile's first K-tile inside A / B
   auto i_set_tile = [&]() {
     const int tm = i_logical / tiles_n, tn = i_logical - tm * tiles_n;
-    Ai = g.A + (int64_t)tm * BM * g.lda + (int64_t)kt0 * BK;
-    Bi = g.B + (int64_t)tn * BN * g.ldb + (int64_t)kt0 * BK;
+    a_soff = (uint32_t)(((int64_t)tm * BM * g.lda + (int64_t)kt0 * BK) * 2);
+    b_soff = (uint32_t)(((int64_t)tn * BN * g.ldb + (int64_t)kt0 * BK) * 2);
   };
   i_set_tile();
   constexpr int P = A_INSTR + B_INSTR;   // DMA pieces (1 KiB each) per K-tile per wave
@@ -378,10 +383,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_pipe_kernel(Bf16Gem
   auto issue_piece = [&](char* base, auto p_c) {
     constexpr int p = decltype(p_c)::value;
     if constexpr (p < A_INSTR)
-      __builtin_amdgcn_global_load_lds((gbl_void_t*)((const char*)(Ai + i_k * BK) + offA[p]), (lds_void_t*)(base + (p * NW + wave) * 1024), 16, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void_t*)(base + (p * NW + wave) * 1024), 16, (int)offA[p], (int)(a_soff + i_k * (BK * 2)), 0, 0);
     else
-      __builtin_amdgcn_global_load_lds((gbl_void_t*)((const char*)(Bi + i_k * BK) + offB[p - A_INSTR]),
-                                       (lds_void_t*)(base + A_BYTES + ((p - A_INSTR) * NW + wave) * 1024), 16, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void_t*)(base + A_BYTES + ((p - A_INSTR) * NW + wave) * 1024), 16,
+                                               (int)offB[p - A_INSTR], (int)(b_soff + i_k * (BK * 2)), 0, 0);
   };
   auto i_advance = [&]() {
     ++issued;
@@ -566,6 +571,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_pipe_kernel(Bf16Gem
 template <int BM, int BN, int WM, int WN, int MODE, int PAT = 0>
 void launch_pipe(const Bf16GemmArgs& g, const EpiParams& ep, hipStream_t s) {
   constexpr int SMEM = 2 * (BM + BN) * BK * 2;
+  // buffer-addressed DMA: 31-bit byte offsets inside each operand; larger operands take the flat-addressed persistent kernel
+  if (((int64_t)ceil_div(g.M, BM) * BM * g.lda + g.K) * 2 >= (1LL << 31) || ((int64_t)ceil_div(g.N, BN) * BN * g.ldb + g.K) * 2 >= (1LL << 31)) {
+    launch_variant<BM, BN, WM, WN, MODE, true, 2>(g, ep, s);
+    return;
+  }
   auto kern = gemm_bf16_nt_pipe_kernel<BM, BN, WM, WN, MODE, PAT>;
   static bool attr_set = false;
   if (!attr_set) {
@@ -650,15 +660,18 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_tn_kernel(Bf16GemmArgs
   constexpr int Q = MT * NT;             // MFMAs per k-step per wave
   // pieces of K-tile kt+2 are issued in k-step 3 of tile kt (after the hand-over) and k-steps 0, 1 of tile kt+1 -- see the NT kernel
   constexpr int N3 = (P + 2) / 3, N0 = (P + 1) / 3, N1 = P - N3 - N0;
+  // buffer-addressed DMA (see the NT pipe kernel): resource per operand, K-tile offset in the scalar offset
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)Ag, 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)Bg, 0, 0x7fffffff, 0x00020000);
+  const uint32_t a_kstep = (uint32_t)(BK * g.lda * 2), b_kstep = (uint32_t)(BK * g.ldb * 2);   // bytes per K-tile (64 token rows)
   auto issue_piece = [&](int buf, int kt, auto p_c) {
     constexpr int p = decltype(p_c)::value;
     char* base = smem + buf * STAGE;
     if constexpr (p < INSTR)
-      __builtin_amdgcn_global_load_lds((gbl_void_t*)((const char*)(Ag + (int64_t)kt * BK * g.lda) + offA[p]),
-                                       (lds_void_t*)(base + (p * NW + wave) * 1024), 16, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void_t*)(base + (p * NW + wave) * 1024), 16, (int)offA[p], (int)(kt * a_kstep), 0, 0);
     else
-      __builtin_amdgcn_global_load_lds((gbl_void_t*)((const char*)(Bg + (int64_t)kt * BK * g.ldb) + offB[p - INSTR]),
-                                       (lds_void_t*)(base + OP_BYTES + ((p - INSTR) * NW + wave) * 1024), 16, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void_t*)(base + OP_BYTES + ((p - INSTR) * NW + wave) * 1024), 16, (int)offB[p - INSTR],
+                                               (int)(kt * b_kstep), 0, 0);
   };
   auto stage = [&](int buf, int kt) { static_for<P>([&](auto p_c) { issue_piece(buf, kt, p_c); }); };
 
