@@ -1,15 +1,20 @@
-// bf16 MFMA GEMM for the Dense layers of the ViT path (vit.py:39,42,59,63,143,156 and their VJPs):
-//   C[M,N] = A[M,K] * B[N,K]^T   ("NT": both operands K-contiguous), fp32 accumulation.
-// gfx950 design:
+// bf16 MFMA GEMMs for the Dense layers of the ViT path (vit.py:39,42,59,63,143,156 and their VJPs), fp32 accumulation.
+//   NT family:  C[M,N] = A[M,K] * B[N,K]^T   (both operands K-contiguous)     forward + input gradients, fused epilogues
+//   TN kernel:  C[M,N] = A[K,M]^T * B[K,N]   (both operands token-major)      weight gradients, split-K partials
+// gfx950 design, shared by every kernel in this file:
 //   * v_mfma_f32_32x32x16_bf16, operands swapped (mfma(Bfrag, Afrag)) so that each lane ends up with
 //     4 consecutive output columns of one row -> 8/16-byte epilogue accesses, fused epilogues.
-//   * direct-to-LDS loads (global_load_lds_dwordx4, 1 KiB per wave instruction), double-buffered
-//     BK = 64 stages, one barrier per K-tile; the next tile's DMA is in flight during the MFMAs.
-//   * LDS image is lane-linear (DMA constraint), so the bank-conflict swizzle is applied to the
+//   * direct-to-LDS loads (1 KiB per wave instruction), double-buffered BK = 64 stages, one barrier per K-tile.
+//   * the LDS image is lane-linear (DMA constraint), so the bank-conflict swizzle is applied to the
 //     per-lane SOURCE address and to the ds_read address: chunk ^= (row >> 1) & 7  (16-B chunks of a
 //     128-B row) -- conflict-free for the 16-lane groups ds_read_b128 is serviced in.
-//   * XCD-aware tile order: the grid is walked so that consecutive logical tiles (sharing an A row
-//     panel) run on the same XCD and hit its private L2.
+//   * XCD-aware work order: the workgroup list is walked so that consecutive logical tiles (sharing an A row
+//     panel / a K-slice) run on the same XCD and hit its private L2.
+// Kernels:
+//   gemm_bf16_nt_kernel        one tile per workgroup (SCHED 0) or persistent with cross-tile prefetch (SCHED 2), lockstep K loop
+//   gemm_bf16_nt_pipe_kernel   persistent, register double-buffered fragments, DMA pieces spread over the K-tile, buffer-addressed
+//   gemm_bf16_tn_kernel        transpose-read (ds_read_b64_tr_b16) fragments, same pipelined loop, K-slice-major 1-D grid
+//   launch_gemm_bf16           variant dispatch; kernel = 0 measures the candidates once per (epilogue, M, N, K) and caches the winner
 #include <algorithm>
 #include <array>
 #include <cstdio>
