@@ -1,0 +1,99 @@
+"""Edge cases of the drop-in boundary on the GPU: batch geometry changes on one handle (the row-padding invariant has to be
+re-established), batch 1 / empty batch, inputs the reference rejects, run-to-run determinism of every variant (no atomics in any
+reduction), and the variant-independent results of the GEMM family through a full model."""
+import numpy as np
+import pytest
+
+from oracle import ref_numpy, spec
+from util import make_engine_model, oracle_cfg, rand_images
+from vit_tensorflow import _native as N
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name,compute,tol", [("vit_small", "fp32", 1e-4), ("vit_bf16_small", "bf16", 8e-2), ("cait_small", "fp32", 1e-4)])
+def test_batch_geometry_changes_on_one_handle(name, compute, tol):
+    """b = 4 -> 1 -> 3 on the same handle: each call must match the oracle (stale rows of the larger batch must not leak in)."""
+    cfg = oracle_cfg(name)
+    P = spec.init_params(cfg, 1, randomize_all=True)
+    m = make_engine_model(name, compute, 4, P)
+    for b in (4, 1, 3, 4):
+        img = rand_images(cfg, b, seed=10 + b)
+        got = m(img, training=False)
+        ref = ref_numpy.forward(cfg, P, img)
+        assert got.shape == ref.shape
+        assert np.abs(got - ref).max() <= tol * max(1.0, np.abs(ref).max()), (b, np.abs(got - ref).max())
+        # backward on the changed geometry as well
+        dl = np.random.default_rng(b).standard_normal(ref.shape).astype(np.float32) / b
+        grads, _ = m.backward(dl)
+        assert all(np.isfinite(g).all() for g in grads.values())
+
+
+def test_batch_larger_than_max_batch():
+    """The C ABI rejects a batch beyond the handle's plan (buffers are sized once); the Python mirror, like a Keras model, accepts
+    any batch by rebuilding the plan with the weights kept."""
+    import ctypes as C
+    cfg = oracle_cfg("vit_small")
+    P = spec.init_params(cfg, 1, randomize_all=True)
+    m = make_engine_model("vit_small", "fp32", 2, P)
+    m(rand_images(cfg, 2, seed=0), training=False)
+    img3 = rand_images(cfg, 3, seed=1)
+    out = np.empty((3, cfg["num_classes"]), np.float32)
+    rc = N.lib().vitx_forward(m._handle, img3.ctypes.data_as(C.c_void_p), 3, img3.shape[1], img3.shape[2], 0, C.c_uint64(0),
+                              out.ctypes.data_as(C.c_void_p))
+    assert rc == N.ERR_INVALID
+    got = m(img3, training=False)                     # mirror: grows the plan
+    assert np.abs(got - ref_numpy.forward(cfg, P, img3)).max() <= 1e-4
+
+
+def test_image_not_divisible_by_patch_is_rejected_with_the_reference_message():
+    cfg = oracle_cfg("vit_small")
+    m = make_engine_model("vit_small", "fp32", 2)
+    bad = np.zeros((1, 60, 64, 3), np.float32)   # 60 % 16 != 0   (vit.py:136)
+    with pytest.raises((N.VitxError, AssertionError)) as ei:
+        m(bad, training=False)
+    assert "divisible by the patch size" in str(ei.value)
+
+
+def test_backward_without_forward_is_a_state_error():
+    m = make_engine_model("vit_small", "fp32", 2)
+    m.build((2,))
+    with pytest.raises(N.VitxError) as ei:
+        m.backward(np.zeros((2, 10), np.float32))
+    assert ei.value.code == N.ERR_STATE
+
+
+@pytest.mark.parametrize("name,compute", [("vit_bf16_small", "bf16"), ("deepvit_bf16_small", "bf16"), ("cait_bf16_small", "bf16"),
+                                          ("deepvit_small", "fp32"), ("cait_small", "fp32")])
+def test_forward_backward_is_bit_deterministic(name, compute):
+    """Two identical steps give bit-identical logits and gradients: every reduction (split-K partials, LayerNorm / bias / mixing
+    matrix sums) runs in a fixed order, nothing uses floating-point atomics."""
+    cfg = oracle_cfg(name)
+    P = spec.init_params(cfg, 1, randomize_all=True)
+    m = make_engine_model(name, compute, 3, P)
+    img = rand_images(cfg, 3, seed=5)
+    dl = np.random.default_rng(1).standard_normal((3, cfg["num_classes"])).astype(np.float32)
+    runs = []
+    for _ in range(2):
+        lg = m(img, training=False)
+        grads, dimg = m.backward(dl, want_dimg=True)
+        runs.append((lg, grads, dimg))
+    assert np.array_equal(runs[0][0], runs[1][0])
+    assert np.array_equal(runs[0][2], runs[1][2])
+    for k in runs[0][1]:
+        assert np.array_equal(runs[0][1][k], runs[1][1][k]), k
+
+
+def test_gemm_variant_choice_does_not_change_results(monkeypatch):
+    """Every NT variant accumulates each output element in the same K order: forcing different variants (and the measured
+    choice) through a whole bf16 model gives bit-identical logits."""
+    cfg = oracle_cfg("vit_bf16_small")
+    P = spec.init_params(cfg, 1, randomize_all=True)
+    img = rand_images(cfg, 3, seed=2)
+    outs = []
+    for kern in ("0", "2", "6", "14", "1"):
+        monkeypatch.setenv("VITX_GEMM_KERNEL", kern)
+        m = make_engine_model("vit_bf16_small", "bf16", 3, P)
+        outs.append(m(img, training=False))
+    for o in outs[1:]:
+        assert np.array_equal(outs[0], o)
