@@ -19,6 +19,11 @@ for s in $STAGES; do
         tag=$(echo $pass | tr ' ' '_' | cut -c1-40)
         (cd /tmp && timeout 300 rocprofv3 --pmc $pass --kernel-trace --output-format csv -d $OLDPWD/$OUT/pmc_$tag -o g -- python $OLDPWD/tools/gemm_bench.py ${PMC_SHAPE:-8192 8192 8192 2 3 3} > $OLDPWD/$OUT/pmc_$tag.log 2>&1); tail -2 $OUT/pmc_$tag.log
       done ;;
+    pmc_sq) for pass in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_WAVES" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU" "SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_SCA GRBM_GUI_ACTIVE"; do
+        tag=$(echo $pass | tr ' ' '_' | cut -c1-40)
+        (cd /tmp && timeout 400 rocprofv3 --pmc $pass --kernel-trace --output-format csv -d $OLDPWD/$OUT/sq_$tag -o b -- python $OLDPWD/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-profile > $OLDPWD/$OUT/sq_$tag.json 2> $OLDPWD/$OUT/sq_$tag.err); tail -c 100 $OUT/sq_$tag.json
+      done
+      find $OUT -name "*kernel_trace.csv" -delete 2>/dev/null ;;
     pmc_bench) for pass in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
         tag=$(echo $pass | tr ' ' '_' | cut -c1-40)
         (cd /tmp && timeout 400 rocprofv3 --pmc $pass --kernel-trace --output-format csv -d $OLDPWD/$OUT/pmc_$tag -o b -- python $OLDPWD/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-profile > $OLDPWD/$OUT/pmc_$tag.json 2> $OLDPWD/$OUT/pmc_$tag.err); tail -c 300 $OUT/pmc_$tag.json

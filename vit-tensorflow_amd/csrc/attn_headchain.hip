@@ -1,0 +1,405 @@
+// Fused head-axis chains of the materialised attention variants (one pass over the score tensor instead of three):
+//   CaiT talking heads      (cait.py:121-125):  S0 -> mix(W_pre) -> softmax_j -> A1 -> mix(W_post) -> A2
+//   DeepViT Re-attention    (deepvit.py:79-84): S0 -> softmax_j -> A0 -> mix(W_re) -> M -> LayerNorm over heads -> A2
+// and their VJPs (mixing-matrix, LayerNorm gamma/beta gradients included).  Score tensors are [b, h, nq, ld] fp32, ld = round_up(nk,4).
+// Mapping: ONE WAVE PER (image, query) ROW.  Lanes run over the keys j (two passes cover nk <= 128), every lane keeps the values of
+// all h heads of its key in registers, so
+//   * the h x h mixes are in-lane FMAs against an LDS-broadcast weight matrix,
+//   * the softmax over j is h wave reductions,
+//   * the LayerNorm over heads is in-lane,
+//   * the mixing-matrix gradient dW[h][g] = sum over (row, j) of in[h] * dout[g] is a [16 x points] x [points x 16] product that goes
+//     to the fp32 matrix pipe (v_mfma_f32_16x16x4_f32, exact fp32 products): the per-lane vectors are transposed into MFMA operand
+//     layout through a per-wave LDS scratch.  Per-wave partial sums are written out and reduced in fixed order (deterministic).
+// Arithmetic order inside each op is the same as in the unfused kernels of attn_generic.hip (same expf, same FMA chains), so the
+// fp32 parity mode is unaffected.  Head counts 4/8/12/16 (padded to 16 for the MFMA), nk <= 128; other shapes use the unfused kernels.
+#include "kernels.h"
+
+namespace {
+
+constexpr int HC_WAVES = 4;          // waves (rows in flight) per workgroup
+constexpr int HC_PITCH = 20;         // floats per point in the transpose scratch (16 + pad, 16-B aligned rows)
+constexpr int HC_BLOCKS = 1024;      // upper bound on workgroups (partials: HC_BLOCKS * HC_WAVES rows)
+
+template <int H>
+__device__ __forceinline__ void load_w(float* dst, const float* __restrict__ w) {
+  for (int i = threadIdx.x; i < H * H; i += blockDim.x) dst[i] = w[i];
+}
+
+// dW[hh][g] += sum over this wave's 64 points of xv[hh] * dv[g]   (acc = MFMA D fragment: hh = 4*(lane>>4)+r, g = lane&15)
+template <int H>
+__device__ __forceinline__ void outer_accumulate(f32x4& acc, const float (&xv)[H], const float (&dv)[H], float* xs, float* ys, int lane) {
+  float* xr = xs + lane * HC_PITCH;
+  float* yr = ys + lane * HC_PITCH;
+#pragma unroll
+  for (int k = 0; k < 16; k += 4) {
+    *(float4*)(xr + k) = make_float4(k + 0 < H ? xv[k + 0 < H ? k + 0 : 0] : 0.f, k + 1 < H ? xv[k + 1 < H ? k + 1 : 0] : 0.f,
+                                     k + 2 < H ? xv[k + 2 < H ? k + 2 : 0] : 0.f, k + 3 < H ? xv[k + 3 < H ? k + 3 : 0] : 0.f);
+    *(float4*)(yr + k) = make_float4(k + 0 < H ? dv[k + 0 < H ? k + 0 : 0] : 0.f, k + 1 < H ? dv[k + 1 < H ? k + 1 : 0] : 0.f,
+                                     k + 2 < H ? dv[k + 2 < H ? k + 2 : 0] : 0.f, k + 3 < H ? dv[k + 3 < H ? k + 3 : 0] : 0.f);
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // same-wave LDS traffic is processed in order: writes are visible to the reads below
+  const int m = lane & 15, kp = lane >> 4;
+#pragma unroll
+  for (int s = 0; s < 16; ++s) {
+    const float a = xs[(4 * s + kp) * HC_PITCH + m];
+    const float bq = ys[(4 * s + kp) * HC_PITCH + m];
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bq, acc, 0, 0, 0);
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
+template <int H>
+__device__ __forceinline__ void store_dw(const f32x4& acc, float* dst, int lane) {   // dst [H][H]
+  const int g = lane & 15;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int hh = 4 * (lane >> 4) + r;
+    if (hh < H && g < H) dst[hh * H + g] = acc[r];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ CaiT
+template <int H, int NP>
+__global__ __launch_bounds__(64 * HC_WAVES) void cait_chain_fwd_kernel(const float* __restrict__ s0, const float* __restrict__ wpre,
+                                                                       const float* __restrict__ wpost, float* __restrict__ a1,
+                                                                       float* __restrict__ a2, int64_t rows, int nq, int nk, int64_t ld) {
+  __shared__ float ws[2][H * H];
+  load_w<H>(ws[0], wpre);
+  load_w<H>(ws[1], wpost);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t plane = (int64_t)nq * ld;
+  for (int64_t row = (int64_t)blockIdx.x * HC_WAVES + wave; row < rows; row += (int64_t)gridDim.x * HC_WAVES) {
+    const int64_t bi = row / nq, i = row - bi * nq;
+    const int64_t base = bi * H * plane + i * ld;
+    float y[NP][H];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const int j = p * 64 + lane;
+      const bool valid = j < nk;
+      float x[H];
+#pragma unroll
+      for (int hh = 0; hh < H; ++hh) x[hh] = valid ? s0[base + (int64_t)hh * plane + j] : 0.f;
+#pragma unroll
+      for (int g = 0; g < H; ++g) {
+        float a = 0.f;
+#pragma unroll
+        for (int hh = 0; hh < H; ++hh) a = fmaf(x[hh], ws[0][hh * H + g], a);
+        y[p][g] = a;
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < H; ++g) {   // softmax over the keys (cait.py:124), same operation order as softmax_rows_kernel
+      float m = -INFINITY;
+#pragma unroll
+      for (int p = 0; p < NP; ++p) if (p * 64 + lane < nk) m = fmaxf(m, y[p][g]);
+      m = wave_max(m);
+      float s = 0.f;
+#pragma unroll
+      for (int p = 0; p < NP; ++p) { const float e = (p * 64 + lane < nk) ? expf(y[p][g] - m) : 0.f; y[p][g] = e; s += e; }
+      s = wave_sum(s);
+      const float inv = 1.0f / s;
+#pragma unroll
+      for (int p = 0; p < NP; ++p) y[p][g] *= inv;
+    }
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const int j = p * 64 + lane;
+      if (j >= nk) continue;
+      if (a1 != nullptr) {
+#pragma unroll
+        for (int g = 0; g < H; ++g) a1[base + (int64_t)g * plane + j] = y[p][g];
+      }
+#pragma unroll
+      for (int g = 0; g < H; ++g) {
+        float a = 0.f;
+#pragma unroll
+        for (int hh = 0; hh < H; ++hh) a = fmaf(y[p][hh], ws[1][hh * H + g], a);
+        a2[base + (int64_t)g * plane + j] = a;
+      }
+    }
+  }
+}
+
+// d(A2) in `da` -> d(S0) written back into `da`; partial[wave][0] = dW_post, partial[wave][1] = dW_pre
+template <int H, int NP>
+__global__ __launch_bounds__(64 * HC_WAVES) void cait_chain_bwd_kernel(const float* __restrict__ s0, const float* __restrict__ a1,
+                                                                       float* __restrict__ da, const float* __restrict__ wpre,
+                                                                       const float* __restrict__ wpost, float* __restrict__ partial,
+                                                                       int64_t rows, int nq, int nk, int64_t ld) {
+  __shared__ float ws[2][H * H];
+  __shared__ __attribute__((aligned(16))) float scratch[HC_WAVES][2][64 * HC_PITCH];
+  load_w<H>(ws[0], wpre);
+  load_w<H>(ws[1], wpost);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* xs = scratch[wave][0];
+  float* ys = scratch[wave][1];
+  const int64_t plane = (int64_t)nq * ld;
+  f32x4 acc_post = {0.f, 0.f, 0.f, 0.f}, acc_pre = {0.f, 0.f, 0.f, 0.f};
+  for (int64_t row = (int64_t)blockIdx.x * HC_WAVES + wave; row < rows; row += (int64_t)gridDim.x * HC_WAVES) {
+    const int64_t bi = row / nq, i = row - bi * nq;
+    const int64_t base = bi * H * plane + i * ld;
+    float av[NP][H], d1[NP][H];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const int j = p * 64 + lane;
+      const bool valid = j < nk;
+      float dz[H];
+#pragma unroll
+      for (int g = 0; g < H; ++g) {
+        av[p][g] = valid ? a1[base + (int64_t)g * plane + j] : 0.f;
+        dz[g] = valid ? da[base + (int64_t)g * plane + j] : 0.f;
+      }
+      outer_accumulate<H>(acc_post, av[p], dz, xs, ys, lane);          // dW_post[hh][g] += A1[hh] * dA2[g]
+#pragma unroll
+      for (int hh = 0; hh < H; ++hh) {
+        float a = 0.f;
+#pragma unroll
+        for (int g = 0; g < H; ++g) a = fmaf(dz[g], ws[1][hh * H + g], a);
+        d1[p][hh] = a;                                                 // dA1
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < H; ++g) {                                      // softmax VJP: dS1 = A1 * (dA1 - sum_j A1 dA1)
+      float s = 0.f;
+#pragma unroll
+      for (int p = 0; p < NP; ++p) s += av[p][g] * d1[p][g];
+      s = wave_sum(s);
+#pragma unroll
+      for (int p = 0; p < NP; ++p) d1[p][g] = av[p][g] * (d1[p][g] - s);
+    }
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const int j = p * 64 + lane;
+      const bool valid = j < nk;
+      float x[H];
+#pragma unroll
+      for (int hh = 0; hh < H; ++hh) x[hh] = valid ? s0[base + (int64_t)hh * plane + j] : 0.f;
+      outer_accumulate<H>(acc_pre, x, d1[p], xs, ys, lane);            // dW_pre[hh][g] += S0[hh] * dS1[g]
+      if (valid) {
+#pragma unroll
+        for (int hh = 0; hh < H; ++hh) {
+          float a = 0.f;
+#pragma unroll
+          for (int g = 0; g < H; ++g) a = fmaf(d1[p][g], ws[0][hh * H + g], a);
+          da[base + (int64_t)hh * plane + j] = a;                      // dS0
+        }
+      }
+    }
+  }
+  float* pw = partial + ((int64_t)blockIdx.x * HC_WAVES + wave) * 2 * H * H;
+  store_dw<H>(acc_post, pw, lane);
+  store_dw<H>(acc_pre, pw + H * H, lane);
+}
+
+// ------------------------------------------------------------------------------------------------ DeepViT
+template <int H, int NP>
+__global__ __launch_bounds__(64 * HC_WAVES) void deepvit_chain_fwd_kernel(float* __restrict__ s0 /* in: scores; out: softmax (if keep) */,
+                                                                          const float* __restrict__ wre, const float* __restrict__ gamma,
+                                                                          const float* __restrict__ beta, float* __restrict__ mixed /* nullable */,
+                                                                          float* __restrict__ a2, int keep, int64_t rows, int nq, int nk,
+                                                                          int64_t ld, float eps) {
+  __shared__ float ws[H * H];
+  load_w<H>(ws, wre);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t plane = (int64_t)nq * ld;
+  float gm[H], bt[H];
+#pragma unroll
+  for (int g = 0; g < H; ++g) { gm[g] = gamma[g]; bt[g] = beta[g]; }
+  for (int64_t row = (int64_t)blockIdx.x * HC_WAVES + wave; row < rows; row += (int64_t)gridDim.x * HC_WAVES) {
+    const int64_t bi = row / nq, i = row - bi * nq;
+    const int64_t base = bi * H * plane + i * ld;
+    float y[NP][H];
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+#pragma unroll
+      for (int hh = 0; hh < H; ++hh) y[p][hh] = (p * 64 + lane < nk) ? s0[base + (int64_t)hh * plane + p * 64 + lane] : 0.f;
+#pragma unroll
+    for (int g = 0; g < H; ++g) {   // softmax over the keys (deepvit.py:80)
+      float m = -INFINITY;
+#pragma unroll
+      for (int p = 0; p < NP; ++p) if (p * 64 + lane < nk) m = fmaxf(m, y[p][g]);
+      m = wave_max(m);
+      float s = 0.f;
+#pragma unroll
+      for (int p = 0; p < NP; ++p) { const float e = (p * 64 + lane < nk) ? expf(y[p][g] - m) : 0.f; y[p][g] = e; s += e; }
+      s = wave_sum(s);
+      const float inv = 1.0f / s;
+#pragma unroll
+      for (int p = 0; p < NP; ++p) y[p][g] *= inv;
+    }
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const int j = p * 64 + lane;
+      if (j >= nk) continue;
+      float v[H];
+      float mu = 0.f;
+#pragma unroll
+      for (int g = 0; g < H; ++g) {
+        if (keep) s0[base + (int64_t)g * plane + j] = y[p][g];
+        float a = 0.f;
+#pragma unroll
+        for (int hh = 0; hh < H; ++hh) a = fmaf(y[p][hh], ws[hh * H + g], a);   // re-attention mix (deepvit.py:83)
+        v[g] = a;
+      }
+#pragma unroll
+      for (int g = 0; g < H; ++g) { if (mixed != nullptr) mixed[base + (int64_t)g * plane + j] = v[g]; mu += v[g]; }
+      mu /= (float)H;
+      float var = 0.f;
+#pragma unroll
+      for (int g = 0; g < H; ++g) var += (v[g] - mu) * (v[g] - mu);
+      const float rs = rsqrtf(var / (float)H + eps);
+#pragma unroll
+      for (int g = 0; g < H; ++g) a2[base + (int64_t)g * plane + j] = (v[g] - mu) * rs * gm[g] + bt[g];   // LayerNorm over heads (deepvit.py:84)
+    }
+  }
+}
+
+// d(A2) in `da` -> d(S0) written back; partial[wave] = [dW_re (H*H) | dgamma (H) | dbeta (H)]
+template <int H, int NP>
+__global__ __launch_bounds__(64 * HC_WAVES) void deepvit_chain_bwd_kernel(const float* __restrict__ a0, const float* __restrict__ mixed,
+                                                                          float* __restrict__ da, const float* __restrict__ wre,
+                                                                          const float* __restrict__ gamma, float* __restrict__ partial,
+                                                                          int64_t rows, int nq, int nk, int64_t ld, float eps) {
+  __shared__ float ws[H * H];
+  __shared__ __attribute__((aligned(16))) float scratch[HC_WAVES][2][64 * HC_PITCH];
+  load_w<H>(ws, wre);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* xs = scratch[wave][0];
+  float* ys = scratch[wave][1];
+  const int64_t plane = (int64_t)nq * ld;
+  float gm[H], ag[H], ab[H];
+#pragma unroll
+  for (int g = 0; g < H; ++g) { gm[g] = gamma[g]; ag[g] = 0.f; ab[g] = 0.f; }
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int64_t row = (int64_t)blockIdx.x * HC_WAVES + wave; row < rows; row += (int64_t)gridDim.x * HC_WAVES) {
+    const int64_t bi = row / nq, i = row - bi * nq;
+    const int64_t base = bi * H * plane + i * ld;
+    float av[NP][H], d0[NP][H];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const int j = p * 64 + lane;
+      const bool valid = j < nk;
+      float xh[H], dm[H];
+      float mu = 0.f;
+#pragma unroll
+      for (int g = 0; g < H; ++g) {
+        av[p][g] = valid ? a0[base + (int64_t)g * plane + j] : 0.f;
+        xh[g] = valid ? mixed[base + (int64_t)g * plane + j] : 0.f;
+        mu += xh[g];
+      }
+      mu /= (float)H;
+      float var = 0.f;
+#pragma unroll
+      for (int g = 0; g < H; ++g) { xh[g] -= mu; var += xh[g] * xh[g]; }
+      const float rs = rsqrtf(var / (float)H + eps);
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int g = 0; g < H; ++g) {                                    // LayerNorm-over-heads VJP (same order as headnorm_bwd_kernel)
+        xh[g] *= rs;
+        const float d = valid ? da[base + (int64_t)g * plane + j] : 0.f;
+        ab[g] += d;
+        ag[g] += d * xh[g];
+        dm[g] = d * gm[g];
+        s1 += dm[g];
+        s2 += dm[g] * xh[g];
+      }
+      s1 /= (float)H;
+      s2 /= (float)H;
+#pragma unroll
+      for (int g = 0; g < H; ++g) dm[g] = valid ? rs * (dm[g] - s1 - xh[g] * s2) : 0.f;
+      outer_accumulate<H>(acc, av[p], dm, xs, ys, lane);               // dW_re[hh][g] += A0[hh] * dM[g]
+#pragma unroll
+      for (int hh = 0; hh < H; ++hh) {
+        float a = 0.f;
+#pragma unroll
+        for (int g = 0; g < H; ++g) a = fmaf(dm[g], ws[hh * H + g], a);
+        d0[p][hh] = a;                                                 // dA0
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < H; ++g) {                                      // softmax VJP
+      float s = 0.f;
+#pragma unroll
+      for (int p = 0; p < NP; ++p) s += av[p][g] * d0[p][g];
+      s = wave_sum(s);
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        const int j = p * 64 + lane;
+        if (j < nk) da[base + (int64_t)g * plane + j] = av[p][g] * (d0[p][g] - s);
+      }
+    }
+  }
+  float* pw = partial + ((int64_t)blockIdx.x * HC_WAVES + wave) * (H * H + 2 * H);
+  store_dw<H>(acc, pw, lane);
+#pragma unroll
+  for (int g = 0; g < H; ++g) {
+    const float sg = wave_sum(ag[g]), sb = wave_sum(ab[g]);
+    if (lane == 0) { pw[H * H + g] = sg; pw[H * H + H + g] = sb; }
+  }
+}
+
+int chain_blocks(int64_t rows) { return (int)std::max<int64_t>(1, std::min<int64_t>(HC_BLOCKS, ceil_div(rows, HC_WAVES))); }
+
+}  // namespace
+
+// nk <= 64 (one key per lane).  The two-pass instantiations (65..128 keys) exist and are correct, but they hold two passes of every
+// per-head vector in registers, spill, and measured SLOWER than the unfused kernels on DeepViT's 65 keys (16.6 vs 7.8 ms per step).
+bool headchain_supported(int h, int nk) { return (h == 4 || h == 8 || h == 12 || h == 16) && nk >= 1 && nk <= 64; }
+int64_t headchain_ws_elems(int h) { return (int64_t)(HC_BLOCKS * HC_WAVES + 40) * (2 * h * h + 2 * h); }
+
+#define HC_DISPATCH(h, np, CALL)                                   \
+  do {                                                             \
+    if (np == 1) {                                                 \
+      if (h == 16) { CALL(16, 1); } else if (h == 12) { CALL(12, 1); } else if (h == 8) { CALL(8, 1); } else { CALL(4, 1); }   \
+    } else {                                                       \
+      if (h == 16) { CALL(16, 2); } else if (h == 12) { CALL(12, 2); } else if (h == 8) { CALL(8, 2); } else { CALL(4, 2); }   \
+    }                                                              \
+  } while (0)
+
+void launch_cait_chain_fwd(const float* s0, const float* wpre, const float* wpost, float* a1_or_null, float* a2, int b, int h, int nq, int nk,
+                           int64_t ld, hipStream_t s) {
+  const int64_t rows = (int64_t)b * nq;
+  const int np = nk <= 64 ? 1 : 2;
+#define CALL(H, NP) hipLaunchKernelGGL((cait_chain_fwd_kernel<H, NP>), dim3(chain_blocks(rows)), dim3(64 * HC_WAVES), 0, s, s0, wpre, wpost, a1_or_null, a2, rows, nq, nk, ld)
+  HC_DISPATCH(h, np, CALL);
+#undef CALL
+}
+void launch_cait_chain_bwd(const float* s0, const float* a1, float* da_inout, const float* wpre, const float* wpost, float* ws, float* dwpre,
+                           float* dwpost, int b, int h, int nq, int nk, int64_t ld, hipStream_t s) {
+  const int64_t rows = (int64_t)b * nq;
+  const int np = nk <= 64 ? 1 : 2;
+  const int nblk = chain_blocks(rows);
+#define CALL(H, NP) hipLaunchKernelGGL((cait_chain_bwd_kernel<H, NP>), dim3(nblk), dim3(64 * HC_WAVES), 0, s, s0, a1, da_inout, wpre, wpost, ws, rows, nq, nk, ld)
+  HC_DISPATCH(h, np, CALL);
+#undef CALL
+  const int nparts = nblk * HC_WAVES;
+  const int64_t stride = 2 * (int64_t)h * h;
+  float* ws2 = ws + (int64_t)nparts * stride;
+  launch_reduce_partials3(ws, nparts, stride, (int64_t)h * h, 2, dwpost, dwpre, nullptr, ws2, 1.0f, s);
+}
+void launch_deepvit_chain_fwd(float* s0_inout, const float* wre, const float* gamma, const float* beta, float* mixed_or_null, float* a2, int keep,
+                              int b, int h, int nq, int nk, int64_t ld, float eps, hipStream_t s) {
+  const int64_t rows = (int64_t)b * nq;
+  const int np = nk <= 64 ? 1 : 2;
+#define CALL(H, NP) hipLaunchKernelGGL((deepvit_chain_fwd_kernel<H, NP>), dim3(chain_blocks(rows)), dim3(64 * HC_WAVES), 0, s, s0_inout, wre, gamma, beta, mixed_or_null, a2, keep, rows, nq, nk, ld, eps)
+  HC_DISPATCH(h, np, CALL);
+#undef CALL
+}
+void launch_deepvit_chain_bwd(const float* a0, const float* mixed, float* da_inout, const float* wre, const float* gamma, float* ws, float* dwre,
+                              float* dgamma, float* dbeta, int b, int h, int nq, int nk, int64_t ld, float eps, hipStream_t s) {
+  const int64_t rows = (int64_t)b * nq;
+  const int np = nk <= 64 ? 1 : 2;
+  const int nblk = chain_blocks(rows);
+#define CALL(H, NP) hipLaunchKernelGGL((deepvit_chain_bwd_kernel<H, NP>), dim3(nblk), dim3(64 * HC_WAVES), 0, s, a0, mixed, da_inout, wre, gamma, ws, rows, nq, nk, ld, eps)
+  HC_DISPATCH(h, np, CALL);
+#undef CALL
+  const int nparts = nblk * HC_WAVES;
+  const int64_t stride = (int64_t)h * h + 2 * h;
+  float* ws2 = ws + (int64_t)nparts * stride;
+  launch_reduce_partials3(ws, nparts, stride, (int64_t)h * h, 1, dwre, nullptr, nullptr, ws2, 1.0f, s);
+  launch_reduce_partials3(ws + (int64_t)h * h, nparts, stride, h, 2, dgamma, dbeta, nullptr, ws2, 1.0f, s);
+}

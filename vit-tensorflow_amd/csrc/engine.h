@@ -116,6 +116,7 @@ struct vitx_engine {
   // env switches
   bool force_generic_gemm = false, force_generic_attn = false, wgrad_via_transpose = true;
   int gemm_kernel = 0;
+  bool unfused_headops = false;      // VITX_UNFUSED_HEADOPS=1: separate mix / softmax / LayerNorm-over-heads kernels (A/B reference)
   int gemm_stagger = 0;
 
   // profiling

@@ -346,7 +346,7 @@ static void bgemm(vitx_engine* e, const void* A, int ta, int64_t sam, int64_t sa
 }
 
 // forward chain into the score workspaces; returns the index of the workspace holding the matrix that multiplies V
-static int attn_generic_scores(vitx_engine* e, const BlockParams& bp, const AttnView& a, int b) {
+static int attn_generic_scores(vitx_engine* e, const BlockParams& bp, const AttnView& a, int b, bool for_bwd) {
   const int h = e->cfg.heads, dh = e->cfg.dim_head;
   const int T = e->bf16;
   const int64_t ld = round_up(a.nk, 4);
@@ -355,6 +355,19 @@ static int attn_generic_scores(vitx_engine* e, const BlockParams& bp, const Attn
   // dots = q k^T * scale   (vit.py:77, deepvit.py:79, cait.py:121)
   bgemm(e, a.q, T, a.ldq, 1, a.qb, dh, a.k, T, 1, a.ldk, a.kb, dh, a.nq, a.nk, dh, b, h, EPI_STORE_F32, 0, e->sc[0], ld, bs, hs, scale);
   const int64_t rows = (int64_t)b * h * a.nq;
+  const bool chain = !e->unfused_headops && headchain_supported(h, a.nk);
+  if (chain && e->cfg.variant == VITX_VARIANT_CAIT) {
+    Prof pr(e, "attn_headchain", 0, 0);     // mix -> softmax -> mix in one pass (cait.py:123-125); A1 is only kept for the backward
+    launch_cait_chain_fwd(e->sc[0], e->params + bp.mix_pre, e->params + bp.mix_post, for_bwd ? e->sc[1] : nullptr, e->sc[2], b, h, a.nq, a.nk,
+                          ld, e->stream);
+    return 2;
+  }
+  if (chain && e->cfg.variant == VITX_VARIANT_DEEPVIT) {
+    Prof pr(e, "attn_headchain", 0, 0);     // softmax -> re-attention mix -> LayerNorm over heads (deepvit.py:80-84)
+    launch_deepvit_chain_fwd(e->sc[0], e->params + bp.re_w, e->params + bp.re_g, e->params + bp.re_b, for_bwd ? e->sc[1] : nullptr, e->sc[2],
+                             for_bwd ? 1 : 0, b, h, a.nq, a.nk, ld, e->cfg.ln_eps, e->stream);
+    return 2;
+  }
   if (e->cfg.variant == VITX_VARIANT_CAIT) {
     Prof pr(e, "attn_generic_headops", 0, 0);
     launch_headmix_fwd(e->sc[0], e->params + bp.mix_pre, e->sc[1], b, h, a.nq, a.nk, ld, e->stream);    // cait.py:123
@@ -380,7 +393,7 @@ static void attn_generic_fwd(vitx_engine* e, const BlockParams& bp, const AttnVi
   const int h = e->cfg.heads, dh = e->cfg.dim_head, T = e->bf16;
   const int64_t ld = round_up(a.nk, 4);
   const int64_t hs = (int64_t)a.nq * ld, bs = (int64_t)h * hs;
-  const int pi = attn_generic_scores(e, bp, a, b);
+  const int pi = attn_generic_scores(e, bp, a, b, false);
   // out = attn v   (vit.py:81, deepvit.py:87, cait.py:127)
   bgemm(e, e->sc[pi], 0, ld, 1, bs, hs, a.v, T, a.ldv, 1, a.vb, dh, a.nq, dh, a.nk, b, h, EPI_STORE, T, a.o, a.ldo, a.ob, dh, 1.0f);
 }
@@ -397,12 +410,21 @@ static void attn_generic_bwd(vitx_engine* e, const BlockParams& bp, const AttnVi
   const int64_t hs = (int64_t)a.nq * ld, bs = (int64_t)h * hs;
   const float scale = 1.0f / std::sqrt((float)dh);
   const int64_t rows = (int64_t)b * h * a.nq;
-  const int pi = attn_generic_scores(e, bp, a, b);   // recompute the forward chain (P is not stored)
+  const int pi = attn_generic_scores(e, bp, a, b, true);   // recompute the forward chain (P is not stored)
   float* dA = e->sc[3];
   // d(attn) = dO v^T ; dV = attn^T dO
   bgemm(e, gr.d_o, T, gr.ldo, 1, gr.ob, dh, a.v, T, 1, a.ldv, a.vb, dh, a.nq, a.nk, dh, b, h, EPI_STORE_F32, 0, dA, ld, bs, hs, 1.0f);
   bgemm(e, e->sc[pi], 0, 1, ld, bs, hs, gr.d_o, T, gr.ldo, 1, gr.ob, dh, a.nk, dh, a.nq, b, h, EPI_STORE, T, gr.dv, gr.lddv, gr.dvb, dh, 1.0f);
-  {
+  const bool chain = !e->unfused_headops && headchain_supported(h, a.nk);
+  if (chain && e->cfg.variant == VITX_VARIANT_CAIT) {
+    Prof pr(e, "attn_headchain", 0, 0);
+    launch_cait_chain_bwd(e->sc[0], e->sc[1], dA, e->params + bp.mix_pre, e->params + bp.mix_post, e->red_ws, e->grads + bp.mix_pre,
+                          e->grads + bp.mix_post, b, h, a.nq, a.nk, ld, e->stream);
+  } else if (chain && e->cfg.variant == VITX_VARIANT_DEEPVIT) {
+    Prof pr(e, "attn_headchain", 0, 0);
+    launch_deepvit_chain_bwd(e->sc[0], e->sc[1], dA, e->params + bp.re_w, e->params + bp.re_g, e->red_ws, e->grads + bp.re_w, e->grads + bp.re_g,
+                             e->grads + bp.re_b, b, h, a.nq, a.nk, ld, e->cfg.ln_eps, e->stream);
+  } else {
     Prof pr(e, "attn_generic_headops", 0, 0);
     if (e->cfg.variant == VITX_VARIANT_CAIT) {
       launch_headmix_bwd(e->sc[1], dA, e->params + bp.mix_post, dA, e->red_ws, e->grads + bp.mix_post, b, h, a.nq, a.nk, ld, e->stream);
@@ -691,6 +713,7 @@ int engine_create(const vitx_config& cfg, vitx_engine** out, std::string& err) {
   e->force_generic_gemm = env_flag("VITX_GENERIC_GEMM");
   e->force_generic_attn = env_flag("VITX_GENERIC_ATTN");
   if (const char* k = getenv("VITX_GEMM_KERNEL")) e->gemm_kernel = atoi(k);
+  if (const char* k = getenv("VITX_UNFUSED_HEADOPS")) e->unfused_headops = atoi(k) != 0;
   e->wgrad_via_transpose = env_flag("VITX_WGRAD_TRANSPOSE");
   if (const char* k = getenv("VITX_GEMM_STAGGER")) e->gemm_stagger = atoi(k);
 
@@ -827,7 +850,8 @@ int engine_create(const vitx_config& cfg, vitx_engine** out, std::string& err) {
   }
   // (+ per-M-tile column sums of the fc2-dgrad epilogue: one row per 256 token rows, 32 second-level rows)
   e->red_elems = std::max<int64_t>({layernorm_bwd_ws_elems(d), colsum_ws_elems((int)maxfeat), headmix_ws_elems((int)B, c.heads, 1, 1),
-                                    (int64_t)256 * 2 * 32, (int64_t)(512 + 32) * d, (ceil_div(std::max<int64_t>(e->mp, e->mpp), 128) + 40) * (int64_t)m});
+                                    (int64_t)256 * 2 * 32, (int64_t)(512 + 32) * d, (ceil_div(std::max<int64_t>(e->mp, e->mpp), 128) + 40) * (int64_t)m,
+                                    headchain_ws_elems(c.heads)});
   DALLOC(e->red_ws, (size_t)e->red_elems * 4, false);
   HIPCHK(hipStreamSynchronize(e->stream));
   *out = e;

@@ -14,6 +14,19 @@ struct GenericGemmArgs {
 };
 void launch_gemm_generic(const GenericGemmArgs& g, const EpiParams& ep, int mode, int ta, int tb, int to, hipStream_t s);
 
+// ---------------------------------------------------------------- attn_headchain.hip
+// fused head-axis chains (one wave per (image, query) row): CaiT talking heads, DeepViT re-attention, and their VJPs
+bool headchain_supported(int h, int nk);
+int64_t headchain_ws_elems(int h);
+void launch_cait_chain_fwd(const float* s0, const float* wpre, const float* wpost, float* a1_or_null, float* a2, int b, int h, int nq, int nk,
+                           int64_t ld, hipStream_t s);
+void launch_cait_chain_bwd(const float* s0, const float* a1, float* da_inout, const float* wpre, const float* wpost, float* ws, float* dwpre,
+                           float* dwpost, int b, int h, int nq, int nk, int64_t ld, hipStream_t s);
+void launch_deepvit_chain_fwd(float* s0_inout, const float* wre, const float* gamma, const float* beta, float* mixed_or_null, float* a2, int keep,
+                              int b, int h, int nq, int nk, int64_t ld, float eps, hipStream_t s);
+void launch_deepvit_chain_bwd(const float* a0, const float* mixed, float* da_inout, const float* wre, const float* gamma, float* ws, float* dwre,
+                              float* dgamma, float* dbeta, int b, int h, int nq, int nk, int64_t ld, float eps, hipStream_t s);
+
 // ---------------------------------------------------------------- attn_bgemm_mfma.hip
 // batched small GEMM (M, N, K <= 128 per (image, head)) on MFMA for the materialised attention path in bf16 mode
 bool bgemm_mfma_supported(const GenericGemmArgs& g, int ta, int tb, int to, int mode);
