@@ -330,7 +330,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_pipe_kernel(Bf16Gem
   constexpr int A_INSTR = BM / 8 / NW, B_INSTR = BN / 8 / NW;
   constexpr int SROW = BN + 4;                     // epilogue staging row (floats); +16 B keeps ds_write_b128 groups conflict-free
   static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile rows must split evenly over the waves");
-  static_assert(BN == 256 && 32 * SROW * 4 <= STAGE, "epilogue staging (32 rows) must fit one pipeline buffer");
+  static_assert(BN == 256 && 2 * 32 * BN * 4 <= STAGE, "two 32-row epilogue staging areas must fit one pipeline buffer");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int nwg = gridDim.x, bid = blockIdx.x;
@@ -474,7 +474,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_pipe_kernel(Bf16Gem
           handover();
           mfma_range(ic<CUR>{}, ic<0>{}, ic<2>{});
           __builtin_amdgcn_sched_barrier(0);
-          load_frags(fa[0], fb[0], smem + ((it + 1) & 1) * STAGE, 0);    // (stale LDS at the very end of the stream: unused)
+          // first fragments of the next K-tile; at the last K-tile of an output tile they are loaded AFTER the epilogue instead
+          // (kept live across it they cost the 320-row variants their last free registers)
+          if (kt + 1 < nk) load_frags(fa[0], fb[0], smem + ((it + 1) & 1) * STAGE, 0);
           // K-tile it+2 goes into the buffer just released; at the last K-tile of an output tile the refill is deferred until
           // after the epilogue, which stages through that buffer.
           pending = i_more && kt + 1 < nk && !(xp & 2);
@@ -512,26 +514,34 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_pipe_kernel(Bf16Gem
       constexpr int RPW = 32 / NW;   // rows per wave per round (one 1-KiB row per wave instruction)
       float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);   // EPI_GELU_BWD: column sums of what this lane stores (fused bias gradient)
       auto cs_add = [&](float4 r) { if (MODE == EPI_GELU_BWD) { cs.x += r.x; cs.y += r.y; cs.z += r.z; cs.w += r.w; } };
+      // Two 32-row staging areas ([32][BN] fp32 = 32 KiB each, 16-B chunks swizzled chunk ^= row & 7 instead of padded rows) used
+      // alternately: ONE barrier per round -- the accumulator rows of round R+1 are written while round R is still being read and
+      // stored (the round trip  barrier - LDS write - barrier - LDS read - global store  was the epilogue's critical path, not HBM).
+      // Reuse of an area two rounds later is ordered by the barrier in between (every wave waits for its own reads first).
 #pragma clang loop unroll(full)
       for (int R = 0; R < BM / 32; ++R) {
         const int wm_r = (R * 32) / WTM, i0 = ((R * 32) % WTM) / 32;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
+        float* sr = st + (R & 1) * (32 * BN);
         if (wm == wm_r) {
+          const int m = lane & 31;
 #pragma unroll
           for (int j = 0; j < NT; ++j)
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-              *(float4*)(st + (lane & 31) * SROW + wn * WTN + j * 32 + 8 * q + 4 * khalf) =
+            for (int q = 0; q < 4; ++q) {
+              const int chunk = (wn * WTN + j * 32 + 8 * q + 4 * khalf) >> 2;
+              *(float4*)(sr + m * BN + ((chunk ^ (m & 7)) << 2)) =
                   make_float4(acc[i0][j][4 * q], acc[i0][j][4 * q + 1], acc[i0][j][4 * q + 2], acc[i0][j][4 * q + 3]);
+            }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         float4 v[RPW];
 #pragma unroll
-        for (int k = 0; k < RPW; ++k) v[k] = *(const float4*)(st + (k * NW + wave) * SROW + lane * 4);
+        for (int k = 0; k < RPW; ++k) {
+          const int r = k * NW + wave;
+          v[k] = *(const float4*)(sr + r * BN + ((lane ^ (r & 7)) << 2));
+        }
         const int grow0 = tile_m * BM + R * 32;
         if (interior) {
           float4 x[RPW];
@@ -569,6 +579,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_pipe_kernel(Bf16Gem
     if (has_next) {
       handover();                                   // staging reads done everywhere
       issue();                                      // deferred refill of the staging buffer: stream item it+1
+      load_frags(fa[0], fb[0], smem + (it & 1) * STAGE, 0);
     }
   }
 }
