@@ -52,21 +52,28 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
 }
 
 // Fast variant for the bf16 throughput mode (Abramowitz-Stegun 7.1.26, |erf error| <= 1.5e-7 -- far below bf16 resolution):
-// ~15 VALU ops instead of the ~60 of the branchy library erff, which made the GELU epilogues VALU-bound.
-// Returns Phi(x) = 0.5*(1+erf(x/sqrt2)) and e = exp(-x^2/2).
+// the branchy library erff (~60 VALU ops) made the GELU epilogues VALU-bound; this form is 13 ops, two of them transcendental.
+//   h(x) = 0.5 * erfc(|x| / sqrt2) = t * P(t) * exp(-x^2/2),  t = 1 / (1 + p |x| / sqrt2)      (0.5 folded into P's coefficients)
+//   Phi(x) = x >= 0 ? 1 - h : h        gelu(x) = x Phi(x) = max(x, 0) - |x| h        gelu'(x) = Phi(x) + x exp(-x^2/2) / sqrt(2 pi)
+__device__ __forceinline__ float gelu_half_erfc(float x, float& e) {
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752440f, fabsf(x), 1.0f));
+  e = __builtin_amdgcn_exp2f(x * x * (-0.5f * 1.44269504088896340736f));
+  float p = fmaf(0.5f * 1.061405429f, t, 0.5f * -1.453152027f);
+  p = fmaf(p, t, 0.5f * 1.421413741f);
+  p = fmaf(p, t, 0.5f * -0.284496736f);
+  p = fmaf(p, t, 0.5f * 0.254829592f);
+  return p * t * e;
+}
 __device__ __forceinline__ float gelu_phi_fast(float x, float& e) {
-  const float ax = fabsf(x);
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752440f, ax, 1.0f));
-  e = __expf(-0.5f * x * x);
-  float p = fmaf(1.061405429f, t, -1.453152027f);
-  p = fmaf(p, t, 1.421413741f);
-  p = fmaf(p, t, -0.284496736f);
-  p = fmaf(p, t, 0.254829592f);
-  const float half_erfc = 0.5f * p * t * e;          // 0.5*(1 - erf(|x|/sqrt2))
-  return x >= 0.f ? 1.0f - half_erfc : half_erfc;
+  const float h = gelu_half_erfc(x, e);
+  return x >= 0.f ? 1.0f - h : h;
 }
 template <typename T> __device__ __forceinline__ float gelu_t(float x) { return gelu_f(x); }
-template <> __device__ __forceinline__ float gelu_t<bf16_t>(float x) { float e; return x * gelu_phi_fast(x, e); }
+template <> __device__ __forceinline__ float gelu_t<bf16_t>(float x) {
+  float e;
+  const float h = gelu_half_erfc(x, e);
+  return fmaf(-fabsf(x), h, fmaxf(x, 0.f));
+}
 template <typename T> __device__ __forceinline__ float gelu_grad_t(float x) { return gelu_grad_f(x); }
 template <> __device__ __forceinline__ float gelu_grad_t<bf16_t>(float x) {
   float e;
