@@ -4,7 +4,7 @@ reduction), and the variant-independent results of the GEMM family through a ful
 import numpy as np
 import pytest
 
-from oracle import ref_numpy, spec
+from oracle import ref_numpy, ref_torch, spec
 from util import make_engine_model, oracle_cfg, rand_images
 from vit_tensorflow import _native as N
 
@@ -97,3 +97,22 @@ def test_gemm_variant_choice_does_not_change_results(monkeypatch):
         outs.append(m(img, training=False))
     for o in outs[1:]:
         assert np.array_equal(outs[0], o)
+
+
+@pytest.mark.parametrize("name,compute,tol", [("deepvit_82tok", "fp32", 2e-4), ("cait_82tok", "fp32", 2e-4), ("deepvit_82tok", "bf16", 6e-2),
+                                              ("cait_82tok", "bf16", 6e-2)])
+def test_head_axis_chains_beyond_64_keys(name, compute, tol):
+    """Rows with more than 64 keys take the multi-sweep fused head-axis kernels (softmax / head mixing / LayerNorm over heads and
+    their VJPs): logits and every gradient against the autograd twin."""
+    cfg = oracle_cfg(name)
+    P = spec.init_params(cfg, 1, randomize_all=True)
+    m = make_engine_model(name, compute, 2, P)
+    img = rand_images(cfg, 2, seed=7)
+    dl = (np.random.default_rng(2).standard_normal((2, cfg["num_classes"])) / 2).astype(np.float32)
+    logits = m(img, training=False)
+    grads, _ = m.backward(dl)
+    q = ref_torch.bf16_round if compute == "bf16" else None
+    ref_logits, ref_grads, _ = ref_torch.forward_backward(cfg, P, img, dl, q=q)
+    assert np.abs(logits - ref_logits).max() <= tol * max(1.0, np.abs(ref_logits).max())
+    for k, r in ref_grads.items():
+        assert np.abs(grads[k] - r).max() <= tol * np.abs(r).max() + 1e-6, (k, np.abs(grads[k] - r).max(), np.abs(r).max())

@@ -11,6 +11,9 @@ CONFIGS = {
     "vit_rect_mean": ("vit", dict(image_size=(64, 32), patch_size=(16, 8), num_classes=12, dim=64, depth=2, heads=4, mlp_dim=192, dim_head=16, pool="mean")),
     "vit_noproj": ("vit", dict(image_size=32, patch_size=8, num_classes=7, dim=64, depth=2, heads=1, mlp_dim=128, dim_head=64)),
     "vit_bf16_small": ("vit", dict(image_size=64, patch_size=16, num_classes=10, dim=128, depth=2, heads=2, mlp_dim=256, dim_head=64)),
+    # more than 64 keys per row: the multi-sweep head-axis kernels (DeepViT 82 tokens; CaiT 81 patch keys / 82 class-attention keys)
+    "deepvit_82tok": ("deepvit", dict(image_size=144, patch_size=16, num_classes=10, dim=64, depth=2, heads=4, mlp_dim=128, dim_head=16)),
+    "cait_82tok": ("cait", dict(image_size=144, patch_size=16, num_classes=10, dim=64, depth=1, cls_depth=1, heads=4, mlp_dim=128, dim_head=16)),
     "deepvit_small": ("deepvit", dict(image_size=64, patch_size=16, num_classes=10, dim=64, depth=2, heads=4, mlp_dim=128, dim_head=16)),
     "deepvit_bf16_small": ("deepvit", dict(image_size=64, patch_size=16, num_classes=10, dim=128, depth=2, heads=4, mlp_dim=256, dim_head=32)),
     "cait_small": ("cait", dict(image_size=64, patch_size=16, num_classes=10, dim=64, depth=2, cls_depth=2, heads=4, mlp_dim=128, dim_head=16)),

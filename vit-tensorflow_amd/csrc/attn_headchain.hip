@@ -11,7 +11,7 @@
 //     to the fp32 matrix pipe (v_mfma_f32_16x16x4_f32, exact fp32 products): the per-lane vectors are transposed into MFMA operand
 //     layout through a per-wave LDS scratch.  Per-wave partial sums are written out and reduced in fixed order (deterministic).
 // Arithmetic order inside each op is the same as in the unfused kernels of attn_generic.hip (same expf, same FMA chains), so the
-// fp32 parity mode is unaffected.  Head counts 4/8/12/16 (padded to 16 for the MFMA), nk <= 128; other shapes use the unfused kernels.
+// fp32 parity mode is unaffected.  Head counts 4/8/12/16 (padded to 16 for the MFMA), nk <= 64; other shapes use the unfused kernels.
 #include "kernels.h"
 
 namespace {
@@ -346,35 +346,30 @@ int chain_blocks(int64_t rows) { return (int)std::max<int64_t>(1, std::min<int64
 
 }  // namespace
 
-// nk <= 64 (one key per lane).  The two-pass instantiations (65..128 keys) exist and are correct, but they hold two passes of every
-// per-head vector in registers, spill, and measured SLOWER than the unfused kernels on DeepViT's 65 keys (16.6 vs 7.8 ms per step).
+// nk <= 64 (one key per lane, everything in registers).  For longer rows a row-per-wave kernel has to hold several passes of every
+// per-head vector (spills: 16.6 ms per DeepViT step at 65 keys) or walk the row in several sweeps (12.4 ms) -- both lose to the unfused
+// point-per-thread kernels (7.8 ms), which have far more loads in flight; those rows keep the unfused kernels.
 bool headchain_supported(int h, int nk) { return (h == 4 || h == 8 || h == 12 || h == 16) && nk >= 1 && nk <= 64; }
 int64_t headchain_ws_elems(int h) { return (int64_t)(HC_BLOCKS * HC_WAVES + 40) * (2 * h * h + 2 * h); }
 
-#define HC_DISPATCH(h, np, CALL)                                   \
-  do {                                                             \
-    if (np == 1) {                                                 \
-      if (h == 16) { CALL(16, 1); } else if (h == 12) { CALL(12, 1); } else if (h == 8) { CALL(8, 1); } else { CALL(4, 1); }   \
-    } else {                                                       \
-      if (h == 16) { CALL(16, 2); } else if (h == 12) { CALL(12, 2); } else if (h == 8) { CALL(8, 2); } else { CALL(4, 2); }   \
-    }                                                              \
-  } while (0)
+#define HC_DISPATCH(h, CALL) \
+  do { if (h == 16) { CALL(16); } else if (h == 12) { CALL(12); } else if (h == 8) { CALL(8); } else { CALL(4); } } while (0)
 
 void launch_cait_chain_fwd(const float* s0, const float* wpre, const float* wpost, float* a1_or_null, float* a2, int b, int h, int nq, int nk,
                            int64_t ld, hipStream_t s) {
   const int64_t rows = (int64_t)b * nq;
-  const int np = nk <= 64 ? 1 : 2;
-#define CALL(H, NP) hipLaunchKernelGGL((cait_chain_fwd_kernel<H, NP>), dim3(chain_blocks(rows)), dim3(64 * HC_WAVES), 0, s, s0, wpre, wpost, a1_or_null, a2, rows, nq, nk, ld)
-  HC_DISPATCH(h, np, CALL);
+  const dim3 grid(chain_blocks(rows)), block(64 * HC_WAVES);
+#define CALL(H) hipLaunchKernelGGL((cait_chain_fwd_kernel<H, 1>), grid, block, 0, s, s0, wpre, wpost, a1_or_null, a2, rows, nq, nk, ld)
+  HC_DISPATCH(h, CALL);
 #undef CALL
 }
 void launch_cait_chain_bwd(const float* s0, const float* a1, float* da_inout, const float* wpre, const float* wpost, float* ws, float* dwpre,
                            float* dwpost, int b, int h, int nq, int nk, int64_t ld, hipStream_t s) {
   const int64_t rows = (int64_t)b * nq;
-  const int np = nk <= 64 ? 1 : 2;
   const int nblk = chain_blocks(rows);
-#define CALL(H, NP) hipLaunchKernelGGL((cait_chain_bwd_kernel<H, NP>), dim3(nblk), dim3(64 * HC_WAVES), 0, s, s0, a1, da_inout, wpre, wpost, ws, rows, nq, nk, ld)
-  HC_DISPATCH(h, np, CALL);
+  const dim3 grid(nblk), block(64 * HC_WAVES);
+#define CALL(H) hipLaunchKernelGGL((cait_chain_bwd_kernel<H, 1>), grid, block, 0, s, s0, a1, da_inout, wpre, wpost, ws, rows, nq, nk, ld)
+  HC_DISPATCH(h, CALL);
 #undef CALL
   const int nparts = nblk * HC_WAVES;
   const int64_t stride = 2 * (int64_t)h * h;
@@ -384,18 +379,18 @@ void launch_cait_chain_bwd(const float* s0, const float* a1, float* da_inout, co
 void launch_deepvit_chain_fwd(float* s0_inout, const float* wre, const float* gamma, const float* beta, float* mixed_or_null, float* a2, int keep,
                               int b, int h, int nq, int nk, int64_t ld, float eps, hipStream_t s) {
   const int64_t rows = (int64_t)b * nq;
-  const int np = nk <= 64 ? 1 : 2;
-#define CALL(H, NP) hipLaunchKernelGGL((deepvit_chain_fwd_kernel<H, NP>), dim3(chain_blocks(rows)), dim3(64 * HC_WAVES), 0, s, s0_inout, wre, gamma, beta, mixed_or_null, a2, keep, rows, nq, nk, ld, eps)
-  HC_DISPATCH(h, np, CALL);
+  const dim3 grid(chain_blocks(rows)), block(64 * HC_WAVES);
+#define CALL(H) hipLaunchKernelGGL((deepvit_chain_fwd_kernel<H, 1>), grid, block, 0, s, s0_inout, wre, gamma, beta, mixed_or_null, a2, keep, rows, nq, nk, ld, eps)
+  HC_DISPATCH(h, CALL);
 #undef CALL
 }
 void launch_deepvit_chain_bwd(const float* a0, const float* mixed, float* da_inout, const float* wre, const float* gamma, float* ws, float* dwre,
                               float* dgamma, float* dbeta, int b, int h, int nq, int nk, int64_t ld, float eps, hipStream_t s) {
   const int64_t rows = (int64_t)b * nq;
-  const int np = nk <= 64 ? 1 : 2;
   const int nblk = chain_blocks(rows);
-#define CALL(H, NP) hipLaunchKernelGGL((deepvit_chain_bwd_kernel<H, NP>), dim3(nblk), dim3(64 * HC_WAVES), 0, s, a0, mixed, da_inout, wre, gamma, ws, rows, nq, nk, ld, eps)
-  HC_DISPATCH(h, np, CALL);
+  const dim3 grid(nblk), block(64 * HC_WAVES);
+#define CALL(H) hipLaunchKernelGGL((deepvit_chain_bwd_kernel<H, 1>), grid, block, 0, s, a0, mixed, da_inout, wre, gamma, ws, rows, nq, nk, ld, eps)
+  HC_DISPATCH(h, CALL);
 #undef CALL
   const int nparts = nblk * HC_WAVES;
   const int64_t stride = (int64_t)h * h + 2 * h;
