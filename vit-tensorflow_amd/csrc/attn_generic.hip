@@ -38,15 +38,113 @@ __global__ __launch_bounds__(256) void softmax_bwd_rows_kernel(const float* __re
   for (int c = lane; c < n; c += 64) dr[c] = pr[c] * (dr[c] - s);
 }
 
+// Short rows (n <= 128: the 64/65-key configurations): 16 lanes per row, four rows per wave -- a 65-key row on a whole wave leaves
+// most lanes idle in its second pass.
+__device__ __forceinline__ float group16_max(float v) {
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float group16_sum(float v) {
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__global__ __launch_bounds__(256) void softmax_rows16_kernel(float* __restrict__ sc, int64_t rows, int n, int64_t ld) {
+  const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+  const int l = threadIdx.x & 15;
+  const bool ok = row < rows;
+  float* r = sc + (ok ? row : 0) * ld;
+  float m = -INFINITY;
+  if (ok) for (int c = l; c < n; c += 16) m = fmaxf(m, r[c]);
+  m = group16_max(m);
+  float s = 0.f;
+  if (ok) for (int c = l; c < n; c += 16) { const float e = expf(r[c] - m); r[c] = e; s += e; }
+  s = group16_sum(s);
+  const float inv = 1.0f / s;
+  if (ok) for (int c = l; c < n; c += 16) r[c] *= inv;
+}
+__global__ __launch_bounds__(256) void softmax_bwd_rows16_kernel(const float* __restrict__ p, float* __restrict__ dp, int64_t rows, int n,
+                                                                 int64_t ld) {
+  const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+  const int l = threadIdx.x & 15;
+  const bool ok = row < rows;
+  const float* pr = p + (ok ? row : 0) * ld;
+  float* dr = dp + (ok ? row : 0) * ld;
+  float s = 0.f;
+  if (ok) for (int c = l; c < n; c += 16) s += pr[c] * dr[c];
+  s = group16_sum(s);
+  if (ok) for (int c = l; c < n; c += 16) dr[c] = pr[c] * (dr[c] - s);
+}
+// row statistics only: stats[row] = (max, 1 / sum exp(x - max))
+__global__ __launch_bounds__(256) void softmax_stats16_kernel(const float* __restrict__ sc, float2* __restrict__ stats, int64_t rows, int n,
+                                                              int64_t ld) {
+  const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+  const int l = threadIdx.x & 15;
+  const bool ok = row < rows;
+  const float* r = sc + (ok ? row : 0) * ld;
+  float m = -INFINITY;
+  if (ok) for (int c = l; c < n; c += 16) m = fmaxf(m, r[c]);
+  m = group16_max(m);
+  float s = 0.f;
+  if (ok) for (int c = l; c < n; c += 16) s += expf(r[c] - m);
+  s = group16_sum(s);
+  if (ok && l == 0) stats[row] = make_float2(m, 1.0f / s);
+}
+
+// DeepViT forward chain with one thread per (image, query, key) point (deepvit.py:80-84): softmax normalisation from the row
+// statistics above, re-attention mix, LayerNorm over heads -- one read of the scores instead of three kernels' worth of passes.
+// Writes the softmax back over the scores and the mixed values only when the backward needs them (`keep`).
+template <int HT>
+__global__ __launch_bounds__(256) void deepvit_point_fwd_kernel(float* __restrict__ s0, const float2* __restrict__ stats,
+                                                                const float* __restrict__ w, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, float* __restrict__ mixed,
+                                                                float* __restrict__ a2, int keep, int b, int nq, int64_t nvalid_per_row,
+                                                                int64_t ld, float eps) {
+  constexpr int h = HT;
+  // the mixing matrix is read straight from global memory with wave-uniform addresses: the compiler turns that into scalar loads
+  // and SGPR operands.  Staged through LDS it gets hoisted into 256 VGPRs per lane and the kernel runs at one wave per SIMD.
+  const int64_t plane = (int64_t)nq * ld;
+  const int64_t total = (int64_t)b * plane;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t bi = e / plane, ij = e - bi * plane;
+    if ((ij % ld) >= nvalid_per_row) continue;
+    const int64_t i = ij / ld;
+    float y[HT], v[HT];
+#pragma unroll
+    for (int hh = 0; hh < h; ++hh) {
+      const float2 st = stats[(bi * h + hh) * nq + i];
+      y[hh] = expf(s0[(bi * h + hh) * plane + ij] - st.x) * st.y;
+      if (keep) s0[(bi * h + hh) * plane + ij] = y[hh];
+    }
+    float mu = 0.f;
+#pragma unroll
+    for (int gg = 0; gg < h; ++gg) {
+      float a = 0.f;
+#pragma unroll
+      for (int hh = 0; hh < h; ++hh) a = fmaf(y[hh], w[hh * h + gg], a);
+      v[gg] = a;
+      mu += a;
+      if (keep) mixed[(bi * h + gg) * plane + ij] = a;
+    }
+    mu /= (float)h;
+    float var = 0.f;
+#pragma unroll
+    for (int gg = 0; gg < h; ++gg) var += (v[gg] - mu) * (v[gg] - mu);
+    const float rs = rsqrtf(var / (float)h + eps);
+#pragma unroll
+    for (int gg = 0; gg < h; ++gg) a2[(bi * h + gg) * plane + ij] = (v[gg] - mu) * rs * gamma[gg] + beta[gg];
+  }
+}
+
 // out[b,g,i,j] = sum_h in[b,h,i,j] W[h,g]    -- one thread per (b,i,j)
 template <int HT>
 __global__ __launch_bounds__(256) void headmix_fwd_kernel(const float* __restrict__ in, const float* __restrict__ w,
                                                           float* __restrict__ out, int b, int h_rt, int64_t plane, int64_t nvalid_per_row,
                                                           int64_t ld) {
   const int h = HT ? HT : h_rt;   // compile-time head count keeps the per-point arrays in registers
-  __shared__ float ws[MAXH * MAXH];
-  for (int i = threadIdx.x; i < h * h; i += blockDim.x) ws[i] = w[i];
-  __syncthreads();
+  // W is read from global memory with wave-uniform addresses (scalar loads, SGPR operands); staged through LDS it was hoisted into
+  // h*h VGPRs per lane and the kernel ran at one wave per SIMD
   const int64_t total = (int64_t)b * plane;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
     const int64_t bi = e / plane, ij = e - bi * plane;
@@ -57,7 +155,7 @@ __global__ __launch_bounds__(256) void headmix_fwd_kernel(const float* __restric
     _Pragma("unroll") for (int hh = 0; hh < h; ++hh) v[hh] = ip[(int64_t)hh * plane];
     _Pragma("unroll") for (int gg = 0; gg < h; ++gg) {
       float a = 0.f;
-      _Pragma("unroll") for (int hh = 0; hh < h; ++hh) a = fmaf(v[hh], ws[hh * h + gg], a);
+      _Pragma("unroll") for (int hh = 0; hh < h; ++hh) a = fmaf(v[hh], w[hh * h + gg], a);
       op[(int64_t)gg * plane] = a;
     }
   }
@@ -154,6 +252,72 @@ __global__ __launch_bounds__(256) void headmix_bwd_kernel(const float* __restric
   for (int k = 0; k < 4; ++k) {
     const int pair = threadIdx.x + 256 * k;
     if (pair < h * h) dw_partial[(int64_t)blockIdx.x * h * h + pair] = acc[k];
+  }
+}
+
+// Same VJP with the mixing-matrix gradient on the fp32 matrix pipe: dW[h][g] = sum over points of in[h] * dout[g] is a
+// [16 x points] x [points x 16] product; each wave transposes the per-lane vectors of its 64 points into MFMA operand layout through
+// a private LDS scratch and issues 16 v_mfma_f32_16x16x4_f32 (exact fp32 products).  The LDS point buffer of the kernel above moved
+// ~1.3 KB per point; this one moves 160 B per point.  Head counts 4 / 8 / 12 / 16 (padded to 16).
+constexpr int HMM_PITCH = 20;
+template <int H>
+__global__ __launch_bounds__(256) void headmix_bwd_mfma_kernel(const float* __restrict__ in, const float* __restrict__ dout,
+                                                               const float* __restrict__ w, float* __restrict__ din,
+                                                               float* __restrict__ dw_partial, int b, int64_t plane, int64_t nvalid_per_row,
+                                                               int64_t ld) {
+  __shared__ __attribute__((aligned(16))) float scratch[4][2][64 * HMM_PITCH];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* xs = scratch[wave][0];
+  float* ys = scratch[wave][1];
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const int64_t total = (int64_t)b * plane;
+  const int64_t span = (int64_t)gridDim.x * blockDim.x;
+  const int64_t iters = (total + span - 1) / span;      // every wave runs the same number of iterations (MFMA needs all lanes)
+  for (int64_t it = 0; it < iters; ++it) {
+    const int64_t e = it * span + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool valid = e < total;
+    int64_t bi = 0, ij = 0;
+    if (valid) { bi = e / plane; ij = e - bi * plane; valid = (ij % ld) < nvalid_per_row; }
+    float xv[H], dv[H];
+#pragma unroll
+    for (int k = 0; k < H; ++k) {
+      xv[k] = valid ? in[(bi * H + k) * plane + ij] : 0.f;
+      dv[k] = valid ? dout[(bi * H + k) * plane + ij] : 0.f;
+    }
+    if (valid) {
+#pragma unroll
+      for (int hh = 0; hh < H; ++hh) {
+        float a = 0.f;
+#pragma unroll
+        for (int gg = 0; gg < H; ++gg) a = fmaf(dv[gg], w[hh * H + gg], a);
+        din[(bi * H + hh) * plane + ij] = a;
+      }
+    }
+    float* xr = xs + lane * HMM_PITCH;
+    float* yr = ys + lane * HMM_PITCH;
+#pragma unroll
+    for (int k = 0; k < 16; k += 4) {
+      *(float4*)(xr + k) = make_float4(k + 0 < H ? xv[k + 0 < H ? k + 0 : 0] : 0.f, k + 1 < H ? xv[k + 1 < H ? k + 1 : 0] : 0.f,
+                                       k + 2 < H ? xv[k + 2 < H ? k + 2 : 0] : 0.f, k + 3 < H ? xv[k + 3 < H ? k + 3 : 0] : 0.f);
+      *(float4*)(yr + k) = make_float4(k + 0 < H ? dv[k + 0 < H ? k + 0 : 0] : 0.f, k + 1 < H ? dv[k + 1 < H ? k + 1 : 0] : 0.f,
+                                       k + 2 < H ? dv[k + 2 < H ? k + 2 : 0] : 0.f, k + 3 < H ? dv[k + 3 < H ? k + 3 : 0] : 0.f);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // same-wave LDS traffic is in order
+    const int m = lane & 15, kp = lane >> 4;
+#pragma unroll
+    for (int st = 0; st < 16; ++st) {
+      const float a = xs[(4 * st + kp) * HMM_PITCH + m];
+      const float bq = ys[(4 * st + kp) * HMM_PITCH + m];
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bq, acc, 0, 0, 0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+  float* pw = dw_partial + ((int64_t)blockIdx.x * 4 + wave) * H * H;
+  const int g = lane & 15;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int hh = 4 * (lane >> 4) + r;
+    if (hh < H && g < H) pw[hh * H + g] = acc[r];
   }
 }
 
@@ -313,17 +477,33 @@ __global__ void broadcast_rows_kernel(const float* __restrict__ src, int d, floa
 
 inline int grid_for(int64_t total, int block = 256) { return (int)std::max<int64_t>(1, std::min<int64_t>(ceil_div(total, block), 256 * 8)); }
 constexpr int HM_BLOCKS = 256;
+constexpr int HMM_BLOCKS = 2048;   // headmix_bwd_mfma_kernel: 4 resident workgroups per CU x 256 CUs x 2
 constexpr int SG_CHUNKS = 512;
 
 }  // namespace
 
 void launch_softmax_rows(float* sc, int64_t rows, int n, int64_t ld, hipStream_t s) {
   if (rows == 0) return;
-  hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)ceil_div(rows, 4)), dim3(256), 0, s, sc, rows, n, ld);
+  if (n <= 128) hipLaunchKernelGGL(softmax_rows16_kernel, dim3((unsigned)ceil_div(rows, 16)), dim3(256), 0, s, sc, rows, n, ld);
+  else hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)ceil_div(rows, 4)), dim3(256), 0, s, sc, rows, n, ld);
 }
 void launch_softmax_bwd_rows(const float* p, float* dp, int64_t rows, int n, int64_t ld, hipStream_t s) {
   if (rows == 0) return;
-  hipLaunchKernelGGL(softmax_bwd_rows_kernel, dim3((unsigned)ceil_div(rows, 4)), dim3(256), 0, s, p, dp, rows, n, ld);
+  if (n <= 128) hipLaunchKernelGGL(softmax_bwd_rows16_kernel, dim3((unsigned)ceil_div(rows, 16)), dim3(256), 0, s, p, dp, rows, n, ld);
+  else hipLaunchKernelGGL(softmax_bwd_rows_kernel, dim3((unsigned)ceil_div(rows, 4)), dim3(256), 0, s, p, dp, rows, n, ld);
+}
+// DeepViT forward chain in two launches: row statistics, then one fused point kernel (see deepvit_point_fwd_kernel)
+bool deepvit_point_fwd_supported(int h, int nk) { return (h == 4 || h == 8 || h == 12 || h == 16) && nk <= 128; }
+int64_t deepvit_point_ws_elems(int b, int h, int nq) { return 2 * (int64_t)b * h * nq; }
+void launch_deepvit_point_fwd(float* s0, float* stats_ws, const float* w, const float* gamma, const float* beta, float* mixed, float* a2,
+                              int keep, int b, int h, int nq, int nk, int64_t ld, float eps, hipStream_t s) {
+  const int64_t rows = (int64_t)b * h * nq;
+  if (rows == 0) return;
+  hipLaunchKernelGGL(softmax_stats16_kernel, dim3((unsigned)ceil_div(rows, 16)), dim3(256), 0, s, s0, (float2*)stats_ws, rows, nk, ld);
+  const int64_t plane = (int64_t)nq * ld;
+#define CALLP(HT) hipLaunchKernelGGL(deepvit_point_fwd_kernel<HT>, dim3(grid_for((int64_t)b * plane)), dim3(256), 0, s, s0, (const float2*)stats_ws, w, gamma, beta, mixed, a2, keep, b, nq, (int64_t)nk, ld, eps)
+  if (h == 16) { CALLP(16); } else if (h == 12) { CALLP(12); } else if (h == 8) { CALLP(8); } else { CALLP(4); }
+#undef CALLP
 }
 void launch_headmix_fwd(const float* in, const float* w, float* out, int b, int h, int nq, int nk, int64_t ld, hipStream_t s) {
   const int64_t plane = (int64_t)nq * ld;
@@ -331,12 +511,21 @@ void launch_headmix_fwd(const float* in, const float* w, float* out, int b, int 
   VITX_H_DISPATCH(h, CALL);
 #undef CALL
 }
-int64_t headmix_ws_elems(int b, int h, int nq, int nk) { return (int64_t)HM_BLOCKS * h * h; }
+int64_t headmix_ws_elems(int b, int h, int nq, int nk) { return (int64_t)(HMM_BLOCKS * 4 + 40) * h * h; }
 void launch_headmix_bwd(const float* in, const float* dout, const float* w, float* din, float* dw_partial_ws, float* dw, int b, int h,
                         int nq, int nk, int64_t ld, hipStream_t s) {
   const int64_t plane = (int64_t)nq * ld;
   const int nblk = (int)std::max<int64_t>(1, std::min<int64_t>(HM_BLOCKS, ceil_div((int64_t)b * plane, 256)));
   const size_t shm = (size_t)std::max(256 * 2 * h, 4096) * sizeof(float);   // points [256][2h]; later the [PG][blocks][16] combine buffer
+  if (h == 4 || h == 8 || h == 12 || h == 16) {   // mixing-matrix gradient on the fp32 matrix pipe, one partial per wave
+    const int nb2 = (int)std::max<int64_t>(1, std::min<int64_t>(HMM_BLOCKS, ceil_div((int64_t)b * plane, 256)));
+#define CALLM(HT) hipLaunchKernelGGL(headmix_bwd_mfma_kernel<HT>, dim3(nb2), dim3(256), 0, s, in, dout, w, din, dw_partial_ws, b, plane, (int64_t)nk, ld)
+    if (h == 16) { CALLM(16); } else if (h == 12) { CALLM(12); } else if (h == 8) { CALLM(8); } else { CALLM(4); }
+#undef CALLM
+    const int nparts = nb2 * 4;
+    launch_reduce_partials3(dw_partial_ws, nparts, (int64_t)h * h, (int64_t)h * h, 1, dw, nullptr, nullptr, dw_partial_ws + (int64_t)nparts * h * h, 1.0f, s);
+    return;
+  }
 #define CALL(HT) hipLaunchKernelGGL(headmix_bwd_kernel<HT>, dim3(nblk), dim3(256), shm, s, in, dout, w, din, dw_partial_ws, b, h, plane, (int64_t)nk, ld)
   VITX_H_DISPATCH(h, CALL);
 #undef CALL

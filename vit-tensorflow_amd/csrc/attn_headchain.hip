@@ -63,10 +63,8 @@ template <int H, int NP>
 __global__ __launch_bounds__(64 * HC_WAVES) void cait_chain_fwd_kernel(const float* __restrict__ s0, const float* __restrict__ wpre,
                                                                        const float* __restrict__ wpost, float* __restrict__ a1,
                                                                        float* __restrict__ a2, int64_t rows, int nq, int nk, int64_t ld) {
-  __shared__ float ws[2][H * H];
-  load_w<H>(ws[0], wpre);
-  load_w<H>(ws[1], wpost);
-  __syncthreads();
+  // (mixing matrices are read from global memory with wave-uniform addresses -> scalar loads / SGPR operands; staged through LDS
+  //  the compiler hoists them into 2 x 256 VGPRs per lane and the kernel drops to one or two waves per SIMD)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t plane = (int64_t)nq * ld;
   for (int64_t row = (int64_t)blockIdx.x * HC_WAVES + wave; row < rows; row += (int64_t)gridDim.x * HC_WAVES) {
@@ -84,7 +82,7 @@ __global__ __launch_bounds__(64 * HC_WAVES) void cait_chain_fwd_kernel(const flo
       for (int g = 0; g < H; ++g) {
         float a = 0.f;
 #pragma unroll
-        for (int hh = 0; hh < H; ++hh) a = fmaf(x[hh], ws[0][hh * H + g], a);
+        for (int hh = 0; hh < H; ++hh) a = fmaf(x[hh], wpre[hh * H + g], a);
         y[p][g] = a;
       }
     }
@@ -114,7 +112,7 @@ __global__ __launch_bounds__(64 * HC_WAVES) void cait_chain_fwd_kernel(const flo
       for (int g = 0; g < H; ++g) {
         float a = 0.f;
 #pragma unroll
-        for (int hh = 0; hh < H; ++hh) a = fmaf(y[p][hh], ws[1][hh * H + g], a);
+        for (int hh = 0; hh < H; ++hh) a = fmaf(y[p][hh], wpost[hh * H + g], a);
         a2[base + (int64_t)g * plane + j] = a;
       }
     }
@@ -156,7 +154,7 @@ __global__ __launch_bounds__(64 * HC_WAVES) void cait_chain_bwd_kernel(const flo
       for (int hh = 0; hh < H; ++hh) {
         float a = 0.f;
 #pragma unroll
-        for (int g = 0; g < H; ++g) a = fmaf(dz[g], ws[1][hh * H + g], a);
+        for (int g = 0; g < H; ++g) a = fmaf(dz[g], wpost[hh * H + g], a);
         d1[p][hh] = a;                                                 // dA1
       }
     }
@@ -182,7 +180,7 @@ __global__ __launch_bounds__(64 * HC_WAVES) void cait_chain_bwd_kernel(const flo
         for (int hh = 0; hh < H; ++hh) {
           float a = 0.f;
 #pragma unroll
-          for (int g = 0; g < H; ++g) a = fmaf(d1[p][g], ws[0][hh * H + g], a);
+          for (int g = 0; g < H; ++g) a = fmaf(d1[p][g], wpre[hh * H + g], a);
           da[base + (int64_t)hh * plane + j] = a;                      // dS0
         }
       }
@@ -200,9 +198,7 @@ __global__ __launch_bounds__(64 * HC_WAVES) void deepvit_chain_fwd_kernel(float*
                                                                           const float* __restrict__ beta, float* __restrict__ mixed /* nullable */,
                                                                           float* __restrict__ a2, int keep, int64_t rows, int nq, int nk,
                                                                           int64_t ld, float eps) {
-  __shared__ float ws[H * H];
-  load_w<H>(ws, wre);
-  __syncthreads();
+  // (mixing matrix via scalar loads, see the CaiT kernels)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t plane = (int64_t)nq * ld;
   float gm[H], bt[H];
@@ -241,7 +237,7 @@ __global__ __launch_bounds__(64 * HC_WAVES) void deepvit_chain_fwd_kernel(float*
         if (keep) s0[base + (int64_t)g * plane + j] = y[p][g];
         float a = 0.f;
 #pragma unroll
-        for (int hh = 0; hh < H; ++hh) a = fmaf(y[p][hh], ws[hh * H + g], a);   // re-attention mix (deepvit.py:83)
+        for (int hh = 0; hh < H; ++hh) a = fmaf(y[p][hh], wre[hh * H + g], a);   // re-attention mix (deepvit.py:83)
         v[g] = a;
       }
 #pragma unroll
@@ -316,7 +312,7 @@ __global__ __launch_bounds__(64 * HC_WAVES) void deepvit_chain_bwd_kernel(const 
       for (int hh = 0; hh < H; ++hh) {
         float a = 0.f;
 #pragma unroll
-        for (int g = 0; g < H; ++g) a = fmaf(dm[g], ws[hh * H + g], a);
+        for (int g = 0; g < H; ++g) a = fmaf(dm[g], wre[hh * H + g], a);
         d0[p][hh] = a;                                                 // dA0
       }
     }

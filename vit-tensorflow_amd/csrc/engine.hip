@@ -368,6 +368,12 @@ static int attn_generic_scores(vitx_engine* e, const BlockParams& bp, const Attn
                              for_bwd ? 1 : 0, b, h, a.nq, a.nk, ld, e->cfg.ln_eps, e->stream);
     return 2;
   }
+  if (!e->unfused_headops && e->cfg.variant == VITX_VARIANT_DEEPVIT && deepvit_point_fwd_supported(h, a.nk)) {
+    Prof pr(e, "attn_headchain", 0, 0);     // 65..128 keys: row statistics + one fused point kernel (deepvit.py:80-84)
+    launch_deepvit_point_fwd(e->sc[0], e->red_ws, e->params + bp.re_w, e->params + bp.re_g, e->params + bp.re_b, e->sc[1], e->sc[2],
+                             for_bwd ? 1 : 0, b, h, a.nq, a.nk, ld, e->cfg.ln_eps, e->stream);
+    return 2;
+  }
   if (e->cfg.variant == VITX_VARIANT_CAIT) {
     Prof pr(e, "attn_generic_headops", 0, 0);
     launch_headmix_fwd(e->sc[0], e->params + bp.mix_pre, e->sc[1], b, h, a.nq, a.nk, ld, e->stream);    // cait.py:123
@@ -851,7 +857,7 @@ int engine_create(const vitx_config& cfg, vitx_engine** out, std::string& err) {
   // (+ per-M-tile column sums of the fc2-dgrad epilogue: one row per 256 token rows, 32 second-level rows)
   e->red_elems = std::max<int64_t>({layernorm_bwd_ws_elems(d), colsum_ws_elems((int)maxfeat), headmix_ws_elems((int)B, c.heads, 1, 1),
                                     (int64_t)256 * 2 * 32, (int64_t)(512 + 32) * d, (ceil_div(std::max<int64_t>(e->mp, e->mpp), 128) + 40) * (int64_t)m,
-                                    headchain_ws_elems(c.heads)});
+                                    headchain_ws_elems(c.heads), deepvit_point_ws_elems((int)B, c.heads, e->ntok_max)});
   DALLOC(e->red_ws, (size_t)e->red_elems * 4, false);
   HIPCHK(hipStreamSynchronize(e->stream));
   *out = e;

@@ -104,6 +104,11 @@ void launch_resid_add(const float* resid, const void* t, int t_bf16, float* out,
 // ---------------------------------------------------------------- attn_generic.hip (materialised attention pieces)
 void launch_softmax_rows(float* sc, int64_t rows, int n, int64_t ld, hipStream_t s);
 void launch_softmax_bwd_rows(const float* p, float* dp_inout, int64_t rows, int n, int64_t ld, hipStream_t s);
+// DeepViT forward chain (softmax -> re-attention mix -> LayerNorm over heads) as row statistics + one fused point kernel
+bool deepvit_point_fwd_supported(int h, int nk);
+int64_t deepvit_point_ws_elems(int b, int h, int nq);
+void launch_deepvit_point_fwd(float* s0_inout, float* stats_ws, const float* w, const float* gamma, const float* beta, float* mixed, float* a2,
+                              int keep, int b, int h, int nq, int nk, int64_t ld, float eps, hipStream_t s);
 // talking-heads style mix over the head axis of [b, h, nq, ld]: out[b,g,i,j] = sum_h in[b,h,i,j] * W[h,g]
 void launch_headmix_fwd(const float* in, const float* w, float* out, int b, int h, int nq, int nk, int64_t ld, hipStream_t s);
 // din[b,h,i,j] = sum_g dout[b,g,i,j] W[h,g];  dW[h,g] = sum_{b,i,j} in[b,h,i,j] dout[b,g,i,j]
