@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void deepvit_point_fwd_kernel(float* __restric
     }
     float mu = 0.f;
 #pragma unroll
-    for (int gg = 0; gg < h; ++gg) {
+    for (int gg = 0; gg < h; ++gg) {   // (column-wise on purpose: the row-wise form makes the scheduler hoist all 16 row loads and spill SGPRs)
       float a = 0.f;
 #pragma unroll
       for (int hh = 0; hh < h; ++hh) a = fmaf(y[hh], w[hh * h + gg], a);
@@ -150,14 +150,17 @@ __global__ __launch_bounds__(256) void headmix_fwd_kernel(const float* __restric
     const int64_t bi = e / plane, ij = e - bi * plane;
     if ((ij % ld) >= nvalid_per_row) continue;
     const float* ip = in + bi * h * plane + ij;
+    const float* wr = w + opaque_zero();   // keeps the scalar weight loads inside the loop (see common.h)
     float* op = out + bi * h * plane + ij;
     float v[MAXH];
     _Pragma("unroll") for (int hh = 0; hh < h; ++hh) v[hh] = ip[(int64_t)hh * plane];
-    _Pragma("unroll") for (int gg = 0; gg < h; ++gg) {
-      float a = 0.f;
-      _Pragma("unroll") for (int hh = 0; hh < h; ++hh) a = fmaf(v[hh], w[hh * h + gg], a);
-      op[(int64_t)gg * plane] = a;
+    // row hh of W at a time (16 contiguous scalars live), every output accumulates over hh in ascending order as before
+    float acc[MAXH];
+    _Pragma("unroll") for (int gg = 0; gg < h; ++gg) acc[gg] = 0.f;
+    _Pragma("unroll") for (int hh = 0; hh < h; ++hh) {
+      _Pragma("unroll") for (int gg = 0; gg < h; ++gg) acc[gg] = fmaf(v[hh], wr[hh * h + gg], acc[gg]);
     }
+    _Pragma("unroll") for (int gg = 0; gg < h; ++gg) op[(int64_t)gg * plane] = acc[gg];
   }
 }
 

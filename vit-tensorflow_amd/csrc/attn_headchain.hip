@@ -70,6 +70,8 @@ __global__ __launch_bounds__(64 * HC_WAVES) void cait_chain_fwd_kernel(const flo
   for (int64_t row = (int64_t)blockIdx.x * HC_WAVES + wave; row < rows; row += (int64_t)gridDim.x * HC_WAVES) {
     const int64_t bi = row / nq, i = row - bi * nq;
     const int64_t base = bi * H * plane + i * ld;
+    const float* wpre_r = wpre + opaque_zero();
+    const float* wpost_r = wpost + opaque_zero();
     float y[NP][H];
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
@@ -79,12 +81,11 @@ __global__ __launch_bounds__(64 * HC_WAVES) void cait_chain_fwd_kernel(const flo
 #pragma unroll
       for (int hh = 0; hh < H; ++hh) x[hh] = valid ? s0[base + (int64_t)hh * plane + j] : 0.f;
 #pragma unroll
-      for (int g = 0; g < H; ++g) {
-        float a = 0.f;
+      for (int g = 0; g < H; ++g) y[p][g] = 0.f;
 #pragma unroll
-        for (int hh = 0; hh < H; ++hh) a = fmaf(x[hh], wpre[hh * H + g], a);
-        y[p][g] = a;
-      }
+      for (int hh = 0; hh < H; ++hh)     // one contiguous row of W (16 scalars) live at a time; every output still sums hh ascending
+#pragma unroll
+        for (int g = 0; g < H; ++g) y[p][g] = fmaf(x[hh], wpre_r[hh * H + g], y[p][g]);
     }
 #pragma unroll
     for (int g = 0; g < H; ++g) {   // softmax over the keys (cait.py:124), same operation order as softmax_rows_kernel
@@ -108,13 +109,15 @@ __global__ __launch_bounds__(64 * HC_WAVES) void cait_chain_fwd_kernel(const flo
 #pragma unroll
         for (int g = 0; g < H; ++g) a1[base + (int64_t)g * plane + j] = y[p][g];
       }
+      float z[H];
 #pragma unroll
-      for (int g = 0; g < H; ++g) {
-        float a = 0.f;
+      for (int g = 0; g < H; ++g) z[g] = 0.f;
 #pragma unroll
-        for (int hh = 0; hh < H; ++hh) a = fmaf(y[p][hh], wpost[hh * H + g], a);
-        a2[base + (int64_t)g * plane + j] = a;
-      }
+      for (int hh = 0; hh < H; ++hh)
+#pragma unroll
+        for (int g = 0; g < H; ++g) z[g] = fmaf(y[p][hh], wpost_r[hh * H + g], z[g]);
+#pragma unroll
+      for (int g = 0; g < H; ++g) a2[base + (int64_t)g * plane + j] = z[g];
     }
   }
 }
@@ -138,6 +141,8 @@ __global__ __launch_bounds__(64 * HC_WAVES) void cait_chain_bwd_kernel(const flo
   for (int64_t row = (int64_t)blockIdx.x * HC_WAVES + wave; row < rows; row += (int64_t)gridDim.x * HC_WAVES) {
     const int64_t bi = row / nq, i = row - bi * nq;
     const int64_t base = bi * H * plane + i * ld;
+    const float* wpre_r = wpre + opaque_zero();
+    const float* wpost_r = wpost + opaque_zero();
     float av[NP][H], d1[NP][H];
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
@@ -154,7 +159,7 @@ __global__ __launch_bounds__(64 * HC_WAVES) void cait_chain_bwd_kernel(const flo
       for (int hh = 0; hh < H; ++hh) {
         float a = 0.f;
 #pragma unroll
-        for (int g = 0; g < H; ++g) a = fmaf(dz[g], wpost[hh * H + g], a);
+        for (int g = 0; g < H; ++g) a = fmaf(dz[g], wpost_r[hh * H + g], a);
         d1[p][hh] = a;                                                 // dA1
       }
     }
@@ -180,7 +185,7 @@ __global__ __launch_bounds__(64 * HC_WAVES) void cait_chain_bwd_kernel(const flo
         for (int hh = 0; hh < H; ++hh) {
           float a = 0.f;
 #pragma unroll
-          for (int g = 0; g < H; ++g) a = fmaf(d1[p][g], wpre[hh * H + g], a);
+          for (int g = 0; g < H; ++g) a = fmaf(d1[p][g], wpre_r[hh * H + g], a);
           da[base + (int64_t)hh * plane + j] = a;                      // dS0
         }
       }
@@ -207,6 +212,7 @@ __global__ __launch_bounds__(64 * HC_WAVES) void deepvit_chain_fwd_kernel(float*
   for (int64_t row = (int64_t)blockIdx.x * HC_WAVES + wave; row < rows; row += (int64_t)gridDim.x * HC_WAVES) {
     const int64_t bi = row / nq, i = row - bi * nq;
     const int64_t base = bi * H * plane + i * ld;
+    const float* wre_r = wre + opaque_zero();
     float y[NP][H];
 #pragma unroll
     for (int p = 0; p < NP; ++p)
@@ -237,7 +243,7 @@ __global__ __launch_bounds__(64 * HC_WAVES) void deepvit_chain_fwd_kernel(float*
         if (keep) s0[base + (int64_t)g * plane + j] = y[p][g];
         float a = 0.f;
 #pragma unroll
-        for (int hh = 0; hh < H; ++hh) a = fmaf(y[p][hh], wre[hh * H + g], a);   // re-attention mix (deepvit.py:83)
+        for (int hh = 0; hh < H; ++hh) a = fmaf(y[p][hh], wre_r[hh * H + g], a);   // re-attention mix (deepvit.py:83)
         v[g] = a;
       }
 #pragma unroll
@@ -274,6 +280,7 @@ __global__ __launch_bounds__(64 * HC_WAVES) void deepvit_chain_bwd_kernel(const 
   for (int64_t row = (int64_t)blockIdx.x * HC_WAVES + wave; row < rows; row += (int64_t)gridDim.x * HC_WAVES) {
     const int64_t bi = row / nq, i = row - bi * nq;
     const int64_t base = bi * H * plane + i * ld;
+    const float* wre_r = wre + opaque_zero();
     float av[NP][H], d0[NP][H];
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
@@ -312,7 +319,7 @@ __global__ __launch_bounds__(64 * HC_WAVES) void deepvit_chain_bwd_kernel(const 
       for (int hh = 0; hh < H; ++hh) {
         float a = 0.f;
 #pragma unroll
-        for (int g = 0; g < H; ++g) a = fmaf(dm[g], wre[hh * H + g], a);
+        for (int g = 0; g < H; ++g) a = fmaf(dm[g], wre_r[hh * H + g], a);
         d0[p][hh] = a;                                                 // dA0
       }
     }

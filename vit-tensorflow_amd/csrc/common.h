@@ -34,16 +34,34 @@ template <> __device__ __forceinline__ void st4<bf16_t>(bf16_t* p, float4 v) {
   *(bf16x4*)p = o;
 }
 
+// Wave-wide reductions on the DPP path (no LDS traffic; the generic __shfl_xor lowers to ds_bpermute_b32, one LDS instruction per
+// step -- 192 of them per row made the fused head-axis kernels LDS-bound).  All 64 lanes must be active.  The result is read from
+// lane 63 into an SGPR, i.e. it is wave-uniform.
+//   quad_perm [1,0,3,2] / [2,3,0,1]: xor 1 / xor 2 inside a quad; row_ror:4 / row_ror:8: rotate inside a 16-lane row;
+//   row_bcast:15 (rows 1,3 += lane 15 of the previous row), row_bcast:31 (rows 2,3 += lane 31): gfx9 DPP controls.
+#define VITX_DPP_STEP(OP, ctrl, rmask, ident)                                                                                         \
+  v = OP(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, (float)(ident)), __builtin_bit_cast(int, v), \
+                                                                    (ctrl), (rmask), 0xF, false)))
+__device__ __forceinline__ float vitx_addf(float a, float b) { return a + b; }
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  VITX_DPP_STEP(vitx_addf, 0xB1, 0xF, 0.f);    // quad_perm [1,0,3,2]
+  VITX_DPP_STEP(vitx_addf, 0x4E, 0xF, 0.f);    // quad_perm [2,3,0,1]
+  VITX_DPP_STEP(vitx_addf, 0x124, 0xF, 0.f);   // row_ror:4
+  VITX_DPP_STEP(vitx_addf, 0x128, 0xF, 0.f);   // row_ror:8  -> every lane holds its row's sum
+  VITX_DPP_STEP(vitx_addf, 0x142, 0xA, 0.f);   // row_bcast:15
+  VITX_DPP_STEP(vitx_addf, 0x143, 0xC, 0.f);   // row_bcast:31 -> lane 63 holds the wave's sum
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+  VITX_DPP_STEP(fmaxf, 0xB1, 0xF, -INFINITY);
+  VITX_DPP_STEP(fmaxf, 0x4E, 0xF, -INFINITY);
+  VITX_DPP_STEP(fmaxf, 0x124, 0xF, -INFINITY);
+  VITX_DPP_STEP(fmaxf, 0x128, 0xF, -INFINITY);
+  VITX_DPP_STEP(fmaxf, 0x142, 0xA, -INFINITY);
+  VITX_DPP_STEP(fmaxf, 0x143, 0xC, -INFINITY);
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
+#undef VITX_DPP_STEP
 
 // exact-erf GELU (vit.py:34) and its derivative
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
@@ -79,6 +97,15 @@ template <> __device__ __forceinline__ float gelu_grad_t<bf16_t>(float x) {
   float e;
   const float phi = gelu_phi_fast(x, e);
   return fmaf(x * 0.39894228040143267794f, e, phi);
+}
+
+// An SGPR zero the optimiser cannot see through.  Adding it to the mixing-matrix pointers INSIDE the row loop keeps the (wave-uniform,
+// scalar) weight loads inside the loop: hoisted out of it they need 256-512 SGPRs at once and the allocator parks them in VGPR lanes
+// (3208 v_readlane per row in the first version of cait_chain_fwd_kernel -- 147 us per launch instead of ~60).
+__device__ __forceinline__ int opaque_zero() {
+  int z;
+  asm volatile("s_mov_b32 %0, 0" : "=s"(z));
+  return z;
 }
 
 static inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
