@@ -324,6 +324,101 @@ __global__ __launch_bounds__(256) void headmix_bwd_mfma_kernel(const float* __re
   }
 }
 
+// DeepViT backward chain up to the softmax, one thread per point: LayerNorm-over-heads VJP -> re-attention mix VJP (dW on the fp32
+// matrix pipe, see headmix_bwd_mfma_kernel).  d(A2) in `da` -> d(A0) written back; the softmax VJP follows as its own (row) kernel.
+// Per-wave partials: [dW (H*H) | dgamma (H) | dbeta (H)].
+template <int H>
+__global__ __launch_bounds__(256) void deepvit_point_bwd_kernel(const float* __restrict__ a0, const float* __restrict__ mixed,
+                                                                float* __restrict__ da, const float* __restrict__ w,
+                                                                const float* __restrict__ gamma, float* __restrict__ partial, int b,
+                                                                int64_t plane, int64_t nvalid_per_row, int64_t ld, float eps) {
+  __shared__ __attribute__((aligned(16))) float scratch[4][2][64 * HMM_PITCH];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* xs = scratch[wave][0];
+  float* ys = scratch[wave][1];
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  float ag[H], ab[H];
+#pragma unroll
+  for (int g = 0; g < H; ++g) { ag[g] = 0.f; ab[g] = 0.f; }
+  const int64_t total = (int64_t)b * plane;
+  const int64_t span = (int64_t)gridDim.x * blockDim.x;
+  const int64_t iters = (total + span - 1) / span;      // uniform trip count: the MFMA needs every lane
+  for (int64_t it = 0; it < iters; ++it) {
+    const int64_t e = it * span + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool valid = e < total;
+    int64_t bi = 0, ij = 0;
+    if (valid) { bi = e / plane; ij = e - bi * plane; valid = (ij % ld) < nvalid_per_row; }
+    float av[H], xh[H], dm[H];
+    float mu = 0.f;
+#pragma unroll
+    for (int g = 0; g < H; ++g) {
+      av[g] = valid ? a0[(bi * H + g) * plane + ij] : 0.f;
+      xh[g] = valid ? mixed[(bi * H + g) * plane + ij] : 0.f;
+      mu += xh[g];
+    }
+    mu /= (float)H;
+    float var = 0.f;
+#pragma unroll
+    for (int g = 0; g < H; ++g) { xh[g] -= mu; var += xh[g] * xh[g]; }
+    const float rs = rsqrtf(var / (float)H + eps);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int g = 0; g < H; ++g) {                                    // same order as headnorm_bwd_kernel
+      xh[g] *= rs;
+      const float d = valid ? da[(bi * H + g) * plane + ij] : 0.f;
+      ab[g] += d;
+      ag[g] += d * xh[g];
+      dm[g] = d * gamma[g];
+      s1 += dm[g];
+      s2 += dm[g] * xh[g];
+    }
+    s1 /= (float)H;
+    s2 /= (float)H;
+#pragma unroll
+    for (int g = 0; g < H; ++g) dm[g] = valid ? rs * (dm[g] - s1 - xh[g] * s2) : 0.f;
+    if (valid) {
+      const float* wr = w + opaque_zero();
+#pragma unroll
+      for (int hh = 0; hh < H; ++hh) {
+        float a = 0.f;
+#pragma unroll
+        for (int g = 0; g < H; ++g) a = fmaf(dm[g], wr[hh * H + g], a);
+        da[(bi * H + hh) * plane + ij] = a;
+      }
+    }
+    float* xr = xs + lane * HMM_PITCH;
+    float* yr = ys + lane * HMM_PITCH;
+#pragma unroll
+    for (int k = 0; k < 16; k += 4) {
+      *(float4*)(xr + k) = make_float4(k + 0 < H ? av[k + 0 < H ? k + 0 : 0] : 0.f, k + 1 < H ? av[k + 1 < H ? k + 1 : 0] : 0.f,
+                                       k + 2 < H ? av[k + 2 < H ? k + 2 : 0] : 0.f, k + 3 < H ? av[k + 3 < H ? k + 3 : 0] : 0.f);
+      *(float4*)(yr + k) = make_float4(k + 0 < H ? dm[k + 0 < H ? k + 0 : 0] : 0.f, k + 1 < H ? dm[k + 1 < H ? k + 1 : 0] : 0.f,
+                                       k + 2 < H ? dm[k + 2 < H ? k + 2 : 0] : 0.f, k + 3 < H ? dm[k + 3 < H ? k + 3 : 0] : 0.f);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const int m = lane & 15, kp = lane >> 4;
+#pragma unroll
+    for (int st = 0; st < 16; ++st) {
+      const float a = xs[(4 * st + kp) * HMM_PITCH + m];
+      const float bq = ys[(4 * st + kp) * HMM_PITCH + m];
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bq, acc, 0, 0, 0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+  float* pw = partial + ((int64_t)blockIdx.x * 4 + wave) * (H * H + 2 * H);
+  const int g16 = lane & 15;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int hh = 4 * (lane >> 4) + r;
+    if (hh < H && g16 < H) pw[hh * H + g16] = acc[r];
+  }
+#pragma unroll
+  for (int g = 0; g < H; ++g) {
+    const float sg = wave_sum(ag[g]), sb = wave_sum(ab[g]);
+    if (lane == 0) { pw[H * H + g] = sg; pw[H * H + H + g] = sb; }
+  }
+}
+
 // LayerNorm over heads at every (b,i,j)  (deepvit.py:59-63)
 template <int HT>
 __global__ __launch_bounds__(256) void headnorm_fwd_kernel(const float* __restrict__ in, const float* __restrict__ gamma,
@@ -494,6 +589,22 @@ void launch_softmax_bwd_rows(const float* p, float* dp, int64_t rows, int n, int
   if (rows == 0) return;
   if (n <= 128) hipLaunchKernelGGL(softmax_bwd_rows16_kernel, dim3((unsigned)ceil_div(rows, 16)), dim3(256), 0, s, p, dp, rows, n, ld);
   else hipLaunchKernelGGL(softmax_bwd_rows_kernel, dim3((unsigned)ceil_div(rows, 4)), dim3(256), 0, s, p, dp, rows, n, ld);
+}
+// DeepViT backward chain: fused point kernel (LayerNorm-over-heads VJP + mix VJP), then the row softmax VJP
+int64_t deepvit_point_bwd_ws_elems(int h) { return (int64_t)(HMM_BLOCKS * 4 + 40) * (h * h + 2 * h); }
+void launch_deepvit_point_bwd(const float* a0, const float* mixed, float* da_inout, const float* w, const float* gamma, float* ws, float* dw,
+                              float* dgamma, float* dbeta, int b, int h, int nq, int nk, int64_t ld, float eps, hipStream_t s) {
+  const int64_t plane = (int64_t)nq * ld;
+  const int nb = (int)std::max<int64_t>(1, std::min<int64_t>(HMM_BLOCKS, ceil_div((int64_t)b * plane, 256)));
+#define CALLB(HT) hipLaunchKernelGGL(deepvit_point_bwd_kernel<HT>, dim3(nb), dim3(256), 0, s, a0, mixed, da_inout, w, gamma, ws, b, plane, (int64_t)nk, ld, eps)
+  if (h == 16) { CALLB(16); } else if (h == 12) { CALLB(12); } else if (h == 8) { CALLB(8); } else { CALLB(4); }
+#undef CALLB
+  const int nparts = nb * 4;
+  const int64_t stride = (int64_t)h * h + 2 * h;
+  float* ws2 = ws + (int64_t)nparts * stride;
+  launch_reduce_partials3(ws, nparts, stride, (int64_t)h * h, 1, dw, nullptr, nullptr, ws2, 1.0f, s);
+  launch_reduce_partials3(ws + (int64_t)h * h, nparts, stride, h, 2, dgamma, dbeta, nullptr, ws2, 1.0f, s);
+  launch_softmax_bwd_rows(a0, da_inout, (int64_t)b * h * nq, nk, ld, s);
 }
 // DeepViT forward chain in two launches: row statistics, then one fused point kernel (see deepvit_point_fwd_kernel)
 bool deepvit_point_fwd_supported(int h, int nk) { return (h == 4 || h == 8 || h == 12 || h == 16) && nk <= 128; }

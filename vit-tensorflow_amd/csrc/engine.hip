@@ -430,6 +430,10 @@ static void attn_generic_bwd(vitx_engine* e, const BlockParams& bp, const AttnVi
     Prof pr(e, "attn_headchain", 0, 0);
     launch_deepvit_chain_bwd(e->sc[0], e->sc[1], dA, e->params + bp.re_w, e->params + bp.re_g, e->red_ws, e->grads + bp.re_w, e->grads + bp.re_g,
                              e->grads + bp.re_b, b, h, a.nq, a.nk, ld, e->cfg.ln_eps, e->stream);
+  } else if (!e->unfused_headops && e->cfg.variant == VITX_VARIANT_DEEPVIT && deepvit_point_fwd_supported(h, a.nk)) {
+    Prof pr(e, "attn_headchain", 0, 0);     // LayerNorm-over-heads VJP + mix VJP in one point kernel, then the softmax VJP
+    launch_deepvit_point_bwd(e->sc[0], e->sc[1], dA, e->params + bp.re_w, e->params + bp.re_g, e->red_ws, e->grads + bp.re_w,
+                             e->grads + bp.re_g, e->grads + bp.re_b, b, h, a.nq, a.nk, ld, e->cfg.ln_eps, e->stream);
   } else {
     Prof pr(e, "attn_generic_headops", 0, 0);
     if (e->cfg.variant == VITX_VARIANT_CAIT) {
@@ -857,7 +861,8 @@ int engine_create(const vitx_config& cfg, vitx_engine** out, std::string& err) {
   // (+ per-M-tile column sums of the fc2-dgrad epilogue: one row per 256 token rows, 32 second-level rows)
   e->red_elems = std::max<int64_t>({layernorm_bwd_ws_elems(d), colsum_ws_elems((int)maxfeat), headmix_ws_elems((int)B, c.heads, 1, 1),
                                     (int64_t)256 * 2 * 32, (int64_t)(512 + 32) * d, (ceil_div(std::max<int64_t>(e->mp, e->mpp), 128) + 40) * (int64_t)m,
-                                    headchain_ws_elems(c.heads), deepvit_point_ws_elems((int)B, c.heads, e->ntok_max)});
+                                    headchain_ws_elems(c.heads), deepvit_point_ws_elems((int)B, c.heads, e->ntok_max),
+                                    deepvit_point_bwd_ws_elems(c.heads)});
   DALLOC(e->red_ws, (size_t)e->red_elems * 4, false);
   HIPCHK(hipStreamSynchronize(e->stream));
   *out = e;

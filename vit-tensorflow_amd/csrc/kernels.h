@@ -105,6 +105,9 @@ void launch_resid_add(const float* resid, const void* t, int t_bf16, float* out,
 void launch_softmax_rows(float* sc, int64_t rows, int n, int64_t ld, hipStream_t s);
 void launch_softmax_bwd_rows(const float* p, float* dp_inout, int64_t rows, int n, int64_t ld, hipStream_t s);
 // DeepViT forward chain (softmax -> re-attention mix -> LayerNorm over heads) as row statistics + one fused point kernel
+int64_t deepvit_point_bwd_ws_elems(int h);
+void launch_deepvit_point_bwd(const float* a0, const float* mixed, float* da_inout, const float* w, const float* gamma, float* ws, float* dw,
+                              float* dgamma, float* dbeta, int b, int h, int nq, int nk, int64_t ld, float eps, hipStream_t s);
 bool deepvit_point_fwd_supported(int h, int nk);
 int64_t deepvit_point_ws_elems(int b, int h, int nq);
 void launch_deepvit_point_fwd(float* s0_inout, float* stats_ws, const float* w, const float* gamma, const float* beta, float* mixed, float* a2,
