@@ -167,13 +167,14 @@ __global__ __launch_bounds__(LNB_THREADS) void layernorm_bwd_kernel(const TD* __
     }
   }
   // fixed-order combine of the block's waves: dgamma, dbeta (, column sums of g_in), through LDS [nw][d]
-  const int npass = want_gsum ? 3 : 2;
-  for (int pass = 0; pass < npass; ++pass) {
+  // (three explicit passes: selecting the accumulator array with a run-time pass index made the compiler keep all three arrays in
+  //  scratch memory for the whole kernel -- 18 KB of scratch traffic per row next to 12 KB of useful HBM traffic)
+  auto combine = [&](const float4(&acc)[VPL], int pass) {
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
       const int c = (lane + 64 * i) * 4;
-      if (c < d) *(float4*)(lds + (int64_t)wib * d + c) = pass == 0 ? ag[i] : (pass == 1 ? ab[i] : as[i]);
+      if (c < d) *(float4*)(lds + (int64_t)wib * d + c) = acc[i];
     }
     __syncthreads();
     for (int c = threadIdx.x; c < d; c += blockDim.x) {
@@ -181,7 +182,10 @@ __global__ __launch_bounds__(LNB_THREADS) void layernorm_bwd_kernel(const TD* __
       for (int w = 0; w < nw; ++w) a += lds[(int64_t)w * d + c];
       partial[((int64_t)blockIdx.x * 3 + pass) * d + c] = a;
     }
-  }
+  };
+  combine(ag, 0);
+  combine(ab, 1);
+  if (want_gsum) combine(as, 2);
 }
 
 // out[c] = alpha * sum_p partial[p*stride + c]; 64 columns x 4 part-groups per block, fixed order.
