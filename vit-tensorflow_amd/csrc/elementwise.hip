@@ -262,24 +262,43 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, in
 
 // ------------------------------------------------------------------ operand preparation
 // fp32 Keras kernel W[in][out] -> bf16 copies: wn[in][ldwn] (dgrad operand) and wt[out][ldwt] (forward operand)
+// 64 x 64 tiles: 16-B loads, 8-B (4 x bf16) stores in both orientations (128-B row segments per 16 lanes); edge tiles element-wise.
 __global__ __launch_bounds__(256) void convert_weight_kernel(const float* __restrict__ w, int in, int out, bf16_t* __restrict__ wn,
                                                              int64_t ldwn, bf16_t* __restrict__ wt, int64_t ldwt) {
-  __shared__ float tile[32][33];
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
-  const int i0 = blockIdx.y * 32, o0 = blockIdx.x * 32;
-  for (int r = ty; r < 32; r += 8) {
-    const int i = i0 + r, o = o0 + tx;
+  __shared__ float tile[64][65];
+  const int i0 = blockIdx.y * 64, o0 = blockIdx.x * 64;
+  const int c4 = (threadIdx.x & 15) * 4, r16 = threadIdx.x >> 4;   // 16 lanes x 4 columns, 16 row slots
+  const bool full = i0 + 64 <= in && o0 + 64 <= out && (out & 3) == 0 && (ldwn & 3) == 0 && (ldwt & 3) == 0;
+  if (full) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int r = r16 + 16 * k;
+      const float4 v = *(const float4*)(w + (int64_t)(i0 + r) * out + o0 + c4);
+      st4<bf16_t>(wn + (int64_t)(i0 + r) * ldwn + o0 + c4, v);
+      tile[r][c4] = v.x; tile[r][c4 + 1] = v.y; tile[r][c4 + 2] = v.z; tile[r][c4 + 3] = v.w;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int o = r16 + 16 * k;   // output row = column o of the tile; this lane writes inputs c4..c4+3 of it
+      st4<bf16_t>(wt + (int64_t)(o0 + o) * ldwt + i0 + c4, make_float4(tile[c4][o], tile[c4 + 1][o], tile[c4 + 2][o], tile[c4 + 3][o]));
+    }
+    return;
+  }
+  for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+    const int r = e >> 6, c = e & 63;
+    const int i = i0 + r, o = o0 + c;
     float v = 0.f;
     if (i < in && o < out) {
       v = w[(int64_t)i * out + o];
       wn[(int64_t)i * ldwn + o] = (bf16_t)v;
     }
-    tile[r][tx] = v;
+    tile[r][c] = v;
   }
   __syncthreads();
-  for (int r = ty; r < 32; r += 8) {
-    const int o = o0 + r, i = i0 + tx;
-    if (i < in && o < out) wt[(int64_t)o * ldwt + i] = (bf16_t)tile[tx][r];
+  for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+    const int o = e >> 6, i = e & 63;
+    if (i0 + i < in && o0 + o < out) wt[(int64_t)(o0 + o) * ldwt + i0 + i] = (bf16_t)tile[i][o];
   }
 }
 
@@ -574,7 +593,7 @@ void launch_colsum(const void* x, int is_bf16, int64_t ld, int rows, int cols, f
 }
 
 void launch_convert_weight(const float* w, int in, int out, bf16_t* wn, int64_t ldwn, bf16_t* wt, int64_t ldwt, hipStream_t s) {
-  dim3 grid((unsigned)ceil_div(out, 32), (unsigned)ceil_div(in, 32)), block(256);
+  dim3 grid((unsigned)ceil_div(out, 64), (unsigned)ceil_div(in, 64)), block(256);
   hipLaunchKernelGGL(convert_weight_kernel, grid, block, 0, s, w, in, out, wn, ldwn, wt, ldwt);
 }
 void launch_transpose_bf16(const bf16_t* in, int64_t ldi, int rows, int cols, bf16_t* out, int64_t ldo, hipStream_t s) {
