@@ -32,6 +32,29 @@ __global__ void unfold_kernel(const float* __restrict__ img, TO* __restrict__ ou
   }
 }
 
+// four consecutive features per thread (16-B load, 8/16-B store); legal when the contiguous (s,c) run and the row pitch are
+// multiples of 4 and the image base / row starts are 16-B aligned -- bit-exact like the scalar form (pure indexing)
+template <typename TO>
+__global__ void unfold4_kernel(const float* __restrict__ img, TO* __restrict__ out, int b, int H, int W, int C, int ph, int pw, int ldo) {
+  const int Hp = H / ph, Wp = W / pw;
+  const int pd = ph * pw * C, run = pw * C, ldo4 = ldo >> 2;
+  const int64_t total = (int64_t)b * Hp * Wp * ldo4;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = e / ldo4;
+    const int f = (int)(e - row * ldo4) * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (f < pd) {
+      const int r = f / run, sc = f - r * run;
+      const int wi = (int)(row % Wp);
+      const int64_t t = row / Wp;
+      const int hi = (int)(t % Hp);
+      const int64_t bi = t / Hp;
+      v = *(const float4*)(img + ((bi * H + (int64_t)hi * ph + r) * W + (int64_t)wi * pw) * C + sc);
+    }
+    st4<TO>(out + row * ldo + f, v);
+  }
+}
+
 // dimg[b][hi*ph+r][wi*pw+s][c] = dpatches[(b,hi,wi)][(r,s,c)]   (inverse of the unfold; bijective)
 __global__ void fold_kernel(const float* __restrict__ dp, int64_t ld, float* __restrict__ dimg, int b, int H, int W, int C, int ph,
                             int pw) {
@@ -385,6 +408,40 @@ __global__ void extract_rows_kernel(const float* __restrict__ g, int b, int ntok
     stf<TO>(out + r * ldo + c, g[((bi * ntok) + tok_off + t) * d + c]);
   }
 }
+template <typename TO>
+__global__ void extract_rows4_kernel(const float* __restrict__ g, int b, int ntok, int tok_off, int np, int d4, TO* __restrict__ out, int64_t ldo) {
+  const int64_t total = (int64_t)b * np * d4;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(e % d4) * 4;
+    const int64_t r = e / d4;
+    const int64_t bi = r / np;
+    const int t = (int)(r - bi * np);
+    st4<TO>(out + r * ldo + c, *(const float4*)(g + ((bi * ntok) + tok_off + t) * (int64_t)(d4 * 4) + c));
+  }
+}
+// out[j][c..c+3] = sum_b g[b][j0+j][c..c+3]: one thread per 4 columns, images summed in ascending order (fixed order)
+__global__ void batch_reduce4_kernel(const float* __restrict__ g, int b, int ntok, int d4, int j0, int nj, float* __restrict__ out) {
+  const int64_t total = (int64_t)nj * d4;
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  const int64_t j = e / d4;
+  const int c = (int)(e - j * d4) * 4;
+  const int64_t d = (int64_t)d4 * 4;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float* p = g + (j0 + j) * d + c;
+  const int64_t stride = (int64_t)ntok * d;
+  int bi = 0;
+  for (; bi + 4 <= b; bi += 4) {   // four independent loads in flight
+    const float4 v0 = *(const float4*)(p + (bi + 0) * stride), v1 = *(const float4*)(p + (bi + 1) * stride);
+    const float4 v2 = *(const float4*)(p + (bi + 2) * stride), v3 = *(const float4*)(p + (bi + 3) * stride);
+    a.x += v0.x; a.y += v0.y; a.z += v0.z; a.w += v0.w;
+    a.x += v1.x; a.y += v1.y; a.z += v1.z; a.w += v1.w;
+    a.x += v2.x; a.y += v2.y; a.z += v2.z; a.w += v2.w;
+    a.x += v3.x; a.y += v3.y; a.z += v3.z; a.w += v3.w;
+  }
+  for (; bi < b; ++bi) { const float4 v = *(const float4*)(p + bi * stride); a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
+  *(float4*)(out + j * d + c) = a;
+}
 __global__ void sum_rows_kernel(const float* __restrict__ in, int rows, int d, float* __restrict__ out) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= d) return;
@@ -505,6 +562,13 @@ inline int grid_for(int64_t total, int block = 256) { return (int)std::min<int64
 void launch_unfold(const float* img, void* out, int out_bf16, int b, int H, int W, int C, int ph, int pw, int64_t ldo, hipStream_t s) {
   const int64_t total = (int64_t)b * (H / ph) * (W / pw) * ldo;
   if (total == 0) return;
+  const bool vec = ((pw * C) % 4 == 0) && (ldo % 4 == 0) && ((W * C) % 4 == 0) && (((uintptr_t)img) % 16 == 0) && (((uintptr_t)out) % 16 == 0) &&
+                   ldo < (1 << 30);
+  if (vec) {
+    if (out_bf16) hipLaunchKernelGGL(unfold4_kernel<bf16_t>, dim3(grid_for(total / 4)), dim3(256), 0, s, img, (bf16_t*)out, b, H, W, C, ph, pw, (int)ldo);
+    else hipLaunchKernelGGL(unfold4_kernel<float>, dim3(grid_for(total / 4)), dim3(256), 0, s, img, (float*)out, b, H, W, C, ph, pw, (int)ldo);
+    return;
+  }
   if (out_bf16) hipLaunchKernelGGL(unfold_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, s, img, (bf16_t*)out, b, H, W, C, ph, pw, ldo);
   else hipLaunchKernelGGL(unfold_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, img, (float*)out, b, H, W, C, ph, pw, ldo);
 }
@@ -621,11 +685,20 @@ void launch_mean_pool_bwd(const float* dp, int b, int ntok, int d, float* g, hip
 }
 void launch_batch_reduce(const float* g, int b, int ntok, int d, int j0, int nj, float* out, hipStream_t s) {
   if (nj <= 0) return;
+  if (d % 4 == 0 && ((uintptr_t)g) % 16 == 0 && ((uintptr_t)out) % 16 == 0) {
+    hipLaunchKernelGGL(batch_reduce4_kernel, dim3((unsigned)ceil_div((int64_t)nj * (d / 4), 64)), dim3(64), 0, s, g, b, ntok, d / 4, j0, nj, out);
+    return;
+  }
   hipLaunchKernelGGL(batch_reduce_kernel, dim3(grid_for((int64_t)nj * d)), dim3(256), 0, s, g, b, ntok, d, j0, nj, out);
 }
 void launch_extract_rows(const float* g, int b, int ntok, int tok_off, int np, int d, void* out, int out_bf16, int64_t ldo, hipStream_t s) {
   const int64_t total = (int64_t)b * np * d;
   if (total == 0) return;
+  if (d % 4 == 0 && ldo % 4 == 0 && ((uintptr_t)g) % 16 == 0 && ((uintptr_t)out) % 16 == 0) {
+    if (out_bf16) hipLaunchKernelGGL(extract_rows4_kernel<bf16_t>, dim3(grid_for(total / 4)), dim3(256), 0, s, g, b, ntok, tok_off, np, d / 4, (bf16_t*)out, ldo);
+    else hipLaunchKernelGGL(extract_rows4_kernel<float>, dim3(grid_for(total / 4)), dim3(256), 0, s, g, b, ntok, tok_off, np, d / 4, (float*)out, ldo);
+    return;
+  }
   if (out_bf16) hipLaunchKernelGGL(extract_rows_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, s, g, b, ntok, tok_off, np, d, (bf16_t*)out, ldo);
   else hipLaunchKernelGGL(extract_rows_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, g, b, ntok, tok_off, np, d, (float*)out, ldo);
 }
