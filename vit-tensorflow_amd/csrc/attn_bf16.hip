@@ -24,7 +24,12 @@ constexpr int ATT_THREADS = 512;   // 8 waves share one head's LDS image (2 per 
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }  // raw v_exp_f32 (inputs are <= 0 or masked)
 
-__device__ __forceinline__ int swz_chunk(int row, int chunk) { return (chunk ^ ((row >> 1) & 7)) << 4; }
+// 16-B chunk swizzle of the 128-B rows.  The key moves in steps of TWO chunks (32 B) per row pair: the transpose reads
+// (ds_read_b64_tr_b16, 32-lane service groups touching 8 rows x 32 B) need rows r and r+2 in different 32-B bank groups -- with a
+// one-chunk step they landed on the same 8 banks (2-way conflict on every transpose read: a quarter of all LDS cycles in these
+// kernels) -- and the row-major ds_read_b128 fragments stay conflict-free (16 distinct (row parity, chunk) pairs per 16-lane group).
+__device__ __forceinline__ int swz_key(int row) { return ((row >> 1) & 3) << 1; }
+__device__ __forceinline__ int swz_chunk(int row, int chunk) { return (chunk ^ swz_key(row)) << 4; }
 
 __device__ __forceinline__ bf16x8 zero8() {
   bf16x8 z;
@@ -60,7 +65,7 @@ __device__ __forceinline__ void stage_head_dma(const bf16_t* src, int64_t stride
   typedef const __attribute__((address_space(1))) void gbl_void_t;
   for (int i = wave; i < npad / 8; i += nwaves) {
     const int row = i * 8 + (lane >> 3);
-    const int c = (lane & 7) ^ ((row >> 1) & 7);
+    const int c = (lane & 7) ^ swz_key(row);
     const bf16_t* p = row < nvalid ? src + (int64_t)row * stride + c * 8 : zero_page + (lane & 7) * 8;
     __builtin_amdgcn_global_load_lds((gbl_void_t*)p, (lds_void_t*)(rm + i * 1024), 16, 0, 0);
   }
@@ -78,8 +83,8 @@ __device__ __forceinline__ bf16x8 frag_trr(const char* rm, int c, int u, int lan
   const int q = lane & 15, g = lane >> 4;
   const int row0 = 32 * u + 4 * g + (q >> 2), row1 = row0 + 16;
   const int b = 32 * c + 8 * (q & 3);
-  const int a0 = row0 * ROWB + ((((b >> 4) ^ ((row0 >> 1) & 7)) << 4) | (b & 15));
-  const int a1 = row1 * ROWB + ((((b >> 4) ^ ((row1 >> 1) & 7)) << 4) | (b & 15));
+  const int a0 = row0 * ROWB + ((((b >> 4) ^ swz_key(row0)) << 4) | (b & 15));
+  const int a1 = row1 * ROWB + ((((b >> 4) ^ swz_key(row1)) << 4) | (b & 15));
   const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(rm + a0));
   const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(rm + a1));
   union { struct { s16x4 a, b; } s; bf16x8 v; } uu;
