@@ -90,6 +90,7 @@ int32_t vitx_param_table_entry(const vitx_config* cfg, int64_t index, char* name
  * CaiT.__init__ (cait.py:156-178).  Validation errors carry the reference's assertion text. */
 int32_t vitx_create(const vitx_config* cfg, vitx_handle* out);
 int32_t vitx_destroy(vitx_handle h);
+int32_t vitx_get_config(vitx_handle h, vitx_config* out);   /* the (defaulted) config a handle was built with */
 
 /* ---- weights: Keras set_weights/get_weights (flat fp32 blob in table order) */
 int32_t vitx_set_params(vitx_handle h, const float* host_blob, int64_t n_elems);
@@ -165,6 +166,54 @@ int32_t vitx_debug_read(vitx_handle h, const char* which, int32_t layer, float* 
  * random data), returns the average ms over `iters` launches; `kernel` selects the tile variant */
 int32_t vitx_bench_gemm(vitx_handle h, int32_t M, int32_t N, int32_t K, int32_t kernel,
                         int32_t epilogue, int32_t iters, float* avg_ms, float* max_abs_err);
+
+/* ---- masked-image-modelling wrappers around a built encoder ("next" row f2 of SURVEY.md section 8):
+ *   MAE(image_size, encoder, decoder_dim, masking_ratio, decoder_depth, decoder_heads, decoder_dim_head)   mae.py:17-45
+ *   SimMIM(image_size, encoder, masking_ratio)                                                            simmim.py:68-84
+ * The wrapper borrows the encoder handle (to_patch / patch_to_emb / pos_embedding[:, 1:] / .transformer: mae.py:36-38,
+ * simmim.py:79-81) and owns its own parameters: MAE {enc_to_dec.kernel/.bias (only when encoder dim != decoder_dim, else the
+ * reference's Identity), mask_token, decoder_pos_emb.embeddings, to_pixels.kernel/.bias} plus a decoder Transformer that is an
+ * ordinary handle (vitx_mim_decoder: use its "transformer.*" table entries); SimMIM {mask_token, to_pixels.kernel/.bias}.
+ * The random masking indices are an input (the reference draws them with tf.random.uniform + argsort / top_k, mae.py:58,
+ * simmim.py:108): MAE int32 [b, num_patches] = rand_indices, whose first num_masked columns are the masked patches;
+ * SimMIM int32 [b, num_masked] = masked_indices.  num_masked = int(masking_ratio * num_patches). */
+enum { VITX_MIM_MAE = 0, VITX_MIM_SIMMIM = 1 };
+typedef struct vitx_mim_config {
+  int32_t kind;
+  int32_t decoder_dim, decoder_depth, decoder_heads, decoder_dim_head; /* MAE only (mae.py:21-25) */
+  /* MAE: 1 = the loss exactly as written, tf.reduce_mean(tf.square(pred_pixel_values, masked_patches)) (mae.py:90), where the
+   * second positional argument of tf.square is `name`, i.e. mean(pred^2); 0 = the evidently intended mean((pred - masked_patches)^2).
+   * SimMIM ignores it (simmim.py:128 is a plain L1). */
+  int32_t literal_loss;
+  double masking_ratio;
+  int32_t reserved[8];
+} vitx_mim_config;
+typedef struct vitx_mim* vitx_mim_handle;
+
+int32_t vitx_mim_create(vitx_handle encoder, const vitx_mim_config* cfg, vitx_mim_handle* out);
+int32_t vitx_mim_destroy(vitx_mim_handle m);           /* does not destroy the encoder */
+vitx_handle vitx_mim_decoder(vitx_mim_handle m);       /* MAE: Transformer(dim=decoder_dim, ..., mlp_dim=4*decoder_dim) mae.py:43; else NULL */
+int32_t vitx_mim_param_table_size(vitx_mim_handle m, int64_t* n_tensors, int64_t* n_elems);
+int32_t vitx_mim_param_table_entry(vitx_mim_handle m, int64_t index, char* name, int32_t name_cap,
+                                   int64_t shape[4], int32_t* rank, int64_t* offset_elems);
+int32_t vitx_mim_set_params(vitx_mim_handle m, const float* host_blob, int64_t n_elems);
+int32_t vitx_mim_get_params(vitx_mim_handle m, float* host_blob, int64_t n_elems);
+int32_t vitx_mim_get_grads(vitx_mim_handle m, float* host_blob, int64_t n_elems);
+int32_t vitx_mim_params_dev(vitx_mim_handle m, float** params_dev, float** grads_dev, int64_t* n_arena_elems);
+int32_t vitx_mim_num_masked(vitx_mim_handle m, int32_t H, int32_t W, int32_t* num_patches, int32_t* num_masked);
+/* MAE.call (mae.py:47-92) / SimMIM.call (simmim.py:86-130): returns the reconstruction loss.  The host variant validates the
+ * indices (range, distinct per image: simmim.py:31) and synchronises; the _dev variant trusts them and stays asynchronous. */
+int32_t vitx_mim_forward(vitx_mim_handle m, const float* img_host, int32_t b, int32_t H, int32_t W,
+                         const int32_t* indices_host, float* loss_host);
+int32_t vitx_mim_forward_dev(vitx_mim_handle m, const float* img_dev, int32_t b, int32_t H, int32_t W,
+                             const int32_t* indices_dev, float* loss_dev_or_null);
+/* VJP of the forward above for d(loss) = 1 (README.md:746-749 style training): wrapper gradients -> vitx_mim_get_grads,
+ * encoder gradients -> the encoder's arena (transformer blocks, patch_embedding.*, pos_embedding rows 1..num_patches; all other
+ * entries zero), decoder gradients -> the decoder handle's arena.  Unlike the reference -- whose `.numpy()` indexing
+ * (mae.py:62, simmim.py:119) silently detaches everything upstream of it from the tape -- the gather is differentiable. */
+int32_t vitx_mim_backward(vitx_mim_handle m);
+/* copy a tensor of the last forward to the host: "pred", "target", "patches", "encoded", "decoded" (MAE) */
+int32_t vitx_mim_read(vitx_mim_handle m, const char* which, float* out_host, int64_t cap_elems, int64_t* n_elems);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,181 @@
+"""GPU parity tier for the masked-image-modelling wrappers (SURVEY.md section 8 "next" row f2): MAE.call / SimMIM.call
+(mae.py:47-92, simmim.py:86-130) through the C ABI against oracle/ref_wrappers.py on the same weights, images and indices:
+loss, predicted pixel values and every gradient (encoder, decoder Transformer, wrapper variables).
+Tolerances: fp32 parity mode 1e-4 of the tensor's max (north_star asks for 1e-3); bf16 mode against the oracle with the
+same bf16 rounding points, bound written at each assert."""
+import numpy as np
+import pytest
+
+from oracle import ref_torch, ref_wrappers as RW, spec
+from vit_tensorflow import _native as N
+
+pytestmark = pytest.mark.gpu
+
+ENC = {
+    "fp32": dict(image_size=32, patch_size=8, num_classes=5, dim=32, depth=2, heads=2, mlp_dim=64, dim_head=16),
+    "bf16": dict(image_size=64, patch_size=8, num_classes=5, dim=128, depth=2, heads=2, mlp_dim=256, dim_head=64),
+}
+DEC = {"fp32": dict(decoder_dim=24, decoder_depth=1, decoder_heads=2, decoder_dim_head=8),
+       "bf16": dict(decoder_dim=64, decoder_depth=1, decoder_heads=2, decoder_dim_head=32)}
+
+
+def _encoder(compute, b, seed=1, variant="vit"):
+    from vit_tensorflow import ViT
+    from vit_tensorflow.deepvit import DeepViT
+    kw = ENC[compute]
+    cfg = spec.make_config(variant, **kw)
+    P = spec.init_params(cfg, seed, randomize_all=True)
+    m = (ViT if variant == "vit" else DeepViT)(**kw, compute=compute, max_batch=b, seed=0)
+    m.load_state_dict({k: np.asarray(a, np.float32) for k, a in P.items()})
+    return cfg, P, m
+
+
+def _randomize(model, seed):
+    rng = np.random.default_rng(seed)
+    sd = {n: (0.3 * rng.standard_normal(w.shape)).astype(np.float32) for n, w in model.state_dict().items()}
+    model.load_state_dict(sd)
+    return {k: v.astype(np.float64) for k, v in sd.items()}
+
+
+def _close(a, ref, tol, what, norm=False):
+    ref = np.asarray(ref)
+    diff = np.asarray(a, np.float64).reshape(ref.shape) - ref
+    if norm:   # gradients of an L1 loss are sums of sign() terms: a bf16-sized change of pred flips a few of them outright
+        assert np.linalg.norm(diff) <= tol * np.linalg.norm(ref) + 1e-7, f"{what}: |diff| {np.linalg.norm(diff):.3e} vs |ref| {np.linalg.norm(ref):.3e}"
+        return
+    err = np.abs(diff).max()
+    assert err <= tol * max(1e-6, np.abs(ref).max()) + 1e-7, f"{what}: err {err:.3e} vs max {np.abs(ref).max():.3e}"
+
+
+def _images(cfg, b, seed=7):
+    h, w = cfg["image_size"]
+    return np.random.default_rng(seed).standard_normal((b, h, w, 3)).astype(np.float32)
+
+
+@pytest.mark.parametrize("compute,literal,same_dim", [("fp32", True, False), ("fp32", False, False), ("fp32", False, True),
+                                                      ("bf16", False, False)])
+def test_mae_matches_the_oracle(compute, literal, same_dim):
+    from vit_tensorflow.mae import MAE
+    b = 3
+    ecfg, E, enc = _encoder(compute, b)
+    dkw = dict(DEC[compute])
+    if same_dim:
+        dkw["decoder_dim"] = ecfg["dim"]          # enc_to_dec is the Identity layer (mae.py:41)
+    mae = MAE(image_size=ecfg["image_size"], encoder=enc, masking_ratio=0.75, literal_loss=literal, seed=3, **dkw)
+    Wm = _randomize(mae, 11)
+    assert ("enc_to_dec.kernel" in Wm) == (not same_dim)
+    dcfg = spec.make_config("vit", image_size=ecfg["image_size"], patch_size=ecfg["patch_size"], num_classes=1, dim=dkw["decoder_dim"],
+                            depth=dkw["decoder_depth"], heads=dkw["decoder_heads"], mlp_dim=4 * dkw["decoder_dim"],
+                            dim_head=dkw["decoder_dim_head"])
+    D = spec.init_params(dcfg, 5, randomize_all=True)
+    assert [n for n, _, _ in mae.decoder._table] == [n for n, _, _ in spec.param_spec(dcfg)]
+    mae.decoder.load_state_dict({k: np.asarray(a, np.float32) for k, a in D.items()})
+    img = _images(ecfg, b)
+    npat, nm = mae.num_masked()
+    assert (npat, nm) == ((ecfg["image_size"][0] // 8) ** 2, int(0.75 * npat))
+    perm = np.argsort(np.random.default_rng(9).uniform(size=(b, npat)), axis=-1).astype(np.int32)
+    loss = mae(img, indices=perm)
+    grads = mae.backward()
+    q = ref_torch.bf16_round if compute == "bf16" else None
+    rl, rpred, ge, gd, gw = RW.mae_forward_backward(ecfg, dcfg, E, D, Wm, img, perm, 0.75, literal_loss=literal, q=q)
+    tol = 1e-4 if compute == "fp32" else 3e-2     # bf16: same rounding points, different accumulation order, bf16 P in attention
+    assert abs(loss - rl) <= tol * abs(rl), (loss, rl)
+    _close(mae.read("pred"), rpred, tol, "pred_pixel_values")
+    gtol = tol if compute == "fp32" else 6e-2
+    for k, r in gw.items():
+        _close(grads[k], r, gtol, k)
+    for k, r in ge.items():
+        _close(grads["encoder." + k], r, gtol, "encoder." + k)
+    for k, r in gd.items():
+        if k.startswith("transformer."):
+            _close(grads["decoder." + k], r, gtol, "decoder." + k)
+    # encoder entries the wrapper never touches are exactly zero; so is the decoder_pos_emb row of the cls slot (mae.py:37)
+    assert not grads["encoder.cls_token"].any() and not grads["encoder.mlp_head.kernel"].any() and not grads["encoder.pos_embedding"][0, 0].any()
+    assert not grads["decoder_pos_emb.embeddings"][npat].any()
+
+
+@pytest.mark.parametrize("compute,variant", [("fp32", "vit"), ("fp32", "deepvit"), ("bf16", "vit")])
+def test_simmim_matches_the_oracle(compute, variant):
+    from vit_tensorflow.simmim import SimMIM
+    b = 3
+    ecfg, E, enc = _encoder(compute, b, variant=variant)
+    mim = SimMIM(image_size=ecfg["image_size"], encoder=enc, masking_ratio=0.5, seed=3)
+    Ws = _randomize(mim, 12)
+    img = _images(ecfg, b, 8)
+    npat, nm = mim.num_masked()
+    midx = np.argsort(-np.random.default_rng(10).uniform(size=(b, npat)), axis=-1)[:, :nm].astype(np.int32)
+    loss = mim(img, indices=midx)
+    grads = mim.backward()
+    q = ref_torch.bf16_round if compute == "bf16" else None
+    rl, rpred, ge, gw = RW.simmim_forward_backward(ecfg, E, Ws, img, midx, 0.5, q=q)
+    tol = 1e-4 if compute == "fp32" else 3e-2
+    assert abs(loss - rl) <= tol * abs(rl), (loss, rl)
+    _close(mim.read("pred"), rpred, tol, "pred_pixel_values")
+    gtol, nrm = (tol, False) if compute == "fp32" else (8e-2, True)   # bf16: relative L2 error per tensor (see _close)
+    for k, r in gw.items():
+        _close(grads[k], r, gtol, k, nrm)
+    for k, r in ge.items():
+        _close(grads["encoder." + k], r, gtol, "encoder." + k, nrm)
+    target = mim.read("target").reshape(b, nm, -1)
+    patches = mim.read("patches").reshape(b, npat, -1)
+    assert np.array_equal(target, np.stack([patches[i][midx[i]] for i in range(b)]))      # index work is bit-exact
+    assert np.array_equal(patches, ref_torch.patch_unfold(__import__("torch").tensor(img), 8, 8).numpy())
+
+
+def test_wrapper_index_properties_and_determinism():
+    """Size-independent properties: the loss does not depend on the order inside the masked / visible index sets, two runs are
+    bit-identical, and the default draws are what the reference draws (a permutation per image / top-k of distinct patches)."""
+    from vit_tensorflow.mae import MAE
+    from vit_tensorflow.simmim import SimMIM
+    b = 4
+    ecfg, _, enc = _encoder("fp32", b)
+    mae = MAE(image_size=32, encoder=enc, decoder_dim=24, masking_ratio=0.75, decoder_depth=1, decoder_heads=2, decoder_dim_head=8,
+              literal_loss=False, seed=1)
+    img = _images(ecfg, b, 3)
+    l0 = mae(img)
+    perm = mae.last_indices
+    assert perm.shape == (b, 16) and all(sorted(r) == list(range(16)) for r in perm.tolist())
+    g0 = mae.backward()
+    l1 = mae(img, indices=perm)
+    g1 = mae.backward()
+    assert l0 == l1 and all(np.array_equal(g0[k], g1[k]) for k in g0)
+    p2 = perm.copy()
+    p2[:, :12] = p2[:, :12][:, ::-1]
+    p2[:, 12:] = p2[:, 12:][:, [3, 1, 0, 2]]
+    assert abs(mae(img, indices=p2) - l0) <= 1e-5 * abs(l0)
+    mim = SimMIM(image_size=32, encoder=enc, masking_ratio=0.5, seed=2)
+    s0 = mim(img)
+    midx = mim.last_indices
+    assert midx.shape == (b, 8) and all(len(set(r)) == 8 for r in midx.tolist())
+    assert abs(mim(img, indices=midx[:, ::-1].copy()) - s0) <= 1e-5 * abs(s0)
+    # the wrappers share one encoder: its ordinary forward still works afterwards, and so does the other wrapper
+    logits = enc(img, training=False)
+    assert np.isfinite(logits).all() and abs(mae(img, indices=perm) - l0) <= 1e-6 * abs(l0)
+
+
+def test_wrapper_errors_and_regrowth():
+    from vit_tensorflow.mae import MAE
+    from vit_tensorflow.simmim import SimMIM
+    from vit_tensorflow.cait import CaiT
+    ecfg, _, enc = _encoder("fp32", 2)
+    with pytest.raises(AssertionError, match="masking ratio must be kept between 0 and 1"):
+        SimMIM(image_size=32, encoder=enc, masking_ratio=1.0)
+    mim = SimMIM(image_size=32, encoder=enc, masking_ratio=0.5, seed=0)
+    img = _images(ecfg, 2)
+    with pytest.raises(N.VitxError, match="between 0 and"):
+        mim(img, indices=np.full((2, 8), 16, np.int32))
+    with pytest.raises(N.VitxError, match="distinct"):
+        mim(img, indices=np.zeros((2, 8), np.int32))
+    fresh = SimMIM(image_size=32, encoder=enc, masking_ratio=0.5, seed=0)
+    with pytest.raises(N.VitxError, match="preceding forward"):
+        fresh.backward()
+    cait = CaiT(image_size=32, patch_size=8, num_classes=5, dim=32, depth=1, cls_depth=1, heads=2, mlp_dim=64, dim_head=16, max_batch=2)
+    with pytest.raises(N.VitxError, match="ViT / DeepViT"):
+        MAE(image_size=32, encoder=cait, decoder_dim=24)
+    # a batch beyond the encoder's device plan rebuilds encoder and wrapper; weights (incl. the decoder's) survive
+    mae = MAE(image_size=32, encoder=enc, decoder_dim=24, decoder_heads=2, decoder_dim_head=8, seed=4)
+    perm = np.argsort(np.random.default_rng(1).uniform(size=(2, 16)), axis=-1).astype(np.int32)
+    l_small = mae(img, indices=perm)
+    big = np.concatenate([img, img, img], axis=0)
+    l_big = mae(big, indices=np.concatenate([perm, perm, perm], axis=0))
+    assert enc._cfg.max_batch >= 6 and abs(l_big - l_small) <= 1e-5 * abs(l_small)

@@ -12,6 +12,7 @@ static int fail(int code, const std::string& msg) {
   g_last_error = msg;
   return code;
 }
+int capi_fail(int code, const std::string& msg) { return fail(code, msg); }   // shared with mim.hip
 #define CAPI_HIP(x)                                                                                    \
   do {                                                                                                 \
     hipError_t e_ = (x);                                                                               \
@@ -77,6 +78,12 @@ int32_t vitx_create(const vitx_config* cfg, vitx_handle* out) {
   *out = e;
   return VITX_OK;
   CAPI_CATCH
+}
+
+int32_t vitx_get_config(vitx_handle h, vitx_config* out) {
+  if (!h || !out) return fail(VITX_ERR_INVALID, "null argument");
+  *out = h->cfg;
+  return VITX_OK;
 }
 
 int32_t vitx_destroy(vitx_handle h) {

@@ -108,6 +108,11 @@ struct vitx_engine {
   bool have_fwd = false;
   bool have_tf = false;              // saved activations describe a transformer_forward(tokens) of [tf_b, tf_n, dim]
   int tf_b = 0, tf_n = 0;
+  bool have_pt = false;              // e->patches holds the unfolded patches of a patch_tokens_forward of [pt_b, pt_np] patches
+  int pt_b = 0, pt_np = 0;
+  int64_t patch_rows = -1;           // rows of e->patches written by the last unfold (rows beyond it are zero)
+  void* pt_dy = nullptr;             // [mpp, dim] T copy of d(tokens) for the patch-embedding weight gradient (allocated on first use)
+  int64_t pt_dy_rows = -1;
   int last_b = 0, last_np = 0, last_ntok = 0, last_H = 0, last_W = 0, last_training = 0;
   uint64_t last_seed = 0;
   std::vector<std::vector<bool>> layer_kept;   // per stage: blocks that survived CaiT layer dropout in the last forward
@@ -136,6 +141,9 @@ int engine_forward(vitx_engine* e, const float* img_dev, int b, int H, int W, in
 int engine_backward(vitx_engine* e, const float* dlogits_dev, float* dimg_dev, std::string& err);
 int engine_transformer_forward(vitx_engine* e, const float* tokens_dev, int b, int n, float* out_dev, std::string& err);
 int engine_transformer_backward(vitx_engine* e, const float* dout_dev, float* dtokens_dev, std::string& err);
+int engine_patch_tokens_forward(vitx_engine* e, const float* img_dev, int b, int H, int W, float* tokens_dev, float* patches_f32_dev_or_null,
+                                std::string& err);
+int engine_patch_tokens_backward(vitx_engine* e, const float* dtokens_dev, std::string& err);
 void engine_refresh_weights(vitx_engine* e);
 int engine_bench_gemm(vitx_engine* e, int M, int N, int K, int kernel, int epilogue, int iters, float* avg_ms, float* max_err,
                       std::string& err);

@@ -886,6 +886,15 @@ static void ensure_geometry(vitx_engine* e, int b, int ntok) {
   e->zero_geom = geom;
 }
 
+// e->patches is written by the full forward (geometry (b, ntok)) and by patch_tokens_forward (its own geometry): keep "rows beyond
+// the last unfold are zero" (K padding of the patch-embedding weight gradient) whichever of the two ran before
+static void prepare_patch_rows(vitx_engine* e, int64_t rows) {
+  if (e->patch_rows >= 0 && e->patch_rows != rows && e->bf16)
+    (void)hipMemsetAsync(e->patches, 0, (size_t)e->mpp * e->pd_k * e->esz, e->stream);
+  e->patch_rows = rows;
+  e->have_pt = false;
+}
+
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
@@ -955,6 +964,7 @@ int engine_forward(vitx_engine* e, const float* img_dev, int b, int H, int W, in
   if (e->params_dirty) engine_refresh_weights(e);
   Stage& s0 = e->stages[0];
   float* x0 = s0.depth > 0 ? s0.ba[0].x_in : e->tmp_f32;
+  prepare_patch_rows(e, (int64_t)b * np);
   {
     Prof pr(e, "patch_unfold", 0, (double)b * H * W * c.channels * 4 + (double)b * np * e->pd_k * e->esz);
     launch_unfold(img_dev, e->patches, T, b, H, W, c.channels, c.patch_h, c.patch_w, e->pd_k, e->stream);   // vit.py:142
@@ -1046,6 +1056,54 @@ int engine_transformer_backward(vitx_engine* e, const float* dout_dev, float* dt
   for (int l = s0.depth - 1; l >= 0; --l)
     if ((rc = block_backward(e, s0, 0, l, b, n, 0, 0.f, 0, err)) != VITX_OK) return rc;
   if (dtokens_dev) HIPCHK(hipMemcpyAsync(dtokens_dev, e->g, bytes, hipMemcpyDeviceToDevice, e->stream));
+  return VITX_OK;
+}
+
+// The first two layers of encoder.patch_embedding plus the position rows the wrappers add themselves (mae.py:49-55,
+// simmim.py:88-100): tokens[b, p] = patches[b, p] @ W + bias + pos_embedding[0, 1 + p], no cls row.  Optionally also the fp32
+// patches (the reconstruction target, mae.py:65 / simmim.py:125).
+int engine_patch_tokens_forward(vitx_engine* e, const float* img_dev, int b, int H, int W, float* tokens_dev, float* patches_f32_dev,
+                                std::string& err) {
+  const vitx_config& c = e->cfg;
+  if (c.variant == VITX_VARIANT_CAIT) { err = "patch_tokens_forward: ViT / DeepViT only"; return VITX_ERR_UNSUPPORTED; }
+  if (b <= 0 || b > c.max_batch) { err = "batch must be in [1, max_batch]"; return VITX_ERR_INVALID; }
+  if (H <= 0 || W <= 0 || H > c.image_h || W > c.image_w || H % c.patch_h || W % c.patch_w) {
+    err = "Image dimensions must be divisible by the patch size.";
+    return VITX_ERR_INVALID;
+  }
+  const int np = (H / c.patch_h) * (W / c.patch_w), d = c.dim, T = e->bf16;
+  if (e->params_dirty) engine_refresh_weights(e);
+  prepare_patch_rows(e, (int64_t)b * np);
+  {
+    Prof pr(e, "patch_unfold", 0, (double)b * H * W * c.channels * 4 + (double)b * np * e->pd_k * e->esz);
+    launch_unfold(img_dev, e->patches, T, b, H, W, c.channels, c.patch_h, c.patch_w, e->pd_k, e->stream);
+    if (patches_f32_dev) launch_unfold(img_dev, patches_f32_dev, 0, b, H, W, c.channels, c.patch_h, c.patch_w, e->pd, e->stream);
+  }
+  EpiParams ep;
+  ep.out = tokens_dev; ep.ldo = d; ep.pos = e->params + e->pos + d; ep.ldr = d;   // pos row of patch p is 1 + p
+  ep.np = np; ep.ntok = np; ep.tok_off = 0;
+  dense_fwd(e, e->patches, e->pd_k, b * np, e->patch, EPI_PATCH, ep);
+  e->have_pt = true; e->pt_b = b; e->pt_np = np;
+  return VITX_OK;
+}
+
+// VJP of the call above: d(tokens) [b, np, dim] -> gradient-arena entries of patch_embedding.kernel / .bias and of
+// pos_embedding rows 1..np (overwritten; call it after transformer_backward, which clears the arena).
+int engine_patch_tokens_backward(vitx_engine* e, const float* dtokens_dev, std::string& err) {
+  if (!e->have_pt) { err = "patch_tokens_backward requires a preceding patch_tokens_forward"; return VITX_ERR_STATE; }
+  const int b = e->pt_b, np = e->pt_np, d = e->cfg.dim, T = e->bf16;
+  const int64_t rows = (int64_t)b * np;
+  if (!e->pt_dy) DALLOC(e->pt_dy, (size_t)e->mpp * d * e->esz, false);
+  if (e->pt_dy_rows >= 0 && e->pt_dy_rows != rows && T) HIPCHK(hipMemsetAsync(e->pt_dy, 0, (size_t)e->mpp * d * e->esz, e->stream));
+  e->pt_dy_rows = rows;
+  {
+    Prof pr(e, "embed_bwd", 0, (double)rows * d * 4);
+    float* dpos = e->grads + e->pos + d;
+    launch_batch_reduce(dtokens_dev, b, np, d, 0, np, dpos, e->stream);                  // dpos[1 + p] = sum_b dtokens[b, p]
+    launch_sum_rows(dpos, np, d, e->grads + e->patch.b, e->stream);                      // dbias = sum over every patch row
+    launch_extract_rows(dtokens_dev, b, np, 0, np, d, e->pt_dy, T, d, e->stream);        // T copy (identity in parity mode)
+  }
+  dense_wgrad(e, e->patches, e->pd_k, e->pt_dy, d, (int)rows, e->patch);
   return VITX_OK;
 }
 

@@ -134,3 +134,25 @@ void launch_scale_grad(const void* fx, int is_bf16, int64_t ldf, const float* g,
 void launch_mul_scale(const float* g, int64_t ldg, const float* scale, void* out, int out_bf16, int64_t ldo, int rows, int d,
                       hipStream_t s);          // out[T] = g * scale[col]
 void launch_broadcast_rows(const float* src, int d, float* dst, int rows, hipStream_t s);  // dst[r][:] = src[:]
+
+// ---------------------------------------------------------------- mim_ops.hip (MAE / SimMIM index, masking and loss kernels)
+// idx: int32 [b, ldi]; inv: int32 [b, n] with inv[b, idx[b, j]] = j for j in [j0, j1), -1 elsewhere
+void launch_index_inverse(const int32_t* idx, int64_t ldi, int b, int j0, int j1, int n, int32_t* inv, hipStream_t s);
+// out[b, j, :] = src[b * src_batch_stride + idx[b, j0 + j] * d + :], j < k   (src_batch_stride = 0: one table for every image)
+void launch_gather_rows(const float* src, int64_t src_batch_stride, const int32_t* idx, int64_t ldi, int j0, int b, int k, int d, float* out,
+                        hipStream_t s);
+// dst[b, t, :] = inv[b, t] in [j0, j1) ? src[b, inv[b, t] - j0, :] : 0        (src: [b, k_src, d], dst: [b, n, d])
+void launch_scatter_rows(const float* src, int k_src, const int32_t* inv, int j0, int j1, int b, int n, int d, float* dst, hipStream_t s);
+// dtab[t, :] (= | +=) sum_b (inv[b, t] in [j0, j1) ? src[b, inv[b, t] - j0, :] : 0)
+void launch_table_grad(const float* src, int k_src, const int32_t* inv, int j0, int j1, int b, int n, int d, int accumulate, float* dtab,
+                       hipStream_t s);
+void launch_mae_assemble(const float* proj, const float* mask_token, const float* dpos, const int32_t* idx, int b, int np, int nm, int d, float* out,
+                         hipStream_t s);
+void launch_select_rowsum(const float* x, const int32_t* inv_or_null, int j0, int j1, int b, int n, int d, float* partial_ws, float* out,
+                          hipStream_t s);   // partial_ws: b * d floats
+void launch_simmim_select(float* x, const int32_t* inv, const float* mask_token, const float* pos, int b, int n, int d, hipStream_t s);
+void launch_zero_selected_rows(float* x, const int32_t* inv, int64_t rows, int d, hipStream_t s);
+int64_t recon_loss_ws_elems(int64_t count);
+// kind 0: squared, 1: absolute; loss_out = scale * sum f(pred - target), dpred = scale * f'(pred - target); target may be null (= 0)
+void launch_recon_loss(const float* pred, const float* target_or_null, int64_t count, int kind, float scale, float* dpred, float* partial_ws,
+                       float* loss_out, hipStream_t s);

@@ -92,6 +92,8 @@ class VitxModel:
         self._cfg = cfg
         self.compute = compute
         self._handle: Optional[C.c_void_p] = None
+        self._handle_gen = 0                           # bumped whenever the device plan is (re)built: wrappers hanging off it follow
+        self._borrowed = False                         # True: the handle belongs to a wrapper object (MAE's decoder)
         self._table, self._n = N.param_table(cfg)      # C library is the single source of the order
         self._blob = np.zeros(self._n, dtype=np.float32)
         self._device_newer = False
@@ -124,6 +126,8 @@ class VitxModel:
         l = N.lib()
         if self._handle is not None and batch <= self._cfg.max_batch:
             return self._handle
+        if self._borrowed:
+            raise N.VitxError(N.ERR_INVALID, "batch must be in [1, max_batch] (this model's device plan belongs to its wrapper)")
         if self._handle is not None:   # grow: keep the weights, rebuild the device plan
             self._pull_params()
             N.check(l.vitx_destroy(self._handle))
@@ -132,6 +136,7 @@ class VitxModel:
         h = C.c_void_p()
         N.check(l.vitx_create(C.byref(self._cfg), C.byref(h)))
         self._handle = h
+        self._handle_gen += 1
         self._push_params()
         return h
 
@@ -147,7 +152,7 @@ class VitxModel:
 
     def __del__(self):
         try:
-            if getattr(self, "_handle", None) is not None:
+            if getattr(self, "_handle", None) is not None and not getattr(self, "_borrowed", False):
                 N.lib().vitx_destroy(self._handle)
                 self._handle = None
         except Exception:

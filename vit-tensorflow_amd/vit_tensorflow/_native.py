@@ -46,6 +46,19 @@ class KernelStat(C.Structure):
                 ("bytes", C.c_double)]
 
 
+MIM_MAE, MIM_SIMMIM = 0, 1
+
+
+class MimConfig(C.Structure):
+    _fields_ = [
+        ("kind", C.c_int32),
+        ("decoder_dim", C.c_int32), ("decoder_depth", C.c_int32), ("decoder_heads", C.c_int32), ("decoder_dim_head", C.c_int32),
+        ("literal_loss", C.c_int32),
+        ("masking_ratio", C.c_double),
+        ("reserved", C.c_int32 * 8),
+    ]
+
+
 GRAD_READY_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int64, C.c_int64)
 
 # every symbol include/vitx.h declares: (name, restype, argtypes)
@@ -57,6 +70,7 @@ SYMBOLS: List[Tuple[str, object, list]] = [
     ("vitx_param_table_entry", C.c_int32, [_P(Config), C.c_int64, C.c_char_p, C.c_int32, _P(C.c_int64), _P(C.c_int32), _P(C.c_int64)]),
     ("vitx_create", C.c_int32, [_P(Config), _P(C.c_void_p)]),
     ("vitx_destroy", C.c_int32, [C.c_void_p]),
+    ("vitx_get_config", C.c_int32, [C.c_void_p, _P(Config)]),
     ("vitx_set_params", C.c_int32, [C.c_void_p, C.c_void_p, C.c_int64]),
     ("vitx_get_params", C.c_int32, [C.c_void_p, C.c_void_p, C.c_int64]),
     ("vitx_get_grads", C.c_int32, [C.c_void_p, C.c_void_p, C.c_int64]),
@@ -85,6 +99,20 @@ SYMBOLS: List[Tuple[str, object, list]] = [
     ("vitx_workspace_bytes", C.c_int32, [C.c_void_p, _P(C.c_int64)]),
     ("vitx_debug_read", C.c_int32, [C.c_void_p, C.c_char_p, C.c_int32, C.c_void_p, C.c_int64, _P(C.c_int64)]),
     ("vitx_bench_gemm", C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P(C.c_float), _P(C.c_float)]),
+    ("vitx_mim_create", C.c_int32, [C.c_void_p, _P(MimConfig), _P(C.c_void_p)]),
+    ("vitx_mim_destroy", C.c_int32, [C.c_void_p]),
+    ("vitx_mim_decoder", C.c_void_p, [C.c_void_p]),
+    ("vitx_mim_param_table_size", C.c_int32, [C.c_void_p, _P(C.c_int64), _P(C.c_int64)]),
+    ("vitx_mim_param_table_entry", C.c_int32, [C.c_void_p, C.c_int64, C.c_char_p, C.c_int32, _P(C.c_int64), _P(C.c_int32), _P(C.c_int64)]),
+    ("vitx_mim_set_params", C.c_int32, [C.c_void_p, C.c_void_p, C.c_int64]),
+    ("vitx_mim_get_params", C.c_int32, [C.c_void_p, C.c_void_p, C.c_int64]),
+    ("vitx_mim_get_grads", C.c_int32, [C.c_void_p, C.c_void_p, C.c_int64]),
+    ("vitx_mim_params_dev", C.c_int32, [C.c_void_p, _P(C.c_void_p), _P(C.c_void_p), _P(C.c_int64)]),
+    ("vitx_mim_num_masked", C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, _P(C.c_int32), _P(C.c_int32)]),
+    ("vitx_mim_forward", C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    ("vitx_mim_forward_dev", C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    ("vitx_mim_backward", C.c_int32, [C.c_void_p]),
+    ("vitx_mim_read", C.c_int32, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64, _P(C.c_int64)]),
 ]
 
 _lib = None
@@ -123,5 +151,20 @@ def param_table(cfg: Config):
     rank, off = C.c_int32(), C.c_int64()
     for i in range(nt.value):
         check(l.vitx_param_table_entry(C.byref(cfg), i, name, 256, shape, C.byref(rank), C.byref(off)))
+        out.append((name.value.decode(), tuple(int(shape[k]) for k in range(rank.value)), int(off.value)))
+    return out, int(ne.value)
+
+
+def mim_param_table(handle):
+    """[(name, shape, offset)] of a MAE / SimMIM wrapper's own parameters."""
+    l = lib()
+    nt, ne = C.c_int64(), C.c_int64()
+    check(l.vitx_mim_param_table_size(handle, C.byref(nt), C.byref(ne)))
+    out = []
+    name = C.create_string_buffer(256)
+    shape = (C.c_int64 * 4)()
+    rank, off = C.c_int32(), C.c_int64()
+    for i in range(nt.value):
+        check(l.vitx_mim_param_table_entry(handle, i, name, 256, shape, C.byref(rank), C.byref(off)))
         out.append((name.value.decode(), tuple(int(shape[k]) for k in range(rank.value)), int(off.value)))
     return out, int(ne.value)
