@@ -200,6 +200,7 @@ int32_t vitx_mim_set_params(vitx_mim_handle m, const float* host_blob, int64_t n
 int32_t vitx_mim_get_params(vitx_mim_handle m, float* host_blob, int64_t n_elems);
 int32_t vitx_mim_get_grads(vitx_mim_handle m, float* host_blob, int64_t n_elems);
 int32_t vitx_mim_params_dev(vitx_mim_handle m, float** params_dev, float** grads_dev, int64_t* n_arena_elems);
+int32_t vitx_mim_params_changed(vitx_mim_handle m);   /* the wrapper's fp32 params changed on device (like vitx_params_changed) */
 int32_t vitx_mim_num_masked(vitx_mim_handle m, int32_t H, int32_t W, int32_t* num_patches, int32_t* num_masked);
 /* MAE.call (mae.py:47-92) / SimMIM.call (simmim.py:86-130): returns the reconstruction loss.  The host variant validates the
  * indices (range, distinct per image: simmim.py:31) and synchronises; the _dev variant trusts them and stays asynchronous. */

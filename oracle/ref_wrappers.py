@@ -79,7 +79,7 @@ def mae_forward(enc_cfg: dict, dec_cfg: dict, E: Dict[str, torch.Tensor], D: Dic
         tokens = tokens.detach()
     encoded = R._transformer(tokens, E, enc_cfg, "transformer", enc_cfg["depth"], q)          # mae.py:69
     if "enc_to_dec.kernel" in Wp:
-        dec_tokens = encoded @ Wp["enc_to_dec.kernel"] + Wp["enc_to_dec.bias"]               # mae.py:72
+        dec_tokens = R._dense(encoded, Wp, "enc_to_dec", q)                                 # mae.py:72
     else:
         dec_tokens = encoded                                                                # Identity mae.py:10-15
     dpos = Wp["decoder_pos_emb.embeddings"]
@@ -87,7 +87,7 @@ def mae_forward(enc_cfg: dict, dec_cfg: dict, E: Dict[str, torch.Tensor], D: Dic
     mask_tokens = Wp["mask_token"].expand(b, nm, -1) + dpos[masked]          # mae.py:78-79
     dec_in = torch.cat([mask_tokens, dec_tokens], dim=1)                     # mae.py:82
     decoded = R._transformer(dec_in, D, dec_cfg, "transformer", dec_cfg["depth"], q)          # mae.py:83
-    pred = decoded[:, :nm] @ Wp["to_pixels.kernel"] + Wp["to_pixels.bias"]   # mae.py:86-87
+    pred = R._dense(decoded[:, :nm], Wp, "to_pixels", q)                     # mae.py:86-87
     if literal_loss:
         loss = (pred ** 2).mean()                                            # mae.py:90 as written
     else:
@@ -113,7 +113,7 @@ def simmim_forward(enc_cfg: dict, E: Dict[str, torch.Tensor], Wp: Dict[str, torc
     enc_m = encoded[br, idx]                                                 # simmim.py:119
     if detach_like_reference:
         enc_m = enc_m.detach()
-    pred = enc_m @ Wp["to_pixels.kernel"] + Wp["to_pixels.bias"]             # simmim.py:122
+    pred = R._dense(enc_m, Wp, "to_pixels", q)                               # simmim.py:122
     masked_patches = patches[br, idx]                                        # simmim.py:125
     loss = (pred - masked_patches).abs().mean() / nm                         # simmim.py:128
     return loss, pred, masked_patches

@@ -14,15 +14,18 @@ pytestmark = pytest.mark.gpu
 ENC = {
     "fp32": dict(image_size=32, patch_size=8, num_classes=5, dim=32, depth=2, heads=2, mlp_dim=64, dim_head=16),
     "bf16": dict(image_size=64, patch_size=8, num_classes=5, dim=128, depth=2, heads=2, mlp_dim=256, dim_head=64),
+    # 48 pixel values per patch: not a multiple of 64, the wrappers' Dense layers take the fp32-FMA GEMM even in bf16 mode
+    "bf16_p4": dict(image_size=32, patch_size=4, num_classes=5, dim=128, depth=2, heads=2, mlp_dim=256, dim_head=64),
 }
 DEC = {"fp32": dict(decoder_dim=24, decoder_depth=1, decoder_heads=2, decoder_dim_head=8),
        "bf16": dict(decoder_dim=64, decoder_depth=1, decoder_heads=2, decoder_dim_head=32)}
 
 
-def _encoder(compute, b, seed=1, variant="vit"):
+def _encoder(key, b, seed=1, variant="vit"):
     from vit_tensorflow import ViT
     from vit_tensorflow.deepvit import DeepViT
-    kw = ENC[compute]
+    kw = ENC[key]
+    compute = key.split("_")[0]
     cfg = spec.make_config(variant, **kw)
     P = spec.init_params(cfg, seed, randomize_all=True)
     m = (ViT if variant == "vit" else DeepViT)(**kw, compute=compute, max_batch=b, seed=0)
@@ -94,11 +97,12 @@ def test_mae_matches_the_oracle(compute, literal, same_dim):
     assert not grads["decoder_pos_emb.embeddings"][npat].any()
 
 
-@pytest.mark.parametrize("compute,variant", [("fp32", "vit"), ("fp32", "deepvit"), ("bf16", "vit")])
-def test_simmim_matches_the_oracle(compute, variant):
+@pytest.mark.parametrize("key,variant", [("fp32", "vit"), ("fp32", "deepvit"), ("bf16", "vit"), ("bf16_p4", "vit")])
+def test_simmim_matches_the_oracle(key, variant):
     from vit_tensorflow.simmim import SimMIM
     b = 3
-    ecfg, E, enc = _encoder(compute, b, variant=variant)
+    compute = key.split("_")[0]
+    ecfg, E, enc = _encoder(key, b, variant=variant)
     mim = SimMIM(image_size=ecfg["image_size"], encoder=enc, masking_ratio=0.5, seed=3)
     Ws = _randomize(mim, 12)
     img = _images(ecfg, b, 8)
@@ -119,7 +123,8 @@ def test_simmim_matches_the_oracle(compute, variant):
     target = mim.read("target").reshape(b, nm, -1)
     patches = mim.read("patches").reshape(b, npat, -1)
     assert np.array_equal(target, np.stack([patches[i][midx[i]] for i in range(b)]))      # index work is bit-exact
-    assert np.array_equal(patches, ref_torch.patch_unfold(__import__("torch").tensor(img), 8, 8).numpy())
+    ps = ecfg["patch_size"][0]
+    assert np.array_equal(patches, ref_torch.patch_unfold(__import__("torch").tensor(img), ps, ps).numpy())
 
 
 def test_wrapper_index_properties_and_determinism():

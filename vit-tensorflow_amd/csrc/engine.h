@@ -25,6 +25,9 @@ struct Dense {
   int64_t w = -1, b = -1;           // arena offsets (Keras kernel [in,out], bias [out])
   bf16_t* wt = nullptr;             // [round_up(out,256)][in_k]   forward operand  (W^T)
   bf16_t* wn = nullptr;             // [round_up(in,256)][out_k]   dgrad operand    (W)
+  // a layer whose fp32 parameters / gradients live outside the engine's arenas (the MAE / SimMIM wrappers' own Dense layers)
+  const float *ext_w = nullptr, *ext_b = nullptr;
+  float *ext_gw = nullptr, *ext_gb = nullptr;
 };
 
 struct BlockParams {
@@ -145,6 +148,13 @@ int engine_patch_tokens_forward(vitx_engine* e, const float* img_dev, int b, int
                                 std::string& err);
 int engine_patch_tokens_backward(vitx_engine* e, const float* dtokens_dev, std::string& err);
 void engine_refresh_weights(vitx_engine* e);
+// Dense layers owned by a wrapper object but run with this engine's GEMM kernels, workspaces and stream (bf16 mode: X / dY are
+// row-padded bf16 buffers as everywhere else in the engine; parity mode: fp32).  y / dx are fp32 [rows, out] / [rows, in].
+int engine_ext_dense_init(vitx_engine* e, Dense& w, int in, int out, const float* W, const float* bias, float* gW, float* gbias, std::string& err);
+void engine_ext_dense_refresh(vitx_engine* e, const Dense& w);
+void engine_ext_dense_fwd(vitx_engine* e, const void* X, int64_t ldx, int rows, const Dense& w, float* y);
+void engine_ext_dense_bwd(vitx_engine* e, const void* X, int64_t ldx, const void* dY, int64_t ldy, const float* dY_f32, int rows, const Dense& w,
+                          float* dx_or_null);
 int engine_bench_gemm(vitx_engine* e, int M, int N, int K, int kernel, int epilogue, int iters, float* avg_ms, float* max_err,
                       std::string& err);
 int prof_class(vitx_engine* e, const char* name);

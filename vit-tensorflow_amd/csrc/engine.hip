@@ -172,6 +172,11 @@ static int init_dense(vitx_engine* e, Dense& w, const std::string& kname, const 
   return VITX_OK;
 }
 
+static inline const float* dense_w(const vitx_engine* e, const Dense& w) { return w.ext_w ? w.ext_w : e->params + w.w; }
+static inline const float* dense_b(const vitx_engine* e, const Dense& w) { return w.ext_b ? w.ext_b : (w.b >= 0 ? e->params + w.b : nullptr); }
+static inline float* dense_gw(const vitx_engine* e, const Dense& w) { return w.ext_gw ? w.ext_gw : e->grads + w.w; }
+static inline float* dense_gb(const vitx_engine* e, const Dense& w) { return w.ext_gb ? w.ext_gb : (w.b >= 0 ? e->grads + w.b : nullptr); }
+
 void engine_refresh_weights(vitx_engine* e) {
   if (!e->bf16) { e->params_dirty = false; return; }
   Prof pr(e, "convert_weights", 0, (double)e->n_params * 8);
@@ -191,7 +196,7 @@ void engine_refresh_weights(vitx_engine* e) {
 static void dense_fwd(vitx_engine* e, const void* X, int64_t ldx, int rows, const Dense& w, int mode, EpiParams ep) {
   ep.M = rows;
   ep.N = w.out;
-  if (w.b >= 0 && mode != EPI_GELU_BWD) ep.bias = e->params + w.b;
+  if (mode != EPI_GELU_BWD) ep.bias = dense_b(e, w);
   const double flops = 2.0 * rows * (double)w.out * w.in;
   const double bytes = (double)rows * w.in * e->esz + (double)rows * w.out * e->esz + (double)w.in * w.out * e->esz;
   if (e->bf16 && !e->force_generic_gemm) {
@@ -206,7 +211,7 @@ static void dense_fwd(vitx_engine* e, const void* X, int64_t ldx, int rows, cons
     launch_gemm_bf16(g, ep, mode, e->stream);
   } else {
     GenericGemmArgs g;
-    g.A = X; g.B = e->params + w.w;
+    g.A = X; g.B = dense_w(e, w);
     g.M = rows; g.N = w.out; g.K = w.in;
     g.sam = ldx; g.sak = 1; g.sbk = w.out; g.sbn = 1;
     ep.zero_pad = 1;
@@ -235,7 +240,7 @@ static void dense_dgrad(vitx_engine* e, const void* dY, int64_t ldy, int rows, c
     launch_gemm_bf16(g, ep, mode, e->stream);
   } else {
     GenericGemmArgs g;
-    g.A = dY; g.B = e->params + w.w;
+    g.A = dY; g.B = dense_w(e, w);
     g.M = rows; g.N = w.in; g.K = w.out;
     g.sam = ldy; g.sak = 1; g.sbk = 1; g.sbn = w.out;
     ep.zero_pad = 1;
@@ -247,7 +252,7 @@ static void dense_dgrad(vitx_engine* e, const void* dY, int64_t ldy, int rows, c
 
 // dW[in,out] = X^T[in,rows] @ dY[rows,out]   (reduction over every token row of the batch)
 static void dense_wgrad(vitx_engine* e, const void* X, int64_t ldx, const void* dY, int64_t ldy, int rows, const Dense& w) {
-  float* dW = e->grads + w.w;
+  float* dW = dense_gw(e, w);
   const double flops = 2.0 * rows * (double)w.out * w.in;
   const double bytes = (double)rows * w.in * e->esz + (double)rows * w.out * e->esz + (double)w.in * w.out * 4;
   if (e->bf16 && !e->force_generic_gemm) {
@@ -299,9 +304,39 @@ static void dense_wgrad(vitx_engine* e, const void* X, int64_t ldx, const void* 
 }
 
 static void bias_grad(vitx_engine* e, const void* dY, int is_bf16, int64_t ld, int rows, const Dense& w) {
-  if (w.b < 0) return;
+  float* gb = dense_gb(e, w);
+  if (!gb) return;
   Prof pr(e, "colsum", 0, (double)rows * w.out * (is_bf16 ? 2 : 4));
-  launch_colsum(dY, is_bf16, ld, rows, w.out, e->red_ws, e->grads + w.b, e->stream);
+  launch_colsum(dY, is_bf16, ld, rows, w.out, e->red_ws, gb, e->stream);
+}
+
+// ---- Dense layers of a wrapper object (MAE enc_to_dec / to_pixels, SimMIM to_pixels: mae.py:41,45, simmim.py:84) on this engine
+int engine_ext_dense_init(vitx_engine* e, Dense& w, int in, int out, const float* W, const float* bias, float* gW, float* gbias, std::string& err) {
+  w.in = in; w.out = out;
+  w.in_k = (int)round_up(in, 64); w.out_k = (int)round_up(out, 64);
+  w.w = -1; w.b = -1;
+  w.ext_w = W; w.ext_b = bias; w.ext_gw = gW; w.ext_gb = gbias;
+  if (e->bf16) {
+    DALLOC(w.wt, (size_t)round_up(out, 256) * w.in_k * 2, false);
+    DALLOC(w.wn, (size_t)round_up(in, 256) * w.out_k * 2, false);
+  }
+  return VITX_OK;
+}
+void engine_ext_dense_refresh(vitx_engine* e, const Dense& w) {
+  if (e->bf16 && w.wt) launch_convert_weight(w.ext_w, w.in, w.out, w.wn, w.out_k, w.wt, w.in_k, e->stream);
+}
+void engine_ext_dense_fwd(vitx_engine* e, const void* X, int64_t ldx, int rows, const Dense& w, float* y) {
+  EpiParams ep; ep.out = y; ep.ldo = w.out;
+  dense_fwd(e, X, ldx, rows, w, EPI_STORE_F32, ep);
+}
+void engine_ext_dense_bwd(vitx_engine* e, const void* X, int64_t ldx, const void* dY, int64_t ldy, const float* dY_f32, int rows, const Dense& w,
+                          float* dx) {
+  if (dx) {
+    EpiParams ep; ep.out = dx; ep.ldo = w.in;
+    dense_dgrad(e, dY, ldy, rows, w, EPI_STORE_F32, ep);
+  }
+  dense_wgrad(e, X, ldx, dY, ldy, rows, w);
+  (void)dY_f32;   // the bias gradient (column sums of the fp32 dY) is the caller's: it sizes its own reduction workspace
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -2,8 +2,8 @@
 // Both take a built ViT, reuse the first two layers of its patch_embedding and rows 1.. of its pos_embedding, run
 // encoder.transformer on a token subset / on mask-substituted tokens, and regress pixel values of the masked patches.
 // Here the whole step stays on the device: launch sequences over the encoder engine (patch tokens, transformer), a second engine
-// for MAE's decoder Transformer, the index kernels of mim_ops.hip and the exact-fp32 GEMM for the wrappers' own small Dense
-// layers (enc_to_dec, to_pixels).  The backward is the true VJP of that forward; the reference cuts its gradient tape wherever it
+// for MAE's decoder Transformer, the index kernels of mim_ops.hip and, in parity mode, the exact-fp32 GEMM for the wrappers' own small Dense
+// layers (enc_to_dec, to_pixels; bf16 mode: the encoder engine's MFMA GEMMs on bf16 copies of their operands).  The backward is the true VJP of that forward; the reference cuts its gradient tape wherever it
 // indexes through `.numpy()` (mae.py:62, simmim.py:119) -- see DESIGN.md for what that means for parity.
 #include <cstring>
 #include <algorithm>
@@ -37,6 +37,11 @@ struct vitx_mim {
   float *g_rows_m = nullptr, *g_a = nullptr, *g_b = nullptr, *g_c = nullptr;   // backward scratch ([B*np, max(d,dd)] each)
   float *ws = nullptr, *loss = nullptr;
   int32_t *idx = nullptr, *inv = nullptr;
+  // bf16 mode: the wrapper's Dense layers run on the encoder engine's MFMA GEMMs (row-padded bf16 copies of their operands)
+  bool mfma = false, w_dirty = true;
+  Dense px, ed;
+  void *x_px_T = nullptr, *x_ed_T = nullptr, *dy_px_T = nullptr, *dy_ed_T = nullptr;   // one buffer per (layer, operand): each keeps its own zero tail
+  int64_t t_rows = 0, glue_geom = -1;
   bool have_fwd = false;
   int b = 0, np = 0, nm = 0;
 };
@@ -119,6 +124,48 @@ void lin_bwd(const float* x, const float* W, const float* dy, int rows, int in, 
   if (db) launch_colsum(dy, 0, out, rows, out, ws, db, s);
 }
 
+// bf16 mode: rows >= `rows` of the bf16 operand copies are K padding of the weight-gradient GEMMs and must stay zero
+int glue_prepare(vitx_mim* m, int b, int np, std::string& err) {
+  if (!m->mfma) return VITX_OK;
+  hipStream_t s = m->enc->stream;
+  const int64_t geom = ((int64_t)b << 32) | (uint32_t)np;
+  if (m->glue_geom >= 0 && m->glue_geom != geom) {
+    const int64_t dm = std::max(m->d, m->dd);
+    HIPCHK(hipMemsetAsync(m->x_px_T, 0, (size_t)m->t_rows * dm * 2, s));
+    HIPCHK(hipMemsetAsync(m->x_ed_T, 0, (size_t)m->t_rows * dm * 2, s));
+    HIPCHK(hipMemsetAsync(m->dy_px_T, 0, (size_t)m->t_rows * m->pd * 2, s));
+    HIPCHK(hipMemsetAsync(m->dy_ed_T, 0, (size_t)m->t_rows * dm * 2, s));
+  }
+  m->glue_geom = geom;
+  if (m->w_dirty) {
+    engine_ext_dense_refresh(m->enc, m->px);
+    if (m->project) engine_ext_dense_refresh(m->enc, m->ed);
+    m->w_dirty = false;
+  }
+  return VITX_OK;
+}
+// y = x @ W + bias through whichever GEMM the compute mode prescribes; keeps the bf16 copy of x for the backward
+void glue_fwd(vitx_mim* m, const Dense& w, void* xT, const float* x, int rows, int in, const float* W, const float* bias, int out, float* y) {
+  hipStream_t s = m->enc->stream;
+  if (m->mfma) {
+    launch_convert(x, in, xT, 1, in, rows, in, in, s);
+    engine_ext_dense_fwd(m->enc, xT, in, rows, w, y);
+  } else {
+    lin_fwd(x, rows, in, W, bias, out, y, s);
+  }
+}
+void glue_bwd(vitx_mim* m, const Dense& w, const void* xT, void* dyT, const float* x, const float* W, const float* dy, int rows, int in, int out,
+              float* dx, float* dW, float* db) {
+  hipStream_t s = m->enc->stream;
+  if (m->mfma) {
+    launch_convert(dy, out, dyT, 1, out, rows, out, out, s);
+    engine_ext_dense_bwd(m->enc, xT, in, dyT, out, dy, rows, w, dx);
+    if (db) launch_colsum(dy, 0, out, rows, out, m->ws, db, s);
+  } else {
+    lin_bwd(x, W, dy, rows, in, out, dx, dW, db, m->ws, s);
+  }
+}
+
 int mim_create(vitx_engine* enc, const vitx_mim_config& cfg, vitx_mim** out, std::string& err) {
   if (!(cfg.masking_ratio > 0.0 && cfg.masking_ratio < 1.0)) { err = "masking ratio must be kept between 0 and 1"; return VITX_ERR_INVALID; }   // mae.py:28, simmim.py:71
   if (cfg.kind != VITX_MIM_MAE && cfg.kind != VITX_MIM_SIMMIM) { err = "unknown wrapper kind"; return VITX_ERR_INVALID; }
@@ -169,6 +216,19 @@ int mim_create(vitx_engine* enc, const vitx_mim_config& cfg, vitx_mim** out, std
   MALLOC(m->loss, 256);
   MALLOC(m->idx, (size_t)R * 4);
   MALLOC(m->inv, (size_t)R * 4);
+  m->mfma = enc->bf16 && !enc->force_generic_gemm && m->d % 64 == 0 && m->dd % 64 == 0 && m->pd % 64 == 0;
+  if (m->mfma) {
+    int rc;
+    const int in_px = m->mae ? m->dd : m->d;
+    if ((rc = engine_ext_dense_init(enc, m->px, in_px, m->pd, m->params + m->w_px, m->params + m->b_px, m->grads + m->w_px, m->grads + m->b_px, err)) != VITX_OK) return rc;
+    if (m->project &&
+        (rc = engine_ext_dense_init(enc, m->ed, m->d, m->dd, m->params + m->w_ed, m->params + m->b_ed, m->grads + m->w_ed, m->grads + m->b_ed, err)) != VITX_OK) return rc;
+    m->t_rows = round_up(R, 256) + 384;   // GEMM tiles may read up to 319 rows past M
+    MALLOC(m->x_px_T, (size_t)m->t_rows * dm * 2);
+    MALLOC(m->x_ed_T, (size_t)m->t_rows * dm * 2);
+    MALLOC(m->dy_px_T, (size_t)m->t_rows * m->pd * 2);
+    MALLOC(m->dy_ed_T, (size_t)m->t_rows * dm * 2);
+  }
   HIPCHK(hipStreamSynchronize(enc->stream));
   *out = m;
   return VITX_OK;
@@ -199,6 +259,7 @@ int mim_forward(vitx_mim* m, const float* img_dev, int b, int H, int W, const in
   if (nm <= 0 || nu <= 0) { err = "masking ratio leaves no masked (or no visible) patch at this image size"; return VITX_ERR_UNSUPPORTED; }
   m->have_fwd = false;
   int rc;
+  if ((rc = glue_prepare(m, b, np, err)) != VITX_OK) return rc;
   if ((rc = engine_patch_tokens_forward(e, img_dev, b, H, W, m->tok, m->patches, err)) != VITX_OK) return rc;   // mae.py:49-55 / simmim.py:88-100
   const float* P = m->params;
   float scale;
@@ -209,11 +270,11 @@ int mim_forward(vitx_mim* m, const float* img_dev, int b, int H, int W, const in
     launch_gather_rows(m->tok, (int64_t)np * d, idx_dev, np, nm, b, nu, d, m->sel, s);                      // mae.py:62
     if ((rc = engine_transformer_forward(e, m->sel, b, nu, m->enc_out, err)) != VITX_OK) return rc;          // mae.py:69
     const float* proj = m->enc_out;
-    if (m->project) { lin_fwd(m->enc_out, b * nu, d, P + m->w_ed, P + m->b_ed, dd, m->proj, s); proj = m->proj; }   // mae.py:72
+    if (m->project) { glue_fwd(m, m->ed, m->x_ed_T, m->enc_out, b * nu, d, P + m->w_ed, P + m->b_ed, dd, m->proj); proj = m->proj; }   // mae.py:72
     launch_mae_assemble(proj, P + m->mask_tok, P + m->dpos, idx_dev, b, np, nm, dd, m->dec_in, s);          // mae.py:75-82
     if ((rc = engine_transformer_forward(m->dec, m->dec_in, b, np, m->dec_out, err)) != VITX_OK) return rc;  // mae.py:83
     HIPCHK(hipMemcpy2DAsync(m->rows_m, (size_t)nm * dd * 4, m->dec_out, (size_t)np * dd * 4, (size_t)nm * dd * 4, b, hipMemcpyDeviceToDevice, s));   // mae.py:86
-    lin_fwd(m->rows_m, b * nm, dd, P + m->w_px, P + m->b_px, pd, m->pred, s);                               // mae.py:87
+    glue_fwd(m, m->px, m->x_px_T, m->rows_m, b * nm, dd, P + m->w_px, P + m->b_px, pd, m->pred);            // mae.py:87
     if (!m->cfg.literal_loss) {
       launch_gather_rows(m->patches, (int64_t)np * pd, idx_dev, np, 0, b, nm, pd, m->target, s);           // mae.py:65
       target = m->target;
@@ -225,7 +286,7 @@ int mim_forward(vitx_mim* m, const float* img_dev, int b, int H, int W, const in
     launch_simmim_select(m->tok, m->inv, P + m->mask_tok, e->params + e->pos + d, b, np, d, s);             // simmim.py:102-113
     if ((rc = engine_transformer_forward(e, m->tok, b, np, m->enc_out, err)) != VITX_OK) return rc;          // simmim.py:116
     launch_gather_rows(m->enc_out, (int64_t)np * d, idx_dev, nm, 0, b, nm, d, m->rows_m, s);                // simmim.py:119
-    lin_fwd(m->rows_m, b * nm, d, P + m->w_px, P + m->b_px, pd, m->pred, s);                                // simmim.py:122
+    glue_fwd(m, m->px, m->x_px_T, m->rows_m, b * nm, d, P + m->w_px, P + m->b_px, pd, m->pred);             // simmim.py:122
     launch_gather_rows(m->patches, (int64_t)np * pd, idx_dev, nm, 0, b, nm, pd, m->target, s);              // simmim.py:125
     target = m->target;
     kind = 1;
@@ -250,7 +311,7 @@ int mim_backward(vitx_mim* m, std::string& err) {
   int rc;
   launch_fill_zero(G, m->n_arena * 4, s);
   if (m->mae) {
-    lin_bwd(m->rows_m, P + m->w_px, m->dpred, b * nm, dd, pd, m->g_rows_m, G + m->w_px, G + m->b_px, m->ws, s);
+    glue_bwd(m, m->px, m->x_px_T, m->dy_px_T, m->rows_m, P + m->w_px, m->dpred, b * nm, dd, pd, m->g_rows_m, G + m->w_px, G + m->b_px);
     launch_fill_zero(m->g_a, (int64_t)round_up((int64_t)b * np * dd, 4) * 4, s);
     HIPCHK(hipMemcpy2DAsync(m->g_a, (size_t)np * dd * 4, m->g_rows_m, (size_t)nm * dd * 4, (size_t)nm * dd * 4, b, hipMemcpyDeviceToDevice, s));
     if ((rc = engine_transformer_backward(m->dec, m->g_a, m->g_b, err)) != VITX_OK) return rc;               // g_b = d(dec_in) [b, np, dd]
@@ -259,14 +320,14 @@ int mim_backward(vitx_mim* m, std::string& err) {
     HIPCHK(hipMemcpy2DAsync(m->g_c, (size_t)nu * dd * 4, m->g_b + (int64_t)nm * dd, (size_t)np * dd * 4, (size_t)nu * dd * 4, b, hipMemcpyDeviceToDevice, s));
     const float* d_enc = m->g_c;                                                                            // d(enc_to_dec out) [b, nu, dd]
     if (m->project) {
-      lin_bwd(m->enc_out, P + m->w_ed, m->g_c, b * nu, d, dd, m->g_a, G + m->w_ed, G + m->b_ed, m->ws, s);
+      glue_bwd(m, m->ed, m->x_ed_T, m->dy_ed_T, m->enc_out, P + m->w_ed, m->g_c, b * nu, d, dd, m->g_a, G + m->w_ed, G + m->b_ed);
       d_enc = m->g_a;
     }
     if ((rc = engine_transformer_backward(e, d_enc, m->g_b, err)) != VITX_OK) return rc;                      // g_b = d(sel) [b, nu, d]
     launch_scatter_rows(m->g_b, nu, m->inv, nm, np, b, np, d, m->g_c, s);                                   // d(tokens) [b, np, d]
     if ((rc = engine_patch_tokens_backward(e, m->g_c, err)) != VITX_OK) return rc;
   } else {
-    lin_bwd(m->rows_m, P + m->w_px, m->dpred, b * nm, d, pd, m->g_rows_m, G + m->w_px, G + m->b_px, m->ws, s);
+    glue_bwd(m, m->px, m->x_px_T, m->dy_px_T, m->rows_m, P + m->w_px, m->dpred, b * nm, d, pd, m->g_rows_m, G + m->w_px, G + m->b_px);
     launch_scatter_rows(m->g_rows_m, nm, m->inv, 0, nm, b, np, d, m->g_a, s);                               // d(encoded) [b, np, d]
     if ((rc = engine_transformer_backward(e, m->g_a, m->g_b, err)) != VITX_OK) return rc;                    // g_b = d(tokens)
     launch_select_rowsum(m->g_b, m->inv, 0, 0, b, np, d, m->ws, G + m->mask_tok, s);
@@ -358,6 +419,7 @@ static int mim_copy_blob(vitx_mim* m, float* arena, float* host, int64_t n, bool
 int32_t vitx_mim_set_params(vitx_mim_handle m, const float* host_blob, int64_t n) {
   MIM_TRY
   if (!m || !host_blob) return capi_fail(VITX_ERR_INVALID, "null argument");
+  m->w_dirty = true;
   return mim_copy_blob(m, m->params, const_cast<float*>(host_blob), n, true);
   MIM_CATCH
 }
@@ -378,6 +440,12 @@ int32_t vitx_mim_params_dev(vitx_mim_handle m, float** params_dev, float** grads
   if (params_dev) *params_dev = m->params;
   if (grads_dev) *grads_dev = m->grads;
   if (n_elems) *n_elems = m->n_arena;
+  return VITX_OK;
+}
+
+int32_t vitx_mim_params_changed(vitx_mim_handle m) {
+  if (!m) return capi_fail(VITX_ERR_INVALID, "null handle");
+  m->w_dirty = true;
   return VITX_OK;
 }
 

@@ -108,6 +108,7 @@ SYMBOLS: List[Tuple[str, object, list]] = [
     ("vitx_mim_get_params", C.c_int32, [C.c_void_p, C.c_void_p, C.c_int64]),
     ("vitx_mim_get_grads", C.c_int32, [C.c_void_p, C.c_void_p, C.c_int64]),
     ("vitx_mim_params_dev", C.c_int32, [C.c_void_p, _P(C.c_void_p), _P(C.c_void_p), _P(C.c_int64)]),
+    ("vitx_mim_params_changed", C.c_int32, [C.c_void_p]),
     ("vitx_mim_num_masked", C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, _P(C.c_int32), _P(C.c_int32)]),
     ("vitx_mim_forward", C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     ("vitx_mim_forward_dev", C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
