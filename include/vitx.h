@@ -216,6 +216,55 @@ int32_t vitx_mim_backward(vitx_mim_handle m);
 /* copy a tensor of the last forward to the host: "pred", "target", "patches", "encoded", "decoded" (MAE) */
 int32_t vitx_mim_read(vitx_mim_handle m, const char* which, float* out_host, int64_t cap_elems, int64_t* n_elems);
 
+/* ---- knowledge distillation ("next" row f3 of SURVEY.md section 8).
+ * DistillableViT.call(img, distill_token) (DistillMixin, distill.py:16-44): the token [dim] is appended after the position
+ * embedding, attended with the other tokens, split off before pooling; returns logits [b,num_classes] and the per-image
+ * distillation tokens [b,dim].  backward: cotangents of both outputs -> gradient arena, d(token) [dim], optional d(img).
+ * Works on any ViT / DeepViT handle (DistillableViT adds no parameters of its own, distill.py:46-57). */
+int32_t vitx_forward_distill(vitx_handle h, const float* img_host, int32_t b, int32_t H, int32_t W, int32_t training, uint64_t seed,
+                             const float* distill_token_host, float* logits_host, float* distill_tokens_host);
+int32_t vitx_backward_distill(vitx_handle h, const float* dlogits_host, const float* d_distill_tokens_host_or_null,
+                              float* d_distill_token_host_or_null, float* dimg_host_or_null);
+
+/* DistillWrapper(teacher, student, temperature, alpha, hard) (distill.py:87-134).  The teacher is any model: its logits are an
+ * input (tf.stop_gradient, distill.py:114).  Own parameters: distillation_token [1,1,dim], distill_mlp.norm.{gamma,beta},
+ * distill_mlp.{kernel,bias} (distill.py:101-106).  loss [b] = CE(labels, student_logits) * (1 - alpha) + distill_loss * alpha,
+ * with labels [b,num_classes] one-hot or soft (categorical_crossentropy(from_logits=True), distill.py:119). */
+typedef struct vitx_distill_config {
+  float temperature, alpha; /* distill.py:88 defaults 1.0, 0.5 */
+  int32_t hard;             /* 0: temperature-scaled KL to the teacher's softmax (distill.py:121-129); 1: cross-entropy against
+                             * the teacher's argmax (distill.py:130-132: as written it passes rank-1 integer labels to
+                             * categorical_crossentropy, which TensorFlow rejects; the engine computes the sparse form) */
+  /* soft mode, 1 = exactly as written: keras.losses.KLDivergence is handed LOG-probabilities as y_pred (distill.py:122-124) and
+   * clips them to [1e-7, 1], so the term is sum(y log(y / 1e-7)), constant in the student (zero gradient);
+   * 0 = the evident intent KL(softmax(teacher / T) || softmax(distill_logits / T)) */
+  int32_t literal_loss;
+  int32_t reserved[8];
+} vitx_distill_config;
+typedef struct vitx_distill* vitx_distill_handle;
+
+int32_t vitx_distill_create(vitx_handle student, const vitx_distill_config* cfg, vitx_distill_handle* out);
+int32_t vitx_distill_destroy(vitx_distill_handle m);   /* does not destroy the student */
+int32_t vitx_distill_param_table_size(vitx_distill_handle m, int64_t* n_tensors, int64_t* n_elems);
+int32_t vitx_distill_param_table_entry(vitx_distill_handle m, int64_t index, char* name, int32_t name_cap,
+                                       int64_t shape[4], int32_t* rank, int64_t* offset_elems);
+int32_t vitx_distill_set_params(vitx_distill_handle m, const float* host_blob, int64_t n_elems);
+int32_t vitx_distill_get_params(vitx_distill_handle m, float* host_blob, int64_t n_elems);
+int32_t vitx_distill_get_grads(vitx_distill_handle m, float* host_blob, int64_t n_elems);
+/* DistillWrapper.call((img, labels), temperature, alpha, training) (distill.py:107-134); temperature <= 0 / alpha < 0 take the
+ * constructor's values (distill.py:110-111).  loss: [b]. */
+int32_t vitx_distill_forward(vitx_distill_handle m, const float* img_host, const float* labels_host, const float* teacher_logits_host,
+                             int32_t b, int32_t H, int32_t W, int32_t training, uint64_t seed, float temperature, float alpha,
+                             float* loss_host);
+int32_t vitx_distill_forward_dev(vitx_distill_handle m, const float* img_dev, const float* labels_dev, const float* teacher_logits_dev,
+                                 int32_t b, int32_t H, int32_t W, int32_t training, uint64_t seed, float temperature, float alpha,
+                                 float* loss_dev_or_null);
+/* VJP for the cotangent dloss [b] (NULL = ones: tape.gradient of a non-scalar target differentiates its sum): wrapper gradients
+ * -> vitx_distill_get_grads, student gradients -> the student's arena. */
+int32_t vitx_distill_backward(vitx_distill_handle m, const float* dloss_host_or_null);
+/* "student_logits", "distill_logits" [b,num_classes], "distill_tokens" [b,dim] of the last forward */
+int32_t vitx_distill_read(vitx_distill_handle m, const char* which, float* out_host, int64_t cap_elems, int64_t* n_elems);
+
 #ifdef __cplusplus
 }
 #endif

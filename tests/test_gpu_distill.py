@@ -1,0 +1,123 @@
+"""GPU parity tier for the distillation path (SURVEY.md section 8 "next" row f3): DistillableViT.call with a distillation token
+(distill.py:16-44) and DistillWrapper.call (distill.py:107-134) through the C ABI against oracle/ref_distill.py.
+Tolerances: fp32 parity mode 1e-4 of each tensor's max; bf16 mode against the oracle with the same rounding points (bounds at the asserts)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_distill as RD, ref_torch, spec
+from vit_tensorflow import _native as N
+
+pytestmark = pytest.mark.gpu
+
+CFGS = {
+    "fp32": dict(image_size=32, patch_size=8, num_classes=10, dim=32, depth=2, heads=2, mlp_dim=64, dim_head=16),
+    "bf16": dict(image_size=64, patch_size=16, num_classes=10, dim=128, depth=2, heads=2, mlp_dim=256, dim_head=64),
+}
+
+
+def _student(compute, pool, b, seed=1):
+    from vit_tensorflow.distill import DistillableViT
+    kw = dict(CFGS[compute], pool=pool)
+    cfg = spec.make_config("vit", **kw)
+    P = spec.init_params(cfg, seed, randomize_all=True)
+    m = DistillableViT(**kw, compute=compute, max_batch=b, seed=0)
+    m.load_state_dict({k: np.asarray(a, np.float32) for k, a in P.items()})
+    return cfg, P, m
+
+
+def _close(a, ref, tol, what):
+    ref = np.asarray(ref)
+    err = np.abs(np.asarray(a, np.float64).reshape(ref.shape) - ref).max()
+    assert err <= tol * max(1e-6, np.abs(ref).max()) + 1e-7, f"{what}: err {err:.3e} vs max {np.abs(ref).max():.3e}"
+
+
+@pytest.mark.parametrize("compute,pool", [("fp32", "cls"), ("fp32", "mean"), ("bf16", "cls"), ("bf16", "mean")])
+def test_distillable_vit_call_and_vjp(compute, pool):
+    b = 3
+    cfg, P, m = _student(compute, pool, b)
+    rng = np.random.default_rng(4)
+    img = rng.standard_normal((b,) + tuple(cfg["image_size"]) + (3,)).astype(np.float32)
+    tok = rng.standard_normal((1, 1, cfg["dim"])).astype(np.float32)
+    dlogits = rng.standard_normal((b, cfg["num_classes"])).astype(np.float32)
+    ddt = rng.standard_normal((b, cfg["dim"])).astype(np.float32)
+    logits, dtok = m(img, distill_token=tok, training=False)
+    grads, dtoken = m.backward_distill(dlogits, ddt)
+    q = ref_torch.bf16_round if compute == "bf16" else None
+    Pt = ref_torch.to_torch(P, torch.float64, True)
+    tt = torch.tensor(tok.astype(np.float64), requires_grad=True)
+    rl, rd = RD.student_forward(cfg, Pt, torch.tensor(img, dtype=torch.float64), tt, q)
+    (rl * torch.tensor(dlogits, dtype=torch.float64)).sum().add((rd * torch.tensor(ddt, dtype=torch.float64)).sum()).backward()
+    tol = 1e-4 if compute == "fp32" else 3e-2
+    gtol = 1e-4 if compute == "fp32" else 6e-2
+    _close(logits, rl.detach().numpy(), tol, "logits")
+    _close(dtok, rd.detach().numpy(), tol, "distill_tokens")
+    _close(dtoken, tt.grad.numpy(), gtol, "d(distill_token)")
+    for k, v in Pt.items():
+        _close(grads[k], v.grad.numpy() if v.grad is not None else np.zeros(tuple(v.shape)), gtol, k)
+    # the ordinary call on the same object is unchanged by the extra capacity, and a plain backward after it still works
+    plain = m(img, training=False)
+    _close(plain, ref_torch.forward(cfg, ref_torch.to_torch(P), torch.tensor(img, dtype=torch.float64), q=q).numpy(), tol, "plain logits")
+    with pytest.raises(N.VitxError, match="forward_distill"):
+        m.backward_distill(dlogits, ddt)
+
+
+@pytest.mark.parametrize("compute,kw", [("fp32", dict(hard=False, literal_loss=True, temperature=2.0, alpha=0.3)),
+                                        ("fp32", dict(hard=False, literal_loss=False, temperature=3.0, alpha=0.5)),
+                                        ("fp32", dict(hard=True, literal_loss=True, temperature=1.0, alpha=0.25)),
+                                        ("bf16", dict(hard=False, literal_loss=False, temperature=2.0, alpha=0.5))])
+def test_distill_wrapper_matches_the_oracle(compute, kw):
+    from vit_tensorflow.distill import DistillWrapper
+    b = 4
+    cfg, P, stu = _student(compute, "cls", b)
+    rng = np.random.default_rng(6)
+    img = rng.standard_normal((b,) + tuple(cfg["image_size"]) + (3,)).astype(np.float32)
+    labels = np.eye(cfg["num_classes"], dtype=np.float32)[rng.integers(0, cfg["num_classes"], b)]
+    labels[1] = 0.5 * labels[1] + 0.05                               # one soft label row (y_true is any distribution)
+    teacher_logits = (2 * rng.standard_normal((b, cfg["num_classes"]))).astype(np.float32)
+    teacher = lambda im, training=True: teacher_logits               # any callable: a Keras ResNet in the reference's README
+    w = DistillWrapper(teacher=teacher, student=stu, temperature=kw["temperature"], alpha=kw["alpha"], hard=kw["hard"],
+                       literal_loss=kw["literal_loss"], seed=2)
+    assert [n for n, _, _ in w._table] == [n for n, _ in RD.wrapper_param_spec(cfg["dim"], cfg["num_classes"])]
+    sd = {n: (0.4 * rng.standard_normal(v.shape)).astype(np.float32) for n, v in w.state_dict().items()}
+    w.load_state_dict(sd)
+    dloss = rng.standard_normal(b).astype(np.float32)
+    loss = w((img, labels), training=False)
+    grads = w.backward(dloss)
+    q = ref_torch.bf16_round if compute == "bf16" else None
+    rl, rsl, rdl, gP, gW = RD.wrapper_forward_backward(cfg, P, {k: v.astype(np.float64) for k, v in sd.items()}, img, labels, teacher_logits,
+                                                     dloss=dloss, temperature=kw["temperature"], alpha=kw["alpha"], hard=kw["hard"],
+                                                     literal_loss=kw["literal_loss"], q=q)
+    tol = 1e-4 if compute == "fp32" else 3e-2
+    gtol = 1e-4 if compute == "fp32" else 6e-2
+    _close(loss, rl, tol, "loss")
+    _close(w.read("student_logits"), rsl, tol, "student_logits")
+    _close(w.read("distill_logits"), rdl, tol, "distill_logits")
+    for k, r in gW.items():
+        _close(grads[k], r, gtol, k)
+    for k, r in gP.items():
+        _close(grads["student." + k], r, gtol, "student." + k)
+    if kw["literal_loss"] and not kw["hard"]:
+        assert not grads["distill_mlp.kernel"].any()                 # distill.py:122-124 as written: the term is constant in the student
+    # call-time overrides (distill.py:110-111) and the default cotangent (ones)
+    l2 = w((img, labels), temperature=1.5, alpha=0.9, training=False)
+    r2 = RD.wrapper_forward_backward(cfg, P, {k: v.astype(np.float64) for k, v in sd.items()}, img, labels, teacher_logits, temperature=1.5,
+                                     alpha=0.9, hard=kw["hard"], literal_loss=kw["literal_loss"], q=q)
+    _close(l2, r2[0], tol, "loss with overrides")
+    g2 = w.backward()
+    _close(g2["distillation_token"], r2[4]["distillation_token"], gtol, "d(token), unit cotangent")
+
+
+def test_distill_errors():
+    from vit_tensorflow import ViT
+    from vit_tensorflow.distill import DistillWrapper
+    cfg, P, stu = _student("fp32", "cls", 2)
+    plain = ViT(**CFGS["fp32"], max_batch=2)
+    with pytest.raises(AssertionError, match="student must be a vision transformer"):
+        DistillWrapper(teacher=None, student=plain)
+    w = DistillWrapper(teacher=lambda im, training=True: np.zeros((2, 10), np.float32), student=stu)
+    with pytest.raises(N.VitxError, match="preceding forward"):
+        w.backward()
+    img = np.zeros((2, 32, 32, 3), np.float32)
+    with pytest.raises(AssertionError, match="labels must be"):
+        w((img, np.zeros((2, 3), np.float32)))

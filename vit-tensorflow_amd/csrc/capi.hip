@@ -225,7 +225,7 @@ int32_t vitx_backward(vitx_handle h, const float* dlogits_host, float* dimg_host
 int32_t vitx_transformer_forward(vitx_handle h, const float* tokens_host, int32_t b, int32_t n, float* out_host) {
   CAPI_TRY
   if (!h || !tokens_host || !out_host) return fail(VITX_ERR_INVALID, "null argument");
-  if (b <= 0 || b > h->cfg.max_batch || n <= 0 || n > h->ntok_max) return fail(VITX_ERR_INVALID, "transformer_forward: b or n out of range");
+  if (b <= 0 || b > h->cfg.max_batch || n <= 0 || n > h->ntok_cap) return fail(VITX_ERR_INVALID, "transformer_forward: b or n out of range");
   const size_t bytes = (size_t)b * n * h->cfg.dim * 4;
   float* tmp = h->g;   // [>= mp, d] fp32 scratch that no forward kernel touches
   CAPI_HIP(hipMemcpyAsync(tmp, tokens_host, bytes, hipMemcpyHostToDevice, h->stream));

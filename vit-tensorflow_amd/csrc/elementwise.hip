@@ -366,22 +366,30 @@ __global__ void to_f32_kernel(const TI* __restrict__ in, int64_t ldi, float* __r
 }
 
 // ------------------------------------------------------------------ pooling (vit.py:170-173)
-__global__ void mean_pool_kernel(const float* __restrict__ x, int b, int ntok, int d, float* __restrict__ out) {
+// x[bi, row, :] = tok[:] for every image (the distillation token appended after the position embedding, distill.py:26-28)
+__global__ void set_token_row_kernel(float* __restrict__ x, const float* __restrict__ tok, int b, int ntok, int row, int d) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (int64_t)b * d) return;
+  const int64_t bi = e / d;
+  const int c = (int)(e - bi * d);
+  x[(bi * ntok + row) * d + c] = tok[c];
+}
+__global__ void mean_pool_kernel(const float* __restrict__ x, int b, int ntok, int d, float* __restrict__ out, int stride_tok) {
   const int64_t total = (int64_t)b * d;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
     const int64_t bi = e / d;
     const int c = (int)(e - bi * d);
     float a = 0.f;
-    for (int t = 0; t < ntok; ++t) a += x[(bi * ntok + t) * d + c];
+    for (int t = 0; t < ntok; ++t) a += x[(bi * stride_tok + t) * d + c];
     out[e] = a / (float)ntok;
   }
 }
-__global__ void mean_pool_bwd_kernel(const float* __restrict__ dp, int b, int ntok, int d, float* __restrict__ g) {
+__global__ void mean_pool_bwd_kernel(const float* __restrict__ dp, int b, int ntok, int d, float* __restrict__ g, int stride_tok) {
   const int64_t total = (int64_t)b * ntok * d;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
     const int c = (int)(e % d);
     const int64_t bi = e / ((int64_t)ntok * d);
-    g[e] = dp[bi * d + c] / (float)ntok;
+    g[e + bi * (int64_t)(stride_tok - ntok) * d] = dp[bi * d + c] / (float)ntok;
   }
 }
 // out[j][c] = sum_b g[b][j0+j][c]   (dpos / dcls: vit.py:163-165 VJP)
@@ -677,11 +685,14 @@ void launch_to_f32(const void* in, int in_bf16, int64_t ldi, float* out, int64_t
   if (in_bf16) hipLaunchKernelGGL(to_f32_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, s, (const bf16_t*)in, ldi, out, ldo, rows, cols);
   else hipLaunchKernelGGL(to_f32_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, (const float*)in, ldi, out, ldo, rows, cols);
 }
-void launch_mean_pool(const float* x, int b, int ntok, int d, float* out, hipStream_t s) {
-  hipLaunchKernelGGL(mean_pool_kernel, dim3(grid_for((int64_t)b * d)), dim3(256), 0, s, x, b, ntok, d, out);
+void launch_set_token_row(float* x, const float* tok, int b, int ntok, int row, int d, hipStream_t s) {
+  hipLaunchKernelGGL(set_token_row_kernel, dim3((unsigned)ceil_div((int64_t)b * d, 256)), dim3(256), 0, s, x, tok, b, ntok, row, d);
 }
-void launch_mean_pool_bwd(const float* dp, int b, int ntok, int d, float* g, hipStream_t s) {
-  hipLaunchKernelGGL(mean_pool_bwd_kernel, dim3(grid_for((int64_t)b * ntok * d)), dim3(256), 0, s, dp, b, ntok, d, g);
+void launch_mean_pool(const float* x, int b, int ntok, int d, float* out, hipStream_t s, int stride_tok) {
+  hipLaunchKernelGGL(mean_pool_kernel, dim3(grid_for((int64_t)b * d)), dim3(256), 0, s, x, b, ntok, d, out, stride_tok ? stride_tok : ntok);
+}
+void launch_mean_pool_bwd(const float* dp, int b, int ntok, int d, float* g, hipStream_t s, int stride_tok) {
+  hipLaunchKernelGGL(mean_pool_bwd_kernel, dim3(grid_for((int64_t)b * ntok * d)), dim3(256), 0, s, dp, b, ntok, d, g, stride_tok ? stride_tok : ntok);
 }
 void launch_batch_reduce(const float* g, int b, int ntok, int d, int j0, int nj, float* out, hipStream_t s) {
   if (nj <= 0) return;

@@ -70,6 +70,7 @@ struct vitx_engine {
   int esz = 4;                       // bytes per "T" element
 
   // derived sizes (configured image)
+  int ntok_cap = 0;                  // rows per image the buffers hold: ntok_max plus one slot for a distillation token (distill.py:26-28)
   int np_max = 0, ntok_max = 0, pd = 0, pd_k = 0, inner = 0, nc_k = 0;
   int64_t mp = 0;                    // max token rows, padded to 256
   int64_t mpp = 0;                   // max patch rows, padded to 256
@@ -104,6 +105,7 @@ struct vitx_engine {
   void* zero_page = nullptr;         // 256 B of zeros (source of the padded rows in the attention DMA staging)
   float* tmp_f32 = nullptr;          // [mp, max(d, pd)] fp32 scratch (dropout / dimg paths)
   float* loss_rows = nullptr;
+  float* distill_ws = nullptr;       // [1 + max_batch, dim]: distillation token / its gradient (row 0) and the per-image tokens / their cotangents (host entry points)
   float *opt_m = nullptr, *opt_v = nullptr; int opt_step = 0;   // optimizer state (allocated on first use)
   bf16_t *bench_a = nullptr, *bench_b = nullptr; float* bench_c = nullptr; int64_t bench_elems = 0;
 
@@ -116,6 +118,7 @@ struct vitx_engine {
   int64_t patch_rows = -1;           // rows of e->patches written by the last unfold (rows beyond it are zero)
   void* pt_dy = nullptr;             // [mpp, dim] T copy of d(tokens) for the patch-embedding weight gradient (allocated on first use)
   int64_t pt_dy_rows = -1;
+  int last_extra = 0;                // 1: the last forward carried a distillation token as its last row (last_ntok includes it)
   int last_b = 0, last_np = 0, last_ntok = 0, last_H = 0, last_W = 0, last_training = 0;
   uint64_t last_seed = 0;
   std::vector<std::vector<bool>> layer_kept;   // per stage: blocks that survived CaiT layer dropout in the last forward
@@ -139,9 +142,13 @@ struct vitx_engine {
 
 int engine_create(const vitx_config& cfg, vitx_engine** out, std::string& err);
 void engine_destroy(vitx_engine* e);
+// distill_token_dev [dim] (optional): DistillMixin.call (distill.py:16-44) -- the token is appended after the position embedding,
+// attended with the rest, split off before pooling and returned per image in distill_out_dev [b, dim]
 int engine_forward(vitx_engine* e, const float* img_dev, int b, int H, int W, int training, uint64_t seed, float* logits_dev,
-                   std::string& err);
-int engine_backward(vitx_engine* e, const float* dlogits_dev, float* dimg_dev, std::string& err);
+                   std::string& err, const float* distill_token_dev = nullptr, float* distill_out_dev = nullptr);
+// d_distill_dev [b, dim]: cotangent of distill_out; d_token_out_dev [dim]: gradient of the distillation token
+int engine_backward(vitx_engine* e, const float* dlogits_dev, float* dimg_dev, std::string& err, const float* d_distill_dev = nullptr,
+                    float* d_token_out_dev = nullptr);
 int engine_transformer_forward(vitx_engine* e, const float* tokens_dev, int b, int n, float* out_dev, std::string& err);
 int engine_transformer_backward(vitx_engine* e, const float* dout_dev, float* dtokens_dev, std::string& err);
 int engine_patch_tokens_forward(vitx_engine* e, const float* img_dev, int b, int H, int W, float* tokens_dev, float* patches_f32_dev_or_null,

@@ -745,6 +745,7 @@ int engine_create(const vitx_config& cfg, vitx_engine** out, std::string& err) {
   e->np_max = (c.image_h / c.patch_h) * (c.image_w / c.patch_w);
   const bool cait = c.variant == VITX_VARIANT_CAIT;
   e->ntok_max = cait ? e->np_max : e->np_max + 1;
+  e->ntok_cap = cait ? e->ntok_max : e->ntok_max + 1;
   e->pd = c.patch_h * c.patch_w * c.channels;
   e->pd_k = (int)round_up(e->pd, 64);
   e->nc_k = (int)round_up(c.num_classes, 64);
@@ -769,7 +770,7 @@ int engine_create(const vitx_config& cfg, vitx_engine** out, std::string& err) {
   const int d = c.dim, inner = e->inner, m = c.mlp_dim, esz = e->esz;
   const int64_t B = c.max_batch;
   // row padding: a multiple of 256 plus 320 spare rows (the 320-row GEMM tile may cover up to 319 rows past M)
-  e->mp = round_up(B * e->ntok_max, 256) + 320;
+  e->mp = round_up(B * e->ntok_cap, 256) + 320;
   e->mpp = round_up(B * e->np_max, 256) + 320;
   e->bp = round_up(B, 256) + 320;
 
@@ -852,7 +853,7 @@ int engine_create(const vitx_config& cfg, vitx_engine** out, std::string& err) {
     if ((rc = make_stage("patch_transformer", c.depth, e->np_max, 0)) != VITX_OK) return rc;
     if ((rc = make_stage("cls_transformer", c.cls_depth, 1, e->np_max)) != VITX_OK) return rc;
   } else {
-    if ((rc = make_stage("transformer", c.depth, e->ntok_max, 0)) != VITX_OK) return rc;
+    if ((rc = make_stage("transformer", c.depth, e->ntok_cap, 0)) != VITX_OK) return rc;
   }
 
   // shared buffers
@@ -879,7 +880,7 @@ int engine_create(const vitx_config& cfg, vitx_engine** out, std::string& err) {
   DALLOC(e->d_qkv, (size_t)(rmax + 256) * 3 * inner * esz + (size_t)crow_max * 2 * inner * esz, true);
   DALLOC(e->d_ctx, (size_t)crow_max * d * esz, true);
   DALLOC(e->d_br, (size_t)rmax * d * esz, true);
-  DALLOC(e->dsum, (size_t)B * c.heads * e->ntok_max * 4 + 16, false);
+  DALLOC(e->dsum, (size_t)B * c.heads * e->ntok_cap * 4 + 16, false);
   DALLOC(e->zero_page, 256, false);
   DALLOC(e->tmp_f32, (size_t)rmax * std::max<int64_t>(d, e->pd) * 4, false);
   const int64_t maxfeat = std::max<int64_t>({(int64_t)d, 3LL * inner, (int64_t)m, (int64_t)e->pd_k, (int64_t)e->nc_k});
@@ -896,7 +897,7 @@ int engine_create(const vitx_config& cfg, vitx_engine** out, std::string& err) {
   // (+ per-M-tile column sums of the fc2-dgrad epilogue: one row per 256 token rows, 32 second-level rows)
   e->red_elems = std::max<int64_t>({layernorm_bwd_ws_elems(d), colsum_ws_elems((int)maxfeat), headmix_ws_elems((int)B, c.heads, 1, 1),
                                     (int64_t)256 * 2 * 32, (int64_t)(512 + 32) * d, (ceil_div(std::max<int64_t>(e->mp, e->mpp), 128) + 40) * (int64_t)m,
-                                    headchain_ws_elems(c.heads), deepvit_point_ws_elems((int)B, c.heads, e->ntok_max),
+                                    headchain_ws_elems(c.heads), deepvit_point_ws_elems((int)B, c.heads, e->ntok_cap),
                                     deepvit_point_bwd_ws_elems(c.heads)});
   DALLOC(e->red_ws, (size_t)e->red_elems * 4, false);
   HIPCHK(hipStreamSynchronize(e->stream));
@@ -960,14 +961,15 @@ static void draw_layer_dropout(vitx_engine* e, uint64_t seed) {
   }
 }
 
-static int head_forward(vitx_engine* e, const float* x_last, int b, int ntok, float* logits_dev, std::string& err) {
+// ntok rows per image in memory, of which the first ntok - extra are pooled (a distillation token is split off first, distill.py:32-33)
+static int head_forward(vitx_engine* e, const float* x_last, int b, int ntok, int extra, float* logits_dev, std::string& err) {
   const vitx_config& c = e->cfg;
   const int d = c.dim, T = e->bf16;
   const float* src = x_last;
   int64_t ldsrc = (int64_t)ntok * d;               // cls pooling: row 0 of every image (vit.py:173, cait.py:192)
   if (c.variant != VITX_VARIANT_CAIT && c.pool == VITX_POOL_MEAN) {   // vit.py:170-171
     Prof pr(e, "pool", 0, 0);
-    launch_mean_pool(x_last, b, ntok, d, e->pooled, e->stream);
+    launch_mean_pool(x_last, b, ntok - extra, d, e->pooled, e->stream, ntok);
     src = e->pooled;
     ldsrc = d;
   }
@@ -984,8 +986,10 @@ static int head_forward(vitx_engine* e, const float* x_last, int b, int ntok, fl
 }
 
 int engine_forward(vitx_engine* e, const float* img_dev, int b, int H, int W, int training, uint64_t seed, float* logits_dev,
-                   std::string& err) {
+                   std::string& err, const float* distill_token_dev, float* distill_out_dev) {
   const vitx_config& c = e->cfg;
+  const int extra = distill_token_dev ? 1 : 0;
+  if (extra && c.variant == VITX_VARIANT_CAIT) { err = "distillation token: ViT / DeepViT only"; return VITX_ERR_UNSUPPORTED; }
   if (b <= 0 || b > c.max_batch) { err = "batch must be in [1, max_batch]"; return VITX_ERR_INVALID; }
   if (H <= 0 || W <= 0 || H > c.image_h || W > c.image_w || H % c.patch_h || W % c.patch_w) {
     err = "Image dimensions must be divisible by the patch size.";            // and fit the configured pos_embedding (vit.py:165)
@@ -993,7 +997,7 @@ int engine_forward(vitx_engine* e, const float* img_dev, int b, int H, int W, in
   }
   const bool cait = c.variant == VITX_VARIANT_CAIT;
   const int np = (H / c.patch_h) * (W / c.patch_w);
-  const int ntok = cait ? np : np + 1;
+  const int ntok = cait ? np : np + 1 + extra;
   const int d = c.dim, T = e->bf16;
   ensure_geometry(e, b, ntok);
   if (e->params_dirty) engine_refresh_weights(e);
@@ -1014,6 +1018,8 @@ int engine_forward(vitx_engine* e, const float* img_dev, int b, int H, int W, in
     ep.np = np; ep.ntok = ntok; ep.tok_off = cait ? 0 : 1;
     dense_fwd(e, e->patches, e->pd_k, b * np, e->patch, EPI_PATCH, ep);                                     // vit.py:143 (+164-165)
   }
+  if (extra)   // x = concat([x, distill_tokens], axis=1), after the position embedding (distill.py:24-28)
+    launch_set_token_row(x0, distill_token_dev, b, ntok, ntok - 1, d, e->stream);
   const float drop = training ? c.dropout : 0.f, emb_drop = training ? c.emb_dropout : 0.f;
   if (emb_drop > 0.f) {
     Prof pr(e, "dropout", 0, 0);
@@ -1047,7 +1053,10 @@ int engine_forward(vitx_engine* e, const float* img_dev, int b, int H, int W, in
     x_last = s1.depth > 0 ? s1.ba[s1.depth - 1].x_out : xc;
     head_tok = 1;
   }
-  if ((rc = head_forward(e, x_last, b, head_tok, logits_dev, err)) != VITX_OK) return rc;
+  if (extra && distill_out_dev)   // x, distill_tokens = x[:, :-1], x[:, -1]  (distill.py:33)
+    HIPCHK(hipMemcpy2DAsync(distill_out_dev, (size_t)d * 4, x_last + (int64_t)(ntok - 1) * d, (size_t)ntok * d * 4, (size_t)d * 4, b, hipMemcpyDeviceToDevice, e->stream));
+  if ((rc = head_forward(e, x_last, b, head_tok, cait ? 0 : extra, logits_dev, err)) != VITX_OK) return rc;
+  e->last_extra = extra;
   e->have_fwd = true;
   e->have_tf = false;
   e->last_b = b; e->last_np = np; e->last_ntok = ntok; e->last_H = H; e->last_W = W; e->last_training = training; e->last_seed = seed;
@@ -1057,7 +1066,7 @@ int engine_forward(vitx_engine* e, const float* img_dev, int b, int H, int W, in
 int engine_transformer_forward(vitx_engine* e, const float* tokens_dev, int b, int n, float* out_dev, std::string& err) {
   const vitx_config& c = e->cfg;
   if (c.variant == VITX_VARIANT_CAIT) { err = "transformer_forward: ViT / DeepViT only"; return VITX_ERR_UNSUPPORTED; }
-  if (b <= 0 || b > c.max_batch || n <= 0 || n > e->ntok_max) { err = "transformer_forward: b or n out of range"; return VITX_ERR_INVALID; }
+  if (b <= 0 || b > c.max_batch || n <= 0 || n > e->ntok_cap) { err = "transformer_forward: b or n out of range"; return VITX_ERR_INVALID; }
   ensure_geometry(e, b, n);
   if (e->params_dirty) engine_refresh_weights(e);
   Stage& s0 = e->stages[0];
@@ -1145,9 +1154,10 @@ int engine_patch_tokens_backward(vitx_engine* e, const float* dtokens_dev, std::
 // ------------------------------------------------------------------------------------------------
 // backward
 // ------------------------------------------------------------------------------------------------
-int engine_backward(vitx_engine* e, const float* dlogits_dev, float* dimg_dev, std::string& err) {
+int engine_backward(vitx_engine* e, const float* dlogits_dev, float* dimg_dev, std::string& err, const float* d_distill_dev, float* d_token_out_dev) {
   const vitx_config& c = e->cfg;
   if (!e->have_fwd) { err = "backward requires a preceding forward"; return VITX_ERR_STATE; }
+  const int extra = e->last_extra;
   const bool cait = c.variant == VITX_VARIANT_CAIT;
   const int b = e->last_b, np = e->last_np, ntok = e->last_ntok, d = c.dim, T = e->bf16;
   const int nc = c.num_classes;
@@ -1155,7 +1165,7 @@ int engine_backward(vitx_engine* e, const float* dlogits_dev, float* dimg_dev, s
   {
     // every gradient tensor is overwritten by its producer; a full clear is only needed when part of the arena will not be
     // produced this step (pos_embedding rows beyond the image's tokens, blocks skipped by CaiT layer dropout)
-    bool need_clear = ntok < e->ntok_max;
+    bool need_clear = ntok - extra < e->ntok_max;
     for (auto& k : e->layer_kept) for (bool kept : k) need_clear = need_clear || !kept;
     if (need_clear) { Prof pr(e, "fill_zero", 0, (double)e->n_arena * 4); launch_fill_zero(e->grads, (int64_t)e->n_arena * 4, e->stream); }
   }
@@ -1195,12 +1205,14 @@ int engine_backward(vitx_engine* e, const float* dlogits_dev, float* dimg_dev, s
     if (mean_pool) {
       launch_layernorm_bwd(e->dyh, T, d, e->pooled, d, e->mean_h, e->rstd_h, e->params + e->head_g, nullptr, 0, e->dpooled, d, nullptr, 0,
                            e->red_ws, e->grads + e->head_g, e->grads + e->head_b, nullptr, b, d, e->stream);
-      launch_mean_pool_bwd(e->dpooled, b, head_tok, d, e->g, e->stream);
+      launch_mean_pool_bwd(e->dpooled, b, head_tok - extra, d, e->g, e->stream, head_tok);
     } else {
       const int64_t ldrow = (int64_t)head_tok * d;
       launch_layernorm_bwd(e->dyh, T, d, x_last, ldrow, e->mean_h, e->rstd_h, e->params + e->head_g, nullptr, 0, e->g, ldrow, nullptr, 0,
                            e->red_ws, e->grads + e->head_g, e->grads + e->head_b, nullptr, b, d, e->stream);
     }
+    if (extra && d_distill_dev)   // cotangent of the split-off distillation token: the last row of every image
+      HIPCHK(hipMemcpy2DAsync(e->g + (int64_t)(ntok - 1) * d, (size_t)ntok * d * 4, d_distill_dev, (size_t)d * 4, (size_t)d * 4, b, hipMemcpyDeviceToDevice, e->stream));
     if (T) launch_convert(e->g, d, e->g_lp, 1, d, head_rows, d, d, e->stream);
   }
   if (e->grad_cb) e->grad_cb(e->grad_cb_user, e->head_g, e->n_arena - e->head_g);
@@ -1229,7 +1241,8 @@ int engine_backward(vitx_engine* e, const float* dlogits_dev, float* dimg_dev, s
   // ---- embedding: x0 = [cls | patches @ W + b] + pos   (vit.py:160-165; cait.py:181-184)
   {
     Prof pr(e, "embed_bwd", 0, (double)b * ntok * d * 4);
-    launch_batch_reduce(e->g, b, ntok, d, 0, ntok, e->grads + e->pos, e->stream);      // dpos[j] = sum_b g[b,j]
+    launch_batch_reduce(e->g, b, ntok, d, 0, ntok - extra, e->grads + e->pos, e->stream);      // dpos[j] = sum_b g[b,j]
+    if (extra && d_token_out_dev) launch_batch_reduce(e->g, b, ntok, d, ntok - 1, 1, d_token_out_dev, e->stream);   // d(distill token) = sum_b g[b,-1]
     const int tok_off = cait ? 0 : 1;
     if (!cait) launch_batch_reduce(e->g, b, ntok, d, 0, 1, e->grads + e->cls, e->stream);   // dcls = sum_b g[b,0]
     launch_sum_rows(e->grads + e->pos + (int64_t)tok_off * d, np, d, e->grads + e->patch.b, e->stream);   // db = sum over patch rows

@@ -939,7 +939,10 @@ void launch_gemm_bf16(const Bf16GemmArgs& g0, const EpiParams& ep, int mode, hip
   }
   Bf16GemmArgs g = g0;
   if (best < 0) {
-    static const int cand[] = {6, 13, 14, 2, 7, 15, 10, 5};   // 256x256 variants first, then 320x256 (only when allowed)
+    static const int cand[] = {6, 13, 14, 2, 7, 15, 10, 5, 3, 1};   // 256x256 variants first, then 320x256 (only when allowed), then small tiles
+    // 256x128 / 128x128 tiles only compete when 256x256 tiles cannot give every CU two of them (token subsets: MAE's encoder
+    // sees 49 of 196 patches, M = 12544 -> 147 tiles for a 768-wide output)
+    const bool small_m = ceil_div(g0.M, 256) * ceil_div(g0.N, 256) < 512;
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0);
     (void)hipEventCreate(&e1);
@@ -948,7 +951,8 @@ void launch_gemm_bf16(const Bf16GemmArgs& g0, const EpiParams& ep, int mode, hip
     for (int c : cand) {
       const bool is320 = c == 5 || c == 7 || c == 10 || c == 15;
       if (is320 && !g_allow_320) continue;
-      if (g_shared_gpu && c != 2 && c != 5) continue;   // no persistent variants beside collectives (see gemm_bf16_set_shared_gpu)
+      if ((c == 1 || c == 3) && !small_m) continue;
+      if (g_shared_gpu && c != 2 && c != 5 && c != 1 && c != 3) continue;   // no persistent variants beside collectives (see gemm_bf16_set_shared_gpu)
       g.kernel = c;
       dispatch_gemm_bf16(g, ep, mode, s);   // warm-up (first-use attribute setup, instruction cache)
       (void)hipEventRecord(e0, s);

@@ -83,8 +83,9 @@ void launch_transpose_bf16(const bf16_t* in, int64_t ldi, int rows, int cols, bf
 void launch_convert(const float* in, int64_t ldi, void* out, int out_bf16, int64_t ldo, int rows, int cols, int64_t out_cols_zero_to,
                     hipStream_t s);
 void launch_to_f32(const void* in, int in_bf16, int64_t ldi, float* out, int64_t ldo, int rows, int cols, hipStream_t s);
-void launch_mean_pool(const float* x, int b, int ntok, int d, float* out, hipStream_t s);
-void launch_mean_pool_bwd(const float* dp, int b, int ntok, int d, float* g, hipStream_t s);
+void launch_set_token_row(float* x, const float* tok, int b, int ntok, int row, int d, hipStream_t s);   // x[b, row, :] = tok[:]
+void launch_mean_pool(const float* x, int b, int ntok, int d, float* out, hipStream_t s, int stride_tok = 0);   // stride_tok: rows per image in memory (0 = ntok)
+void launch_mean_pool_bwd(const float* dp, int b, int ntok, int d, float* g, hipStream_t s, int stride_tok = 0);   // rows >= ntok of an image are left alone
 void launch_batch_reduce(const float* g, int b, int ntok, int d, int j0, int nj, float* out, hipStream_t s);  // out[j][c] = sum_b g[b][j0+j][c]
 void launch_extract_rows(const float* g, int b, int ntok, int tok_off, int np, int d, void* out, int out_bf16, int64_t ldo, hipStream_t s);
 void launch_sum_rows(const float* in, int rows, int d, float* out, hipStream_t s);  // out[c] = sum_r in[r][c] (small)

@@ -59,6 +59,10 @@ class MimConfig(C.Structure):
     ]
 
 
+class DistillConfig(C.Structure):
+    _fields_ = [("temperature", C.c_float), ("alpha", C.c_float), ("hard", C.c_int32), ("literal_loss", C.c_int32), ("reserved", C.c_int32 * 8)]
+
+
 GRAD_READY_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int64, C.c_int64)
 
 # every symbol include/vitx.h declares: (name, restype, argtypes)
@@ -114,6 +118,19 @@ SYMBOLS: List[Tuple[str, object, list]] = [
     ("vitx_mim_forward_dev", C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     ("vitx_mim_backward", C.c_int32, [C.c_void_p]),
     ("vitx_mim_read", C.c_int32, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64, _P(C.c_int64)]),
+    ("vitx_forward_distill", C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("vitx_backward_distill", C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("vitx_distill_create", C.c_int32, [C.c_void_p, _P(DistillConfig), _P(C.c_void_p)]),
+    ("vitx_distill_destroy", C.c_int32, [C.c_void_p]),
+    ("vitx_distill_param_table_size", C.c_int32, [C.c_void_p, _P(C.c_int64), _P(C.c_int64)]),
+    ("vitx_distill_param_table_entry", C.c_int32, [C.c_void_p, C.c_int64, C.c_char_p, C.c_int32, _P(C.c_int64), _P(C.c_int32), _P(C.c_int64)]),
+    ("vitx_distill_set_params", C.c_int32, [C.c_void_p, C.c_void_p, C.c_int64]),
+    ("vitx_distill_get_params", C.c_int32, [C.c_void_p, C.c_void_p, C.c_int64]),
+    ("vitx_distill_get_grads", C.c_int32, [C.c_void_p, C.c_void_p, C.c_int64]),
+    ("vitx_distill_forward", C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_uint64, C.c_float, C.c_float, C.c_void_p]),
+    ("vitx_distill_forward_dev", C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_uint64, C.c_float, C.c_float, C.c_void_p]),
+    ("vitx_distill_backward", C.c_int32, [C.c_void_p, C.c_void_p]),
+    ("vitx_distill_read", C.c_int32, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64, _P(C.c_int64)]),
 ]
 
 _lib = None
@@ -156,16 +173,17 @@ def param_table(cfg: Config):
     return out, int(ne.value)
 
 
-def mim_param_table(handle):
-    """[(name, shape, offset)] of a MAE / SimMIM wrapper's own parameters."""
+def mim_param_table(handle, prefix="vitx_mim"):
+    """[(name, shape, offset)] of a wrapper object's own parameters (prefix 'vitx_mim': MAE / SimMIM, 'vitx_distill': DistillWrapper)."""
     l = lib()
+    size_fn, entry_fn = getattr(l, prefix + "_param_table_size"), getattr(l, prefix + "_param_table_entry")
     nt, ne = C.c_int64(), C.c_int64()
-    check(l.vitx_mim_param_table_size(handle, C.byref(nt), C.byref(ne)))
+    check(size_fn(handle, C.byref(nt), C.byref(ne)))
     out = []
     name = C.create_string_buffer(256)
     shape = (C.c_int64 * 4)()
     rank, off = C.c_int32(), C.c_int64()
     for i in range(nt.value):
-        check(l.vitx_mim_param_table_entry(handle, i, name, 256, shape, C.byref(rank), C.byref(off)))
+        check(entry_fn(handle, i, name, 256, shape, C.byref(rank), C.byref(off)))
         out.append((name.value.decode(), tuple(int(shape[k]) for k in range(rank.value)), int(off.value)))
     return out, int(ne.value)
