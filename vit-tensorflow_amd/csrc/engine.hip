@@ -1307,6 +1307,12 @@ int engine_bench_gemm(vitx_engine* e, int M, int N, int K, int kernel, int epilo
   }
   finalize_epi(ep);
   launch_gemm_bf16(g, ep, mode, e->stream);   // warm-up (+ attribute setup)
+  unsigned long long* stamps = nullptr;
+  if (getenv("VITX_GEMM_STAMPS")) {
+    HIPCHK(hipMalloc((void**)&stamps, 256 * 16 * 4 * 8));
+    HIPCHK(hipMemsetAsync(stamps, 0, 256 * 16 * 4 * 8, e->stream));
+    g.stamps = stamps;
+  }
   hipEvent_t e0, e1;
   HIPCHK(hipEventCreate(&e0));
   HIPCHK(hipEventCreate(&e1));
@@ -1317,6 +1323,23 @@ int engine_bench_gemm(vitx_engine* e, int M, int N, int K, int kernel, int epilo
   float ms = 0.f;
   HIPCHK(hipEventElapsedTime(&ms, e0, e1));
   *avg_ms = ms / std::max(1, iters);
+  if (stamps) {   // phase durations of the last launch, averaged over the workgroups, per tile index (cycles of the shader clock counter)
+    std::vector<unsigned long long> hs(256 * 16 * 4);
+    HIPCHK(hipMemcpy(hs.data(), stamps, hs.size() * 8, hipMemcpyDeviceToHost));
+    (void)hipFree(stamps);
+    g.stamps = nullptr;
+    for (int t = 0; t < 16; ++t) {
+      double kl = 0, ep_ = 0, dr = 0, gap = 0; int n = 0, ng = 0;
+      for (int w = 0; w < 256; ++w) {
+        const unsigned long long* p = &hs[((size_t)w * 16 + t) * 4];
+        if (!p[0] || !p[3]) continue;
+        kl += (double)(p[1] - p[0]); ep_ += (double)(p[2] - p[1]); dr += (double)(p[3] - p[2]); ++n;
+        if (t + 1 < 16) { const unsigned long long* q = &hs[((size_t)w * 16 + t + 1) * 4]; if (q[0]) { gap += (double)(q[0] - p[3]); ++ng; } }
+      }
+      if (n) fprintf(stderr, "[stamps] tile %2d (%3d WGs): k-loop %8.0f  epilogue %8.0f  drain+refill %8.0f  gap %6.0f cycles\n", t, n, kl / n, ep_ / n, dr / n,
+                     ng ? gap / ng : 0.0);
+    }
+  }
   *max_err = -1.f;
   if (check) {
     // reference: generic fp32-FMA kernel on the same operands; the fused epilogue is re-stated on the host

@@ -143,7 +143,7 @@ __device__ __forceinline__ float4 epilogue_fast4(const EpiParams& p, int row, in
     *(float4*)((float*)p.out + out_off + (int64_t)row * p.ldo + col) = v;
   } else if (MODE == EPI_BIAS_GELU) {
     st4<T>((T*)p.out + (int64_t)row * p.ldo + col, v);
-    const float4 g = make_float4(gelu_t<T>((float)(T)v.x), gelu_t<T>((float)(T)v.y), gelu_t<T>((float)(T)v.z), gelu_t<T>((float)(T)v.w));
+    const float4 g = gelu4_t<T>(make_float4((float)(T)v.x, (float)(T)v.y, (float)(T)v.z, (float)(T)v.w));   // on the value as stored
     st4<T>((T*)p.out2 + (int64_t)row * p.ldo2 + col, g);
   } else if (MODE == EPI_BIAS_RESID) {
     if (HAS_SCALE) {
@@ -152,7 +152,8 @@ __device__ __forceinline__ float4 epilogue_fast4(const EpiParams& p, int row, in
     }
     *(float4*)((float*)p.out + (int64_t)row * p.ldo + col) = make_float4(x.x + v.x, x.y + v.y, x.z + v.z, x.w + v.w);
   } else if (MODE == EPI_GELU_BWD) {
-    const float4 gq = make_float4(v.x * gelu_grad_t<T>(x.x), v.y * gelu_grad_t<T>(x.y), v.z * gelu_grad_t<T>(x.z), v.w * gelu_grad_t<T>(x.w));
+    const float4 gd = gelu_grad4_t<T>(x);
+    const float4 gq = make_float4(v.x * gd.x, v.y * gd.y, v.z * gd.z, v.w * gd.w);
     st4<T>((T*)p.out + (int64_t)row * p.ldo + col, gq);
     return make_float4((float)(T)gq.x, (float)(T)gq.y, (float)(T)gq.z, (float)(T)gq.w);   // as stored (see epilogue_apply4)
   }

@@ -363,6 +363,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_pipe_kernel(Bf16Gem
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave - wm * WN;
 
+  if (g.phase > 0 && persistent) {   // de-phase the workgroups of an XCD: their store-heavy epilogues stop coinciding
+    const int ph = (bid >> 3) & 7;
+    for (int i = 0; i < ph * g.phase; ++i) __builtin_amdgcn_s_sleep(64);
+  }
+
   // per-lane DMA source offsets in BYTES, unsigned: address = uniform 64-bit base (SGPR pair) + zero-extended 32-bit lane offset,
   // which selects the saddr form of global_load_lds (one address dword per lane, no per-piece VALU address arithmetic)
   uint32_t offA[A_INSTR], offB[B_INSTR];
@@ -463,10 +468,15 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_pipe_kernel(Bf16Gem
   handover();
   load_frags(fa[0], fb[0], smem, 0);
   int it = 0;   // consumed K-tile counter of the stream
-  for (int logical = logical0; logical < total_tiles; logical += nwg) {
+  int tile_idx = 0;
+  auto stamp = [&](int k) {
+    if (g.stamps && tid == 0 && bid < 256 && tile_idx < 16) g.stamps[((int64_t)bid * 16 + tile_idx) * 4 + k] = __builtin_readcyclecounter();
+  };
+  for (int logical = logical0; logical < total_tiles; logical += nwg, ++tile_idx) {
     int tile_m, tile_n;
     decode_tile(logical, tiles_m, tiles_n, gm, tile_m, tile_n);
     const bool has_next = persistent && logical + nwg < total_tiles;
+    stamp(0);
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -523,6 +533,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_pipe_kernel(Bf16Gem
     }
 
     // ---- epilogue: 32 output rows per round through the buffer of the last K-tile (its refill is deferred until after the epilogue)
+    stamp(1);
     {
       const bool interior = epilogue_fast_ok(ep, MODE) && (tile_m + 1) * BM <= ep.M && (tile_n + 1) * BN <= ep.N;
       float* st = (float*)(smem + ((it + 1) & 1) * STAGE);
@@ -595,11 +606,13 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_pipe_kernel(Bf16Gem
         }
       }
     }
+    stamp(2);
     if (has_next) {
       handover();                                   // staging reads done everywhere
       issue();                                      // deferred refill of the staging buffer: stream item it+1
       load_frags(fa[0], fb[0], smem + (it & 1) * STAGE, 0);
     }
+    stamp(3);
   }
 }
 
@@ -622,9 +635,13 @@ void launch_pipe(const Bf16GemmArgs& g, const EpiParams& ep, hipStream_t s) {
   const int split = g.split_k > 1 ? g.split_k : 1;
   const int per = (int)ceil_div(nk, split);
   const int zs = (int)ceil_div(nk, per);
-  const unsigned gx = zs == 1 ? (unsigned)std::min(tiles_m * tiles_n, 256) : (unsigned)(tiles_m * tiles_n);
+  static const int phase_env = [] { const char* v = getenv("VITX_GEMM_PHASE"); return v ? atoi(v) : 0; }();
+  Bf16GemmArgs gp = g;
+  if (gp.phase == 0) gp.phase = phase_env;
+  static const int grid_cap = [] { const char* v = getenv("VITX_GEMM_GRID"); return v ? atoi(v) : 256; }();   // experiment: fewer persistent workgroups
+  const unsigned gx = zs == 1 ? (unsigned)std::min(tiles_m * tiles_n, grid_cap) : (unsigned)(tiles_m * tiles_n);
   dim3 grid(gx, (unsigned)zs), block(WM * WN * 64);
-  hipLaunchKernelGGL(kern, grid, block, SMEM, s, g, ep, tiles_m, tiles_n, per);
+  hipLaunchKernelGGL(kern, grid, block, SMEM, s, gp, ep, tiles_m, tiles_n, per);
 }
 
 // ------------------------------------------------------------------------------------------------

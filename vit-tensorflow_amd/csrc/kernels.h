@@ -41,6 +41,8 @@ struct Bf16GemmArgs {
   int M = 0, N = 0, K = 0;   // K multiple of 64; A has >= round_up(M,tile) rows, B >= round_up(N,tile) rows
   int split_k = 1;           // >1: EPI_PARTIAL slices of K/split_k (each a multiple of 64)
   int kernel = 0;            // tile variant: 0 auto, 1 = 128x128 (4 waves), 2 = 256x256 (8 waves), 3 = 256x128
+  unsigned long long* stamps = nullptr;   // diagnostics (VITX_GEMM_STAMPS=1 in vitx_bench_gemm): cycle stamps of the tile phases, [256 WGs][16 tiles][4]
+  int phase = 0;             // persistent pipelined kernels: workgroup i starts ((i >> 3) & 7) * phase * 4096 cycles late (de-phases the tile loops)
   int stagger = 0;           // >0: first-wave workgroups start (cu_slot & 3) * stagger * 2048 cycles late (de-phases store-heavy epilogues)
 };
 void launch_gemm_bf16(const Bf16GemmArgs& g, const EpiParams& ep, int mode, hipStream_t s);
