@@ -765,8 +765,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_tn_kernel(Bf16GemmArgs
       acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[CUR][j], fa[CUR][i], acc[i][j], 0, 0, 0);
     });
   };
+  const int xp = g.stagger;   // timing experiments only (VITX_TN_XP; results are wrong): 1 = no DMA wait, 2 = no DMA issue in the K loop, 4 = no fragment reads in the K loop
   auto handover = [&]() {
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    if (xp & 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
   };
@@ -786,13 +788,13 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_tn_kernel(Bf16GemmArgs
       if constexpr (ks + 1 < BK / 16) {
         mfma_range(ic<CUR>{}, ic<0>{}, ic<QH>{});
         __builtin_amdgcn_sched_barrier(0);
-        load_frags(fa[CUR ^ 1], fb[CUR ^ 1], base, ks + 1);
+        if (!(xp & 4)) load_frags(fa[CUR ^ 1], fb[CUR ^ 1], base, ks + 1);
       } else {
         handover();                                                   // K-tile kt+1 landed; buffer kt&1 fully read by every wave
         mfma_range(ic<CUR>{}, ic<0>{}, ic<QH>{});
         __builtin_amdgcn_sched_barrier(0);
-        load_frags(fa[0], fb[0], smem + ((kt + 1) & 1) * STAGE, 0);    // (stale LDS after the last K-tile: unused)
-        pending = kt + 2 < nk;
+        if (!(xp & 4)) load_frags(fa[0], fb[0], smem + ((kt + 1) & 1) * STAGE, 0);    // (stale LDS after the last K-tile: unused)
+        pending = kt + 2 < nk && !(xp & 2);
       }
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (NP > 0) {
@@ -993,7 +995,10 @@ void launch_gemm_bf16(const Bf16GemmArgs& g0, const EpiParams& ep, int mode, hip
 
 // C[M=in][N=out] (split-K partials) = A[K=tokens][in]^T * B[K=tokens][out]; kernel: 1 = 128x128 tile, else 256x256
 int gemm_bf16_tn_tile(int kernel, int M, int N) { kernel &= 15; return (kernel == 1 || (M <= 128 && N <= 128)) ? 128 : 256; }
-void launch_gemm_bf16_tn(const Bf16GemmArgs& g, const EpiParams& ep, hipStream_t s) {
+void launch_gemm_bf16_tn(const Bf16GemmArgs& g0, const EpiParams& ep, hipStream_t s) {
+  static const int xp = [] { const char* v = getenv("VITX_TN_XP"); return v ? atoi(v) : 0; }();
+  Bf16GemmArgs g = g0;
+  g.stagger = xp;
   if (gemm_bf16_tn_tile(g.kernel, g.M, g.N) == 128) launch_tn_variant<128, 2, 2>(g, ep, s);
   else launch_tn_variant<256, 2, 4>(g, ep, s);
 }
