@@ -151,8 +151,21 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(const bf16_t* __r
     float m[QB];
 #pragma unroll
     for (int s = 0; s < QB; ++s) m[s] = -INFINITY;
+    // only the last key tiles reach past n: the key mask (a compare + select per score, in kernels whose softmax arithmetic keeps
+    // the VALU as busy as the matrix pipe) is applied there alone
+    const int t_full = n >> 4;                      // tiles [0, t_full) hold valid keys only
 #pragma unroll 2
-    for (int t = 0; t < NTP; ++t) {
+    for (int t = 0; t < t_full; ++t) {
+      const bf16x8 kf0 = frag_rm(k_rm, t * 16 + qi, g), kf1 = frag_rm(k_rm, t * 16 + qi, g + 4);
+#pragma unroll
+      for (int s = 0; s < QB; ++s) {
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+        a = mfma16(kf0, qf[s][0], a);
+        a = mfma16(kf1, qf[s][1], a);
+        m[s] = fmaxf(fmaxf(m[s], fmaxf(a[0], a[1])), fmaxf(a[2], a[3]));
+      }
+    }
+    for (int t = t_full; t < NTP && t * 16 < n; ++t) {
       const bf16x8 kf0 = frag_rm(k_rm, t * 16 + qi, g), kf1 = frag_rm(k_rm, t * 16 + qi, g + 4);
 #pragma unroll
       for (int s = 0; s < QB; ++s) {
@@ -178,9 +191,12 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(const bf16_t* __r
 #pragma unroll
       for (int c = 0; c < 4; ++c) oacc[s][c] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
+    const int u_full = n >> 5;                      // tile pairs [0, u_full) hold valid keys only
+    const int u_end = min(NTP / 2, (n + 31) >> 5);  // pairs beyond hold no valid key at all (P = 0: nothing to accumulate)
 #pragma unroll 1
-    for (int u = 0; u < NTP / 2; ++u) {
+    for (int u = 0; u < u_end; ++u) {
       f32x4 p[QB][2];
+      const bool masked = u >= u_full;              // wave-uniform
 #pragma unroll
       for (int tt = 0; tt < 2; ++tt) {
         const int t = 2 * u + tt;
@@ -190,12 +206,14 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(const bf16_t* __r
           f32x4 a = {0.f, 0.f, 0.f, 0.f};
           a = mfma16(kf0, qf[s][0], a);
           a = mfma16(kf1, qf[s][1], a);
+          if (!masked) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float e = (t * 16 + 4 * g + r) < n ? fast_exp2(a[r] * sl2 - m[s]) : 0.f;
-            p[s][tt][r] = e;
-            l[s] += e;
+            for (int r = 0; r < 4; ++r) p[s][tt][r] = fast_exp2(fmaf(a[r], sl2, -m[s]));
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) p[s][tt][r] = (t * 16 + 4 * g + r) < n ? fast_exp2(fmaf(a[r], sl2, -m[s])) : 0.f;
           }
+          l[s] += (p[s][tt][0] + p[s][tt][1]) + (p[s][tt][2] + p[s][tt][3]);
         }
       }
       bf16x8 pf[QB];
@@ -280,9 +298,13 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dq_kernel(const bf16_t* 
 #pragma unroll
       for (int c = 0; c < 4; ++c) dq[s][c] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
+    // key masks only where a tile pair reaches past n (wave-uniform branch); query rows >= n of the last block compute on the
+    // clamped row n-1 (finite) and are never stored, so they need no mask here
+    const int u_full = n >> 5, u_end = min(NTP / 2, (n + 31) >> 5);
 #pragma unroll 1
-    for (int u = 0; u < NTP / 2; ++u) {
+    for (int u = 0; u < u_end; ++u) {
       f32x4 ds[QB][2];
+      const bool masked = u >= u_full;
 #pragma unroll
       for (int tt = 0; tt < 2; ++tt) {
         const int t = 2 * u + tt;
@@ -295,11 +317,12 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dq_kernel(const bf16_t* 
           sa = mfma16(kf1, qf[s][1], sa);
           dp = mfma16(vf0, dof[s][0], dp);
           dp = mfma16(vf1, dof[s][1], dp);
+          const float nds = -dpart[s] * scale;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const int key = t * 16 + 4 * g + r;
-            const float p = (key < n && q[s] < n) ? fast_exp2(sa[r] * sl2 - l2[s]) : 0.f;
-            ds[s][tt][r] = p * (dp[r] - dpart[s]) * scale;
+            float p = fast_exp2(fmaf(sa[r], sl2, -l2[s]));
+            if (masked) p = (t * 16 + 4 * g + r) < n ? p : 0.f;
+            ds[s][tt][r] = p * fmaf(dp[r], scale, nds);
           }
         }
       }
@@ -374,8 +397,11 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dkv_kernel(const bf16_t*
 #pragma unroll
       for (int c = 0; c < 4; ++c) { dk[s][c] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[s][c] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     }
+    // No masks: query rows >= n are zero rows of q / dO with lse = D = 0 staged above, so their P = 1 meets dO = 0 and their
+    // dS = 1 * (0 - 0); key lanes >= n compute on the clamped key n-1 and are never stored.  Tile pairs past n are skipped.
+    const int u_end = min(NTP / 2, (n + 31) >> 5);
 #pragma unroll 1
-    for (int u = 0; u < NTP / 2; ++u) {
+    for (int u = 0; u < u_end; ++u) {
       f32x4 pp[QB][2], ds[QB][2];
 #pragma unroll
       for (int tt = 0; tt < 2; ++tt) {
@@ -394,10 +420,9 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dkv_kernel(const bf16_t*
           dp = mfma16(da1, vf[s][1], dp);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const int qq = t * 16 + 4 * g + r;
-            const float p = (qq < n && key[s] < n) ? fast_exp2(sa[r] * sl2 - lq[r]) : 0.f;
+            const float p = fast_exp2(fmaf(sa[r], sl2, -lq[r]));
             pp[s][tt][r] = p;
-            ds[s][tt][r] = p * (dp[r] - dd[r]) * scale;
+            ds[s][tt][r] = p * ((dp[r] - dd[r]) * scale);
           }
         }
       }
