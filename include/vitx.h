@@ -148,6 +148,15 @@ int32_t vitx_sgd_step(vitx_handle h, float lr, float momentum, float weight_deca
 int32_t vitx_set_stream(vitx_handle h, void* hip_stream); /* NULL = the handle's own stream */
 int32_t vitx_sync(vitx_handle h);
 
+/* ---- HIP graphs (no reference counterpart: replaces ~300 launches of a step by one when the step is launch-bound, e.g. the
+ * README's batch-1 example).  Everything enqueued on the handle through the *_dev entry points between begin and end is recorded
+ * instead of run; the captured device pointers (images, labels, logits) are baked in.  Run one eager step of the same geometry
+ * first (first-use allocations and the GEMM variant measurements cannot be captured). */
+int32_t vitx_graph_capture_begin(vitx_handle h);
+int32_t vitx_graph_capture_end(vitx_handle h, void** graph_exec_out);
+int32_t vitx_graph_launch(vitx_handle h, void* graph_exec);
+int32_t vitx_graph_destroy(void* graph_exec);
+
 /* ---- data parallel (no reference counterpart: batch-sharded replicas, mean-reduced gradients) */
 int32_t vitx_set_grad_ready_callback(vitx_handle h, vitx_grad_ready_fn fn, void* user);
 int32_t vitx_comm_unique_id(void* out_128_bytes);

@@ -116,3 +116,46 @@ def test_head_axis_chains_beyond_64_keys(name, compute, tol):
     assert np.abs(logits - ref_logits).max() <= tol * max(1.0, np.abs(ref_logits).max())
     for k, r in ref_grads.items():
         assert np.abs(grads[k] - r).max() <= tol * np.abs(r).max() + 1e-6, (k, np.abs(grads[k] - r).max(), np.abs(r).max())
+
+
+def test_hip_graph_replay_equals_eager_steps():
+    """vitx_graph_*: a captured training step (operand refresh, forward, CE gradient, backward, SGD) replayed as one launch leaves
+    exactly the parameters that the same number of eager steps leaves (bit-identical: the same kernels in the same order)."""
+    import ctypes as C
+    import torch
+    from vit_tensorflow import _native as N
+    lib = N.lib()
+    P = spec.init_params(oracle_cfg("vit_bf16_small"), 1, randomize_all=True)
+    rng = np.random.default_rng(0)
+    b = 3
+    img = torch.tensor(rng.standard_normal((b, 64, 64, 3)).astype(np.float32), device="cuda:0")
+    labels = torch.tensor(rng.integers(0, 10, b).astype(np.int32), device="cuda:0")
+    outs = []
+    for use_graph in (False, True):
+        m = make_engine_model("vit_bf16_small", "bf16", b, P)
+        h = m._ensure_handle(b)
+
+        def step():
+            N.check(lib.vitx_params_changed(h))
+            N.check(lib.vitx_forward_dev(h, C.c_void_p(img.data_ptr()), b, 64, 64, 0, 0, None))
+            N.check(lib.vitx_ce_loss_grad_dev(h, C.c_void_p(labels.data_ptr()), 1.0 / b, None))
+            N.check(lib.vitx_backward_dev(h, None, None))
+            N.check(lib.vitx_sgd_step(h, 1e-2, 0.0, 0.0))
+
+        step()                                   # eager warm-up: first-use setup cannot be captured
+        if use_graph:
+            N.check(lib.vitx_graph_capture_begin(h))
+            step()                               # recorded, not run
+            g = C.c_void_p()
+            N.check(lib.vitx_graph_capture_end(h, C.byref(g)))
+            for _ in range(3):
+                N.check(lib.vitx_graph_launch(h, g))
+            N.check(lib.vitx_sync(h))
+            N.check(lib.vitx_graph_destroy(g))
+        else:
+            for _ in range(3):
+                step()
+        m._device_newer = True
+        outs.append(np.concatenate([w.reshape(-1) for w in m.get_weights()]))
+    assert np.array_equal(outs[0], outs[1])
+    assert not np.array_equal(outs[0], np.concatenate([np.asarray(P[n], np.float32).reshape(-1) for n, _, _ in m._table]))

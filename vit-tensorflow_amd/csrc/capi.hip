@@ -327,6 +327,49 @@ int32_t vitx_set_stream(vitx_handle h, void* s) {
   h->stream = s ? (hipStream_t)s : h->own_stream;
   return VITX_OK;
 }
+// ---- HIP graphs: the launch sequence of a step (operand refresh, forward, loss gradient, backward, optimizer) is fixed once the
+// batch geometry is, so it can be captured from the handle's stream and replayed with ONE launch: at small batches (the
+// reference's README example runs b = 1) the step is bound by the ~300 kernel launches, not by the kernels.
+int32_t vitx_graph_capture_begin(vitx_handle h) {
+  CAPI_TRY
+  if (!h) return fail(VITX_ERR_INVALID, "null handle");
+  if (h->grad_cb) return fail(VITX_ERR_STATE, "graph capture cannot record the host-side gradient-ready callback: unregister it first");
+  if (h->profiling) return fail(VITX_ERR_STATE, "graph capture while profiling");
+  CAPI_HIP(hipStreamSynchronize(h->stream));
+  CAPI_HIP(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+  return VITX_OK;
+  CAPI_CATCH
+}
+int32_t vitx_graph_capture_end(vitx_handle h, void** graph_exec_out) {
+  CAPI_TRY
+  if (!h || !graph_exec_out) return fail(VITX_ERR_INVALID, "null argument");
+  hipGraph_t graph = nullptr;
+  hipError_t rc = hipStreamEndCapture(h->stream, &graph);
+  if (rc != hipSuccess || !graph)
+    return fail(VITX_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(rc) +
+                                  " (run one eager step first: first-use allocations, kernel attributes and GEMM variant measurements cannot be captured)");
+  hipGraphExec_t exec = nullptr;
+  rc = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(graph);
+  if (rc != hipSuccess) return fail(VITX_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(rc));
+  *graph_exec_out = exec;
+  return VITX_OK;
+  CAPI_CATCH
+}
+int32_t vitx_graph_launch(vitx_handle h, void* graph_exec) {
+  CAPI_TRY
+  if (!h || !graph_exec) return fail(VITX_ERR_INVALID, "null argument");
+  CAPI_HIP(hipGraphLaunch((hipGraphExec_t)graph_exec, h->stream));
+  return VITX_OK;
+  CAPI_CATCH
+}
+int32_t vitx_graph_destroy(void* graph_exec) {
+  CAPI_TRY
+  if (graph_exec) CAPI_HIP(hipGraphExecDestroy((hipGraphExec_t)graph_exec));
+  return VITX_OK;
+  CAPI_CATCH
+}
+
 int32_t vitx_sync(vitx_handle h) {
   if (!h) return fail(VITX_ERR_INVALID, "null handle");
   CAPI_HIP(hipStreamSynchronize(h->stream));

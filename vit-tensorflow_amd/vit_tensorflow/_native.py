@@ -94,6 +94,10 @@ SYMBOLS: List[Tuple[str, object, list]] = [
     ("vitx_sgd_step", C.c_int32, [C.c_void_p, C.c_float, C.c_float, C.c_float]),
     ("vitx_set_stream", C.c_int32, [C.c_void_p, C.c_void_p]),
     ("vitx_sync", C.c_int32, [C.c_void_p]),
+    ("vitx_graph_capture_begin", C.c_int32, [C.c_void_p]),
+    ("vitx_graph_capture_end", C.c_int32, [C.c_void_p, _P(C.c_void_p)]),
+    ("vitx_graph_launch", C.c_int32, [C.c_void_p, C.c_void_p]),
+    ("vitx_graph_destroy", C.c_int32, [C.c_void_p]),
     ("vitx_set_grad_ready_callback", C.c_int32, [C.c_void_p, GRAD_READY_FN, C.c_void_p]),
     ("vitx_comm_unique_id", C.c_int32, [C.c_void_p]),
     ("vitx_comm_init", C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
