@@ -280,7 +280,8 @@ static void dense_wgrad(vitx_engine* e, const void* X, int64_t ldx, const void* 
     g.split_k = split;
     const int slices = gemm_bf16_num_slices(kext, split);
     EpiParams ep;
-    ep.out = e->partial_ws; ep.ldo = w.out; ep.partial_stride = (int64_t)w.in * w.out;
+    // a single K slice (small batches: few token rows) is the gradient itself: written in place, no partial buffer, no reduction pass
+    ep.out = slices == 1 ? dW : e->partial_ws; ep.ldo = w.out; ep.partial_stride = (int64_t)w.in * w.out;
     ep.M = w.in; ep.N = w.out;
     finalize_epi(ep);
     {
@@ -288,8 +289,10 @@ static void dense_wgrad(vitx_engine* e, const void* X, int64_t ldx, const void* 
       if (e->wgrad_via_transpose) launch_gemm_bf16(g, ep, EPI_PARTIAL, e->stream);
       else launch_gemm_bf16_tn(g, ep, e->stream);
     }
-    Prof pr(e, "reduce_partials", 0, (double)(slices + 1) * w.in * w.out * 4);
-    launch_reduce_partials(e->partial_ws, slices, (int64_t)w.in * w.out, (int64_t)w.in * w.out, dW, 1.0f, e->stream);
+    if (slices > 1) {
+      Prof pr(e, "reduce_partials", 0, (double)(slices + 1) * w.in * w.out * 4);
+      launch_reduce_partials(e->partial_ws, slices, (int64_t)w.in * w.out, (int64_t)w.in * w.out, dW, 1.0f, e->stream);
+    }
   } else {
     GenericGemmArgs g;
     g.A = X; g.B = dY;

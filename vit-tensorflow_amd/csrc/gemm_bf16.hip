@@ -946,7 +946,10 @@ static int autotune_enabled() {
   return on;
 }
 void launch_gemm_bf16(const Bf16GemmArgs& g0, const EpiParams& ep, int mode, hipStream_t s) {
-  const bool tunable = g0.kernel == 0 && autotune_enabled() && (g0.N % 256 == 0 || g0.N > 512) && (double)g0.M * g0.N * g0.K >= 2.0e9 &&
+  // small batches: a few hundred token rows give the 256x256 tiles less than two per CU, where the smaller tiles can win by a lot
+  const bool few_tiles = ceil_div(g0.M, 256) * ceil_div(g0.N, 256) < 512;
+  const double work = (double)g0.M * g0.N * g0.K;
+  const bool tunable = g0.kernel == 0 && autotune_enabled() && (g0.N % 256 == 0 || g0.N > 512) && (work >= 2.0e9 || (few_tiles && work >= 1.0e8)) &&
                        !(mode == EPI_BIAS_RESID && ep.out == (void*)ep.resid);
   if (!tunable) { dispatch_gemm_bf16(g0, ep, mode, s); return; }
   const std::array<int64_t, 6> key = {mode, g0.M, g0.N, g0.K, g0.split_k > 1 ? g0.split_k : 1, (ep.scale != nullptr) + 2 * g_shared_gpu};
