@@ -270,6 +270,9 @@ static void dense_wgrad(vitx_engine* e, const void* X, int64_t ldx, const void* 
     } else {
       g.A = (const bf16_t*)X; g.lda = ldx;
       g.B = (const bf16_t*)dY; g.ldb = ldy;
+      // few token rows (small batches): the K extent cannot be split, so 256x256 tiles leave most CUs idle and each workgroup's
+      // time is its prologue plus a 256-KiB partial store; 128x128 tiles give four times the workgroups and a quarter of that store
+      if (g.kernel == 0 && ceil_div(w.in, 256) * ceil_div(w.out, 256) * std::max<int64_t>(1, ceil_div(kext / 64, 4)) <= 128) g.kernel = 1;
       tm = tn = gemm_bf16_tn_tile(g.kernel, g.M, g.N);
     }
     const int64_t tiles = ceil_div(w.in, tm) * ceil_div(w.out, tn);
