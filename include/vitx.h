@@ -58,7 +58,11 @@ typedef struct vitx_config {
   int32_t compute;
   int32_t max_batch;          /* device buffers are sized once for this batch */
   int32_t device_id;
-  int32_t reserved[8];
+  /* parallel_vit.ViT(..., num_parallel_branches=2) (parallel_vit.py:119-133): every layer is a sum of this many attention blocks
+   * followed by a sum of this many feed-forward blocks, each with its own PreNorm (parallel_vit.py:36-42,104-117).  0 or 1 = the
+   * ordinary ViT.  variant must be VITX_VARIANT_VIT. */
+  int32_t num_parallel_branches;
+  int32_t reserved[7];
 } vitx_config;
 
 typedef struct vitx_engine* vitx_handle;

@@ -89,7 +89,35 @@ def _attention(x, P, pre, cfg, q, context=None):
     return out
 
 
+def _parallel_transformer(x, P, cfg, prefix, depth, q):
+    """parallel_vit.py:99-117: x = sum_i attn_i(norm_i(x)) + x; x = sum_i ff_i(norm_i(x)) + x (every branch has its own PreNorm)."""
+    nb = cfg["num_parallel_branches"]
+    for l in range(depth):
+        acc = x
+        for i in range(nb):                                                         # Parallel.call: sum of the branches  parallel_vit.py:41-42
+            pa = f"{prefix}.{l}.attn.{i}"
+            y = q(layer_norm(x, P[f"{pa}.norm.gamma"], P[f"{pa}.norm.beta"]))       # PreNorm  parallel_vit.py:44-52
+            qkv = q(q(y) @ q(P[f"{pa}.to_qkv.kernel"]))
+            qq, kk, vv = (_heads(t, cfg["heads"]) for t in qkv.chunk(3, dim=-1))
+            attn = torch.softmax((qq @ kk.transpose(-1, -2)) * cfg["dim_head"] ** -0.5, dim=-1)
+            out = q(_merge(q(attn) @ vv))
+            if f"{pa}.to_out.kernel" in P:
+                out = q(out) @ q(P[f"{pa}.to_out.kernel"]) + P[f"{pa}.to_out.bias"]
+            acc = acc + out
+        x = acc                                                                     # attns(x) + x  parallel_vit.py:114
+        acc = x
+        for i in range(nb):
+            pm = f"{prefix}.{l}.mlp.{i}"
+            y = q(layer_norm(x, P[f"{pm}.norm.gamma"], P[f"{pm}.norm.beta"]))
+            hpre = q(q(y) @ q(P[f"{pm}.fc1.kernel"]) + P[f"{pm}.fc1.bias"])
+            acc = acc + (q(gelu(hpre)) @ q(P[f"{pm}.fc2.kernel"]) + P[f"{pm}.fc2.bias"])
+        x = acc                                                                     # ffs(x) + x  parallel_vit.py:115
+    return x
+
+
 def _transformer(x, P, cfg, prefix, depth, q, context=None):
+    if cfg.get("num_parallel_branches", 1) > 1:
+        return _parallel_transformer(x, P, cfg, prefix, depth, q)
     cait = cfg["variant"] == "cait"
     for i in range(depth):
         pa, pm = f"{prefix}.{i}.attn", f"{prefix}.{i}.mlp"

@@ -36,7 +36,7 @@ def pair(t):
 
 
 def make_config(variant="vit", image_size=256, patch_size=32, num_classes=1000, dim=1024, depth=6,
-                heads=16, mlp_dim=2048, pool="cls", dim_head=64, cls_depth=0, **_ignored) -> dict:
+                heads=16, mlp_dim=2048, pool="cls", dim_head=64, cls_depth=0, num_parallel_branches=1, **_ignored) -> dict:
     assert variant in VARIANTS
     ih, iw = pair(image_size)
     ph, pw = pair(patch_size)
@@ -47,7 +47,7 @@ def make_config(variant="vit", image_size=256, patch_size=32, num_classes=1000, 
         assert pool in {'cls', 'mean'}, 'pool type must be either cls (cls token) or mean (mean pooling)'
     return dict(variant=variant, image_size=(ih, iw), patch_size=(ph, pw), num_classes=num_classes,
                 dim=dim, depth=depth, heads=heads, mlp_dim=mlp_dim, pool=pool, dim_head=dim_head,
-                cls_depth=cls_depth, channels=3)
+                cls_depth=cls_depth, channels=3, num_parallel_branches=max(1, int(num_parallel_branches)))
 
 
 def layer_scale_init(depth_1based: int) -> float:
@@ -111,11 +111,33 @@ def param_spec(cfg: dict) -> List[Tuple[str, Tuple[int, ...], str]]:
         add(f"{prefix}.mlp.fc2.kernel", (m, d), "glorot")
         add(f"{prefix}.mlp.fc2.bias", (d,), "zeros")
 
+    P = cfg.get("num_parallel_branches", 1)
     if v == "cait":
         for i in range(cfg["depth"]):
             block(f"patch_transformer.{i}", i)
         for i in range(cfg["cls_depth"]):
             block(f"cls_transformer.{i}", i)  # LayerScale depth restarts: cait.py:142,173
+    elif P > 1:
+        # parallel_vit.py:104-111: layers[l] = [Parallel([PreNorm(Attention)] * P), Parallel([PreNorm(MLP)] * P)]
+        assert v == "vit"
+        project_out = not (h == 1 and dh == d)
+        for l in range(cfg["depth"]):
+            for i in range(P):
+                pre = f"transformer.{l}.attn.{i}"
+                add(f"{pre}.norm.gamma", (d,), "ones")
+                add(f"{pre}.norm.beta", (d,), "zeros")
+                add(f"{pre}.to_qkv.kernel", (d, 3 * inner), "glorot")
+                if project_out:
+                    add(f"{pre}.to_out.kernel", (inner, d), "glorot")
+                    add(f"{pre}.to_out.bias", (d,), "zeros")
+            for i in range(P):
+                pre = f"transformer.{l}.mlp.{i}"
+                add(f"{pre}.norm.gamma", (d,), "ones")
+                add(f"{pre}.norm.beta", (d,), "zeros")
+                add(f"{pre}.fc1.kernel", (d, m), "glorot")
+                add(f"{pre}.fc1.bias", (m,), "zeros")
+                add(f"{pre}.fc2.kernel", (m, d), "glorot")
+                add(f"{pre}.fc2.bias", (d,), "zeros")
     else:
         for i in range(cfg["depth"]):
             block(f"transformer.{i}", i)
@@ -177,5 +199,6 @@ def flops_per_image(cfg: dict, fwd_only: bool = False) -> float:
     np_ = (ih // ph) * (iw // pw)
     pd = ph * pw * cfg["channels"]
     n = np_ if cfg["variant"] == "cait" else np_ + 1
+    L = L * cfg.get("num_parallel_branches", 1)   # parallel_vit: every layer runs P attention and P feed-forward blocks
     fwd = 2 * np_ * pd * d + L * (2 * n * d * 3 * inner + 4 * n * n * inner + 2 * n * inner * d + 4 * n * d * m) + 2 * d * nc
     return float(fwd if fwd_only else 3 * fwd)

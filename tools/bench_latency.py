@@ -17,6 +17,8 @@ from vit_tensorflow import ViT, _native as N   # noqa: E402
 WORKLOADS = {
     "vit_readme_256": dict(image_size=256, patch_size=32, num_classes=1000, dim=1024, depth=6, heads=16, mlp_dim=2048),
     "vit_b16_224": dict(image_size=224, patch_size=16, num_classes=1000, dim=768, depth=12, heads=12, mlp_dim=3072),
+    # parallel_vit.py:177-188 (the reference's usage example: 257 tokens, two parallel branches per layer)
+    "parallel_vit_readme": dict(image_size=256, patch_size=16, num_classes=1000, dim=1024, depth=6, heads=8, mlp_dim=2048, num_parallel_branches=2),
 }
 
 
@@ -25,7 +27,11 @@ def main():
     b = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     steps = int(sys.argv[3]) if len(sys.argv) > 3 else 200
     kw = WORKLOADS[name]
-    m = ViT(**kw, compute="bf16", max_batch=b, seed=0)
+    if "num_parallel_branches" in kw:
+        from vit_tensorflow.parallel_vit import ViT as Model
+    else:
+        Model = ViT
+    m = Model(**kw, compute="bf16", max_batch=b, seed=0)
     h = m._ensure_handle(b)
     lib = N.lib()
     dev = torch.device("cuda:0")

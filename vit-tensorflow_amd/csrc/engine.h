@@ -45,6 +45,12 @@ struct BlockActs {
   void *y1 = nullptr, *qkv = nullptr, *q = nullptr, *kv = nullptr, *ctx = nullptr, *o = nullptr, *fa = nullptr;
   void *y2 = nullptr, *hpre = nullptr, *act = nullptr, *fm = nullptr;
   float *mean1 = nullptr, *rstd1 = nullptr, *mean2 = nullptr, *rstd2 = nullptr, *lse = nullptr;
+  // parallel branches (parallel_vit.py:36-42): a layer of P attention + P feed-forward blocks is laid out as 2P half-blocks.  Each
+  // adds its branch to the running residual (x_in -> x_mid, or x_mid -> x_out) but normalises the LAYER's input (ln*_src) --
+  // null = the residual input itself, i.e. the ordinary block.
+  const float *ln1_src = nullptr, *ln2_src = nullptr;
+  bool skip_attn = false, skip_mlp = false;
+  int par_first = 0, par_last = 0;   // backward order inside a group of parallel half-blocks: first / last one processed (1 + 1 = alone)
 };
 
 struct Stage {
@@ -95,6 +101,7 @@ struct vitx_engine {
   void* patches = nullptr;
   float* pooled = nullptr; void* yh = nullptr; float *mean_h = nullptr, *rstd_h = nullptr;
   float *logits = nullptr, *dlogits = nullptr; void* dl_lp = nullptr; void* dyh = nullptr; float* dpooled = nullptr;
+  float* g2 = nullptr;               // parallel branches: the layer-input gradient being accumulated while g still feeds the other branches
   float* g = nullptr; void* g_lp = nullptr; float* g_ctx = nullptr;  // residual gradient stream (+T copy), CaiT patch-output grad
   void *d_h = nullptr, *d_y = nullptr, *d_o = nullptr, *d_qkv = nullptr, *d_ctx = nullptr, *d_br = nullptr;
   bf16_t *xt = nullptr, *dyt = nullptr; int64_t t_rows = 0;

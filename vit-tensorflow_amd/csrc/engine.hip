@@ -80,9 +80,32 @@ std::string build_param_table(const vitx_config& c, std::vector<ParamDesc>& out)
     add(pre + ".mlp.fc2.kernel", {m, d});
     add(pre + ".mlp.fc2.bias", {d});
   };
+  const int P = c.num_parallel_branches > 1 ? c.num_parallel_branches : 1;
+  if (P > 1 && (c.variant != VITX_VARIANT_VIT || P > 8)) return "num_parallel_branches needs the ViT variant and at most 8 branches";
   if (cait) {
     for (int i = 0; i < c.depth; ++i) block("patch_transformer." + std::to_string(i));
     for (int i = 0; i < c.cls_depth; ++i) block("cls_transformer." + std::to_string(i));
+  } else if (P > 1) {
+    // parallel_vit.py:104-111: layers[l] = [Parallel([PreNorm(Attention)] * P), Parallel([PreNorm(MLP)] * P)]
+    const bool project_out = !(h == 1 && dh == d);
+    for (int l = 0; l < c.depth; ++l) {
+      for (int i = 0; i < P; ++i) {
+        const std::string pre = "transformer." + std::to_string(l) + ".attn." + std::to_string(i);
+        add(pre + ".norm.gamma", {d});
+        add(pre + ".norm.beta", {d});
+        add(pre + ".to_qkv.kernel", {d, 3 * inner});
+        if (project_out) { add(pre + ".to_out.kernel", {inner, d}); add(pre + ".to_out.bias", {d}); }
+      }
+      for (int i = 0; i < P; ++i) {
+        const std::string pre = "transformer." + std::to_string(l) + ".mlp." + std::to_string(i);
+        add(pre + ".norm.gamma", {d});
+        add(pre + ".norm.beta", {d});
+        add(pre + ".fc1.kernel", {d, m});
+        add(pre + ".fc1.bias", {m});
+        add(pre + ".fc2.kernel", {m, d});
+        add(pre + ".fc2.bias", {d});
+      }
+    }
   } else {
     for (int i = 0; i < c.depth; ++i) block("transformer." + std::to_string(i));
   }
@@ -513,9 +536,11 @@ static int block_forward(vitx_engine* e, Stage& st, int si, int l, int b, int nq
   const int rows = b * nq;
   const int nk = nq + nc;
   const double lnb = (double)rows * d * (4 + esz);
+  if (!ba.skip_attn) {
   {
     Prof pr(e, "layernorm_fwd", 0, lnb);
-    launch_layernorm_fwd(ba.x_in, d, e->params + bp.ln1_g, e->params + bp.ln1_b, ba.y1, T, d, ba.mean1, ba.rstd1, rows, d, c.ln_eps, e->stream);
+    launch_layernorm_fwd(ba.ln1_src ? ba.ln1_src : ba.x_in, d, e->params + bp.ln1_g, e->params + bp.ln1_b, ba.y1, T, d, ba.mean1, ba.rstd1, rows, d, c.ln_eps,
+                         e->stream);
   }
   AttnView av;
   av.nq = nq; av.nk = nk; av.o = ba.o; av.ldo = inner; av.ob = (int64_t)nq * inner;
@@ -566,9 +591,12 @@ static int block_forward(vitx_engine* e, Stage& st, int si, int l, int b, int nq
     Prof pr(e, "resid_add", 0, 0);
     launch_resid_add(ba.x_in, ba.o, T, ba.x_mid, (int64_t)rows * d, e->stream);   // vit.py:53 (to_out is identity)
   }
+  }   // !skip_attn
+  if (ba.skip_mlp) return VITX_OK;
   {
     Prof pr(e, "layernorm_fwd", 0, lnb);
-    launch_layernorm_fwd(ba.x_mid, d, e->params + bp.ln2_g, e->params + bp.ln2_b, ba.y2, T, d, ba.mean2, ba.rstd2, rows, d, c.ln_eps, e->stream);
+    launch_layernorm_fwd(ba.ln2_src ? ba.ln2_src : ba.x_mid, d, e->params + bp.ln2_g, e->params + bp.ln2_b, ba.y2, T, d, ba.mean2, ba.rstd2, rows, d, c.ln_eps,
+                         e->stream);
   }
   {
     EpiParams ep; ep.out = ba.hpre; ep.ldo = m; ep.out2 = ba.act; ep.ldo2 = m;
@@ -604,9 +632,17 @@ static int block_backward(vitx_engine* e, Stage& st, int si, int l, int b, int n
   const int rows = b * nq, nk = nq + nc;
   const void* gT = T ? e->g_lp : (const void*)e->g;   // T view of the residual gradient
   const double lnb = (double)rows * d * (4 + 4 + 4 + esz + esz);
+  // Parallel half-blocks (parallel_vit.py:36-42): every branch of a group sees the SAME output gradient g, and the gradient of the
+  // group's common LayerNorm input is g + sum_i LN_i^T(...): it is accumulated in g2 while g / g_lp keep feeding the remaining
+  // branches, and becomes the new g (and g_lp) with the last branch processed.
+  const bool grouped = ba.par_first || ba.par_last || ba.ln1_src || ba.ln2_src;
+  const float* ln_gin = (!grouped || ba.par_first) ? e->g : e->g2;
+  float* ln_gout = (!grouped || ba.par_last) ? e->g : e->g2;
+  void* ln_glp = (T && (!grouped || ba.par_last)) ? e->g_lp : nullptr;
 
-  // ---- MLP branch: x_out = x_mid + scale * fc2(gelu(fc1(LN(x_mid))))
   const void* dbranch = gT;
+  if (!ba.skip_mlp) {
+  // ---- MLP branch: x_out = x_mid + scale * fc2(gelu(fc1(LN(x_mid))))
   if (bp.m_scale >= 0 || drop > 0.f) {   // LayerScale VJP (cait.py:47-48): dscale = sum g*f(x), d f = g*scale; Dropout VJP: same mask
     Prof pr(e, "branch_grad", 0, 0);
     if (bp.m_scale >= 0) launch_scale_grad(ba.fm, T, d, e->g, d, rows, d, e->red_ws, e->grads + bp.m_scale, e->stream);
@@ -634,8 +670,8 @@ static int block_backward(vitx_engine* e, Stage& st, int si, int l, int b, int n
     }
   }
   dense_wgrad(e, ba.act, m, dbranch, d, rows, bp.fc2);
-  const bool fc2_bias_in_ln = dbranch != e->d_br;   // db_fc2 = column sums of g: fused into the LayerNorm backward pass below
-  if (!fc2_bias_in_ln) bias_grad(e, e->d_br, T, d, rows, bp.fc2);
+  const bool fc2_bias_in_ln = dbranch != e->d_br && !grouped;   // db_fc2 = column sums of g: fused into the LayerNorm backward pass below
+  if (!fc2_bias_in_ln) bias_grad(e, dbranch == e->d_br ? (const void*)e->d_br : (const void*)e->g, dbranch == e->d_br ? T : 0, d, rows, bp.fc2);
   {
     EpiParams ep; ep.out = e->d_y; ep.ldo = d;
     dense_dgrad(e, e->d_h, m, rows, bp.fc1, EPI_STORE, ep);
@@ -644,8 +680,13 @@ static int block_backward(vitx_engine* e, Stage& st, int si, int l, int b, int n
   if (!fc1_bias_fused) bias_grad(e, e->d_h, T, m, rows, bp.fc1);
   {
     Prof pr(e, "layernorm_bwd", 0, lnb);
-    launch_layernorm_bwd(e->d_y, T, d, ba.x_mid, d, ba.mean2, ba.rstd2, e->params + bp.ln2_g, e->g, d, e->g, d, T ? e->g_lp : nullptr, d,
+    launch_layernorm_bwd(e->d_y, T, d, ba.ln2_src ? ba.ln2_src : ba.x_mid, d, ba.mean2, ba.rstd2, e->params + bp.ln2_g, ln_gin, d, ln_gout, d, ln_glp, d,
                          e->red_ws, e->grads + bp.ln2_g, e->grads + bp.ln2_b, fc2_bias_in_ln ? e->grads + bp.fc2.b : nullptr, rows, d, e->stream);
+  }
+  }   // !skip_mlp
+  if (ba.skip_attn) {
+    if (e->grad_cb) e->grad_cb(e->grad_cb_user, bp.p_begin, bp.p_end - bp.p_begin);
+    return VITX_OK;
   }
 
   // ---- attention branch: x_mid = x_in + scale * to_out(attn(LN(x_in)))
@@ -663,8 +704,8 @@ static int block_backward(vitx_engine* e, Stage& st, int si, int l, int b, int n
     EpiParams ep; ep.out = e->d_o; ep.ldo = inner;
     dense_dgrad(e, dbranch, d, rows, bp.out, EPI_STORE, ep);
     dense_wgrad(e, ba.o, inner, dbranch, d, rows, bp.out);
-    out_bias_in_ln = dbranch != e->d_br;
-    if (!out_bias_in_ln) bias_grad(e, e->d_br, T, d, rows, bp.out);
+    out_bias_in_ln = dbranch != e->d_br && !grouped;
+    if (!out_bias_in_ln) bias_grad(e, dbranch == e->d_br ? (const void*)e->d_br : (const void*)e->g, dbranch == e->d_br ? T : 0, d, rows, bp.out);
     d_o = e->d_o;
   }
   AttnView av;
@@ -722,7 +763,7 @@ static int block_backward(vitx_engine* e, Stage& st, int si, int l, int b, int n
   }
   {
     Prof pr(e, "layernorm_bwd", 0, lnb);
-    launch_layernorm_bwd(e->d_y, T, d, ba.x_in, d, ba.mean1, ba.rstd1, e->params + bp.ln1_g, e->g, d, e->g, d, T ? e->g_lp : nullptr, d,
+    launch_layernorm_bwd(e->d_y, T, d, ba.ln1_src ? ba.ln1_src : ba.x_in, d, ba.mean1, ba.rstd1, e->params + bp.ln1_g, ln_gin, d, ln_gout, d, ln_glp, d,
                          e->red_ws, e->grads + bp.ln1_g, e->grads + bp.ln1_b, out_bias_in_ln ? e->grads + bp.out.b : nullptr, rows, d, e->stream);
   }
   if (e->grad_cb) e->grad_cb(e->grad_cb_user, bp.p_begin, bp.p_end - bp.p_begin);
@@ -855,9 +896,77 @@ int engine_create(const vitx_config& cfg, vitx_engine** out, std::string& err) {
     e->stages.push_back(std::move(st));
     return VITX_OK;
   };
+  // parallel_vit.py:104-117: layer l = P attention half-blocks then P feed-forward half-blocks, all normalising the layer's input
+  // and adding into one running residual.  Each half-block is a Stage entry with only its own half's parameters and activations.
+  auto make_parallel_stage = [&](int depth, int P, int nq) -> int {
+    Stage st;
+    st.prefix = "transformer"; st.depth = depth * 2 * P; st.nq_max = nq; st.nc_max = 0;
+    st.bp.resize(st.depth);
+    st.ba.resize(st.depth);
+    const int64_t rows = round_up(B * nq, 256) + 320;
+    float* x_prev = nullptr;
+    if (st.depth > 0) DALLOC(x_prev, (size_t)rows * d * 4, false);
+    for (int l = 0; l < depth; ++l) {
+      float* x_layer = x_prev;                     // what the attention branches normalise
+      for (int i = 0; i < P; ++i) {
+        BlockParams& bp = st.bp[(size_t)(l * 2 * P + i)];
+        BlockActs& ba = st.ba[(size_t)(l * 2 * P + i)];
+        const std::string pre = "transformer." + std::to_string(l) + ".attn." + std::to_string(i);
+        bp.ln1_g = find_param(e, pre + ".norm.gamma");
+        bp.ln1_b = find_param(e, pre + ".norm.beta");
+        if ((rc = init_dense(e, bp.qkv, pre + ".to_qkv.kernel", "", d, 3 * inner, err)) != VITX_OK) return rc;
+        bp.has_out = find_param(e, pre + ".to_out.kernel") >= 0;
+        if (bp.has_out && (rc = init_dense(e, bp.out, pre + ".to_out.kernel", pre + ".to_out.bias", inner, d, err)) != VITX_OK) return rc;
+        if (!bp.has_out && inner != d) { err = "to_out missing but inner_dim != dim"; return VITX_ERR_INVALID; }
+        bp.p_begin = bp.ln1_g;
+        bp.p_end = bp.has_out ? bp.out.b + d : bp.qkv.w + (int64_t)d * 3 * inner;
+        ba.skip_mlp = true;
+        ba.x_in = x_prev;
+        ba.ln1_src = i == 0 ? nullptr : x_layer;
+        DALLOC(ba.x_mid, (size_t)rows * d * 4, false);
+        ba.x_out = ba.x_mid;
+        x_prev = ba.x_mid;
+        ba.par_last = i == 0; ba.par_first = i == P - 1;   // the backward walks the half-blocks in reverse
+        DALLOC(ba.y1, (size_t)rows * d * esz, true);
+        DALLOC(ba.qkv, (size_t)rows * 3 * inner * esz, true);
+        DALLOC(ba.o, (size_t)rows * inner * esz, true);
+        DALLOC(ba.mean1, (size_t)rows * 4, false);
+        DALLOC(ba.rstd1, (size_t)rows * 4, false);
+        DALLOC(ba.lse, (size_t)B * c.heads * nq * 4 + 16, false);
+      }
+      x_layer = x_prev;                            // what the feed-forward branches normalise
+      for (int i = 0; i < P; ++i) {
+        BlockParams& bp = st.bp[(size_t)(l * 2 * P + P + i)];
+        BlockActs& ba = st.ba[(size_t)(l * 2 * P + P + i)];
+        const std::string pre = "transformer." + std::to_string(l) + ".mlp." + std::to_string(i);
+        bp.ln2_g = find_param(e, pre + ".norm.gamma");
+        bp.ln2_b = find_param(e, pre + ".norm.beta");
+        if ((rc = init_dense(e, bp.fc1, pre + ".fc1.kernel", pre + ".fc1.bias", d, m, err)) != VITX_OK) return rc;
+        if ((rc = init_dense(e, bp.fc2, pre + ".fc2.kernel", pre + ".fc2.bias", m, d, err)) != VITX_OK) return rc;
+        bp.p_begin = bp.ln2_g;
+        bp.p_end = bp.fc2.b + d;
+        ba.skip_attn = true;
+        ba.x_in = x_prev; ba.x_mid = x_prev;
+        ba.ln2_src = i == 0 ? nullptr : x_layer;
+        DALLOC(ba.x_out, (size_t)rows * d * 4, false);
+        x_prev = ba.x_out;
+        ba.par_last = i == 0; ba.par_first = i == P - 1;
+        DALLOC(ba.y2, (size_t)rows * d * esz, true);
+        DALLOC(ba.hpre, (size_t)rows * m * esz, true);
+        DALLOC(ba.act, (size_t)rows * m * esz, true);
+        DALLOC(ba.mean2, (size_t)rows * 4, false);
+        DALLOC(ba.rstd2, (size_t)rows * 4, false);
+      }
+    }
+    e->stages.push_back(std::move(st));
+    return VITX_OK;
+  };
+  const int nbranch = c.num_parallel_branches > 1 ? c.num_parallel_branches : 1;
   if (cait) {
     if ((rc = make_stage("patch_transformer", c.depth, e->np_max, 0)) != VITX_OK) return rc;
     if ((rc = make_stage("cls_transformer", c.cls_depth, 1, e->np_max)) != VITX_OK) return rc;
+  } else if (nbranch > 1) {
+    if ((rc = make_parallel_stage(c.depth, nbranch, e->ntok_cap)) != VITX_OK) return rc;
   } else {
     if ((rc = make_stage("transformer", c.depth, e->ntok_cap, 0)) != VITX_OK) return rc;
   }
@@ -878,6 +987,7 @@ int engine_create(const vitx_config& cfg, vitx_engine** out, std::string& err) {
   DALLOC(e->dpooled, (size_t)e->bp * d * 4, false);
   DALLOC(e->loss_rows, (size_t)e->bp * 4, false);
   DALLOC(e->g, (size_t)rmax * d * 4, false);
+  if (c.num_parallel_branches > 1) DALLOC(e->g2, (size_t)rmax * d * 4, false);
   if (e->bf16) DALLOC(e->g_lp, (size_t)rmax * d * esz, true);
   if (cait) DALLOC(e->g_ctx, (size_t)e->mpp * d * 4, false);
   DALLOC(e->d_h, (size_t)rmax * m * esz, true);

@@ -68,7 +68,7 @@ class VitxModel:
     _variant = N.VARIANT_VIT
 
     def _init_common(self, *, image_size, patch_size, num_classes, dim, depth, heads, mlp_dim, pool, dim_head, dropout,
-                     emb_dropout, layer_dropout=0.0, cls_depth=0, compute="fp32", max_batch=None, device=0, seed=None):
+                     emb_dropout, layer_dropout=0.0, cls_depth=0, num_parallel_branches=1, compute="fp32", max_batch=None, device=0, seed=None):
         ih, iw = pair(image_size)
         ph, pw = pair(patch_size)
         assert ih % ph == 0 and iw % pw == 0, 'Image dimensions must be divisible by the patch size.'
@@ -87,6 +87,7 @@ class VitxModel:
         cfg.ln_eps = 1e-3  # Keras LayerNormalization default
         assert compute in ("fp32", "bf16"), "compute must be 'fp32' (parity) or 'bf16' (throughput)"
         cfg.compute = N.COMPUTE_BF16 if compute == "bf16" else N.COMPUTE_FP32
+        cfg.num_parallel_branches = int(num_parallel_branches)
         cfg.max_batch = int(max_batch or 0)
         cfg.device_id = int(device)
         self._cfg = cfg

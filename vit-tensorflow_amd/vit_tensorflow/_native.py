@@ -37,7 +37,8 @@ class Config(C.Structure):
         ("compute", C.c_int32),
         ("max_batch", C.c_int32),
         ("device_id", C.c_int32),
-        ("reserved", C.c_int32 * 8),
+        ("num_parallel_branches", C.c_int32),
+        ("reserved", C.c_int32 * 7),
     ]
 
 
