@@ -35,7 +35,7 @@ extern "C" {
 #define VITX_ERR_STATE (-4)        /* call order (e.g. backward without forward) */
 #define VITX_ERR_COMM (-5)         /* RCCL failure */
 
-enum { VITX_VARIANT_VIT = 0, VITX_VARIANT_DEEPVIT = 1, VITX_VARIANT_CAIT = 2 };
+enum { VITX_VARIANT_VIT = 0, VITX_VARIANT_DEEPVIT = 1, VITX_VARIANT_CAIT = 2, VITX_VARIANT_PATCH_MERGER = 3 };
 enum { VITX_POOL_CLS = 0, VITX_POOL_MEAN = 1 };
 /* FP32_PARITY: fp32 storage and fp32 FMA everywhere (gates "logits within 1e-3 of the reference").
  * BF16: bf16 GEMM/attention operands on MFMA, fp32 accumulation, statistics and residual stream. */
@@ -62,7 +62,12 @@ typedef struct vitx_config {
    * followed by a sum of this many feed-forward blocks, each with its own PreNorm (parallel_vit.py:36-42,104-117).  0 or 1 = the
    * ordinary ViT.  variant must be VITX_VARIANT_VIT. */
   int32_t num_parallel_branches;
-  int32_t reserved[7];
+  /* VITX_VARIANT_PATCH_MERGER = vit_with_patch_merger.ViT(..., patch_merge_layer=None, patch_merge_num_tokens=8)
+   * (vit_with_patch_merger.py:136-183): no cls token, mean pooling, and after layer index
+   * (patch_merge_layer > 0 ? patch_merge_layer : depth / 2) - 1 the tokens are merged to patch_merge_num_tokens by PatchMerger
+   * (LayerNorm + learned-query attention pooling, vit_with_patch_merger.py:42-55,117,131-132). */
+  int32_t patch_merge_layer, patch_merge_num_tokens;
+  int32_t reserved[5];
 } vitx_config;
 
 typedef struct vitx_engine* vitx_handle;

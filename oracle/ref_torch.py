@@ -119,6 +119,7 @@ def _transformer(x, P, cfg, prefix, depth, q, context=None):
     if cfg.get("num_parallel_branches", 1) > 1:
         return _parallel_transformer(x, P, cfg, prefix, depth, q)
     cait = cfg["variant"] == "cait"
+    merge_at = cfg.get("patch_merge_index", -1) if cfg["variant"] == "patch_merger" else -1
     for i in range(depth):
         pa, pm = f"{prefix}.{i}.attn", f"{prefix}.{i}.mlp"
         a = _attention(q(layer_norm(x, P[f"{pa}.norm.gamma"], P[f"{pa}.norm.beta"])), P, pa, cfg, q, context)
@@ -130,7 +131,16 @@ def _transformer(x, P, cfg, prefix, depth, q, context=None):
         if cait:
             f = f * P[f"{pm}.scale"]
         x = f + x
+        if i == merge_at:                                                      # vit_with_patch_merger.py:131-132
+            x = patch_merger(x, P, f"{prefix}.patch_merger", cfg["dim"])
     return x
+
+
+def patch_merger(x, P, pre, dim):
+    """PatchMerger.call (vit_with_patch_merger.py:49-55): exact fp32 in both engine modes, so no rounding hook here."""
+    xn = layer_norm(x, P[f"{pre}.norm.gamma"], P[f"{pre}.norm.beta"])                       # :50
+    sim = P[f"{pre}.queries"] @ (xn.transpose(-1, -2) * dim ** -0.5)                       # :51
+    return torch.softmax(sim, dim=-1) @ xn                                                 # :52-53
 
 
 def forward(cfg: dict, P: Dict[str, torch.Tensor], img: torch.Tensor,
@@ -139,6 +149,11 @@ def forward(cfg: dict, P: Dict[str, torch.Tensor], img: torch.Tensor,
     ph, pw = cfg["patch_size"]
     x = _dense(q(patch_unfold(img, ph, pw)), P, "patch_embedding", q)
     b, n, d = x.shape
+    if cfg["variant"] == "patch_merger":                                       # vit_with_patch_merger.py:173-183
+        x = x + P["pos_embedding"][:, :n]
+        x = _transformer(x, P, cfg, "transformer", cfg["depth"], q)
+        x = q(layer_norm(x.mean(dim=1), P["mlp_head.norm.gamma"], P["mlp_head.norm.beta"]))   # Reduce mean, LayerNorm  :168-171
+        return _dense(x, P, "mlp_head", q)
     cls = P["cls_token"].expand(b, 1, d)
     if cfg["variant"] == "cait":
         x = x + P["pos_embedding"][:, :n]

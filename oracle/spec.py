@@ -27,7 +27,7 @@ from typing import Dict, List, Tuple
 
 import numpy as np
 
-VARIANTS = ("vit", "deepvit", "cait")
+VARIANTS = ("vit", "deepvit", "cait", "patch_merger")
 
 
 def pair(t):
@@ -36,18 +36,21 @@ def pair(t):
 
 
 def make_config(variant="vit", image_size=256, patch_size=32, num_classes=1000, dim=1024, depth=6,
-                heads=16, mlp_dim=2048, pool="cls", dim_head=64, cls_depth=0, num_parallel_branches=1, **_ignored) -> dict:
+                heads=16, mlp_dim=2048, pool="cls", dim_head=64, cls_depth=0, num_parallel_branches=1, patch_merge_layer=None,
+                patch_merge_num_tokens=8, **_ignored) -> dict:
     assert variant in VARIANTS
     ih, iw = pair(image_size)
     ph, pw = pair(patch_size)
     # vit.py:136 / deepvit.py:117 / cait.py:160
     assert ih % ph == 0 and iw % pw == 0, 'Image dimensions must be divisible by the patch size.'
-    if variant != "cait":
+    if variant not in ("cait", "patch_merger"):
         # vit.py:139 / deepvit.py:119
         assert pool in {'cls', 'mean'}, 'pool type must be either cls (cls token) or mean (mean pooling)'
     return dict(variant=variant, image_size=(ih, iw), patch_size=(ph, pw), num_classes=num_classes,
                 dim=dim, depth=depth, heads=heads, mlp_dim=mlp_dim, pool=pool, dim_head=dim_head,
-                cls_depth=cls_depth, channels=3, num_parallel_branches=max(1, int(num_parallel_branches)))
+                cls_depth=cls_depth, channels=3, num_parallel_branches=max(1, int(num_parallel_branches)),
+                # default(patch_merge_layer, depth // 2) - 1   vit_with_patch_merger.py:117
+                patch_merge_index=(patch_merge_layer if patch_merge_layer else depth // 2) - 1, patch_merge_num_tokens=patch_merge_num_tokens)
 
 
 def layer_scale_init(depth_1based: int) -> float:
@@ -77,7 +80,8 @@ def param_spec(cfg: dict) -> List[Tuple[str, Tuple[int, ...], str]]:
     add = lambda n, s, k: spec.append((n, tuple(s), k))
 
     add("pos_embedding", (1, np_ if v == "cait" else np_ + 1, d), "normal")
-    add("cls_token", (1, 1, d), "normal")
+    if v != "patch_merger":   # vit_with_patch_merger.ViT has no cls token (vit_with_patch_merger.py:163-166)
+        add("cls_token", (1, 1, d), "normal")
     add("patch_embedding.kernel", (pd, d), "glorot")
     add("patch_embedding.bias", (d,), "zeros")
 
@@ -98,7 +102,7 @@ def param_spec(cfg: dict) -> List[Tuple[str, Tuple[int, ...], str]]:
             add(f"{prefix}.attn.reattn_norm.gamma", (h,), "ones")
             add(f"{prefix}.attn.reattn_norm.beta", (h,), "zeros")
         # vit.py:53 -- to_out disappears iff heads == 1 and dim_head == dim (ViT only)
-        project_out = not (v == "vit" and h == 1 and dh == d)
+        project_out = not (v in ("vit", "patch_merger") and h == 1 and dh == d)
         if project_out:
             add(f"{prefix}.attn.to_out.kernel", (inner, d), "glorot")
             add(f"{prefix}.attn.to_out.bias", (d,), "zeros")
@@ -112,6 +116,10 @@ def param_spec(cfg: dict) -> List[Tuple[str, Tuple[int, ...], str]]:
         add(f"{prefix}.mlp.fc2.bias", (d,), "zeros")
 
     P = cfg.get("num_parallel_branches", 1)
+    if v == "patch_merger":   # attribute order of its Transformer: patch_merger, then the layers (vit_with_patch_merger.py:118-124)
+        add("transformer.patch_merger.norm.gamma", (d,), "ones")
+        add("transformer.patch_merger.norm.beta", (d,), "zeros")
+        add("transformer.patch_merger.queries", (cfg["patch_merge_num_tokens"], d), "normal")
     if v == "cait":
         for i in range(cfg["depth"]):
             block(f"patch_transformer.{i}", i)

@@ -160,7 +160,7 @@ bool al16(std::initializer_list<const void*> ps) {
 }
 
 int distill_create(vitx_engine* stu, const vitx_distill_config& cfg, vitx_distill** out, std::string& err) {
-  if (stu->cfg.variant == VITX_VARIANT_CAIT) { err = "student must be a vision transformer"; return VITX_ERR_INVALID; }   // distill.py:91 (Distillable* classes)
+  if (stu->cfg.variant == VITX_VARIANT_CAIT || stu->cfg.variant == VITX_VARIANT_PATCH_MERGER) { err = "student must be a vision transformer"; return VITX_ERR_INVALID; }   // distill.py:91 (Distillable* classes)
   if (!(cfg.temperature > 0.f)) { err = "temperature must be positive"; return VITX_ERR_INVALID; }
   vitx_distill* m = new vitx_distill();
   m->cfg = cfg; m->stu = stu;

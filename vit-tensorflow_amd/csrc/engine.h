@@ -88,6 +88,12 @@ struct vitx_engine {
   bool own_params = true, own_grads = true;
   bool params_dirty = true;
 
+  // PatchMerger (vit_with_patch_merger.py:42-55): merge_after = index of the layer it follows (-1: never), merge_t = tokens out
+  int merge_after = -1, merge_t = 0;
+  int64_t pm_g = -1, pm_b = -1, pm_q = -1;
+  float *pm_xn = nullptr, *pm_mean = nullptr, *pm_rstd = nullptr, *pm_attn = nullptr, *pm_dattn = nullptr, *pm_out = nullptr, *pm_dxn = nullptr,
+        *pm_dxn2 = nullptr, *pm_dq = nullptr;
+
   // parameter handles
   int64_t pos = -1, cls = -1, head_g = -1, head_b = -1;
   Dense patch, head;

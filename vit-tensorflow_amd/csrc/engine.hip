@@ -21,7 +21,7 @@
 // ------------------------------------------------------------------------------------------------
 std::string build_param_table(const vitx_config& c, std::vector<ParamDesc>& out) {
   out.clear();
-  if (c.variant < 0 || c.variant > 2) return "unknown variant";
+  if (c.variant < 0 || c.variant > 3) return "unknown variant";
   if (c.patch_h <= 0 || c.patch_w <= 0 || c.image_h <= 0 || c.image_w <= 0) return "image/patch size must be positive";
   if (c.image_h % c.patch_h != 0 || c.image_w % c.patch_w != 0)
     return "Image dimensions must be divisible by the patch size.";   // vit.py:136, deepvit.py:117, cait.py:160
@@ -45,9 +45,10 @@ std::string build_param_table(const vitx_config& c, std::vector<ParamDesc>& out)
     aoff += round_up(p.count, 4);
     out.push_back(p);
   };
-  const bool cait = c.variant == VITX_VARIANT_CAIT, deep = c.variant == VITX_VARIANT_DEEPVIT;
+  const bool cait = c.variant == VITX_VARIANT_CAIT, deep = c.variant == VITX_VARIANT_DEEPVIT, merger = c.variant == VITX_VARIANT_PATCH_MERGER;
+  if (merger && c.patch_merge_num_tokens <= 0) return "patch_merge_num_tokens must be positive";
   add("pos_embedding", {1, cait ? np : np + 1, d});
-  add("cls_token", {1, 1, d});
+  if (!merger) add("cls_token", {1, 1, d});          // vit_with_patch_merger.ViT has no cls token (vit_with_patch_merger.py:163-166)
   add("patch_embedding.kernel", {pd, d});
   add("patch_embedding.bias", {d});
   auto block = [&](const std::string& pre) {
@@ -67,7 +68,7 @@ std::string build_param_table(const vitx_config& c, std::vector<ParamDesc>& out)
       add(pre + ".attn.reattn_norm.gamma", {h});
       add(pre + ".attn.reattn_norm.beta", {h});
     }
-    const bool project_out = !(c.variant == VITX_VARIANT_VIT && h == 1 && dh == d);  // vit.py:53
+    const bool project_out = !((c.variant == VITX_VARIANT_VIT || merger) && h == 1 && dh == d);  // vit.py:53
     if (project_out) {
       add(pre + ".attn.to_out.kernel", {inner, d});
       add(pre + ".attn.to_out.bias", {d});
@@ -80,6 +81,11 @@ std::string build_param_table(const vitx_config& c, std::vector<ParamDesc>& out)
     add(pre + ".mlp.fc2.kernel", {m, d});
     add(pre + ".mlp.fc2.bias", {d});
   };
+  if (merger) {   // attribute order of its Transformer: patch_merger before the layers (vit_with_patch_merger.py:118-124)
+    add("transformer.patch_merger.norm.gamma", {d});
+    add("transformer.patch_merger.norm.beta", {d});
+    add("transformer.patch_merger.queries", {c.patch_merge_num_tokens, d});
+  }
   const int P = c.num_parallel_branches > 1 ? c.num_parallel_branches : 1;
   if (P > 1 && (c.variant != VITX_VARIANT_VIT || P > 8)) return "num_parallel_branches needs the ViT variant and at most 8 branches";
   if (cait) {
@@ -791,7 +797,7 @@ int engine_create(const vitx_config& cfg, vitx_engine** out, std::string& err) {
   e->inner = c.heads * c.dim_head;
   e->np_max = (c.image_h / c.patch_h) * (c.image_w / c.patch_w);
   const bool cait = c.variant == VITX_VARIANT_CAIT;
-  e->ntok_max = cait ? e->np_max : e->np_max + 1;
+  e->ntok_max = cait ? e->np_max : e->np_max + 1;        // rows of pos_embedding (the merger ViT keeps np + 1 rows and uses np)
   e->ntok_cap = cait ? e->ntok_max : e->ntok_max + 1;
   e->pd = c.patch_h * c.patch_w * c.channels;
   e->pd_k = (int)round_up(e->pd, 64);
@@ -961,6 +967,7 @@ int engine_create(const vitx_config& cfg, vitx_engine** out, std::string& err) {
     e->stages.push_back(std::move(st));
     return VITX_OK;
   };
+  const bool merger = c.variant == VITX_VARIANT_PATCH_MERGER;
   const int nbranch = c.num_parallel_branches > 1 ? c.num_parallel_branches : 1;
   if (cait) {
     if ((rc = make_stage("patch_transformer", c.depth, e->np_max, 0)) != VITX_OK) return rc;
@@ -969,6 +976,29 @@ int engine_create(const vitx_config& cfg, vitx_engine** out, std::string& err) {
     if ((rc = make_parallel_stage(c.depth, nbranch, e->ntok_cap)) != VITX_OK) return rc;
   } else {
     if ((rc = make_stage("transformer", c.depth, e->ntok_cap, 0)) != VITX_OK) return rc;
+  }
+  if (merger) {
+    e->cfg.pool = VITX_POOL_MEAN;                                          // Reduce('b n d -> b d', 'mean')  vit_with_patch_merger.py:169
+    e->merge_t = c.patch_merge_num_tokens;
+    e->merge_after = (c.patch_merge_layer > 0 ? c.patch_merge_layer : c.depth / 2) - 1;   // default(patch_merge_layer, depth // 2) - 1  :117
+    if (e->merge_after >= c.depth) e->merge_after = -1;                   // `index == patch_merge_layer_index` never holds (:131)
+    e->pm_g = find_param(e, "transformer.patch_merger.norm.gamma");
+    e->pm_b = find_param(e, "transformer.patch_merger.norm.beta");
+    e->pm_q = find_param(e, "transformer.patch_merger.queries");
+    if (e->merge_after >= 0) {
+      const int64_t rn = round_up(B * e->np_max, 256) + 320, rt = round_up(B * e->merge_t, 256) + 320;
+      DALLOC(e->pm_xn, (size_t)rn * d * 4, false);
+      DALLOC(e->pm_mean, (size_t)rn * 4, false);
+      DALLOC(e->pm_rstd, (size_t)rn * 4, false);
+      DALLOC(e->pm_attn, (size_t)B * e->merge_t * round_up(e->np_max, 4) * 4, false);
+      DALLOC(e->pm_dattn, (size_t)B * e->merge_t * round_up(e->np_max, 4) * 4, false);
+      DALLOC(e->pm_out, (size_t)rt * d * 4, false);
+      DALLOC(e->pm_dxn, (size_t)rn * d * 4, false);
+      DALLOC(e->pm_dxn2, (size_t)rn * d * 4, false);
+      DALLOC(e->pm_dq, (size_t)rt * d * 4, false);
+      Stage& st = e->stages[0];
+      if (e->merge_after + 1 < st.depth) st.ba[(size_t)e->merge_after + 1].x_in = e->pm_out;   // the next layer reads the merged tokens
+    }
   }
 
   // shared buffers
@@ -1048,6 +1078,70 @@ static void prepare_patch_rows(vitx_engine* e, int64_t rows) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// PatchMerger (vit_with_patch_merger.py:42-55): x [b, n, d] -> LayerNorm -> softmax(queries @ xn^T * d^-0.5) @ xn -> [b, t, d].
+// t is a handful of tokens: exact-fp32 batched GEMMs of the generic kernel in both compute modes (launch-bound, not FLOP-bound).
+// ------------------------------------------------------------------------------------------------
+static void merger_gemm(vitx_engine* e, const float* A, int64_t sam, int64_t sak, int64_t sAb, const float* B, int64_t sbk, int64_t sbn, int64_t sBb,
+                        int M, int N, int K, int nb, float alpha, float* out, int64_t ldo, int64_t out_bstride, const float* resid) {
+  GenericGemmArgs g;
+  g.A = A; g.B = B; g.M = M; g.N = N; g.K = K; g.sam = sam; g.sak = sak; g.sbk = sbk; g.sbn = sbn; g.nb = nb; g.sAb = sAb; g.sBb = sBb;
+  EpiParams ep;
+  ep.out = out; ep.ldo = ldo; ep.out_batch_stride = out_bstride; ep.M = M; ep.N = N; ep.alpha = alpha;
+  (void)resid;
+  finalize_epi(ep);
+  Prof pr(e, "patch_merger", 2.0 * nb * M * (double)N * K, 0);
+  launch_gemm_generic(g, ep, EPI_STORE_F32, 0, 0, 0, e->stream);
+}
+
+static void merger_forward(vitx_engine* e, const float* x, int b, int n) {
+  const vitx_config& c = e->cfg;
+  const int d = c.dim, t = e->merge_t;
+  const int64_t ldn = round_up(n, 4);
+  const float scale = 1.0f / std::sqrt((float)d);                                        // self.scale = dim ** -0.5   :45
+  {
+    Prof pr(e, "layernorm_fwd", 0, (double)b * n * d * 8);
+    launch_layernorm_fwd(x, d, e->params + e->pm_g, e->params + e->pm_b, e->pm_xn, 0, d, e->pm_mean, e->pm_rstd, b * n, d, c.ln_eps, e->stream);   // :50
+  }
+  // sim = queries @ (xn^T * scale)   :51
+  merger_gemm(e, e->params + e->pm_q, d, 1, 0, e->pm_xn, 1, d, (int64_t)n * d, t, n, d, b, scale, e->pm_attn, ldn, (int64_t)t * ldn, nullptr);
+  {
+    Prof pr(e, "softmax", 0, 0);
+    launch_softmax_rows(e->pm_attn, (int64_t)b * t, n, ldn, e->stream);                  // :52
+  }
+  merger_gemm(e, e->pm_attn, ldn, 1, (int64_t)t * ldn, e->pm_xn, d, 1, (int64_t)n * d, t, d, n, b, 1.0f, e->pm_out, d, (int64_t)t * d, nullptr);   // :53
+}
+
+// g holds d(out) [b, t, d] on entry and d(x) [b, n, d] on exit (plus its T copy); queries / norm gradients go to the arena
+static int merger_backward(vitx_engine* e, const float* x, int b, int n, std::string& err) {
+  const vitx_config& c = e->cfg;
+  const int d = c.dim, t = e->merge_t, T = e->bf16;
+  const int64_t ldn = round_up(n, 4);
+  const float scale = 1.0f / std::sqrt((float)d);
+  float* dout = e->tmp_f32;                                                              // [b, t, d]: g is overwritten below
+  HIPCHK(hipMemcpyAsync(dout, e->g, (size_t)b * t * d * 4, hipMemcpyDeviceToDevice, e->stream));
+  // d attn = d out @ xn^T;  d xn = attn^T @ d out
+  merger_gemm(e, dout, d, 1, (int64_t)t * d, e->pm_xn, 1, d, (int64_t)n * d, t, n, d, b, 1.0f, e->pm_dattn, ldn, (int64_t)t * ldn, nullptr);
+  merger_gemm(e, e->pm_attn, 1, ldn, (int64_t)t * ldn, dout, d, 1, (int64_t)t * d, n, d, t, b, 1.0f, e->pm_dxn, d, (int64_t)n * d, nullptr);
+  {
+    Prof pr(e, "softmax_bwd", 0, 0);
+    launch_softmax_bwd_rows(e->pm_attn, e->pm_dattn, (int64_t)b * t, n, ldn, e->stream);  // d sim (in place)
+  }
+  // d queries = scale * sum_b d sim[b] @ xn[b]: per image, then a fixed-order sum over the batch
+  merger_gemm(e, e->pm_dattn, ldn, 1, (int64_t)t * ldn, e->pm_xn, d, 1, (int64_t)n * d, t, d, n, b, scale, e->pm_dq, d, (int64_t)t * d, nullptr);
+  launch_batch_reduce(e->pm_dq, b, t, d, 0, t, e->grads + e->pm_q, e->stream);
+  // d xn += scale * d sim^T @ queries
+  merger_gemm(e, e->pm_dattn, 1, ldn, (int64_t)t * ldn, e->params + e->pm_q, d, 1, 0, n, d, t, b, scale, e->pm_dxn2, d, (int64_t)n * d, nullptr);
+  launch_resid_add(e->pm_dxn, e->pm_dxn2, 0, e->pm_dxn2, (int64_t)b * n * d, e->stream);
+  {
+    Prof pr(e, "layernorm_bwd", 0, 0);
+    launch_layernorm_bwd(e->pm_dxn2, 0, d, x, d, e->pm_mean, e->pm_rstd, e->params + e->pm_g, nullptr, 0, e->g, d, nullptr, 0, e->red_ws,
+                         e->grads + e->pm_g, e->grads + e->pm_b, nullptr, b * n, d, e->stream);
+    if (T) launch_convert(e->g, d, e->g_lp, 1, d, b * n, d, d, e->stream);   // the fp32-dy form of the kernel has no bf16 side output
+  }
+  return VITX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
 // cait.py:17-31: python-level random skipping of whole blocks (numpy RNG in the reference; NOT gated by `training`,
@@ -1111,9 +1205,11 @@ int engine_forward(vitx_engine* e, const float* img_dev, int b, int H, int W, in
     err = "Image dimensions must be divisible by the patch size.";            // and fit the configured pos_embedding (vit.py:165)
     return VITX_ERR_INVALID;
   }
-  const bool cait = c.variant == VITX_VARIANT_CAIT;
+  const bool cait = c.variant == VITX_VARIANT_CAIT, merger = c.variant == VITX_VARIANT_PATCH_MERGER;
+  if (extra && merger) { err = "distillation token: ViT / DeepViT only"; return VITX_ERR_UNSUPPORTED; }
+  const bool no_cls = cait || merger;                                   // cait.py:181-184; vit_with_patch_merger.py:173-177
   const int np = (H / c.patch_h) * (W / c.patch_w);
-  const int ntok = cait ? np : np + 1 + extra;
+  const int ntok = no_cls ? np : np + 1 + extra;
   const int d = c.dim, T = e->bf16;
   ensure_geometry(e, b, ntok);
   if (e->params_dirty) engine_refresh_weights(e);
@@ -1124,14 +1220,14 @@ int engine_forward(vitx_engine* e, const float* img_dev, int b, int H, int W, in
     Prof pr(e, "patch_unfold", 0, (double)b * H * W * c.channels * 4 + (double)b * np * e->pd_k * e->esz);
     launch_unfold(img_dev, e->patches, T, b, H, W, c.channels, c.patch_h, c.patch_w, e->pd_k, e->stream);   // vit.py:142
   }
-  if (!cait) {
+  if (!no_cls) {
     Prof pr(e, "cls_pos_row", 0, 0);
     launch_cls_pos_row(x0, e->params + e->cls, e->params + e->pos, b, ntok, d, d, e->stream);              // vit.py:163-165
   }
   {
     EpiParams ep;
     ep.out = x0; ep.ldo = d; ep.pos = e->params + e->pos; ep.ldr = d;
-    ep.np = np; ep.ntok = ntok; ep.tok_off = cait ? 0 : 1;
+    ep.np = np; ep.ntok = ntok; ep.tok_off = no_cls ? 0 : 1;
     dense_fwd(e, e->patches, e->pd_k, b * np, e->patch, EPI_PATCH, ep);                                     // vit.py:143 (+164-165)
   }
   if (extra)   // x = concat([x, distill_tokens], axis=1), after the position embedding (distill.py:24-28)
@@ -1148,10 +1244,16 @@ int engine_forward(vitx_engine* e, const float* img_dev, int b, int H, int W, in
       HIPCHK(hipMemcpyAsync(s0.ba[l].x_out, s0.ba[l].x_in, (size_t)b * ntok * d * 4, hipMemcpyDeviceToDevice, e->stream));
       continue;
     }
-    if ((rc = block_forward(e, s0, 0, l, b, ntok, 0, nullptr, drop, seed, err)) != VITX_OK) return rc;
+    const bool merged = merger && e->merge_after >= 0 && l > e->merge_after;
+    if ((rc = block_forward(e, s0, 0, l, b, merged ? e->merge_t : ntok, 0, nullptr, drop, seed, err)) != VITX_OK) return rc;
+    if (merger && l == e->merge_after) merger_forward(e, s0.ba[l].x_out, b, ntok);      // vit_with_patch_merger.py:131-132
   }
   const float* x_last = s0.depth > 0 ? s0.ba[s0.depth - 1].x_out : x0;
   int head_tok = ntok;
+  if (merger && e->merge_after >= 0) {
+    head_tok = e->merge_t;
+    if (e->merge_after == s0.depth - 1) x_last = e->pm_out;
+  }
   if (cait) {
     Stage& s1 = e->stages[1];
     float* xc = s1.depth > 0 ? s1.ba[0].x_in : e->pooled;
@@ -1181,7 +1283,7 @@ int engine_forward(vitx_engine* e, const float* img_dev, int b, int H, int W, in
 
 int engine_transformer_forward(vitx_engine* e, const float* tokens_dev, int b, int n, float* out_dev, std::string& err) {
   const vitx_config& c = e->cfg;
-  if (c.variant == VITX_VARIANT_CAIT) { err = "transformer_forward: ViT / DeepViT only"; return VITX_ERR_UNSUPPORTED; }
+  if (c.variant == VITX_VARIANT_CAIT || c.variant == VITX_VARIANT_PATCH_MERGER) { err = "transformer_forward: ViT / DeepViT only"; return VITX_ERR_UNSUPPORTED; }
   if (b <= 0 || b > c.max_batch || n <= 0 || n > e->ntok_cap) { err = "transformer_forward: b or n out of range"; return VITX_ERR_INVALID; }
   ensure_geometry(e, b, n);
   if (e->params_dirty) engine_refresh_weights(e);
@@ -1225,7 +1327,7 @@ int engine_transformer_backward(vitx_engine* e, const float* dout_dev, float* dt
 int engine_patch_tokens_forward(vitx_engine* e, const float* img_dev, int b, int H, int W, float* tokens_dev, float* patches_f32_dev,
                                 std::string& err) {
   const vitx_config& c = e->cfg;
-  if (c.variant == VITX_VARIANT_CAIT) { err = "patch_tokens_forward: ViT / DeepViT only"; return VITX_ERR_UNSUPPORTED; }
+  if (c.variant == VITX_VARIANT_CAIT || c.variant == VITX_VARIANT_PATCH_MERGER) { err = "patch_tokens_forward: ViT / DeepViT only"; return VITX_ERR_UNSUPPORTED; }
   if (b <= 0 || b > c.max_batch) { err = "batch must be in [1, max_batch]"; return VITX_ERR_INVALID; }
   if (H <= 0 || W <= 0 || H > c.image_h || W > c.image_w || H % c.patch_h || W % c.patch_w) {
     err = "Image dimensions must be divisible by the patch size.";
@@ -1274,7 +1376,9 @@ int engine_backward(vitx_engine* e, const float* dlogits_dev, float* dimg_dev, s
   const vitx_config& c = e->cfg;
   if (!e->have_fwd) { err = "backward requires a preceding forward"; return VITX_ERR_STATE; }
   const int extra = e->last_extra;
-  const bool cait = c.variant == VITX_VARIANT_CAIT;
+  const bool cait = c.variant == VITX_VARIANT_CAIT, merger = c.variant == VITX_VARIANT_PATCH_MERGER;
+  const bool no_cls = cait || merger;
+  const bool merging = merger && e->merge_after >= 0;
   const int b = e->last_b, np = e->last_np, ntok = e->last_ntok, d = c.dim, T = e->bf16;
   const int nc = c.num_classes;
   const float drop = e->last_training ? c.dropout : 0.f;
@@ -1300,6 +1404,21 @@ int engine_backward(vitx_engine* e, const float* dlogits_dev, float* dimg_dev, s
   } else {
     x_last = s0.depth > 0 ? s0.ba[s0.depth - 1].x_out : e->tmp_f32;
     head_tok = ntok;
+    if (merging) {
+      head_tok = e->merge_t;
+      if (e->merge_after == s0.depth - 1) x_last = e->pm_out;
+      // The shared bf16 gradient buffers were last used at b*ntok rows and are about to be used at b*merge_t: the rows between the
+      // new extent and its next multiple of 64 are K padding of the weight-gradient GEMMs and must read as zero.
+      if (T) {
+        const int64_t r0 = (int64_t)b * e->merge_t, r1 = round_up(r0, 64);
+        if (r1 > r0) {
+          HIPCHK(hipMemsetAsync(boff(e->g_lp, r0 * d, 2), 0, (size_t)(r1 - r0) * d * 2, e->stream));
+          HIPCHK(hipMemsetAsync(boff(e->d_br, r0 * d, 2), 0, (size_t)(r1 - r0) * d * 2, e->stream));
+          HIPCHK(hipMemsetAsync(boff(e->d_qkv, r0 * 3 * e->inner, 2), 0, (size_t)(r1 - r0) * 3 * e->inner * 2, e->stream));
+          HIPCHK(hipMemsetAsync(boff(e->d_o, r0 * e->inner, 2), 0, (size_t)(r1 - r0) * e->inner * 2, e->stream));
+        }
+      }
+    }
   }
   (void)s_last;
   {
@@ -1347,8 +1466,11 @@ int engine_backward(vitx_engine* e, const float* dlogits_dev, float* dimg_dev, s
       if (T) launch_convert(e->g, d, e->g_lp, 1, d, b * np, d, d, e->stream);
     }
   }
-  for (int l = s0.depth - 1; l >= 0; --l)
-    if (e->layer_kept[0][(size_t)l] && (rc = block_backward(e, s0, 0, l, b, ntok, 0, drop, e->last_seed, err)) != VITX_OK) return rc;
+  for (int l = s0.depth - 1; l >= 0; --l) {
+    if (merging && l == e->merge_after && (rc = merger_backward(e, s0.ba[l].x_out, b, ntok, err)) != VITX_OK) return rc;
+    const int rows_tok = (merging && l > e->merge_after) ? e->merge_t : ntok;
+    if (e->layer_kept[0][(size_t)l] && (rc = block_backward(e, s0, 0, l, b, rows_tok, 0, drop, e->last_seed, err)) != VITX_OK) return rc;
+  }
   if (e->last_training && c.emb_dropout > 0.f) {
     Prof pr(e, "dropout", 0, 0);
     launch_dropout(e->g, 0, (int64_t)b * ntok * d, c.emb_dropout, e->last_seed, 0u, e->stream);   // same mask as the forward (vit.py:166)
@@ -1359,8 +1481,8 @@ int engine_backward(vitx_engine* e, const float* dlogits_dev, float* dimg_dev, s
     Prof pr(e, "embed_bwd", 0, (double)b * ntok * d * 4);
     launch_batch_reduce(e->g, b, ntok, d, 0, ntok - extra, e->grads + e->pos, e->stream);      // dpos[j] = sum_b g[b,j]
     if (extra && d_token_out_dev) launch_batch_reduce(e->g, b, ntok, d, ntok - 1, 1, d_token_out_dev, e->stream);   // d(distill token) = sum_b g[b,-1]
-    const int tok_off = cait ? 0 : 1;
-    if (!cait) launch_batch_reduce(e->g, b, ntok, d, 0, 1, e->grads + e->cls, e->stream);   // dcls = sum_b g[b,0]
+    const int tok_off = no_cls ? 0 : 1;
+    if (!no_cls) launch_batch_reduce(e->g, b, ntok, d, 0, 1, e->grads + e->cls, e->stream);   // dcls = sum_b g[b,0]
     launch_sum_rows(e->grads + e->pos + (int64_t)tok_off * d, np, d, e->grads + e->patch.b, e->stream);   // db = sum over patch rows
     launch_extract_rows(e->g, b, ntok, tok_off, np, d, e->d_y, T, d, e->stream);        // dE = g[:, tok_off:, :]
   }

@@ -169,7 +169,7 @@ void glue_bwd(vitx_mim* m, const Dense& w, const void* xT, void* dyT, const floa
 int mim_create(vitx_engine* enc, const vitx_mim_config& cfg, vitx_mim** out, std::string& err) {
   if (!(cfg.masking_ratio > 0.0 && cfg.masking_ratio < 1.0)) { err = "masking ratio must be kept between 0 and 1"; return VITX_ERR_INVALID; }   // mae.py:28, simmim.py:71
   if (cfg.kind != VITX_MIM_MAE && cfg.kind != VITX_MIM_SIMMIM) { err = "unknown wrapper kind"; return VITX_ERR_INVALID; }
-  if (enc->cfg.variant == VITX_VARIANT_CAIT) { err = "MAE / SimMIM need an encoder with pos_embedding[:, 1:] and .transformer (ViT / DeepViT)"; return VITX_ERR_UNSUPPORTED; }
+  if (enc->cfg.variant == VITX_VARIANT_CAIT || enc->cfg.variant == VITX_VARIANT_PATCH_MERGER) { err = "MAE / SimMIM need an encoder with pos_embedding[:, 1:] and .transformer (ViT / DeepViT)"; return VITX_ERR_UNSUPPORTED; }
   vitx_mim* m = new vitx_mim();
   m->cfg = cfg; m->enc = enc;
   m->mae = cfg.kind == VITX_MIM_MAE;

@@ -68,11 +68,12 @@ class VitxModel:
     _variant = N.VARIANT_VIT
 
     def _init_common(self, *, image_size, patch_size, num_classes, dim, depth, heads, mlp_dim, pool, dim_head, dropout,
-                     emb_dropout, layer_dropout=0.0, cls_depth=0, num_parallel_branches=1, compute="fp32", max_batch=None, device=0, seed=None):
+                     emb_dropout, layer_dropout=0.0, cls_depth=0, num_parallel_branches=1, patch_merge_layer=None, patch_merge_num_tokens=8,
+                     compute="fp32", max_batch=None, device=0, seed=None):
         ih, iw = pair(image_size)
         ph, pw = pair(patch_size)
         assert ih % ph == 0 and iw % pw == 0, 'Image dimensions must be divisible by the patch size.'
-        if self._variant != N.VARIANT_CAIT:
+        if self._variant not in (N.VARIANT_CAIT, N.VARIANT_PATCH_MERGER):
             assert pool in {'cls', 'mean'}, 'pool type must be either cls (cls token) or mean (mean pooling)'
         self.pool = pool
         self.heads, self.dim, self.depth, self.mlp_dim, self.dim_head = heads, dim, depth, mlp_dim, dim_head
@@ -88,6 +89,8 @@ class VitxModel:
         assert compute in ("fp32", "bf16"), "compute must be 'fp32' (parity) or 'bf16' (throughput)"
         cfg.compute = N.COMPUTE_BF16 if compute == "bf16" else N.COMPUTE_FP32
         cfg.num_parallel_branches = int(num_parallel_branches)
+        cfg.patch_merge_layer = int(patch_merge_layer or 0)
+        cfg.patch_merge_num_tokens = int(patch_merge_num_tokens)
         cfg.max_batch = int(max_batch or 0)
         cfg.device_id = int(device)
         self._cfg = cfg
@@ -108,7 +111,7 @@ class VitxModel:
         for name, shape, off in self._table:
             n = int(np.prod(shape))
             leaf = name.split(".")[-1]
-            if name in ("pos_embedding", "cls_token") or leaf in ("reattn_weights", "mix_heads_pre_attn", "mix_heads_post_attn"):
+            if name in ("pos_embedding", "cls_token") or leaf in ("reattn_weights", "mix_heads_pre_attn", "mix_heads_post_attn", "queries"):
                 v = rng.standard_normal(n)
             elif leaf == "kernel":
                 lim = math.sqrt(6.0 / (shape[0] + shape[1]))

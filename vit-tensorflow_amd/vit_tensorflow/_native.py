@@ -10,7 +10,7 @@ from typing import List, Tuple
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VITX_LIB", os.path.join(_HERE, "..", "lib", "libvitx.so"))
 
-VARIANT_VIT, VARIANT_DEEPVIT, VARIANT_CAIT = 0, 1, 2
+VARIANT_VIT, VARIANT_DEEPVIT, VARIANT_CAIT, VARIANT_PATCH_MERGER = 0, 1, 2, 3
 POOL_CLS, POOL_MEAN = 0, 1
 COMPUTE_FP32, COMPUTE_BF16 = 0, 1
 OK, ERR_INVALID, ERR_HIP, ERR_UNSUPPORTED, ERR_STATE, ERR_COMM = 0, -1, -2, -3, -4, -5
@@ -38,7 +38,8 @@ class Config(C.Structure):
         ("max_batch", C.c_int32),
         ("device_id", C.c_int32),
         ("num_parallel_branches", C.c_int32),
-        ("reserved", C.c_int32 * 7),
+        ("patch_merge_layer", C.c_int32), ("patch_merge_num_tokens", C.c_int32),
+        ("reserved", C.c_int32 * 5),
     ]
 
 
