@@ -814,7 +814,10 @@ int engine_create(const vitx_config& cfg, vitx_engine** out, std::string& err) {
   if (const char* k = getenv("VITX_GEMM_KERNEL")) e->gemm_kernel = atoi(k);
   if (const char* k = getenv("VITX_UNFUSED_HEADOPS")) e->unfused_headops = atoi(k) != 0;
   e->wgrad_via_transpose = env_flag("VITX_WGRAD_TRANSPOSE");
-  if (const char* k = getenv("VITX_GEMM_STAGGER")) e->gemm_stagger = atoi(k);
+  if (const char* k = getenv("VITX_GEMM_STAGGER")) {
+    e->gemm_stagger = atoi(k);
+    if (e->gemm_stagger & 3) fprintf(stderr, "[vitx] VITX_GEMM_STAGGER=%d: timing experiment bits set -- GEMM results are WRONG in this process\n", e->gemm_stagger);
+  }
 
   HIPCHK(hipSetDevice(c.device_id));
   HIPCHK(hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking));

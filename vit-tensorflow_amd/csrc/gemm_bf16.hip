@@ -999,7 +999,12 @@ void launch_gemm_bf16(const Bf16GemmArgs& g0, const EpiParams& ep, int mode, hip
 // C[M=in][N=out] (split-K partials) = A[K=tokens][in]^T * B[K=tokens][out]; kernel: 1 = 128x128 tile, else 256x256
 int gemm_bf16_tn_tile(int kernel, int M, int N) { kernel &= 15; return (kernel == 1 || (M <= 128 && N <= 128)) ? 128 : 256; }
 void launch_gemm_bf16_tn(const Bf16GemmArgs& g0, const EpiParams& ep, hipStream_t s) {
-  static const int xp = [] { const char* v = getenv("VITX_TN_XP"); return v ? atoi(v) : 0; }();
+  static const int xp = [] {
+    const char* v = getenv("VITX_TN_XP");
+    const int x = v ? atoi(v) : 0;
+    if (x) fprintf(stderr, "[vitx] VITX_TN_XP=%d: timing experiment -- weight gradients are WRONG in this process\n", x);
+    return x;
+  }();
   Bf16GemmArgs g = g0;
   g.stagger = xp;
   if (gemm_bf16_tn_tile(g.kernel, g.M, g.N) == 128) launch_tn_variant<128, 2, 2>(g, ep, s);
