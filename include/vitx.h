@@ -142,6 +142,39 @@ int32_t vitx_transformer_backward(vitx_handle h, const float* dout_host, float* 
 int32_t vitx_patch_unfold(const float* img_host, int32_t b, int32_t H, int32_t W, int32_t C,
                           int32_t ph, int32_t pw, float* out_host);
 
+/* ---- efficient.ViT(image_size, patch_size, num_classes, dim, transformer, pool='cls') (efficient.py:12-56): the model is a shell
+ * around a transformer object supplied by the caller.  On a ViT handle (normally built with depth = 0; the block parameters of a
+ * deeper handle are simply not used) the four entry points below are that shell and its VJP:
+ *   embed_forward   patch_embedding + cls token + pos_embedding[:, :n+1] (efficient.py:40-46): img NHWC -> tokens [b, np+1, dim]
+ *   head_forward    pooling + mlp_head (efficient.py:49-54): x [b, n, dim] (whatever the transformer returned) -> logits
+ *   head_backward   d(logits) -> d(x) [b, n, dim]; fills the mlp_head.* entries of the gradient arena
+ *   embed_backward  d(tokens) [b, np+1, dim] -> fills pos_embedding (rows beyond np+1 zero), cls_token, patch_embedding.*;
+ *                   optional d(img)
+ * Validation error text follows efficient.py:18.  The _dev forms take device pointers and stay asynchronous on the handle's
+ * stream (dlogits_dev NULL = the engine's internal dlogits); tokens / x are contiguous fp32. */
+int32_t vitx_embed_forward(vitx_handle h, const float* img_host, int32_t b, int32_t H, int32_t W, float* tokens_host);
+int32_t vitx_embed_forward_dev(vitx_handle h, const float* img_dev, int32_t b, int32_t H, int32_t W, float* tokens_dev);
+int32_t vitx_head_forward(vitx_handle h, const float* x_host, int32_t b, int32_t n, float* logits_host);
+int32_t vitx_head_forward_dev(vitx_handle h, const float* x_dev, int32_t b, int32_t n, float* logits_dev_or_null);
+int32_t vitx_head_backward(vitx_handle h, const float* dlogits_host, float* dx_host);
+int32_t vitx_head_backward_dev(vitx_handle h, const float* dlogits_dev_or_null, float* dx_dev);
+int32_t vitx_embed_backward(vitx_handle h, const float* dtokens_host, float* dimg_host_or_null);
+int32_t vitx_embed_backward_dev(vitx_handle h, const float* dtokens_dev, float* dimg_dev_or_null);
+
+/* ---- T2T tokenizer: tf.image.extract_patches(x, sizes=[1,k,k,1], strides=[1,s,s,1], rates=[1,1,1,1], padding='SAME')
+ * (RearrangeUnfoldTransformer.call, t2t.py:39-47) on NHWC x [b,H,W,C] -> [b, ceil(H/s), ceil(W/s), k*k*C], feature order
+ * (ki, kj, c), TensorFlow's SAME rule (pad_total = max((out-1)*s + k - in, 0), pad_before = pad_total / 2, zeros outside).
+ * Pure index arithmetic: bit-exact.  _backward is its VJP (overlapping windows summed in a fixed order).  Handle-free; the _dev
+ * forms enqueue on `hip_stream` (NULL = the default stream). */
+int32_t vitx_extract_patches_shape(int32_t H, int32_t W, int32_t C, int32_t k, int32_t stride, int32_t* oh, int32_t* ow, int32_t* feat);
+int32_t vitx_extract_patches(const float* x_host, int32_t b, int32_t H, int32_t W, int32_t C, int32_t k, int32_t stride, float* out_host);
+int32_t vitx_extract_patches_backward(const float* dout_host, int32_t b, int32_t H, int32_t W, int32_t C, int32_t k, int32_t stride,
+                                      float* dx_host);
+int32_t vitx_extract_patches_dev(const float* x_dev, int32_t b, int32_t H, int32_t W, int32_t C, int32_t k, int32_t stride, float* out_dev,
+                                 void* hip_stream);
+int32_t vitx_extract_patches_backward_dev(const float* dout_dev, int32_t b, int32_t H, int32_t W, int32_t C, int32_t k, int32_t stride,
+                                          float* dx_dev, void* hip_stream);
+
 /* ---- loss gradient on device: d/dlogits of mean softmax cross-entropy
  * (tf.keras.losses.categorical_crossentropy(from_logits=True), distill.py:119).  Writes the
  * engine's internal dlogits (used by vitx_backward_dev(h, NULL, ...)) and optionally the mean loss. */

@@ -275,6 +275,180 @@ int32_t vitx_patch_unfold(const float* img_host, int32_t b, int32_t H, int32_t W
   CAPI_CATCH
 }
 
+// ---- efficient.ViT shell (efficient.py:12-56)
+int32_t vitx_embed_forward_dev(vitx_handle h, const float* img_dev, int32_t b, int32_t H, int32_t W, float* tokens_dev) {
+  CAPI_TRY
+  if (!h || !img_dev || !tokens_dev) return fail(VITX_ERR_INVALID, "null argument");
+  std::string err;
+  int rc = engine_embed_forward(h, img_dev, b, H, W, tokens_dev, err);
+  if (rc != VITX_OK) return fail(rc, err);
+  return VITX_OK;
+  CAPI_CATCH
+}
+int32_t vitx_embed_forward(vitx_handle h, const float* img_host, int32_t b, int32_t H, int32_t W, float* tokens_host) {
+  CAPI_TRY
+  if (!h || !img_host || !tokens_host) return fail(VITX_ERR_INVALID, "null argument");
+  if (b <= 0 || b > h->cfg.max_batch) return fail(VITX_ERR_INVALID, "batch must be in [1, max_batch]");
+  if (H <= 0 || W <= 0 || H > h->cfg.image_h || W > h->cfg.image_w) return fail(VITX_ERR_INVALID, "image larger than the configured image_size");
+  CAPI_HIP(hipMemcpyAsync(h->img_dev, img_host, (size_t)b * H * W * h->cfg.channels * 4, hipMemcpyHostToDevice, h->stream));
+  std::string err;
+  float* tmp = h->tmp_f32;   // [>= mp, max(d, pd)] fp32 scratch
+  int rc = engine_embed_forward(h, h->img_dev, b, H, W, tmp, err);
+  if (rc != VITX_OK) return fail(rc, err);
+  CAPI_HIP(hipMemcpyAsync(tokens_host, tmp, (size_t)b * h->last_ntok * h->cfg.dim * 4, hipMemcpyDeviceToHost, h->stream));
+  CAPI_HIP(hipStreamSynchronize(h->stream));
+  return VITX_OK;
+  CAPI_CATCH
+}
+int32_t vitx_head_forward_dev(vitx_handle h, const float* x_dev, int32_t b, int32_t n, float* logits_dev) {
+  CAPI_TRY
+  if (!h || !x_dev) return fail(VITX_ERR_INVALID, "null argument");
+  std::string err;
+  int rc = engine_head_forward(h, x_dev, b, n, logits_dev, err);
+  if (rc != VITX_OK) return fail(rc, err);
+  return VITX_OK;
+  CAPI_CATCH
+}
+int32_t vitx_head_forward(vitx_handle h, const float* x_host, int32_t b, int32_t n, float* logits_host) {
+  CAPI_TRY
+  if (!h || !x_host || !logits_host) return fail(VITX_ERR_INVALID, "null argument");
+  if (b <= 0 || b > h->cfg.max_batch || n <= 0 || n > h->ntok_cap) return fail(VITX_ERR_INVALID, "head_forward: b or n out of range");
+  float* tmp = h->tmp_f32;
+  CAPI_HIP(hipMemcpyAsync(tmp, x_host, (size_t)b * n * h->cfg.dim * 4, hipMemcpyHostToDevice, h->stream));
+  std::string err;
+  int rc = engine_head_forward(h, tmp, b, n, nullptr, err);
+  if (rc != VITX_OK) return fail(rc, err);
+  CAPI_HIP(hipMemcpy2DAsync(logits_host, (size_t)h->cfg.num_classes * 4, h->logits, (size_t)h->nc_k * 4, (size_t)h->cfg.num_classes * 4,
+                            (size_t)b, hipMemcpyDeviceToHost, h->stream));
+  CAPI_HIP(hipStreamSynchronize(h->stream));
+  return VITX_OK;
+  CAPI_CATCH
+}
+int32_t vitx_head_backward_dev(vitx_handle h, const float* dlogits_dev_or_null, float* dx_dev) {
+  CAPI_TRY
+  if (!h) return fail(VITX_ERR_INVALID, "null handle");
+  std::string err;
+  int rc = engine_head_backward(h, dlogits_dev_or_null, dx_dev, err);
+  if (rc != VITX_OK) return fail(rc, err);
+  return VITX_OK;
+  CAPI_CATCH
+}
+int32_t vitx_head_backward(vitx_handle h, const float* dlogits_host, float* dx_host) {
+  CAPI_TRY
+  if (!h || !dlogits_host || !dx_host) return fail(VITX_ERR_INVALID, "null argument");
+  if (!h->have_head) return fail(VITX_ERR_STATE, "head_backward requires a preceding head_forward");
+  const int b = h->shell_b, nc = h->cfg.num_classes;
+  CAPI_HIP(hipMemcpy2DAsync(h->dlogits, (size_t)h->nc_k * 4, dlogits_host, (size_t)nc * 4, (size_t)nc * 4, (size_t)b, hipMemcpyHostToDevice,
+                            h->stream));
+  std::string err;
+  int rc = engine_head_backward(h, nullptr, nullptr, err);
+  if (rc != VITX_OK) return fail(rc, err);
+  CAPI_HIP(hipMemcpyAsync(dx_host, h->g, (size_t)b * h->shell_n * h->cfg.dim * 4, hipMemcpyDeviceToHost, h->stream));
+  CAPI_HIP(hipStreamSynchronize(h->stream));
+  return VITX_OK;
+  CAPI_CATCH
+}
+int32_t vitx_embed_backward_dev(vitx_handle h, const float* dtokens_dev, float* dimg_dev_or_null) {
+  CAPI_TRY
+  if (!h || !dtokens_dev) return fail(VITX_ERR_INVALID, "null argument");
+  std::string err;
+  int rc = engine_embed_backward(h, dtokens_dev, dimg_dev_or_null, err);
+  if (rc != VITX_OK) return fail(rc, err);
+  return VITX_OK;
+  CAPI_CATCH
+}
+int32_t vitx_embed_backward(vitx_handle h, const float* dtokens_host, float* dimg_host_or_null) {
+  CAPI_TRY
+  if (!h || !dtokens_host) return fail(VITX_ERR_INVALID, "null argument");
+  if (!h->have_embed) return fail(VITX_ERR_STATE, "embed_backward requires a preceding embed_forward");
+  const int b = h->last_b;
+  CAPI_HIP(hipMemcpyAsync(h->g, dtokens_host, (size_t)b * h->last_ntok * h->cfg.dim * 4, hipMemcpyHostToDevice, h->stream));
+  float* dimg_dev = dimg_host_or_null ? h->img_dev : nullptr;   // the staged image is no longer needed once patches are unfolded
+  std::string err;
+  int rc = engine_embed_backward(h, h->g, dimg_dev, err);
+  if (rc != VITX_OK) return fail(rc, err);
+  if (dimg_host_or_null)
+    CAPI_HIP(hipMemcpyAsync(dimg_host_or_null, dimg_dev, (size_t)b * h->last_H * h->last_W * h->cfg.channels * 4, hipMemcpyDeviceToHost, h->stream));
+  CAPI_HIP(hipStreamSynchronize(h->stream));
+  return VITX_OK;
+  CAPI_CATCH
+}
+
+// ---- T2T tokenizer: tf.image.extract_patches(..., padding='SAME') (t2t.py:42)
+static int extract_patches_check(int b, int H, int W, int C, int k, int st) {
+  if (b < 0 || H <= 0 || W <= 0 || C <= 0 || k <= 0 || st <= 0) return fail(VITX_ERR_INVALID, "sizes must be positive");
+  return VITX_OK;
+}
+int32_t vitx_extract_patches_shape(int32_t H, int32_t W, int32_t C, int32_t k, int32_t stride, int32_t* oh, int32_t* ow, int32_t* feat) {
+  CAPI_TRY
+  int rc = extract_patches_check(0, H, W, C, k, stride);
+  if (rc != VITX_OK) return rc;
+  int a, bb, pt, pl;
+  extract_patches_geometry(H, W, k, stride, &a, &bb, &pt, &pl);
+  if (oh) *oh = a;
+  if (ow) *ow = bb;
+  if (feat) *feat = k * k * C;
+  return VITX_OK;
+  CAPI_CATCH
+}
+int32_t vitx_extract_patches_dev(const float* x_dev, int32_t b, int32_t H, int32_t W, int32_t C, int32_t k, int32_t stride, float* out_dev,
+                                 void* hip_stream) {
+  CAPI_TRY
+  if (!x_dev || !out_dev) return fail(VITX_ERR_INVALID, "null argument");
+  int rc = extract_patches_check(b, H, W, C, k, stride);
+  if (rc != VITX_OK) return rc;
+  launch_extract_patches(x_dev, out_dev, b, H, W, C, k, stride, (hipStream_t)hip_stream);
+  return VITX_OK;
+  CAPI_CATCH
+}
+int32_t vitx_extract_patches_backward_dev(const float* dout_dev, int32_t b, int32_t H, int32_t W, int32_t C, int32_t k, int32_t stride,
+                                          float* dx_dev, void* hip_stream) {
+  CAPI_TRY
+  if (!dout_dev || !dx_dev) return fail(VITX_ERR_INVALID, "null argument");
+  int rc = extract_patches_check(b, H, W, C, k, stride);
+  if (rc != VITX_OK) return rc;
+  launch_extract_patches_bwd(dout_dev, dx_dev, b, H, W, C, k, stride, (hipStream_t)hip_stream);
+  return VITX_OK;
+  CAPI_CATCH
+}
+static int extract_patches_host(const float* in_host, float* out_host, int b, int H, int W, int C, int k, int st, bool backward) {
+  int rc = extract_patches_check(b, H, W, C, k, st);
+  if (rc != VITX_OK) return rc;
+  if (b == 0) return VITX_OK;   // empty batch: nothing to do
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(VITX_ERR_HIP, "no HIP device available (no CPU fallback)");
+  int oh, ow, pt, pl;
+  extract_patches_geometry(H, W, k, st, &oh, &ow, &pt, &pl);
+  const size_t nx = (size_t)b * H * W * C, no = (size_t)b * oh * ow * k * k * C;
+  const size_t nin = backward ? no : nx, nout = backward ? nx : no;
+  float *din = nullptr, *dout = nullptr;
+  CAPI_HIP(hipMalloc((void**)&din, nin * 4));
+  if (hipMalloc((void**)&dout, nout * 4) != hipSuccess) { (void)hipFree(din); return fail(VITX_ERR_HIP, "hipMalloc failed"); }
+  hipError_t e1 = hipMemcpy(din, in_host, nin * 4, hipMemcpyHostToDevice);
+  if (e1 == hipSuccess) {
+    if (backward) launch_extract_patches_bwd(din, dout, b, H, W, C, k, st, nullptr);
+    else launch_extract_patches(din, dout, b, H, W, C, k, st, nullptr);
+    e1 = hipMemcpy(out_host, dout, nout * 4, hipMemcpyDeviceToHost);
+  }
+  (void)hipFree(din);
+  (void)hipFree(dout);
+  if (e1 != hipSuccess) return fail(VITX_ERR_HIP, std::string("extract_patches: ") + hipGetErrorString(e1));
+  return VITX_OK;
+}
+int32_t vitx_extract_patches(const float* x_host, int32_t b, int32_t H, int32_t W, int32_t C, int32_t k, int32_t stride, float* out_host) {
+  CAPI_TRY
+  if (!x_host || !out_host) return fail(VITX_ERR_INVALID, "null argument");
+  return extract_patches_host(x_host, out_host, b, H, W, C, k, stride, false);
+  CAPI_CATCH
+}
+int32_t vitx_extract_patches_backward(const float* dout_host, int32_t b, int32_t H, int32_t W, int32_t C, int32_t k, int32_t stride,
+                                      float* dx_host) {
+  CAPI_TRY
+  if (!dout_host || !dx_host) return fail(VITX_ERR_INVALID, "null argument");
+  return extract_patches_host(dout_host, dx_host, b, H, W, C, k, stride, true);
+  CAPI_CATCH
+}
+
 int32_t vitx_ce_loss_grad_dev(vitx_handle h, const int32_t* labels_dev, float inv_global_batch, float* loss_dev) {
   CAPI_TRY
   if (!h || !labels_dev) return fail(VITX_ERR_INVALID, "null argument");

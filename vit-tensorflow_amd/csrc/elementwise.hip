@@ -758,3 +758,86 @@ void launch_resid_add(const float* resid, const void* t, int t_bf16, float* out,
   if (t_bf16) hipLaunchKernelGGL(resid_add_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, s, resid, (const bf16_t*)t, out, n);
   else hipLaunchKernelGGL(resid_add_kernel<float>, dim3(grid_for(n)), dim3(256), 0, s, resid, (const float*)t, out, n);
 }
+
+// ------------------------------------------------------------------------------------------------
+// T2T tokenizer (t2t.py:39-47): tf.image.extract_patches(x, sizes=[1,k,k,1], strides=[1,s,s,1], rates=[1,1,1,1], padding='SAME')
+// on NHWC x.  Output [b, oh, ow, k*k*C] with oh = ceil(H/s), the k x k window of output pixel (oi, oj) starts at
+// (oi*s - pad_top, oj*s - pad_left), pad_total = max((o-1)*s + k - in, 0), pad_before = pad_total / 2 (TensorFlow's SAME rule: the
+// odd pixel goes to the bottom / right), out-of-image taps read as 0.  Feature order (ki, kj, c).  Pure index arithmetic: bit-exact.
+// One thread per output element: consecutive threads walk (ki, kj, c), i.e. k*C-float contiguous runs of an input row.
+// ------------------------------------------------------------------------------------------------
+namespace {
+__global__ void extract_patches_kernel(const float* __restrict__ x, float* __restrict__ out, int b, int H, int W, int C, int k, int st,
+                                       int oh, int ow, int pt, int pl) {
+  const int feat = k * k * C, run = k * C;
+  const int64_t total = (int64_t)b * oh * ow * feat;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = e / feat;
+    const int f = (int)(e - row * feat);
+    const int ki = f / run, r = f - ki * run;      // r = kj*C + c
+    const int kj = r / C;
+    const int oj = (int)(row % ow);
+    const int64_t t = row / ow;
+    const int oi = (int)(t % oh);
+    const int64_t bi = t / oh;
+    const int y = oi * st - pt + ki, xx = oj * st - pl + kj;
+    float v = 0.f;
+    if (y >= 0 && y < H && xx >= 0 && xx < W) v = x[((bi * H + y) * W + xx) * C + (r - kj * C)];
+    out[e] = v;
+  }
+}
+
+// VJP: dx[b, y, xx, c] = sum over the (ki, kj) with (y + pt - ki) % st == 0 and (xx + pl - kj) % st == 0 of
+// dout[b, (y + pt - ki)/st, (xx + pl - kj)/st, (ki, kj, c)] -- a gather per input element in ascending (ki, kj): fixed summation order
+__global__ void extract_patches_bwd_kernel(const float* __restrict__ dout, float* __restrict__ dx, int b, int H, int W, int C, int k, int st,
+                                           int oh, int ow, int pt, int pl) {
+  const int feat = k * k * C;
+  const int64_t total = (int64_t)b * H * W * C;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(e % C);
+    int64_t t = e / C;
+    const int xx = (int)(t % W);
+    t /= W;
+    const int y = (int)(t % H);
+    const int64_t bi = t / H;
+    float a = 0.f;
+    for (int ki = 0; ki < k; ++ki) {
+      const int ny = y + pt - ki;
+      if (ny < 0 || ny % st) continue;
+      const int oi = ny / st;
+      if (oi >= oh) continue;
+      for (int kj = 0; kj < k; ++kj) {
+        const int nx = xx + pl - kj;
+        if (nx < 0 || nx % st) continue;
+        const int oj = nx / st;
+        if (oj >= ow) continue;
+        a += dout[((bi * oh + oi) * ow + oj) * (int64_t)feat + (ki * k + kj) * C + c];
+      }
+    }
+    dx[e] = a;
+  }
+}
+inline int grid_for_ep(int64_t total) { return (int)std::min<int64_t>(ceil_div(total, 256), 256 * 8); }
+}  // namespace
+
+void extract_patches_geometry(int H, int W, int k, int st, int* oh, int* ow, int* pt, int* pl) {
+  *oh = (H + st - 1) / st;
+  *ow = (W + st - 1) / st;
+  const int ph = std::max((*oh - 1) * st + k - H, 0), pw = std::max((*ow - 1) * st + k - W, 0);
+  *pt = ph / 2;
+  *pl = pw / 2;
+}
+void launch_extract_patches(const float* x, float* out, int b, int H, int W, int C, int k, int st, hipStream_t s) {
+  int oh, ow, pt, pl;
+  extract_patches_geometry(H, W, k, st, &oh, &ow, &pt, &pl);
+  const int64_t total = (int64_t)b * oh * ow * k * k * C;
+  if (total == 0) return;
+  hipLaunchKernelGGL(extract_patches_kernel, dim3(grid_for_ep(total)), dim3(256), 0, s, x, out, b, H, W, C, k, st, oh, ow, pt, pl);
+}
+void launch_extract_patches_bwd(const float* dout, float* dx, int b, int H, int W, int C, int k, int st, hipStream_t s) {
+  int oh, ow, pt, pl;
+  extract_patches_geometry(H, W, k, st, &oh, &ow, &pt, &pl);
+  const int64_t total = (int64_t)b * H * W * C;
+  if (total == 0) return;
+  hipLaunchKernelGGL(extract_patches_bwd_kernel, dim3(grid_for_ep(total)), dim3(256), 0, s, dout, dx, b, H, W, C, k, st, oh, ow, pt, pl);
+}

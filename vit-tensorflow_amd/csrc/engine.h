@@ -126,6 +126,9 @@ struct vitx_engine {
   bool have_fwd = false;
   bool have_tf = false;              // saved activations describe a transformer_forward(tokens) of [tf_b, tf_n, dim]
   int tf_b = 0, tf_n = 0;
+  bool have_embed = false, have_head = false;   // efficient.ViT shell: state of the last embed_forward / head_forward
+  int shell_b = 0, shell_n = 0;
+  float* shell_x = nullptr;          // [mp, dim] fp32 copy of the head's input (allocated on first use)
   bool have_pt = false;              // e->patches holds the unfolded patches of a patch_tokens_forward of [pt_b, pt_np] patches
   int pt_b = 0, pt_np = 0;
   int64_t patch_rows = -1;           // rows of e->patches written by the last unfold (rows beyond it are zero)
@@ -167,6 +170,11 @@ int engine_transformer_backward(vitx_engine* e, const float* dout_dev, float* dt
 int engine_patch_tokens_forward(vitx_engine* e, const float* img_dev, int b, int H, int W, float* tokens_dev, float* patches_f32_dev_or_null,
                                 std::string& err);
 int engine_patch_tokens_backward(vitx_engine* e, const float* dtokens_dev, std::string& err);
+// efficient.ViT shell (efficient.py:12-56): embedding in front of / pooling + mlp_head behind a caller-supplied transformer
+int engine_embed_forward(vitx_engine* e, const float* img_dev, int b, int H, int W, float* tokens_dev, std::string& err);
+int engine_head_forward(vitx_engine* e, const float* x_dev, int b, int n, float* logits_dev, std::string& err);
+int engine_head_backward(vitx_engine* e, const float* dlogits_dev, float* dx_dev, std::string& err);
+int engine_embed_backward(vitx_engine* e, const float* dtokens_dev, float* dimg_dev, std::string& err);
 void engine_refresh_weights(vitx_engine* e);
 // Dense layers owned by a wrapper object but run with this engine's GEMM kernels, workspaces and stream (bf16 mode: X / dY are
 // row-padded bf16 buffers as everywhere else in the engine; parity mode: fp32).  y / dx are fp32 [rows, out] / [rows, in].

@@ -1284,6 +1284,133 @@ int engine_forward(vitx_engine* e, const float* img_dev, int b, int H, int W, in
   return VITX_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// efficient.ViT (efficient.py:12-56): the model is a shell around a transformer object supplied by the caller --
+// patch embedding + cls token + position embedding (efficient.py:40-46) in front of it, pooling + mlp_head (efficient.py:49-54)
+// behind it.  The four pieces below are that shell and its VJP; the tokens cross the boundary as fp32 [b, n, dim].
+// ------------------------------------------------------------------------------------------------
+static int shell_check(const vitx_engine* e, std::string& err) {
+  const vitx_config& c = e->cfg;
+  if (c.variant != VITX_VARIANT_VIT && c.variant != VITX_VARIANT_DEEPVIT) { err = "embed / head entry points: ViT / DeepViT handles only"; return VITX_ERR_UNSUPPORTED; }
+  if (c.num_parallel_branches > 1) { err = "embed / head entry points: not for parallel_vit handles"; return VITX_ERR_UNSUPPORTED; }
+  return VITX_OK;
+}
+
+int engine_embed_forward(vitx_engine* e, const float* img_dev, int b, int H, int W, float* tokens_dev, std::string& err) {
+  const vitx_config& c = e->cfg;
+  int rc;
+  if ((rc = shell_check(e, err)) != VITX_OK) return rc;
+  if (b <= 0 || b > c.max_batch) { err = "batch must be in [1, max_batch]"; return VITX_ERR_INVALID; }
+  if (H <= 0 || W <= 0 || H > c.image_h || W > c.image_w || H % c.patch_h || W % c.patch_w) {
+    err = "image dimensions must be divisible by the patch size";            // efficient.py:18
+    return VITX_ERR_INVALID;
+  }
+  const int np = (H / c.patch_h) * (W / c.patch_w), ntok = np + 1, d = c.dim, T = e->bf16;
+  ensure_geometry(e, b, ntok);
+  if (e->params_dirty) engine_refresh_weights(e);
+  prepare_patch_rows(e, (int64_t)b * np);
+  {
+    Prof pr(e, "patch_unfold", 0, (double)b * H * W * c.channels * 4 + (double)b * np * e->pd_k * e->esz);
+    launch_unfold(img_dev, e->patches, T, b, H, W, c.channels, c.patch_h, c.patch_w, e->pd_k, e->stream);   // efficient.py:23
+  }
+  {
+    Prof pr(e, "cls_pos_row", 0, 0);
+    launch_cls_pos_row(tokens_dev, e->params + e->cls, e->params + e->pos, b, ntok, d, d, e->stream);       // efficient.py:43-45, row 0
+  }
+  EpiParams ep;
+  ep.out = tokens_dev; ep.ldo = d; ep.pos = e->params + e->pos; ep.ldr = d;
+  ep.np = np; ep.ntok = ntok; ep.tok_off = 1;
+  dense_fwd(e, e->patches, e->pd_k, b * np, e->patch, EPI_PATCH, ep);                                       // efficient.py:24 (+44-45)
+  e->have_fwd = false;          // e->patches no longer describes a full forward
+  e->have_embed = true;
+  e->last_b = b; e->last_np = np; e->last_ntok = ntok; e->last_H = H; e->last_W = W; e->last_training = 0; e->last_extra = 0;
+  return VITX_OK;
+}
+
+int engine_head_forward(vitx_engine* e, const float* x_dev, int b, int n, float* logits_dev, std::string& err) {
+  const vitx_config& c = e->cfg;
+  int rc;
+  if ((rc = shell_check(e, err)) != VITX_OK) return rc;
+  if (b <= 0 || b > c.max_batch || n <= 0 || n > e->ntok_cap) { err = "head_forward: b or n out of range"; return VITX_ERR_INVALID; }
+  const int d = c.dim;
+  if (e->params_dirty) engine_refresh_weights(e);
+  if (!e->shell_x) DALLOC(e->shell_x, (size_t)e->mp * d * 4, false);
+  if (x_dev != e->shell_x) HIPCHK(hipMemcpyAsync(e->shell_x, x_dev, (size_t)b * n * d * 4, hipMemcpyDeviceToDevice, e->stream));
+  if (e->bf16) {   // rows [b, next multiple of 64) of the normalised input are K padding of the head's weight-gradient GEMM
+    const int64_t r1 = round_up(b, 64);
+    if (r1 > b) HIPCHK(hipMemsetAsync(boff(e->yh, (int64_t)b * d, 2), 0, (size_t)(r1 - b) * d * 2, e->stream));
+  }
+  if ((rc = head_forward(e, e->shell_x, b, n, 0, logits_dev, err)) != VITX_OK) return rc;                   // efficient.py:49-54
+  e->have_head = true; e->shell_b = b; e->shell_n = n;
+  return VITX_OK;
+}
+
+// d(logits) [b, num_classes] (NULL: the engine's internal dlogits, e.g. from vitx_ce_loss_grad_dev) -> d(x) [b, n, dim];
+// fills the mlp_head.* entries of the gradient arena
+int engine_head_backward(vitx_engine* e, const float* dlogits_dev, float* dx_dev, std::string& err) {
+  const vitx_config& c = e->cfg;
+  if (!e->have_head) { err = "head_backward requires a preceding head_forward"; return VITX_ERR_STATE; }
+  const int b = e->shell_b, n = e->shell_n, d = c.dim, T = e->bf16, nc = c.num_classes;
+  if (dlogits_dev)
+    HIPCHK(hipMemcpy2DAsync(e->dlogits, (size_t)e->nc_k * 4, dlogits_dev, (size_t)nc * 4, (size_t)nc * 4, b, hipMemcpyDeviceToDevice, e->stream));
+  {
+    Prof pr(e, "head_prep", 0, 0);
+    launch_colsum(e->dlogits, 0, e->nc_k, b, nc, e->red_ws, e->grads + e->head.b, e->stream);
+    if (T) {
+      const int64_t r1 = round_up(b, 64);
+      if (r1 > b) HIPCHK(hipMemsetAsync(boff(e->dl_lp, (int64_t)b * e->nc_k, 2), 0, (size_t)(r1 - b) * e->nc_k * 2, e->stream));
+      launch_convert(e->dlogits, e->nc_k, e->dl_lp, 1, e->nc_k, b, nc, e->nc_k, e->stream);
+    }
+  }
+  const void* dlT = T ? e->dl_lp : (const void*)e->dlogits;
+  {
+    EpiParams ep; ep.out = e->dyh; ep.ldo = d;
+    dense_dgrad(e, dlT, e->nc_k, b, e->head, EPI_STORE, ep);
+  }
+  dense_wgrad(e, e->yh, d, dlT, e->nc_k, b, e->head);
+  const int rows = b * n;
+  { Prof pr(e, "fill_zero", 0, (double)rows * d * 4); launch_fill_zero(e->g, (int64_t)round_up(rows, 256) * d * 4, e->stream); }
+  {
+    Prof pr(e, "layernorm_bwd", 0, 0);
+    if (c.pool == VITX_POOL_MEAN) {
+      launch_layernorm_bwd(e->dyh, T, d, e->pooled, d, e->mean_h, e->rstd_h, e->params + e->head_g, nullptr, 0, e->dpooled, d, nullptr, 0,
+                           e->red_ws, e->grads + e->head_g, e->grads + e->head_b, nullptr, b, d, e->stream);
+      launch_mean_pool_bwd(e->dpooled, b, n, d, e->g, e->stream, n);
+    } else {
+      const int64_t ldrow = (int64_t)n * d;
+      launch_layernorm_bwd(e->dyh, T, d, e->shell_x, ldrow, e->mean_h, e->rstd_h, e->params + e->head_g, nullptr, 0, e->g, ldrow, nullptr, 0,
+                           e->red_ws, e->grads + e->head_g, e->grads + e->head_b, nullptr, b, d, e->stream);
+    }
+  }
+  if (dx_dev && dx_dev != e->g) HIPCHK(hipMemcpyAsync(dx_dev, e->g, (size_t)rows * d * 4, hipMemcpyDeviceToDevice, e->stream));
+  return VITX_OK;
+}
+
+// d(tokens) [b, np + 1, dim] -> the pos_embedding, cls_token and patch_embedding.* entries of the gradient arena (+ optional d(img))
+int engine_embed_backward(vitx_engine* e, const float* dtokens_dev, float* dimg_dev, std::string& err) {
+  const vitx_config& c = e->cfg;
+  if (!e->have_embed) { err = "embed_backward requires a preceding embed_forward"; return VITX_ERR_STATE; }
+  const int b = e->last_b, np = e->last_np, ntok = e->last_ntok, d = c.dim, T = e->bf16;
+  if (dtokens_dev != e->g) HIPCHK(hipMemcpyAsync(e->g, dtokens_dev, (size_t)b * ntok * d * 4, hipMemcpyDeviceToDevice, e->stream));
+  {
+    Prof pr(e, "embed_bwd", 0, (double)b * ntok * d * 4);
+    if (ntok < e->ntok_max)   // position rows the image did not reach (efficient.py:45 slices the table)
+      launch_fill_zero(e->grads + e->pos + (int64_t)ntok * d, (int64_t)(e->ntok_max - ntok) * d * 4, e->stream);
+    launch_batch_reduce(e->g, b, ntok, d, 0, ntok, e->grads + e->pos, e->stream);             // dpos[j] = sum_b g[b,j]
+    launch_batch_reduce(e->g, b, ntok, d, 0, 1, e->grads + e->cls, e->stream);                // dcls = sum_b g[b,0]
+    launch_sum_rows(e->grads + e->pos + d, np, d, e->grads + e->patch.b, e->stream);          // db = sum over patch rows
+    launch_extract_rows(e->g, b, ntok, 1, np, d, e->d_y, T, d, e->stream);                    // dE = g[:, 1:, :]
+  }
+  dense_wgrad(e, e->patches, e->pd_k, e->d_y, d, b * np, e->patch);
+  if (dimg_dev) {
+    EpiParams ep; ep.out = e->tmp_f32; ep.ldo = e->pd;
+    dense_dgrad(e, e->d_y, d, b * np, e->patch, EPI_STORE_F32, ep);
+    Prof pr(e, "patch_fold", 0, 0);
+    launch_fold_add(e->tmp_f32, e->pd, dimg_dev, b, e->last_H, e->last_W, c.channels, c.patch_h, c.patch_w, e->stream);
+  }
+  return VITX_OK;
+}
+
 int engine_transformer_forward(vitx_engine* e, const float* tokens_dev, int b, int n, float* out_dev, std::string& err) {
   const vitx_config& c = e->cfg;
   if (c.variant == VITX_VARIANT_CAIT || c.variant == VITX_VARIANT_PATCH_MERGER) { err = "transformer_forward: ViT / DeepViT only"; return VITX_ERR_UNSUPPORTED; }

@@ -66,6 +66,10 @@ void launch_attn_bf16_bwd(const bf16_t* qkv, const bf16_t* o, const bf16_t* d_o,
 void launch_unfold(const float* img, void* out, int out_bf16, int b, int H, int W, int C, int ph, int pw,
                    int64_t ldo, hipStream_t s);
 void launch_fold_add(const float* dpatches, int64_t ld, float* dimg, int b, int H, int W, int C, int ph, int pw, hipStream_t s);
+// tf.image.extract_patches(..., rates 1, padding 'SAME') (t2t.py:42) and its VJP; out [b, ceil(H/st), ceil(W/st), k*k*C]
+void extract_patches_geometry(int H, int W, int k, int st, int* oh, int* ow, int* pad_top, int* pad_left);
+void launch_extract_patches(const float* x, float* out, int b, int H, int W, int C, int k, int st, hipStream_t s);
+void launch_extract_patches_bwd(const float* dout, float* dx, int b, int H, int W, int C, int k, int st, hipStream_t s);
 void launch_cls_pos_row(float* x, const float* cls, const float* pos, int b, int ntok, int d, int64_t ldx, hipStream_t s);
 void launch_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, void* y, int y_bf16,
                           int64_t ldy, float* mean, float* rstd, int rows, int d, float eps, hipStream_t s);

@@ -91,6 +91,19 @@ SYMBOLS: List[Tuple[str, object, list]] = [
     ("vitx_transformer_forward", C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     ("vitx_transformer_backward", C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p]),
     ("vitx_patch_unfold", C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    ("vitx_embed_forward", C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    ("vitx_embed_forward_dev", C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    ("vitx_head_forward", C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    ("vitx_head_forward_dev", C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    ("vitx_head_backward", C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("vitx_head_backward_dev", C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("vitx_embed_backward", C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("vitx_embed_backward_dev", C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("vitx_extract_patches_shape", C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P(C.c_int32), _P(C.c_int32), _P(C.c_int32)]),
+    ("vitx_extract_patches", C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    ("vitx_extract_patches_backward", C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    ("vitx_extract_patches_dev", C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    ("vitx_extract_patches_backward_dev", C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     ("vitx_ce_loss_grad_dev", C.c_int32, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]),
     ("vitx_adamw_step", C.c_int32, [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float]),
     ("vitx_sgd_step", C.c_int32, [C.c_void_p, C.c_float, C.c_float, C.c_float]),
