@@ -767,54 +767,89 @@ void launch_resid_add(const float* resid, const void* t, int t_bf16, float* out,
 // One thread per output element: consecutive threads walk (ki, kj, c), i.e. k*C-float contiguous runs of an input row.
 // ------------------------------------------------------------------------------------------------
 namespace {
-__global__ void extract_patches_kernel(const float* __restrict__ x, float* __restrict__ out, int b, int H, int W, int C, int k, int st,
-                                       int oh, int ow, int pt, int pl) {
-  const int feat = k * k * C, run = k * C;
-  const int64_t total = (int64_t)b * oh * ow * feat;
-  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t row = e / feat;
-    const int f = (int)(e - row * feat);
-    const int ki = f / run, r = f - ki * run;      // r = kj*C + c
-    const int kj = r / C;
-    const int oj = (int)(row % ow);
-    const int64_t t = row / ow;
-    const int oi = (int)(t % oh);
-    const int64_t bi = t / oh;
-    const int y = oi * st - pt + ki, xx = oj * st - pl + kj;
-    float v = 0.f;
-    if (y >= 0 && y < H && xx >= 0 && xx < W) v = x[((bi * H + y) * W + xx) * C + (r - kj * C)];
-    out[e] = v;
+// division by a run-time constant as multiply-high + add + shift (exact for n < 2^31): the index chains below would otherwise spend
+// ~400 instructions per 4-byte element on 64-bit divides (first version: 1.3-1.5 TB/s, ALU-bound)
+struct FastDiv {
+  uint32_t d, m, s;
+  FastDiv() : d(1), m(1), s(0) {}
+  explicit FastDiv(uint32_t dd) : d(dd) {
+    s = 0;
+    while ((1ull << s) < dd) ++s;
+    m = (uint32_t)(((1ull << 32) * ((1ull << s) - dd)) / dd + 1);
+  }
+  __device__ __forceinline__ uint32_t div(uint32_t n) const { return (__umulhi(n, m) + n) >> s; }
+};
+
+// elements [0, n) of the output rows [row0, ...): n < 2^31 per launch (the host splits larger tensors at row boundaries)
+template <bool VEC>
+__global__ void __launch_bounds__(256) extract_patches_kernel(const float* __restrict__ x, float* __restrict__ out, uint32_t n, uint32_t row0,
+                                                              FastDiv feat, FastDiv run, FastDiv ow, FastDiv oh, int H, int W, int C, int k, int st,
+                                                              int pt, int pl) {
+  const uint32_t stride = gridDim.x * blockDim.x;
+  auto src_of = [&](uint32_t e, bool& ok) -> int64_t {
+    const uint32_t rl = feat.div(e), f = e - rl * feat.d;
+    const uint32_t ki = run.div(f), r = f - ki * run.d;             // r = kj*C + c
+    const uint32_t row = row0 + rl;
+    const uint32_t t = ow.div(row), oj = row - t * ow.d;
+    const uint32_t bi = oh.div(t), oi = t - bi * oh.d;
+    const int y = (int)oi * st - pt + (int)ki, x0 = (int)oj * st - pl;
+    const int lo = max(0, -x0) * C, hi = min(k, W - x0) * C;          // taps kj with 0 <= x0 + kj < W, as a range of r
+    ok = y >= 0 && y < H && (int)r >= lo && (int)r < hi;
+    return (((int64_t)bi * H + y) * W + x0) * C + (int)r;
+  };
+  if (VEC) {   // four consecutive output floats per lane, one 16-B store (the output is 2-3x the input: stores dominate)
+    const uint32_t n4 = n >> 2;
+    for (uint32_t e4 = blockIdx.x * blockDim.x + threadIdx.x; e4 < n4; e4 += stride) {
+      bool k0, k1, k2, k3;
+      const uint32_t e = e4 << 2;
+      const int64_t s0 = src_of(e, k0), s1 = src_of(e + 1, k1), s2 = src_of(e + 2, k2), s3 = src_of(e + 3, k3);
+      *(float4*)(out + e) = make_float4(k0 ? x[s0] : 0.f, k1 ? x[s1] : 0.f, k2 ? x[s2] : 0.f, k3 ? x[s3] : 0.f);
+    }
+    const uint32_t e = (n4 << 2) + blockIdx.x * blockDim.x + threadIdx.x;     // the last n % 4 elements
+    if (e < n) {
+      bool ok;
+      const int64_t s0 = src_of(e, ok);
+      out[e] = ok ? x[s0] : 0.f;
+    }
+    return;
+  }
+  uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+  for (; e < n && (uint64_t)e + 3ull * stride < n; e += 4 * stride) {   // four independent loads in flight per lane
+    bool k0, k1, k2, k3;
+    const int64_t s0 = src_of(e, k0), s1 = src_of(e + stride, k1), s2 = src_of(e + 2 * stride, k2), s3 = src_of(e + 3 * stride, k3);
+    const float v0 = k0 ? x[s0] : 0.f, v1 = k1 ? x[s1] : 0.f, v2 = k2 ? x[s2] : 0.f, v3 = k3 ? x[s3] : 0.f;
+    out[e] = v0; out[e + stride] = v1; out[e + 2 * stride] = v2; out[e + 3 * stride] = v3;
+  }
+  for (; e < n; e += stride) {
+    bool ok;
+    const int64_t s0 = src_of(e, ok);
+    out[e] = ok ? x[s0] : 0.f;
   }
 }
 
-// VJP: dx[b, y, xx, c] = sum over the (ki, kj) with (y + pt - ki) % st == 0 and (xx + pl - kj) % st == 0 of
-// dout[b, (y + pt - ki)/st, (xx + pl - kj)/st, (ki, kj, c)] -- a gather per input element in ascending (ki, kj): fixed summation order
-__global__ void extract_patches_bwd_kernel(const float* __restrict__ dout, float* __restrict__ dx, int b, int H, int W, int C, int k, int st,
-                                           int oh, int ow, int pt, int pl) {
-  const int feat = k * k * C;
-  const int64_t total = (int64_t)b * H * W * C;
-  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-    const int c = (int)(e % C);
-    int64_t t = e / C;
-    const int xx = (int)(t % W);
-    t /= W;
-    const int y = (int)(t % H);
-    const int64_t bi = t / H;
+// VJP: dx[b, y, xx, c] = sum over the windows that cover (y, xx): oi with 0 <= y + pt - oi*st < k, likewise oj, of
+// dout[b, oi, oj, (ki, kj, c)] -- a gather per input element, windows visited in ascending (ki, kj): fixed summation order
+__global__ void __launch_bounds__(256) extract_patches_bwd_kernel(const float* __restrict__ dout, float* __restrict__ dx, uint32_t n, uint32_t pix0,
+                                                                  FastDiv Cd, FastDiv Wd, FastDiv Hd, FastDiv sd, int k, int st, int oh, int ow,
+                                                                  int pt, int pl) {
+  const uint32_t stride = gridDim.x * blockDim.x;
+  const int C = (int)Cd.d, feat = k * k * C;
+  for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride) {
+    const uint32_t pl_ = Cd.div(e), c = e - pl_ * Cd.d;
+    const uint32_t pix = pix0 + pl_;
+    const uint32_t t = Wd.div(pix), xx = pix - t * Wd.d;
+    const uint32_t bi = Hd.div(t), y = t - bi * Hd.d;
+    const int ay = (int)y + pt, ax = (int)xx + pl;
+    const int oi_hi = min((int)sd.div((uint32_t)ay), oh - 1), oj_hi = min((int)sd.div((uint32_t)ax), ow - 1);
+    const int oi_lo = ay - k + 1 > 0 ? (int)sd.div((uint32_t)(ay - k + st)) : 0;      // ceil((ay - k + 1) / st)
+    const int oj_lo = ax - k + 1 > 0 ? (int)sd.div((uint32_t)(ax - k + st)) : 0;
     float a = 0.f;
-    for (int ki = 0; ki < k; ++ki) {
-      const int ny = y + pt - ki;
-      if (ny < 0 || ny % st) continue;
-      const int oi = ny / st;
-      if (oi >= oh) continue;
-      for (int kj = 0; kj < k; ++kj) {
-        const int nx = xx + pl - kj;
-        if (nx < 0 || nx % st) continue;
-        const int oj = nx / st;
-        if (oj >= ow) continue;
-        a += dout[((bi * oh + oi) * ow + oj) * (int64_t)feat + (ki * k + kj) * C + c];
-      }
+    for (int oi = oi_hi; oi >= oi_lo; --oi) {          // descending window index = ascending tap index
+      const int ki = ay - oi * st;
+      const float* rowp = dout + (((int64_t)bi * oh + oi) * ow) * (int64_t)feat + (int64_t)ki * k * C + c;
+      for (int oj = oj_hi; oj >= oj_lo; --oj) a += rowp[(int64_t)oj * feat + (ax - oj * st) * C];
     }
-    dx[e] = a;
+    dx[(uint64_t)pl_ * Cd.d + c] = a;
   }
 }
 inline int grid_for_ep(int64_t total) { return (int)std::min<int64_t>(ceil_div(total, 256), 256 * 8); }
@@ -830,14 +865,30 @@ void extract_patches_geometry(int H, int W, int k, int st, int* oh, int* ow, int
 void launch_extract_patches(const float* x, float* out, int b, int H, int W, int C, int k, int st, hipStream_t s) {
   int oh, ow, pt, pl;
   extract_patches_geometry(H, W, k, st, &oh, &ow, &pt, &pl);
-  const int64_t total = (int64_t)b * oh * ow * k * k * C;
-  if (total == 0) return;
-  hipLaunchKernelGGL(extract_patches_kernel, dim3(grid_for_ep(total)), dim3(256), 0, s, x, out, b, H, W, C, k, st, oh, ow, pt, pl);
+  const int64_t feat = (int64_t)k * k * C, rows = (int64_t)b * oh * ow;
+  if (rows == 0) return;
+  // 32-bit element indices inside a launch: at most 2^30 elements (whole rows) per launch
+  const int64_t rows_per = std::max<int64_t>(1, (1ll << 30) / feat);
+  for (int64_t r0 = 0; r0 < rows; r0 += rows_per) {
+    const int64_t nr = std::min(rows_per, rows - r0), n = nr * feat;
+    float* o = out + r0 * feat;
+    if (((uintptr_t)o) % 16 == 0 && n >= 4)
+      hipLaunchKernelGGL(extract_patches_kernel<true>, dim3(grid_for_ep(n / 4)), dim3(256), 0, s, x, o, (uint32_t)n, (uint32_t)r0,
+                         FastDiv((uint32_t)feat), FastDiv((uint32_t)(k * C)), FastDiv((uint32_t)ow), FastDiv((uint32_t)oh), H, W, C, k, st, pt, pl);
+    else
+      hipLaunchKernelGGL(extract_patches_kernel<false>, dim3(grid_for_ep(n)), dim3(256), 0, s, x, o, (uint32_t)n, (uint32_t)r0,
+                         FastDiv((uint32_t)feat), FastDiv((uint32_t)(k * C)), FastDiv((uint32_t)ow), FastDiv((uint32_t)oh), H, W, C, k, st, pt, pl);
+  }
 }
 void launch_extract_patches_bwd(const float* dout, float* dx, int b, int H, int W, int C, int k, int st, hipStream_t s) {
   int oh, ow, pt, pl;
   extract_patches_geometry(H, W, k, st, &oh, &ow, &pt, &pl);
-  const int64_t total = (int64_t)b * H * W * C;
-  if (total == 0) return;
-  hipLaunchKernelGGL(extract_patches_bwd_kernel, dim3(grid_for_ep(total)), dim3(256), 0, s, dout, dx, b, H, W, C, k, st, oh, ow, pt, pl);
+  const int64_t pixels = (int64_t)b * H * W;
+  if (pixels == 0) return;
+  const int64_t pix_per = std::max<int64_t>(1, (1ll << 30) / C);
+  for (int64_t p0 = 0; p0 < pixels; p0 += pix_per) {
+    const int64_t np = std::min(pix_per, pixels - p0), n = np * C;
+    hipLaunchKernelGGL(extract_patches_bwd_kernel, dim3(grid_for_ep(n)), dim3(256), 0, s, dout, dx + p0 * C, (uint32_t)n, (uint32_t)p0,
+                       FastDiv((uint32_t)C), FastDiv((uint32_t)W), FastDiv((uint32_t)H), FastDiv((uint32_t)st), k, st, oh, ow, pt, pl);
+  }
 }
