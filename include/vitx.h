@@ -161,6 +161,11 @@ int32_t vitx_head_backward_dev(vitx_handle h, const float* dlogits_dev_or_null, 
 int32_t vitx_embed_backward(vitx_handle h, const float* dtokens_host, float* dimg_host_or_null);
 int32_t vitx_embed_backward_dev(vitx_handle h, const float* dtokens_dev, float* dimg_dev_or_null);
 
+/* ---- encoder.patch_embedding.layers[1] on its own: the nn.Dense(units=dim) of vit.py:143 as the wrappers borrow it (mae.py:37,52;
+ * simmim.py:79,92; mpp.py:200) -- rows of unfolded patches [rows, p1*p2*C] -> [rows, dim]; no cls token, no position embedding.
+ * Forward only (the trainable wrappers are vitx_mim_* / vitx_distill_*). */
+int32_t vitx_patch_dense_forward(vitx_handle h, const float* patches_host, int32_t rows, float* out_host);
+
 /* ---- T2T tokenizer: tf.image.extract_patches(x, sizes=[1,k,k,1], strides=[1,s,s,1], rates=[1,1,1,1], padding='SAME')
  * (RearrangeUnfoldTransformer.call, t2t.py:39-47) on NHWC x [b,H,W,C] -> [b, ceil(H/s), ceil(W/s), k*k*C], feature order
  * (ki, kj, c), TensorFlow's SAME rule (pad_total = max((out-1)*s + k - in, 0), pad_before = pad_total / 2, zeros outside).

@@ -242,3 +242,53 @@ def test_shell_entry_points_report_call_order_and_ranges():
     with pytest.raises(N.VitxError, match="no backward"):
         m(np.zeros((1, 32, 48, 3), np.float32))
         m.backward(np.zeros((1, 7), np.float32))
+
+
+# ------------------------------------------------------------------------------------------------
+# the rest of the surface the reference's wrappers reach into (SURVEY.md section 8b "extended surface"):
+# patch_embedding(.layers), pos_embedding[...], cls_token, dropout, transformer, pool, mlp_head
+@pytest.mark.gpu
+@pytest.mark.parametrize("compute,name", [("fp32", "vit_small"), ("fp32", "vit_rect_mean"), ("bf16", "vit_bf16_small"), ("fp32", "deepvit_small")])
+def test_wrapper_surface_composes_to_the_forward(compute, name):
+    from oracle import ref_numpy
+    from util import make_engine_model, oracle_cfg, rand_images
+    cfg = oracle_cfg(name)
+    P = spec.init_params(cfg, 3, randomize_all=True)
+    b = 3
+    m = make_engine_model(name, compute, max_batch=b, params=P)
+    img = rand_images(cfg, b, seed=5)
+    # mae.py:36-38 / simmim.py:78-80
+    num_patches, encoder_dim = m.pos_embedding.shape[-2:]
+    to_patch, patch_to_emb = m.patch_embedding.layers[:2]
+    ph, pw = cfg["patch_size"]
+    assert encoder_dim == cfg["dim"] and patch_to_emb.weights[0].shape[0] == ph * pw * 3
+    patches = to_patch(img)
+    assert np.array_equal(patches, ref_numpy.patch_unfold(img, ph, pw))                                   # pure indexing: bit-exact
+    tokens = patch_to_emb(patches)
+    ref_tok = patches.astype(np.float64) @ P["patch_embedding.kernel"] + P["patch_embedding.bias"]
+    ttol = 1e-5 if compute == "fp32" else 2e-2
+    assert np.abs(tokens - ref_tok).max() <= ttol * np.abs(ref_tok).max()
+    # DistillMixin.call (distill.py:19-40) written against the model's attributes, as a user of the reference would
+    x = m.patch_embedding(img)
+    bb, n, d = x.shape
+    cls_tokens = np.repeat(np.asarray(m.cls_token), bb, axis=0)
+    x = np.concatenate([cls_tokens, x], axis=1)
+    x = x + m.pos_embedding[:, :(n + 1)]
+    x = m.dropout(x, training=False)
+    x = m.transformer(x, training=False)
+    x = x.mean(axis=1) if m.pool == 'mean' else x[:, 0]
+    logits = m.mlp_head(np.ascontiguousarray(x))
+    rl = ref_torch.forward(cfg, ref_torch.to_torch(P), torch.tensor(img, dtype=torch.float64), ref_torch.bf16_round if compute == "bf16" else None).numpy()
+    ltol = 1e-4 if compute == "fp32" else 3e-2
+    assert np.abs(logits - rl).max() <= ltol * max(1.0, np.abs(rl).max())
+    full = m(img, training=False)
+    assert np.abs(logits - full).max() <= ltol * max(1.0, np.abs(rl).max())
+    # a stand-alone head call overwrites the head state of the full forward: its backward must refuse, not return wrong gradients
+    m.mlp_head(np.ascontiguousarray(x))
+    with pytest.raises(N.VitxError, match="preceding forward"):
+        m.backward(np.zeros((b, cfg["num_classes"]), np.float32))
+    m(img, training=False)
+    grads, _ = m.backward(np.ones((b, cfg["num_classes"]), np.float32))                                    # and works again after a forward
+    assert np.isfinite(grads["mlp_head.kernel"]).all()
+    with pytest.raises(NotImplementedError):
+        type(m.dropout)(0.5)(x, training=True)

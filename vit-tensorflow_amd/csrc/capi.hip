@@ -300,6 +300,20 @@ int32_t vitx_embed_forward(vitx_handle h, const float* img_host, int32_t b, int3
   return VITX_OK;
   CAPI_CATCH
 }
+int32_t vitx_patch_dense_forward(vitx_handle h, const float* patches_host, int32_t rows, float* out_host) {
+  CAPI_TRY
+  if (!h || !patches_host || !out_host) return fail(VITX_ERR_INVALID, "null argument");
+  if (rows <= 0 || (int64_t)rows > (int64_t)h->cfg.max_batch * h->np_max)
+    return fail(VITX_ERR_INVALID, "patch_dense_forward: rows must be in [1, max_batch * num_patches]");
+  CAPI_HIP(hipMemcpyAsync(h->tmp_f32, patches_host, (size_t)rows * h->pd * 4, hipMemcpyHostToDevice, h->stream));
+  std::string err;
+  int rc = engine_patch_dense_forward(h, h->tmp_f32, rows, h->g, err);
+  if (rc != VITX_OK) return fail(rc, err);
+  CAPI_HIP(hipMemcpyAsync(out_host, h->g, (size_t)rows * h->cfg.dim * 4, hipMemcpyDeviceToHost, h->stream));
+  CAPI_HIP(hipStreamSynchronize(h->stream));
+  return VITX_OK;
+  CAPI_CATCH
+}
 int32_t vitx_head_forward_dev(vitx_handle h, const float* x_dev, int32_t b, int32_t n, float* logits_dev) {
   CAPI_TRY
   if (!h || !x_dev) return fail(VITX_ERR_INVALID, "null argument");

@@ -172,6 +172,7 @@ int engine_patch_tokens_forward(vitx_engine* e, const float* img_dev, int b, int
 int engine_patch_tokens_backward(vitx_engine* e, const float* dtokens_dev, std::string& err);
 // efficient.ViT shell (efficient.py:12-56): embedding in front of / pooling + mlp_head behind a caller-supplied transformer
 int engine_embed_forward(vitx_engine* e, const float* img_dev, int b, int H, int W, float* tokens_dev, std::string& err);
+int engine_patch_dense_forward(vitx_engine* e, const float* patches_dev, int rows, float* out_dev, std::string& err);
 int engine_head_forward(vitx_engine* e, const float* x_dev, int b, int n, float* logits_dev, std::string& err);
 int engine_head_backward(vitx_engine* e, const float* dlogits_dev, float* dx_dev, std::string& err);
 int engine_embed_backward(vitx_engine* e, const float* dtokens_dev, float* dimg_dev, std::string& err);

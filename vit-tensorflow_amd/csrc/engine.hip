@@ -1078,6 +1078,7 @@ static void prepare_patch_rows(vitx_engine* e, int64_t rows) {
     (void)hipMemsetAsync(e->patches, 0, (size_t)e->mpp * e->pd_k * e->esz, e->stream);
   e->patch_rows = rows;
   e->have_pt = false;
+  e->have_embed = false;       // whoever overwrites e->patches re-establishes its own state afterwards
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1177,6 +1178,7 @@ static void draw_layer_dropout(vitx_engine* e, uint64_t seed) {
 // ntok rows per image in memory, of which the first ntok - extra are pooled (a distillation token is split off first, distill.py:32-33)
 static int head_forward(vitx_engine* e, const float* x_last, int b, int ntok, int extra, float* logits_dev, std::string& err) {
   const vitx_config& c = e->cfg;
+  e->have_head = false;        // the head's saved statistics are about to be overwritten (engine_head_forward sets it again)
   const int d = c.dim, T = e->bf16;
   const float* src = x_last;
   int64_t ldsrc = (int64_t)ntok * d;               // cls pooling: row 0 of every image (vit.py:173, cait.py:192)
@@ -1327,11 +1329,26 @@ int engine_embed_forward(vitx_engine* e, const float* img_dev, int b, int H, int
   return VITX_OK;
 }
 
+// patch_embedding.layers[1] on its own (mae.py:37, simmim.py:79, mpp.py:200): nn.Dense(units=dim) (vit.py:143) on rows of unfolded
+// patches [rows, p1*p2*C] -> [rows, dim], no cls token, no position embedding.  Forward only.
+int engine_patch_dense_forward(vitx_engine* e, const float* patches_dev, int rows, float* out_dev, std::string& err) {
+  const vitx_config& c = e->cfg;
+  if (rows <= 0 || (int64_t)rows > (int64_t)c.max_batch * e->np_max) { err = "patch_dense_forward: rows must be in [1, max_batch * num_patches]"; return VITX_ERR_INVALID; }
+  if (e->params_dirty) engine_refresh_weights(e);
+  prepare_patch_rows(e, rows);
+  launch_convert(patches_dev, e->pd, e->patches, e->bf16, e->pd_k, rows, e->pd, e->pd_k, e->stream);
+  EpiParams ep;
+  ep.out = out_dev; ep.ldo = c.dim;
+  dense_fwd(e, e->patches, e->pd_k, rows, e->patch, EPI_STORE_F32, ep);
+  e->have_fwd = false; e->have_embed = false;   // e->patches no longer describes a forward that can be differentiated
+  return VITX_OK;
+}
+
 int engine_head_forward(vitx_engine* e, const float* x_dev, int b, int n, float* logits_dev, std::string& err) {
   const vitx_config& c = e->cfg;
   int rc;
-  if ((rc = shell_check(e, err)) != VITX_OK) return rc;
   if (b <= 0 || b > c.max_batch || n <= 0 || n > e->ntok_cap) { err = "head_forward: b or n out of range"; return VITX_ERR_INVALID; }
+  e->have_fwd = false;          // the head state of a preceding full forward is overwritten: its backward must not run on it
   const int d = c.dim;
   if (e->params_dirty) engine_refresh_weights(e);
   if (!e->shell_x) DALLOC(e->shell_x, (size_t)e->mp * d * 4, false);

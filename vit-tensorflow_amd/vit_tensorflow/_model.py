@@ -48,6 +48,10 @@ class _Weight:
         a = self.numpy()
         return a.astype(dtype) if dtype is not None else a
 
+    def __getitem__(self, idx):
+        """`encoder.pos_embedding[:, 1:(num_patches + 1)]` (mae.py:54, simmim.py:95, distill.py:24)."""
+        return self.numpy()[idx]
+
 
 class _TransformerProxy:
     """`model.transformer(tokens, training=...)` as used by mae.py:69, simmim.py:116, mpp.py:212."""
@@ -62,6 +66,91 @@ class _TransformerProxy:
         """VJP of the last `transformer(tokens)` call: returns ({name: grad}, dtokens|None); gradients of parameters outside the
         transformer are zero."""
         return self._owner._transformer_backward(dout, want_dtokens)
+
+
+class _ToPatch:
+    """`encoder.patch_embedding.layers[0]`: Rearrange('b (h p1) (w p2) c -> b (h w) (p1 p2 c)') (vit.py:142; borrowed at mae.py:37,
+    simmim.py:79).  Bit-exact HIP gather."""
+
+    def __init__(self, owner: "VitxModel"):
+        self._owner = owner
+
+    def __call__(self, img, training=None, **_):
+        o = self._owner
+        x, proto = o._as_host(img)
+        assert x.ndim == 4, "expected NHWC images [b, H, W, C]"
+        b, H, W, Cc = x.shape
+        ph, pw = o._cfg.patch_h, o._cfg.patch_w
+        assert H % ph == 0 and W % pw == 0, 'Image dimensions must be divisible by the patch size.'
+        out = np.empty((b, (H // ph) * (W // pw), ph * pw * Cc), dtype=np.float32)
+        N.check(N.lib().vitx_patch_unfold(x.ctypes.data_as(C.c_void_p), b, H, W, Cc, ph, pw, out.ctypes.data_as(C.c_void_p)))
+        return o._like(out, proto)
+
+
+class _PatchToEmb:
+    """`encoder.patch_embedding.layers[1]`: nn.Dense(units=dim) (vit.py:143); `.weights[0].shape` is read at mae.py:38 / simmim.py:80."""
+
+    def __init__(self, owner: "VitxModel"):
+        self._owner = owner
+
+    @property
+    def weights(self):
+        return [w for w in self._owner.weights if w.name in ("patch_embedding.kernel", "patch_embedding.bias")]
+
+    def __call__(self, patches, training=None, **_):
+        o = self._owner
+        x, proto = o._as_host(patches)
+        pd = o._cfg.patch_h * o._cfg.patch_w * o._cfg.channels
+        assert x.shape[-1] == pd, f"expected patches of {pd} features"
+        rows = int(np.prod(x.shape[:-1]))
+        npatch = (o._cfg.image_h // o._cfg.patch_h) * (o._cfg.image_w // o._cfg.patch_w)
+        h = o._ensure_handle(max(1, -(-rows // npatch)))
+        out = np.empty(x.shape[:-1] + (o.dim,), dtype=np.float32)
+        N.check(N.lib().vitx_patch_dense_forward(h, x.ctypes.data_as(C.c_void_p), rows, out.ctypes.data_as(C.c_void_p)))
+        return o._like(out, proto)
+
+
+class _PatchEmbedding:
+    """`model.patch_embedding` (a Keras Sequential in the reference, vit.py:141-144): callable, with `.layers` (distill.py:19,
+    mae.py:37, mpp.py:200)."""
+
+    def __init__(self, owner: "VitxModel"):
+        self.layers = [_ToPatch(owner), _PatchToEmb(owner)]
+
+    def __call__(self, img, training=None, **_):
+        return self.layers[1](self.layers[0](img))
+
+
+class _MlpHead:
+    """`model.mlp_head` (vit.py:154-157): LayerNormalization + Dense on pooled features [b, dim] (distill.py:40)."""
+
+    def __init__(self, owner: "VitxModel"):
+        self._owner = owner
+
+    def __call__(self, x, training=None, **_):
+        o = self._owner
+        a, proto = o._as_host(x)
+        assert a.ndim == 2 and a.shape[1] == o.dim, "expected pooled features [b, dim]"
+        b = a.shape[0]
+        h = o._ensure_handle(b)
+        out = np.empty((b, o.num_classes), dtype=np.float32)
+        # one token per image: cls and mean pooling are both the identity on it, so this is exactly LayerNorm + Dense
+        N.check(N.lib().vitx_head_forward(h, a.ctypes.data_as(C.c_void_p), b, 1, out.ctypes.data_as(C.c_void_p)))
+        return o._like(out, proto)
+
+
+class _Dropout:
+    """`model.dropout` (nn.Dropout(rate=emb_dropout), vit.py:148) as called by distill.py:56 / mpp.py:209.  Inside the engine's own
+    forward the mask comes from the device-side counter RNG; this stand-alone layer is the identity unless a rate > 0 is asked to
+    act in training mode, which only the full forward offers."""
+
+    def __init__(self, rate: float):
+        self.rate = float(rate)
+
+    def __call__(self, x, training=False, **_):
+        if training and self.rate > 0.0:
+            raise NotImplementedError("stand-alone dropout with rate > 0: use model(img, training=True) (the mask is drawn inside the engine)")
+        return x
 
 
 class VitxModel:
@@ -103,6 +192,10 @@ class VitxModel:
         self._device_newer = False
         self._init_weights(np.random.default_rng(seed))
         self.transformer = _TransformerProxy(self)
+        # the rest of the surface the reference's wrappers reach into: distill.py:19-40, mae.py:36-38, mpp.py:200-209
+        self.patch_embedding = _PatchEmbedding(self)
+        self.mlp_head = _MlpHead(self)
+        self.dropout = _Dropout(emb_dropout)
         self._cb_keepalive = None
 
     # ---- initialisers: tf.random.normal (vit.py:146-147), Keras Dense glorot_uniform / zeros,

@@ -93,6 +93,7 @@ SYMBOLS: List[Tuple[str, object, list]] = [
     ("vitx_patch_unfold", C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     ("vitx_embed_forward", C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     ("vitx_embed_forward_dev", C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    ("vitx_patch_dense_forward", C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     ("vitx_head_forward", C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     ("vitx_head_forward_dev", C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     ("vitx_head_backward", C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p]),
