@@ -175,7 +175,11 @@ def main():
         if dist.is_initialized():
             dist.barrier()
 
-    for _ in range(args.warmup):
+    # The first step of a process also measures the GEMM tile variants of every shape it meets (a few extra launches per shape) and
+    # makes the first-use allocations; with --warmup 0 that step would land inside the timed region, so one untimed priming step
+    # runs in that case (reported as "priming_steps"; "warmup" stays what was asked for).
+    priming = 1 if args.warmup == 0 else 0
+    for _ in range(args.warmup + priming):
         step()
     full_sync()
     t0 = time.perf_counter()
@@ -201,6 +205,8 @@ def main():
         "path_mfma_frac": round(value / world * fpi / MFMA_BF16_PEAK, 4),
         "flops_per_image": fpi,
     }
+    if priming:
+        out["priming_steps"] = priming
 
     if rank == 0 and not args.no_profile:
         try:   # per-kernel-class HIP-event timing of two more steps (outside the timed region)
