@@ -50,6 +50,12 @@ struct BlockActs {
   // null = the residual input itself, i.e. the ordinary block.
   const float *ln1_src = nullptr, *ln2_src = nullptr;
   bool skip_attn = false, skip_mlp = false;
+  // materialised-attention path (DeepViT / CaiT, and ViT in parity mode): the score tensors of the last forward of THIS block, kept
+  // for its backward instead of recomputing QK^T and the head-axis chain (sized once for max_batch; HBM is 288 GB)
+  float* sc_keep[3] = {nullptr, nullptr, nullptr};
+  int64_t sc_keep_elems = 0;        // 0: not tried yet, -1: over the budget (this block recomputes), else elements per buffer
+  int64_t sc_geom = -1;             // (b, nq, nk) the kept tensors describe
+  int sc_pi = 0;                    // index of the tensor that multiplies V
   int par_first = 0, par_last = 0;   // backward order inside a group of parallel half-blocks: first / last one processed (1 + 1 = alone)
 };
 
@@ -140,6 +146,8 @@ struct vitx_engine {
   std::vector<std::vector<bool>> layer_kept;   // per stage: blocks that survived CaiT layer dropout in the last forward
   int64_t zero_geom = -1;
 
+  bool keep_scores = true;           // VITX_RECOMPUTE_SCORES=1: recompute in the backward as before (A/B)
+  int64_t sc_keep_bytes = 0, sc_keep_budget = 48LL << 30;
   // env switches
   bool force_generic_gemm = false, force_generic_attn = false, wgrad_via_transpose = true;
   int gemm_kernel = 0;

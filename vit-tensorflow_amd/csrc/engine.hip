@@ -416,62 +416,67 @@ static void bgemm(vitx_engine* e, const void* A, int ta, int64_t sam, int64_t sa
 }
 
 // forward chain into the score workspaces; returns the index of the workspace holding the matrix that multiplies V
-static int attn_generic_scores(vitx_engine* e, const BlockParams& bp, const AttnView& a, int b, bool for_bwd) {
+static int attn_generic_scores(vitx_engine* e, const BlockParams& bp, const AttnView& a, int b, bool for_bwd, float* const* sc) {
   const int h = e->cfg.heads, dh = e->cfg.dim_head;
   const int T = e->bf16;
   const int64_t ld = round_up(a.nk, 4);
   const int64_t hs = (int64_t)a.nq * ld, bs = (int64_t)h * hs;
   const float scale = 1.0f / std::sqrt((float)dh);
   // dots = q k^T * scale   (vit.py:77, deepvit.py:79, cait.py:121)
-  bgemm(e, a.q, T, a.ldq, 1, a.qb, dh, a.k, T, 1, a.ldk, a.kb, dh, a.nq, a.nk, dh, b, h, EPI_STORE_F32, 0, e->sc[0], ld, bs, hs, scale);
+  bgemm(e, a.q, T, a.ldq, 1, a.qb, dh, a.k, T, 1, a.ldk, a.kb, dh, a.nq, a.nk, dh, b, h, EPI_STORE_F32, 0, sc[0], ld, bs, hs, scale);
   const int64_t rows = (int64_t)b * h * a.nq;
   const bool chain = !e->unfused_headops && headchain_supported(h, a.nk);
   if (chain && e->cfg.variant == VITX_VARIANT_CAIT) {
     Prof pr(e, "attn_headchain", 0, 0);     // mix -> softmax -> mix in one pass (cait.py:123-125); A1 is only kept for the backward
-    launch_cait_chain_fwd(e->sc[0], e->params + bp.mix_pre, e->params + bp.mix_post, for_bwd ? e->sc[1] : nullptr, e->sc[2], b, h, a.nq, a.nk,
+    launch_cait_chain_fwd(sc[0], e->params + bp.mix_pre, e->params + bp.mix_post, for_bwd ? sc[1] : nullptr, sc[2], b, h, a.nq, a.nk,
                           ld, e->stream);
     return 2;
   }
   if (chain && e->cfg.variant == VITX_VARIANT_DEEPVIT) {
     Prof pr(e, "attn_headchain", 0, 0);     // softmax -> re-attention mix -> LayerNorm over heads (deepvit.py:80-84)
-    launch_deepvit_chain_fwd(e->sc[0], e->params + bp.re_w, e->params + bp.re_g, e->params + bp.re_b, for_bwd ? e->sc[1] : nullptr, e->sc[2],
+    launch_deepvit_chain_fwd(sc[0], e->params + bp.re_w, e->params + bp.re_g, e->params + bp.re_b, for_bwd ? sc[1] : nullptr, sc[2],
                              for_bwd ? 1 : 0, b, h, a.nq, a.nk, ld, e->cfg.ln_eps, e->stream);
     return 2;
   }
   if (!e->unfused_headops && e->cfg.variant == VITX_VARIANT_DEEPVIT && deepvit_point_fwd_supported(h, a.nk)) {
     Prof pr(e, "attn_headchain", 0, 0);     // 65..128 keys: row statistics + one fused point kernel (deepvit.py:80-84)
-    launch_deepvit_point_fwd(e->sc[0], e->red_ws, e->params + bp.re_w, e->params + bp.re_g, e->params + bp.re_b, e->sc[1], e->sc[2],
+    launch_deepvit_point_fwd(sc[0], e->red_ws, e->params + bp.re_w, e->params + bp.re_g, e->params + bp.re_b, sc[1], sc[2],
                              for_bwd ? 1 : 0, b, h, a.nq, a.nk, ld, e->cfg.ln_eps, e->stream);
     return 2;
   }
   if (e->cfg.variant == VITX_VARIANT_CAIT) {
     Prof pr(e, "attn_generic_headops", 0, 0);
-    launch_headmix_fwd(e->sc[0], e->params + bp.mix_pre, e->sc[1], b, h, a.nq, a.nk, ld, e->stream);    // cait.py:123
-    launch_softmax_rows(e->sc[1], rows, a.nk, ld, e->stream);                                            // cait.py:124
-    launch_headmix_fwd(e->sc[1], e->params + bp.mix_post, e->sc[2], b, h, a.nq, a.nk, ld, e->stream);   // cait.py:125
+    launch_headmix_fwd(sc[0], e->params + bp.mix_pre, sc[1], b, h, a.nq, a.nk, ld, e->stream);    // cait.py:123
+    launch_softmax_rows(sc[1], rows, a.nk, ld, e->stream);                                            // cait.py:124
+    launch_headmix_fwd(sc[1], e->params + bp.mix_post, sc[2], b, h, a.nq, a.nk, ld, e->stream);   // cait.py:125
     return 2;
   }
   {
     Prof pr(e, "attn_generic_softmax", 0, 0);
-    launch_softmax_rows(e->sc[0], rows, a.nk, ld, e->stream);                                            // vit.py:78
+    launch_softmax_rows(sc[0], rows, a.nk, ld, e->stream);                                            // vit.py:78
   }
   if (e->cfg.variant == VITX_VARIANT_DEEPVIT) {
     Prof pr(e, "attn_generic_headops", 0, 0);
-    launch_headmix_fwd(e->sc[0], e->params + bp.re_w, e->sc[1], b, h, a.nq, a.nk, ld, e->stream);       // deepvit.py:83
-    launch_headnorm_fwd(e->sc[1], e->params + bp.re_g, e->params + bp.re_b, e->sc[2], b, h, a.nq, a.nk, ld, e->cfg.ln_eps,
+    launch_headmix_fwd(sc[0], e->params + bp.re_w, sc[1], b, h, a.nq, a.nk, ld, e->stream);       // deepvit.py:83
+    launch_headnorm_fwd(sc[1], e->params + bp.re_g, e->params + bp.re_b, sc[2], b, h, a.nq, a.nk, ld, e->cfg.ln_eps,
                         e->stream);                                                                      // deepvit.py:84
     return 2;
   }
   return 0;
 }
 
-static void attn_generic_fwd(vitx_engine* e, const BlockParams& bp, const AttnView& a, int b) {
+static inline int64_t score_geom(int b, int nq, int nk) { return ((int64_t)b << 40) | ((int64_t)nq << 20) | (int64_t)nk; }
+
+// keep != null: the score tensors go to that block's own buffers and stay there for its backward
+static void attn_generic_fwd(vitx_engine* e, const BlockParams& bp, const AttnView& a, int b, BlockActs* keep) {
   const int h = e->cfg.heads, dh = e->cfg.dim_head, T = e->bf16;
   const int64_t ld = round_up(a.nk, 4);
   const int64_t hs = (int64_t)a.nq * ld, bs = (int64_t)h * hs;
-  const int pi = attn_generic_scores(e, bp, a, b, false);
+  float* const* sc = keep ? keep->sc_keep : e->sc;
+  const int pi = attn_generic_scores(e, bp, a, b, keep != nullptr, sc);
+  if (keep) { keep->sc_geom = score_geom(b, a.nq, a.nk); keep->sc_pi = pi; }
   // out = attn v   (vit.py:81, deepvit.py:87, cait.py:127)
-  bgemm(e, e->sc[pi], 0, ld, 1, bs, hs, a.v, T, a.ldv, 1, a.vb, dh, a.nq, dh, a.nk, b, h, EPI_STORE, T, a.o, a.ldo, a.ob, dh, 1.0f);
+  bgemm(e, sc[pi], 0, ld, 1, bs, hs, a.v, T, a.ldv, 1, a.vb, dh, a.nq, dh, a.nk, b, h, EPI_STORE, T, a.o, a.ldo, a.ob, dh, 1.0f);
 }
 
 struct AttnGrad {   // gradients, same addressing conventions as AttnView
@@ -480,43 +485,46 @@ struct AttnGrad {   // gradients, same addressing conventions as AttnView
   int64_t lddq = 0, lddk = 0, lddv = 0, dqb = 0, dkb = 0, dvb = 0;
 };
 
-static void attn_generic_bwd(vitx_engine* e, const BlockParams& bp, const AttnView& a, const AttnGrad& gr, int b) {
+static void attn_generic_bwd(vitx_engine* e, const BlockParams& bp, const AttnView& a, const AttnGrad& gr, int b, const BlockActs* keep) {
   const int h = e->cfg.heads, dh = e->cfg.dim_head, T = e->bf16;
   const int64_t ld = round_up(a.nk, 4);
   const int64_t hs = (int64_t)a.nq * ld, bs = (int64_t)h * hs;
   const float scale = 1.0f / std::sqrt((float)dh);
   const int64_t rows = (int64_t)b * h * a.nq;
-  const int pi = attn_generic_scores(e, bp, a, b, true);   // recompute the forward chain (P is not stored)
+  // the forward chain: as the block's forward left it, or recomputed (kept tensors absent / describing another geometry)
+  const bool kept = keep && keep->sc_keep[0] && keep->sc_geom == score_geom(b, a.nq, a.nk);
+  float* const* sc = kept ? keep->sc_keep : e->sc;
+  const int pi = kept ? keep->sc_pi : attn_generic_scores(e, bp, a, b, true, e->sc);
   float* dA = e->sc[3];
   // d(attn) = dO v^T ; dV = attn^T dO
   bgemm(e, gr.d_o, T, gr.ldo, 1, gr.ob, dh, a.v, T, 1, a.ldv, a.vb, dh, a.nq, a.nk, dh, b, h, EPI_STORE_F32, 0, dA, ld, bs, hs, 1.0f);
-  bgemm(e, e->sc[pi], 0, 1, ld, bs, hs, gr.d_o, T, gr.ldo, 1, gr.ob, dh, a.nk, dh, a.nq, b, h, EPI_STORE, T, gr.dv, gr.lddv, gr.dvb, dh, 1.0f);
+  bgemm(e, sc[pi], 0, 1, ld, bs, hs, gr.d_o, T, gr.ldo, 1, gr.ob, dh, a.nk, dh, a.nq, b, h, EPI_STORE, T, gr.dv, gr.lddv, gr.dvb, dh, 1.0f);
   const bool chain = !e->unfused_headops && headchain_supported(h, a.nk);
   if (chain && e->cfg.variant == VITX_VARIANT_CAIT) {
     Prof pr(e, "attn_headchain", 0, 0);
-    launch_cait_chain_bwd(e->sc[0], e->sc[1], dA, e->params + bp.mix_pre, e->params + bp.mix_post, e->red_ws, e->grads + bp.mix_pre,
+    launch_cait_chain_bwd(sc[0], sc[1], dA, e->params + bp.mix_pre, e->params + bp.mix_post, e->red_ws, e->grads + bp.mix_pre,
                           e->grads + bp.mix_post, b, h, a.nq, a.nk, ld, e->stream);
   } else if (chain && e->cfg.variant == VITX_VARIANT_DEEPVIT) {
     Prof pr(e, "attn_headchain", 0, 0);
-    launch_deepvit_chain_bwd(e->sc[0], e->sc[1], dA, e->params + bp.re_w, e->params + bp.re_g, e->red_ws, e->grads + bp.re_w, e->grads + bp.re_g,
+    launch_deepvit_chain_bwd(sc[0], sc[1], dA, e->params + bp.re_w, e->params + bp.re_g, e->red_ws, e->grads + bp.re_w, e->grads + bp.re_g,
                              e->grads + bp.re_b, b, h, a.nq, a.nk, ld, e->cfg.ln_eps, e->stream);
   } else if (!e->unfused_headops && e->cfg.variant == VITX_VARIANT_DEEPVIT && deepvit_point_fwd_supported(h, a.nk)) {
     Prof pr(e, "attn_headchain", 0, 0);     // LayerNorm-over-heads VJP + mix VJP in one point kernel, then the softmax VJP
-    launch_deepvit_point_bwd(e->sc[0], e->sc[1], dA, e->params + bp.re_w, e->params + bp.re_g, e->red_ws, e->grads + bp.re_w,
+    launch_deepvit_point_bwd(sc[0], sc[1], dA, e->params + bp.re_w, e->params + bp.re_g, e->red_ws, e->grads + bp.re_w,
                              e->grads + bp.re_g, e->grads + bp.re_b, b, h, a.nq, a.nk, ld, e->cfg.ln_eps, e->stream);
   } else {
     Prof pr(e, "attn_generic_headops", 0, 0);
     if (e->cfg.variant == VITX_VARIANT_CAIT) {
-      launch_headmix_bwd(e->sc[1], dA, e->params + bp.mix_post, dA, e->red_ws, e->grads + bp.mix_post, b, h, a.nq, a.nk, ld, e->stream);
-      launch_softmax_bwd_rows(e->sc[1], dA, rows, a.nk, ld, e->stream);
-      launch_headmix_bwd(e->sc[0], dA, e->params + bp.mix_pre, dA, e->red_ws, e->grads + bp.mix_pre, b, h, a.nq, a.nk, ld, e->stream);
+      launch_headmix_bwd(sc[1], dA, e->params + bp.mix_post, dA, e->red_ws, e->grads + bp.mix_post, b, h, a.nq, a.nk, ld, e->stream);
+      launch_softmax_bwd_rows(sc[1], dA, rows, a.nk, ld, e->stream);
+      launch_headmix_bwd(sc[0], dA, e->params + bp.mix_pre, dA, e->red_ws, e->grads + bp.mix_pre, b, h, a.nq, a.nk, ld, e->stream);
     } else if (e->cfg.variant == VITX_VARIANT_DEEPVIT) {
-      launch_headnorm_bwd(e->sc[1], dA, e->params + bp.re_g, dA, e->red_ws, e->grads + bp.re_g, e->grads + bp.re_b, b, h, a.nq, a.nk, ld,
+      launch_headnorm_bwd(sc[1], dA, e->params + bp.re_g, dA, e->red_ws, e->grads + bp.re_g, e->grads + bp.re_b, b, h, a.nq, a.nk, ld,
                           e->cfg.ln_eps, e->stream);
-      launch_headmix_bwd(e->sc[0], dA, e->params + bp.re_w, dA, e->red_ws, e->grads + bp.re_w, b, h, a.nq, a.nk, ld, e->stream);
-      launch_softmax_bwd_rows(e->sc[0], dA, rows, a.nk, ld, e->stream);
+      launch_headmix_bwd(sc[0], dA, e->params + bp.re_w, dA, e->red_ws, e->grads + bp.re_w, b, h, a.nq, a.nk, ld, e->stream);
+      launch_softmax_bwd_rows(sc[0], dA, rows, a.nk, ld, e->stream);
     } else {
-      launch_softmax_bwd_rows(e->sc[0], dA, rows, a.nk, ld, e->stream);
+      launch_softmax_bwd_rows(sc[0], dA, rows, a.nk, ld, e->stream);
     }
   }
   // dQ = scale dS k ; dK = scale dS^T q
@@ -576,9 +584,24 @@ static int block_forward(vitx_engine* e, Stage& st, int si, int l, int b, int nq
     launch_attn_bf16_fwd((const bf16_t*)ba.qkv, (bf16_t*)ba.o, ba.lse, b, nq, c.heads, 1.0f / std::sqrt((float)c.dim_head), (const bf16_t*)e->zero_page, e->stream);
   } else {
     const int need = c.variant == VITX_VARIANT_VIT ? 1 : 3;
-    int rc = ensure_scores(e, need, (int64_t)b * c.heads * nq * round_up(nk, 4), err);
-    if (rc != VITX_OK) return rc;
-    attn_generic_fwd(e, bp, av, b);
+    if (e->keep_scores && ba.sc_keep_elems == 0) {   // first use: this block's own score buffers, sized for the largest call
+      const int64_t emax = (int64_t)c.max_batch * c.heads * st.nq_max * round_up(st.nq_max + st.nc_max, 4);
+      if (e->sc_keep_bytes + need * emax * 4 <= e->sc_keep_budget) {
+        for (int i = 0; i < need; ++i) DALLOC(ba.sc_keep[i], (size_t)emax * 4, false);
+        ba.sc_keep_elems = emax;
+        e->sc_keep_bytes += need * emax * 4;
+      } else {
+        ba.sc_keep_elems = -1;
+      }
+    }
+    const int64_t elems = (int64_t)b * c.heads * nq * round_up(nk, 4);
+    const bool keep = e->keep_scores && ba.sc_keep_elems >= elems;
+    if (!keep) {
+      ba.sc_geom = -1;
+      int rc = ensure_scores(e, need, elems, err);
+      if (rc != VITX_OK) return rc;
+    }
+    attn_generic_fwd(e, bp, av, b, keep ? &ba : nullptr);
   }
   if (bp.has_out && drop > 0.f) {
     // Dense -> Dropout -> (LayerScale) -> + residual, unfused (vit.py:61-69,83,101)
@@ -730,7 +753,7 @@ static int block_backward(vitx_engine* e, Stage& st, int si, int l, int b, int n
     ag.dv = boff(dkv, inner, esz); ag.lddv = 2 * inner; ag.dvb = ag.dkb;
     int rc = ensure_scores(e, 4, (int64_t)b * c.heads * nq * round_up(nk, 4), err);
     if (rc != VITX_OK) return rc;
-    attn_generic_bwd(e, bp, av, ag, b);
+    attn_generic_bwd(e, bp, av, ag, b, &ba);
     // to_q / to_kv VJPs
     const void* ctx = nc > 0 ? ba.ctx : ba.y1;
     EpiParams ep; ep.out = e->d_y; ep.ldo = d;
@@ -761,7 +784,7 @@ static int block_backward(vitx_engine* e, Stage& st, int si, int l, int b, int n
     } else {
       int rc = ensure_scores(e, 4, (int64_t)b * c.heads * nq * round_up(nk, 4), err);
       if (rc != VITX_OK) return rc;
-      attn_generic_bwd(e, bp, av, ag, b);
+      attn_generic_bwd(e, bp, av, ag, b, &ba);
     }
     EpiParams ep; ep.out = e->d_y; ep.ldo = d;
     dense_dgrad(e, e->d_qkv, 3 * inner, rows, bp.qkv, EPI_STORE, ep);
@@ -814,6 +837,7 @@ int engine_create(const vitx_config& cfg, vitx_engine** out, std::string& err) {
   if (const char* k = getenv("VITX_GEMM_KERNEL")) e->gemm_kernel = atoi(k);
   if (const char* k = getenv("VITX_UNFUSED_HEADOPS")) e->unfused_headops = atoi(k) != 0;
   e->wgrad_via_transpose = env_flag("VITX_WGRAD_TRANSPOSE");
+  e->keep_scores = !env_flag("VITX_RECOMPUTE_SCORES");
   if (const char* k = getenv("VITX_GEMM_STAGGER")) {
     e->gemm_stagger = atoi(k);
     if (e->gemm_stagger & 3) fprintf(stderr, "[vitx] VITX_GEMM_STAGGER=%d: timing experiment bits set -- GEMM results are WRONG in this process\n", e->gemm_stagger);
