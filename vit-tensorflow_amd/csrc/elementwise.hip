@@ -132,8 +132,10 @@ constexpr int LNB_BLOCKS = 512;
 constexpr int LNB_THREADS = 512;   // 8 waves per block: 4096 waves in flight with only 512 partial rows to reduce
 
 // dx = r * (g*gamma - mean_d(g*gamma) - xhat * mean_d(g*gamma*xhat));  dgamma += g*xhat; dbeta += g
+// VPL = 4 (d = 1024) lands on 134 VGPRs by itself = 3 waves per SIMD = ONE 8-wave block per CU where d = 768 runs two; asking for
+// 4 waves per SIMD caps it at 128 (ViT-L / DeepViT / CaiT: 3.9 -> 5.5 TB/s)
 template <typename TD, typename TL, int VPL>
-__global__ __launch_bounds__(LNB_THREADS) void layernorm_bwd_kernel(const TD* __restrict__ dy, int64_t lddy, const float* __restrict__ x,
+__global__ __launch_bounds__(LNB_THREADS, (VPL == 4 ? 4 : 1)) void layernorm_bwd_kernel(const TD* __restrict__ dy, int64_t lddy, const float* __restrict__ x,
                                                             int64_t ldx, const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             const float* __restrict__ gamma, const float* g_in, int64_t ldgi,
                                                             float* g_out, int64_t ldgo, TL* g_lp, int64_t ldglp,
