@@ -240,6 +240,25 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
   }
 }
 
+// Single-output, single-level case on 16-B friendly operands (the split-K slices of a weight gradient: 7-28 parts of up to 2.4 M
+// columns): four columns per lane, four parts in flight, parts summed in index order ((p0 + p1) + (p2 + p3) per group of four).
+__global__ __launch_bounds__(256) void reduce_partials4_kernel(const float4* __restrict__ partial, int nparts, int64_t stride4, int64_t n4,
+                                                               float4* __restrict__ out, float alpha) {
+  const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (c >= n4) return;
+  const float4* src = partial + c;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  int p = 0;
+  for (; p + 4 <= nparts; p += 4) {
+    const float4 v0 = src[(int64_t)p * stride4], v1 = src[(int64_t)(p + 1) * stride4], v2 = src[(int64_t)(p + 2) * stride4],
+                 v3 = src[(int64_t)(p + 3) * stride4];
+    a.x += (v0.x + v1.x) + (v2.x + v3.x); a.y += (v0.y + v1.y) + (v2.y + v3.y);
+    a.z += (v0.z + v1.z) + (v2.z + v3.z); a.w += (v0.w + v1.w) + (v2.w + v3.w);
+  }
+  for (; p < nparts; ++p) { const float4 v = src[(int64_t)p * stride4]; a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
+  out[c] = make_float4(a.x * alpha, a.y * alpha, a.z * alpha, a.w * alpha);
+}
+
 // ------------------------------------------------------------------ column sums (Dense bias gradients: db = sum_rows dY)
 constexpr int CS_CHUNKS = 128;
 // block = 4 waves; a wave owns 64 x 8 = 512 consecutive columns of its rows (16-B bf16 / 2 x 16-B fp32 loads); the 4 waves
@@ -652,6 +671,11 @@ void launch_reduce_partials3(const float* partial, int nparts, int64_t stride, i
   }
 }
 void launch_reduce_partials(const float* partial, int nparts, int64_t stride, int64_t n, float* out, float alpha, hipStream_t s) {
+  if (n >= 4096 && nparts <= 32 && (n & 3) == 0 && (stride & 3) == 0 && ((uintptr_t)partial) % 16 == 0 && ((uintptr_t)out) % 16 == 0) {
+    hipLaunchKernelGGL(reduce_partials4_kernel, dim3((unsigned)ceil_div(n / 4, 256)), dim3(256), 0, s, (const float4*)partial, nparts, stride / 4,
+                       n / 4, (float4*)out, alpha);
+    return;
+  }
   launch_reduce_partials3(partial, nparts, stride, n, 1, out, nullptr, nullptr, nullptr, alpha, s);
 }
 
