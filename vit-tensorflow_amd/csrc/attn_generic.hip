@@ -522,24 +522,34 @@ __global__ void add_T_kernel(T* __restrict__ a, const T* __restrict__ b2, int64_
 // take interleaved rows (same shape as the bias column sums)
 template <typename T>
 __global__ __launch_bounds__(256) void scale_grad_kernel(const T* __restrict__ fx, int64_t ldf_, const float* __restrict__ g, int64_t ldg,
-                                                         int rows, int d, float* __restrict__ partial) {
+                                                         int rows, int d, float* __restrict__ partial, const float* __restrict__ scale,
+                                                         T* __restrict__ out, int64_t ldo) {
   __shared__ float red[4][256];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int c = blockIdx.x * 256 + lane * 4;
   const int rows_per = (rows + gridDim.y - 1) / gridDim.y;
   const int r0 = blockIdx.y * rows_per, r1 = min(rows, r0 + rows_per);
   float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  // out != null (host: only when d % 4 == 0): the same pass also writes the gradient entering the branch, out = g * scale
+  // (cait.py:47-48 VJP), instead of a second kernel reading g again
   if (c + 3 < d) {
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (out) sc = *(const float4*)(scale + c);
     int r = r0 + w;
     for (; r + 4 < r1; r += 8) {
       const float4 g0 = *(const float4*)(g + (int64_t)r * ldg + c), g1 = *(const float4*)(g + (int64_t)(r + 4) * ldg + c);
       const float4 f0 = ld4<T>(fx + (int64_t)r * ldf_ + c), f1 = ld4<T>(fx + (int64_t)(r + 4) * ldf_ + c);
       a.x += g0.x * f0.x + g1.x * f1.x; a.y += g0.y * f0.y + g1.y * f1.y; a.z += g0.z * f0.z + g1.z * f1.z; a.w += g0.w * f0.w + g1.w * f1.w;
+      if (out) {
+        st4<T>(out + (int64_t)r * ldo + c, make_float4(g0.x * sc.x, g0.y * sc.y, g0.z * sc.z, g0.w * sc.w));
+        st4<T>(out + (int64_t)(r + 4) * ldo + c, make_float4(g1.x * sc.x, g1.y * sc.y, g1.z * sc.z, g1.w * sc.w));
+      }
     }
     for (; r < r1; r += 4) {
       const float4 g0 = *(const float4*)(g + (int64_t)r * ldg + c);
       const float4 f0 = ld4<T>(fx + (int64_t)r * ldf_ + c);
       a.x += g0.x * f0.x; a.y += g0.y * f0.y; a.z += g0.z * f0.z; a.w += g0.w * f0.w;
+      if (out) st4<T>(out + (int64_t)r * ldo + c, make_float4(g0.x * sc.x, g0.y * sc.y, g0.z * sc.z, g0.w * sc.w));
     }
   } else if (c < d) {
     float* ap = (float*)&a;
@@ -678,12 +688,12 @@ void launch_add_T(void* a, const void* b2, int is_bf16, int64_t n, hipStream_t s
   else hipLaunchKernelGGL(add_T_kernel<float>, dim3(grid_for(n)), dim3(256), 0, s, (float*)a, (const float*)b2, n);
 }
 void launch_scale_grad(const void* fx, int is_bf16, int64_t ldf_, const float* g, int64_t ldg, int rows, int d, float* partial_ws,
-                       float* dscale, hipStream_t s) {
+                       float* dscale, hipStream_t s, const float* scale, void* out, int64_t ldo) {
   const int cblocks = (int)ceil_div(d, 256);
   const int chunks = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)SG_CHUNKS, ceil_div(rows, 16), ceil_div(2048, cblocks)}));
   dim3 grid((unsigned)cblocks, chunks), block(256);
-  if (is_bf16) hipLaunchKernelGGL(scale_grad_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)fx, ldf_, g, ldg, rows, d, partial_ws);
-  else hipLaunchKernelGGL(scale_grad_kernel<float>, grid, block, 0, s, (const float*)fx, ldf_, g, ldg, rows, d, partial_ws);
+  if (is_bf16) hipLaunchKernelGGL(scale_grad_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)fx, ldf_, g, ldg, rows, d, partial_ws, scale, (bf16_t*)out, ldo);
+  else hipLaunchKernelGGL(scale_grad_kernel<float>, grid, block, 0, s, (const float*)fx, ldf_, g, ldg, rows, d, partial_ws, scale, (float*)out, ldo);
   launch_reduce_partials3(partial_ws, chunks, d, d, 1, dscale, nullptr, nullptr, partial_ws + (int64_t)SG_CHUNKS * d, 1.0f, s);
 }
 void launch_mul_scale(const float* g, int64_t ldg, const float* scale, void* out, int out_bf16, int64_t ldo, int rows, int d, hipStream_t s) {

@@ -674,8 +674,12 @@ static int block_backward(vitx_engine* e, Stage& st, int si, int l, int b, int n
   // ---- MLP branch: x_out = x_mid + scale * fc2(gelu(fc1(LN(x_mid))))
   if (bp.m_scale >= 0 || drop > 0.f) {   // LayerScale VJP (cait.py:47-48): dscale = sum g*f(x), d f = g*scale; Dropout VJP: same mask
     Prof pr(e, "branch_grad", 0, 0);
-    if (bp.m_scale >= 0) launch_scale_grad(ba.fm, T, d, e->g, d, rows, d, e->red_ws, e->grads + bp.m_scale, e->stream);
-    launch_branch_grad(e->g, bp.m_scale >= 0 ? e->params + bp.m_scale : nullptr, e->d_br, T, rows, d, drop, seed, site0 + 3, e->stream);
+    // LayerScale without dropout: one pass over g gives dscale AND the branch gradient g * scale
+    const bool one_pass = bp.m_scale >= 0 && drop == 0.f && d % 4 == 0;
+    if (bp.m_scale >= 0)
+      launch_scale_grad(ba.fm, T, d, e->g, d, rows, d, e->red_ws, e->grads + bp.m_scale, e->stream, one_pass ? e->params + bp.m_scale : nullptr,
+                        one_pass ? e->d_br : nullptr, d);
+    if (!one_pass) launch_branch_grad(e->g, bp.m_scale >= 0 ? e->params + bp.m_scale : nullptr, e->d_br, T, rows, d, drop, seed, site0 + 3, e->stream);
     dbranch = e->d_br;
   }
   // fc1 bias gradient = column sums of d hpre: produced per M-tile by the fc2-dgrad epilogue itself (no second pass over the
@@ -722,9 +726,12 @@ static int block_backward(vitx_engine* e, Stage& st, int si, int l, int b, int n
   dbranch = gT;
   if (bp.a_scale >= 0 || (drop > 0.f && bp.has_out)) {
     Prof pr(e, "branch_grad", 0, 0);
-    if (bp.a_scale >= 0) launch_scale_grad(ba.fa, T, d, e->g, d, rows, d, e->red_ws, e->grads + bp.a_scale, e->stream);
-    launch_branch_grad(e->g, bp.a_scale >= 0 ? e->params + bp.a_scale : nullptr, e->d_br, T, rows, d, bp.has_out ? drop : 0.f, seed, site0 + 1,
-                       e->stream);
+    const float adrop = bp.has_out ? drop : 0.f;
+    const bool one_pass = bp.a_scale >= 0 && adrop == 0.f && d % 4 == 0;
+    if (bp.a_scale >= 0)
+      launch_scale_grad(ba.fa, T, d, e->g, d, rows, d, e->red_ws, e->grads + bp.a_scale, e->stream, one_pass ? e->params + bp.a_scale : nullptr,
+                        one_pass ? e->d_br : nullptr, d);
+    if (!one_pass) launch_branch_grad(e->g, bp.a_scale >= 0 ? e->params + bp.a_scale : nullptr, e->d_br, T, rows, d, adrop, seed, site0 + 1, e->stream);
     dbranch = e->d_br;
   }
   bool out_bias_in_ln = false;
