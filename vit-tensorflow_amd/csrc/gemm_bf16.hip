@@ -965,9 +965,11 @@ void launch_gemm_bf16(const Bf16GemmArgs& g0, const EpiParams& ep, int mode, hip
     // 256x128 / 128x128 tiles only compete when 256x256 tiles cannot give every CU two of them (token subsets: MAE's encoder
     // sees 49 of 196 patches, M = 12544 -> 147 tiles for a 768-wide output)
     const bool small_m = ceil_div(g0.M, 256) * ceil_div(g0.N, 256) < 512;
-    hipEvent_t e0, e1;
-    (void)hipEventCreate(&e0);
-    (void)hipEventCreate(&e1);
+    // each candidate: one warm-up, then NREP individually timed launches; the candidate's time is the FASTEST of them (a launch can
+    // only be delayed by interference, never sped up), so one hiccup does not hand the shape to a slower variant for the whole process
+    constexpr int NREP = 5;
+    hipEvent_t ev[NREP + 1];
+    for (auto& x : ev) (void)hipEventCreate(&x);
     float best_ms = 1e30f;
     best = gemm_bf16_pick(g0.M, g0.N);
     for (int c : cand) {
@@ -977,18 +979,23 @@ void launch_gemm_bf16(const Bf16GemmArgs& g0, const EpiParams& ep, int mode, hip
       if (g_shared_gpu && c != 2 && c != 5 && c != 1 && c != 3) continue;   // no persistent variants beside collectives (see gemm_bf16_set_shared_gpu)
       g.kernel = c;
       dispatch_gemm_bf16(g, ep, mode, s);   // warm-up (first-use attribute setup, instruction cache)
-      (void)hipEventRecord(e0, s);
-      for (int r = 0; r < 3; ++r) dispatch_gemm_bf16(g, ep, mode, s);
-      (void)hipEventRecord(e1, s);
-      if (hipEventSynchronize(e1) != hipSuccess) continue;
-      float ms = 0.f;
-      if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess && ms < best_ms) { best_ms = ms; best = c; }
+      (void)hipEventRecord(ev[0], s);
+      for (int r = 0; r < NREP; ++r) {
+        dispatch_gemm_bf16(g, ep, mode, s);
+        (void)hipEventRecord(ev[r + 1], s);
+      }
+      if (hipEventSynchronize(ev[NREP]) != hipSuccess) continue;
+      float fastest = 1e30f;
+      for (int r = 0; r < NREP; ++r) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, ev[r], ev[r + 1]) == hipSuccess && ms < fastest) fastest = ms;
+      }
+      if (fastest < best_ms) { best_ms = fastest; best = c; }
     }
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
+    for (auto& x : ev) (void)hipEventDestroy(x);
     if (getenv("VITX_GEMM_AUTOTUNE_LOG"))
       fprintf(stderr, "[vitx] gemm autotune: mode %d M %d N %d K %d split %d -> variant %d (%.4f ms)\n", mode, g0.M, g0.N, g0.K, g0.split_k, best,
-              best_ms / 3.f);
+              best_ms);
     std::lock_guard<std::mutex> lk(g_tune_mu);
     g_tuned[key] = best;
   }
