@@ -292,3 +292,61 @@ def test_wrapper_surface_composes_to_the_forward(compute, name):
     assert np.isfinite(grads["mlp_head.kernel"]).all()
     with pytest.raises(NotImplementedError):
         type(m.dropout)(0.5)(x, training=True)
+
+
+# ------------------------------------------------------------------------------------------------
+# committed golden fixture (tests/golden/tokenizer_and_shell.npz, written by `python -m oracle.gen_golden`)
+def _golden():
+    import os
+    return np.load(os.path.join(os.path.dirname(__file__), "golden", "tokenizer_and_shell.npz"))
+
+
+def test_oracle_reproduces_the_golden_fixture():
+    from oracle.gen_golden import SHELL_KW, TOKENIZER_GEOMS, shell_middle
+    z = _golden()
+    assert [tuple(int(v) for v in g) for g in z["geoms"]] == TOKENIZER_GEOMS
+    for i, (H, W, Cc, k, s) in enumerate(TOKENIZER_GEOMS):
+        assert np.array_equal(R.extract_patches(z[f"x{i}"], k, s), z[f"y{i}"])
+        xt = torch.tensor(z[f"x{i}"].astype(np.float64), requires_grad=True)
+        (R.extract_patches_unfold(xt, k, s) * torch.tensor(z[f"dy{i}"].astype(np.float64))).sum().backward()
+        assert np.abs(xt.grad.numpy() - z[f"dx{i}"]).max() < 1e-12
+    cfg = spec.make_config("vit", **SHELL_KW, depth=0, heads=1, mlp_dim=64, dim_head=64)
+    P = spec.init_params(cfg, seed=11, randomize_all=True)
+    assert abs(sum(float(np.abs(v).sum()) for v in P.values()) - float(z["shell/param_checksum"])) < 1e-9
+    logits, grads, dimg, _ = R.shell_forward_backward(cfg, P, z["shell/img"], z["shell/dlogits"], shell_middle)
+    assert np.abs(logits - z["shell/logits"]).max() < 1e-12 and np.abs(dimg - z["shell/dimg"]).max() < 1e-12
+    for k_, v in grads.items():
+        assert np.abs(v - z["shell/grad/" + k_]).max() <= 1e-6 * max(1.0, np.abs(v).max()), k_      # stored as fp32
+
+
+@pytest.mark.gpu
+def test_kernels_match_the_golden_fixture():
+    from oracle.gen_golden import SHELL_KW, TOKENIZER_GEOMS
+    from vit_tensorflow import t2t
+    from vit_tensorflow.efficient import ViT
+    z = _golden()
+    for i, (H, W, Cc, k, s) in enumerate(TOKENIZER_GEOMS):
+        assert np.array_equal(t2t.extract_patches(z[f"x{i}"], k, s), z[f"y{i}"])                            # bit-exact
+        dx = t2t.extract_patches_backward(z[f"dy{i}"], z[f"x{i}"].shape, k, s)
+        assert np.abs(dx - z[f"dx{i}"]).max() <= 1e-5 * max(1.0, np.abs(z[f"dx{i}"]).max())
+
+    class Drop:      # the fixture's middle (oracle.gen_golden.shell_middle) with its VJP
+        def __call__(self, x, training=True):
+            self.n = x.shape[1]
+            return np.ascontiguousarray(x[:, ::2]) * 2.0
+
+        def backward(self, dout):
+            dx = np.zeros((dout.shape[0], self.n, dout.shape[2]), np.float32)
+            dx[:, ::2] = 2.0 * dout
+            return dx
+    cfg = spec.make_config("vit", **SHELL_KW, depth=0, heads=1, mlp_dim=64, dim_head=64)
+    P = spec.init_params(cfg, seed=11, randomize_all=True)
+    m = ViT(**SHELL_KW, transformer=Drop(), max_batch=3, seed=0)
+    m.load_state_dict({k_: np.asarray(v, np.float32) for k_, v in P.items()})
+    logits = m(z["shell/img"], training=False)
+    grads, dimg = m.backward(z["shell/dlogits"], want_dimg=True)
+    assert np.abs(logits - z["shell/logits"]).max() <= 1e-4 * max(1.0, np.abs(z["shell/logits"]).max())
+    for k_ in grads:
+        r = z["shell/grad/" + k_]
+        assert np.abs(grads[k_] - r).max() <= 2e-4 * max(1e-6, np.abs(r).max()) + 1e-7, k_
+    assert np.abs(dimg - z["shell/dimg"]).max() <= 2e-4 * np.abs(z["shell/dimg"]).max() + 1e-7
