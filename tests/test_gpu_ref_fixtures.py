@@ -1,0 +1,148 @@
+"""GPU tier (-m gpu): the HIP engine, through the C ABI, against fixtures produced by the REFERENCE'S OWN SOURCE
+(tests/golden/ref_*.npz; oracle/gen_ref_fixtures.py runs /root/reference/vit_tensorflow/*.py unmodified under oracle/tf_shim).
+Gates: fp32-parity mode logits <= 1e-3 abs (north_star), every gradient and d(img) <= 1e-3 of the tensor's max.  bf16 mode (the
+benchmarked mode) at the BASELINE.json widths -- ViT-B/16 224 (d=768, N=197, h=12), DeepViT cfg4 and CaiT cfg5 (d=1024, h=16,
+65 / 64 tokens) -- logits and gradients against the same reference outputs, gated at <= 2x the errors observed on MI355X."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import gen_ref_fixtures as G
+from oracle import spec
+from util import rel_max_err
+
+pytestmark = pytest.mark.gpu
+GOLDEN_DIR = os.path.join(os.path.dirname(__file__), "golden")
+FP32_LOGIT_TOL = 1e-3
+FP32_GRAD_RTOL = 1e-3
+# bf16 mode vs the exact (float64) reference: operands rounded to bf16 (2^-9 relative) at every GEMM / attention input.
+BF16_LOGIT_TOL = 3.5e-2      # x logit std; observed 0.9e-2 .. 1.7e-2
+BF16_GRAD_RTOL = 5e-2        # of each tensor's max; observed worst 0.8e-2 .. 2.8e-2 (see profiles/r2/pytest_gpu_*.log)
+
+
+def _model(case, compute, b, P):
+    module, _, vtag, _, kw = {**G.CASES, **G.WIDE_CASES}[case]
+    if module == "vit":
+        from vit_tensorflow import ViT as cls
+    elif module == "deepvit":
+        from vit_tensorflow.deepvit import DeepViT as cls
+    elif module == "cait":
+        from vit_tensorflow.cait import CaiT as cls
+    elif module == "parallel_vit":
+        from vit_tensorflow.parallel_vit import ViT as cls
+    else:
+        from vit_tensorflow.vit_with_patch_merger import ViT as cls
+    m = cls(**kw, compute=compute, max_batch=b, seed=0)
+    m.load_state_dict({k: np.asarray(v, np.float32) for k, v in P.items()})
+    return m
+
+
+def _case(case):
+    z = np.load(os.path.join(GOLDEN_DIR, f"ref_{case}.npz"))
+    cfg = G.oracle_cfg_of(case)
+    P = spec.init_params(cfg, seed=int(z["param_seed"]), randomize_all=True)
+    assert abs(sum(float(np.abs(v).sum()) for v in P.values()) - float(z["param_checksum"])) < 1e-6
+    return z, cfg, P
+
+
+@pytest.mark.parametrize("case", list(G.CASES))
+def test_fp32_engine_matches_reference_source(case):
+    z, cfg, P = _case(case)
+    m = _model(case, "fp32", 2, P)
+    logits = m(z["img"], training=True)          # the reference's default call mode; dropout rates are 0
+    err = float(np.abs(logits - z["logits"]).max())
+    assert err <= FP32_LOGIT_TOL, err
+    grads, dimg = m.backward(z["dlogits"], want_dimg=True)
+    worst = ("", 0.0)
+    for n, _, _ in spec.param_spec(cfg):
+        e = rel_max_err(grads[n], z["grad/" + n])
+        worst = max(worst, (n, e), key=lambda t: t[1])
+        assert e <= FP32_GRAD_RTOL, f"{case}: grad {n} rel err {e:.3e}"
+    assert rel_max_err(dimg, z["dimg"]) <= FP32_GRAD_RTOL
+    print(f"[ref:{case}] fp32 max|dlogit| {err:.3e}, worst grad rel err {worst[1]:.3e} ({worst[0]})")
+
+
+def _check_digest(case, cfg, z, grads, dimg, rtol):
+    """Per tensor: a strided 256-element sample (relative to the tensor's max), the signed sum and the abs-sum (relative to the
+    abs-sum): a gradient that is right on the sample but wrong elsewhere (a missed tile, a dropped K slice) moves the sums."""
+    worst = ("", 0.0)
+    for n, _, _ in spec.param_spec(cfg):
+        f = np.asarray(grads[n], np.float64).reshape(-1)
+        gmax, gabs = float(z["gmax/" + n]) + 1e-30, float(z["gabs/" + n]) + 1e-30
+        e = float(np.abs(f[::max(1, f.size // 256)][:256] - z["gsample/" + n]).max()) / gmax
+        es = abs(float(f.sum()) - float(z["gsum/" + n])) / gabs
+        ea = abs(float(np.abs(f).sum()) - gabs) / gabs
+        worst = max(worst, (n, max(e, es, ea / 3)), key=lambda t: t[1])
+        assert e <= rtol, f"{case}: grad {n} sample rel err {e:.3e}"
+        assert es <= rtol, f"{case}: grad {n} sum rel err {es:.3e}"
+        assert ea <= 3 * rtol, f"{case}: grad {n} abs-sum rel err {ea:.3e}"     # |g + noise| is biased upwards where |g| < |noise|
+    ed = float(np.abs(np.asarray(dimg, np.float64).reshape(-1)[::997] - z["dimg_sample"]).max()) / (float(z["dimg_max"]) + 1e-30)
+    assert ed <= rtol, f"{case}: dimg rel err {ed:.3e}"
+    return worst
+
+
+@pytest.mark.parametrize("case", list(G.WIDE_CASES))
+def test_fp32_engine_matches_reference_source_at_baseline_widths(case):
+    z, cfg, P = _case(case)
+    m = _model(case, "fp32", 2, P)
+    logits = m(z["img"], training=True)
+    err = float(np.abs(logits - z["logits"]).max())
+    assert err <= FP32_LOGIT_TOL, err
+    grads, dimg = m.backward(z["dlogits"], want_dimg=True)
+    worst = _check_digest(case, cfg, z, grads, dimg, FP32_GRAD_RTOL)
+    print(f"[ref:{case}] fp32 max|dlogit| {err:.3e}, worst grad digest err {worst[1]:.3e} ({worst[0]})")
+
+
+@pytest.mark.parametrize("case", list(G.WIDE_CASES))
+def test_bf16_engine_matches_reference_source_at_baseline_widths(case):
+    """The benchmarked mode on the benchmarked kernels (attn_bwd at N=197, 320x256 / 256x256 tiles, split-K weight gradients;
+    bgemm_mfma + head chains at h=16) against the reference's float64 outputs."""
+    z, cfg, P = _case(case)
+    m = _model(case, "bf16", 2, P)
+    logits = m(z["img"], training=True)
+    std = float(z["logits"].std())
+    err = float(np.abs(logits - z["logits"]).max())
+    grads, dimg = m.backward(z["dlogits"], want_dimg=True)
+    worst = _check_digest(case, cfg, z, grads, dimg, BF16_GRAD_RTOL)
+    print(f"[ref:{case}] bf16 max|dlogit| {err:.3e} (logit std {std:.3f}), worst grad digest err {worst[1]:.3e} ({worst[0]})")
+    assert err <= BF16_LOGIT_TOL * max(1.0, std), err
+
+
+@pytest.mark.parametrize("compute", ["fp32", "bf16"])
+def test_ce_loss_gradient_matches_softmax_minus_onehot(compute):
+    """vitx_ce_loss_grad_dev (inside every timed benchmark step): mean softmax cross-entropy from logits
+    (tf.keras.losses.categorical_crossentropy(from_logits=True), the reference's only loss, distill.py:119) and its gradient
+    (softmax - onehot) / global_batch, against float64 numpy on the engine's own logits; then the parameter gradients that the
+    device-resident dlogits produce against the gradients of the same dlogits handed over from the host."""
+    import ctypes as C
+    import torch
+    from vit_tensorflow import _native as N
+    case = "vit_small"
+    z, cfg, P = _case(case)
+    b, nc = 2, cfg["num_classes"]
+    m = _model(case, compute, b, P)
+    logits = np.asarray(m(z["img"], training=True), np.float64)
+    labels = np.array([3, nc - 1], dtype=np.int32)
+    lab_dev = torch.tensor(labels, device="cuda:0")
+    loss_dev = torch.zeros(1, dtype=torch.float32, device="cuda:0")
+    inv_global = 1.0 / 8.0                                    # a global batch of 8 (4 ranks x 2): the factor is an input
+    h = m._handle
+    N.check(N.lib().vitx_ce_loss_grad_dev(h, C.c_void_p(lab_dev.data_ptr()), inv_global, C.c_void_p(loss_dev.data_ptr())))
+    N.check(N.lib().vitx_sync(h))
+    p = np.exp(logits - logits.max(-1, keepdims=True))
+    p /= p.sum(-1, keepdims=True)
+    onehot = np.eye(nc)[labels]
+    want_dl = (p - onehot) * inv_global
+    want_loss = float(-(np.log(p[np.arange(b), labels])).sum() * inv_global)
+    got_dl = m.debug_read("dlogits").reshape(b, nc)
+    assert np.abs(got_dl - want_dl).max() <= 2e-6 * np.abs(want_dl).max() + 1e-8
+    assert abs(float(loss_dev.cpu()[0]) - want_loss) <= 2e-6 * abs(want_loss)
+    N.check(N.lib().vitx_backward_dev(h, None, None))        # consumes the device-resident dlogits
+    g = np.empty(m._n, dtype=np.float32)
+    N.check(N.lib().vitx_get_grads(h, g.ctypes.data_as(C.c_void_p), m._n))
+    m(z["img"], training=True)
+    ref, _ = m.backward(want_dl.astype(np.float32))
+    for n, s, o in m._table:
+        a = g[o:o + int(np.prod(s))].reshape(s)
+        assert np.abs(a - ref[n]).max() <= 1e-5 * np.abs(ref[n]).max() + 1e-9, n

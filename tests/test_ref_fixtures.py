@@ -1,0 +1,87 @@
+"""CPU tier: the oracle against fixtures produced by the REFERENCE'S OWN SOURCE (tests/golden/ref_*.npz, written by
+oracle/gen_ref_fixtures.py, which imports /root/reference/vit_tensorflow/{vit,deepvit,cait,parallel_vit,vit_with_patch_merger}.py
+unmodified under oracle/tf_shim).  This is what pins parity: oracle/ref_numpy.py and oracle/ref_torch.py must reproduce the
+reference's logits, every variable's gradient and d(img) to float64 rounding.  Where /root/reference is present (this container,
+not the GPU box) the reference is also re-executed live and compared with the committed files, so the fixtures cannot drift from
+the source they claim to come from."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from oracle import gen_ref_fixtures as G
+from oracle import ref_numpy, ref_torch, spec
+
+GOLDEN_DIR = os.path.join(os.path.dirname(__file__), "golden")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+F64_TOL = 1e-12
+
+
+def _load(case):
+    return np.load(os.path.join(GOLDEN_DIR, f"ref_{case}.npz"))
+
+
+def _params(case, z):
+    cfg = G.oracle_cfg_of(case)
+    P = spec.init_params(cfg, seed=int(z["param_seed"]), randomize_all=True)
+    assert abs(sum(float(np.abs(v).sum()) for v in P.values()) - float(z["param_checksum"])) < 1e-6
+    return cfg, P
+
+
+@pytest.mark.parametrize("case", list(G.CASES))
+def test_oracle_reproduces_reference_fixture(case):
+    z = _load(case)
+    cfg, P = _params(case, z)
+    assert z["logits"].shape == (2, cfg["num_classes"])
+    if cfg["variant"] != "patch_merger" and cfg["num_parallel_branches"] == 1:   # ref_numpy covers vit / deepvit / cait
+        assert np.abs(ref_numpy.forward(cfg, P, z["img"]) - z["logits"]).max() <= F64_TOL
+    logits, grads, dimg = ref_torch.forward_backward(cfg, P, z["img"], z["dlogits"], want_dimg=True)
+    assert np.abs(logits - z["logits"]).max() <= F64_TOL
+    names = [n for n, _, _ in spec.param_spec(cfg)]
+    assert sorted("grad/" + n for n in names) == sorted(k for k in z.files if k.startswith("grad/"))
+    for n in names:
+        ref = z["grad/" + n]
+        assert np.abs(ref).max() > 0, n          # every variable of the reference received a gradient
+        assert np.abs(grads[n] - ref).max() <= F64_TOL * max(1.0, np.abs(ref).max()), n
+    assert np.abs(dimg - z["dimg"]).max() <= F64_TOL * max(1.0, np.abs(z["dimg"]).max())
+
+
+@pytest.mark.parametrize("case", list(G.WIDE_CASES))
+def test_oracle_reproduces_reference_fixture_at_baseline_widths(case):
+    """BASELINE.json widths (ViT-B/16 224, DeepViT cfg4, CaiT cfg5) at depth 2, batch 2: logits in full, gradients by digest."""
+    z = _load(case)
+    cfg, P = _params(case, z)
+    logits, grads, dimg = ref_torch.forward_backward(cfg, P, z["img"], z["dlogits"], want_dimg=True)
+    assert np.abs(logits - z["logits"]).max() <= 1e-11
+    for n, _, _ in spec.param_spec(cfg):
+        f = grads[n].reshape(-1)
+        scale = max(1.0, float(z["gabs/" + n]))
+        assert abs(f.sum() - float(z["gsum/" + n])) <= 1e-10 * scale, n
+        assert abs(np.abs(f).sum() - float(z["gabs/" + n])) <= 1e-10 * scale, n
+        assert np.abs(f[::max(1, f.size // 256)][:256] - z["gsample/" + n]).max() <= 1e-6 * max(1.0, np.abs(f).max()), n
+    assert np.abs(dimg.reshape(-1)[::997] - z["dimg_sample"]).max() <= 1e-6 * max(1.0, np.abs(dimg).max())
+
+
+@pytest.mark.skipif(not os.path.isdir(G.REF), reason="/root/reference is not present on this machine (GPU box)")
+@pytest.mark.parametrize("case", ["vit_small", "deepvit_small", "cait_small", "parallel_vit_2", "patch_merger_default"])
+def test_committed_fixture_is_what_the_reference_source_produces(case):
+    """Re-run the reference's source under the shim in a fresh interpreter (the shim registers a fake `tensorflow` in sys.modules,
+    which must not leak into this process) and compare with the committed file bit for bit."""
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "from oracle import gen_ref_fixtures as G\n"
+        "d = G.make(%r); z = np.load(%r)\n"
+        "assert sorted(d) == sorted(z.files), (sorted(d), sorted(z.files))\n"
+        "bad = [k for k in d if not np.array_equal(np.asarray(d[k]), z[k])]\n"
+        "assert not bad, bad\n"
+        "import vit, inspect; assert inspect.getsourcefile(vit).startswith(%r)\n"
+        "print('OK')\n" % (ROOT, os.path.join(ROOT, "tests"), case, os.path.join(GOLDEN_DIR, f"ref_{case}.npz"), os.path.dirname(G.REF))
+    )
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stderr[-2000:]
+
+
+def test_shim_does_not_leak_into_this_process():
+    assert "tensorflow" not in sys.modules or not getattr(sys.modules["tensorflow"], "__vitx_shim__", False)

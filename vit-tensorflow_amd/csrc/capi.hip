@@ -697,6 +697,7 @@ int32_t vitx_debug_read(vitx_handle h, const char* which, int32_t layer, float* 
   bool is_t = false;
   if (w == "pooled_ln") { src = h->yh; rows = b; cols = ld = c.dim; is_t = true; }
   else if (w == "logits") { src = h->logits; rows = b; cols = c.num_classes; ld = h->nc_k; }
+  else if (w == "dlogits") { src = h->dlogits; rows = b; cols = c.num_classes; ld = h->nc_k; }
   else if (w == "patches") { src = h->patches; rows = (int64_t)b * h->last_np; cols = h->pd; ld = h->pd_k; is_t = true; }
   else {
     if (!st) return fail(VITX_ERR_INVALID, "layer out of range");
