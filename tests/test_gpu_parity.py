@@ -129,7 +129,10 @@ def test_transformer_entry_point():
     assert np.abs(out - ref).max() <= 1e-4
 
 
-BF16_GRAD_RTOL = 6e-2
+# bf16-mode gradients vs the exact (float64) oracle, relative to each tensor's max: <= 2x the worst error observed on MI355X
+# (profiles/r1/pytest_gpu_r10.log: vit 0.78e-2 at patch_embedding.kernel, deepvit 2.8e-2 at reattn_norm.beta, cait 2.2e-2 at mix_heads_pre_attn)
+BF16_GRAD_RTOL = 5.6e-2
+BF16_GRAD_RTOL_BY_CASE = {"vit_bf16_small": 1.6e-2, "deepvit_bf16_small": 5.6e-2, "cait_bf16_small": 4.4e-2}
 
 
 @pytest.mark.parametrize("name,compute,b,n", [("vit_small", "fp32", 2, 5), ("vit_noproj", "fp32", 1, 9), ("deepvit_small", "fp32", 2, 7),
@@ -164,8 +167,8 @@ def test_transformer_backward_entry_point(name, compute, b, n):
 
 
 # ------------------------------------------------------------------------------------------------ bf16 throughput mode
-BF16_LOGIT_TOL_VS_EMULATED = 2e-2   # same rounding points, different accumulation order / exp2 / bf16 P in attention
-BF16_LOGIT_TOL_VS_EXACT = 8e-2      # documented loose bound (bf16 operands cost ~1.5e-2 on logits of std ~1)
+BF16_LOGIT_TOL_VS_EMULATED = 2.5e-2  # same rounding points, different accumulation order / exp2 / bf16 P in attention (observed 0.6e-2 .. 1.3e-2)
+BF16_LOGIT_TOL_VS_EXACT = 3.4e-2     # 2x the worst observed (0.9e-2 .. 1.7e-2 on logits of std ~1; SURVEY.md 7.2 #1 predicted ~1.5e-2)
 
 
 @pytest.mark.parametrize("name,b", [("vit_bf16_small", 3), ("cfg1_readme", 2), ("cfg2_vit_b16", 2), ("deepvit_bf16_small", 2),
@@ -192,7 +195,7 @@ def test_bf16_grads(name):
         if e > worst[1]:
             worst = (k, e)
     print(f"[{name}] bf16 worst grad rel err {worst[1]:.3e} at {worst[0]}")
-    assert worst[1] <= BF16_GRAD_RTOL, worst
+    assert worst[1] <= BF16_GRAD_RTOL_BY_CASE[name], worst
 
 
 def test_bf16_fused_attention_equals_materialised_path(monkeypatch):

@@ -17,8 +17,10 @@ GOLDEN_DIR = os.path.join(os.path.dirname(__file__), "golden")
 FP32_LOGIT_TOL = 1e-3
 FP32_GRAD_RTOL = 1e-3
 # bf16 mode vs the exact (float64) reference: operands rounded to bf16 (2^-9 relative) at every GEMM / attention input.
-BF16_LOGIT_TOL = 3.5e-2      # x logit std; observed 0.9e-2 .. 1.7e-2
-BF16_GRAD_RTOL = 5e-2        # of each tensor's max; observed worst 0.8e-2 .. 2.8e-2 (see profiles/r2/pytest_gpu_*.log)
+# Gates = 2x what was observed on MI355X (profiles/r2/pytest_gpu_ref_fixtures_r2a.log): (max|dlogit| / logit std, worst gradient digest error)
+#   vit_b16_depth2 0.96e-2 / 0.58e-2, deepvit_cfg4_depth2 1.6e-2 / 0.78e-2, cait_cfg5_depth2 2.9e-2 / 4.4e-2 (the class-attention
+#   stage has ONE query per image: its 16 x 16 head-mixing gradients sum b x 65 bf16-rounded terms, nothing averages out)
+BF16_GATES = {"vit_b16_depth2": (2.0e-2, 1.2e-2), "deepvit_cfg4_depth2": (3.3e-2, 1.6e-2), "cait_cfg5_depth2": (6.0e-2, 8.8e-2)}
 
 
 def _model(case, compute, b, P):
@@ -104,9 +106,10 @@ def test_bf16_engine_matches_reference_source_at_baseline_widths(case):
     std = float(z["logits"].std())
     err = float(np.abs(logits - z["logits"]).max())
     grads, dimg = m.backward(z["dlogits"], want_dimg=True)
-    worst = _check_digest(case, cfg, z, grads, dimg, BF16_GRAD_RTOL)
+    logit_tol, grad_tol = BF16_GATES[case]
+    worst = _check_digest(case, cfg, z, grads, dimg, grad_tol)
     print(f"[ref:{case}] bf16 max|dlogit| {err:.3e} (logit std {std:.3f}), worst grad digest err {worst[1]:.3e} ({worst[0]})")
-    assert err <= BF16_LOGIT_TOL * max(1.0, std), err
+    assert err <= logit_tol * max(1.0, std), err
 
 
 @pytest.mark.parametrize("compute", ["fp32", "bf16"])
