@@ -128,10 +128,11 @@ int32_t vitx_forward_dev(vitx_handle h, const float* img_dev, int32_t b, int32_t
 int32_t vitx_backward(vitx_handle h, const float* dlogits_host, float* dimg_host_or_null);
 int32_t vitx_backward_dev(vitx_handle h, const float* dlogits_dev, float* dimg_dev_or_null);
 
-/* ---- encoder.transformer(tokens) on arbitrary [b,n,dim] tokens (mae.py:69, simmim.py:116,
- * mpp.py:212).  ViT / DeepViT only. */
+/* ---- encoder.transformer(tokens, training=training) on arbitrary [b,n,dim] tokens (mae.py:69, simmim.py:116,
+ * efficient.py:47, mpp.py:212).  ViT / DeepViT only.  training != 0 applies the model's Dropout layers (vit.py:41,43,64) with
+ * masks drawn from `seed`, as vitx_forward does; the VJP below replays them. */
 int32_t vitx_transformer_forward(vitx_handle h, const float* tokens_host, int32_t b, int32_t n,
-                                 float* out_host);
+                                 int32_t training, uint64_t seed, float* out_host);
 /* VJP of the call above (what GradientTape gives the wrappers that train through encoder.transformer: mae.py:69 + README.md:746-749):
  * d(out) [b,n,dim] -> d(tokens) [b,n,dim] (may be NULL); the gradient arena holds the transformer's parameter gradients, every
  * other entry is zero.  Requires a preceding vitx_transformer_forward (same handle, no full forward in between). */
@@ -190,6 +191,13 @@ int32_t vitx_ce_loss_grad_dev(vitx_handle h, const int32_t* labels_dev, float in
  * all; this turns forward+backward into a training step).  Uses the gradients of the last backward (all-reduced or not). */
 int32_t vitx_adamw_step(vitx_handle h, float lr, float beta1, float beta2, float eps, float weight_decay);
 int32_t vitx_sgd_step(vitx_handle h, float lr, float momentum, float weight_decay);
+
+/* Optimizer state of a handle (AdamW first / second moments, SGD momentum: fp32 in the packed host order of vitx_get_params; the
+ * AdamW step count).  A handle owns this state, so a caller that rebuilds its handle (a larger max_batch) carries it across with
+ * this pair; have_m / have_v report which buffers exist, NULL host pointers skip the copy. */
+int32_t vitx_get_opt_state(vitx_handle h, float* m_host_or_null, float* v_host_or_null, int64_t n_elems, int64_t* step,
+                           int32_t* have_m, int32_t* have_v);
+int32_t vitx_set_opt_state(vitx_handle h, const float* m_host_or_null, const float* v_host_or_null, int64_t n_elems, int64_t step);
 
 /* ---- streams / sync */
 int32_t vitx_set_stream(vitx_handle h, void* hip_stream); /* NULL = the handle's own stream */
@@ -261,9 +269,9 @@ int32_t vitx_mim_num_masked(vitx_mim_handle m, int32_t H, int32_t W, int32_t* nu
 /* MAE.call (mae.py:47-92) / SimMIM.call (simmim.py:86-130): returns the reconstruction loss.  The host variant validates the
  * indices (range, distinct per image: simmim.py:31) and synchronises; the _dev variant trusts them and stays asynchronous. */
 int32_t vitx_mim_forward(vitx_mim_handle m, const float* img_host, int32_t b, int32_t H, int32_t W,
-                         const int32_t* indices_host, float* loss_host);
+                         const int32_t* indices_host, int32_t training, uint64_t seed, float* loss_host);
 int32_t vitx_mim_forward_dev(vitx_mim_handle m, const float* img_dev, int32_t b, int32_t H, int32_t W,
-                             const int32_t* indices_dev, float* loss_dev_or_null);
+                             const int32_t* indices_dev, int32_t training, uint64_t seed, float* loss_dev_or_null);
 /* VJP of the forward above for d(loss) = 1 (README.md:746-749 style training): wrapper gradients -> vitx_mim_get_grads,
  * encoder gradients -> the encoder's arena (transformer blocks, patch_embedding.*, pos_embedding rows 1..num_patches; all other
  * entries zero), decoder gradients -> the decoder handle's arena.  Unlike the reference -- whose `.numpy()` indexing

@@ -80,3 +80,44 @@ def test_backward_reuses_the_forward_masks(variant, over):
         assert live_blocks, "at least one layer per stage survives"
         for blk in zero_blocks:
             assert not np.any(grads[blk + ".attn.to_out.kernel"])
+
+
+def test_transformer_tokens_entry_point_applies_dropout_when_training():
+    """`encoder.transformer(tokens, training=training)` as mae.py:69 / simmim.py:116 / efficient.py:47 call it: with training (the
+    reference's default) the Dropout layers inside the blocks (vit.py:41,43,64) are live, identically seeded calls agree, inference
+    is the deterministic oracle value, and the VJP replays the forward's masks (directional finite difference of the engine itself)."""
+    m, cfg = _model(dropout=0.3)
+    rng = np.random.default_rng(4)
+    tok = rng.standard_normal((3, 7, cfg["dim"])).astype(np.float32)
+    P = {k: np.asarray(v, np.float64) for k, v in m.state_dict().items()}
+    ref = ref_numpy.transformer(tok.astype(np.float64), P, cfg, "transformer", cfg["depth"])
+    assert np.abs(m.transformer(tok, training=False) - ref).max() <= 1e-4
+    a = m.transformer(tok, training=True, seed=9)
+    b = m.transformer(tok, training=True, seed=9)
+    c = m.transformer(tok, seed=10)                      # training=True is the default (vit.py:99)
+    assert np.array_equal(a, b)
+    assert np.abs(a - ref).max() > 1e-2 and np.abs(a - c).max() > 1e-2
+    # VJP with the same masks: d/d eps of <transformer(tok + eps v), dout> equals <dtok, v>
+    dout = rng.standard_normal(tok.shape).astype(np.float32)
+    v = rng.standard_normal(tok.shape).astype(np.float32)
+    m.transformer(tok, training=True, seed=9)
+    _, dtok = m.transformer.backward(dout)
+    eps = 1e-2
+    f = [float((m.transformer(tok + s * eps * v, training=True, seed=9).astype(np.float64) * dout).sum()) for s in (+1, -1)]
+    fd, analytic = (f[0] - f[1]) / (2 * eps), float((dtok.astype(np.float64) * v).sum())
+    assert abs(fd - analytic) <= 2e-2 * max(1.0, abs(analytic)), (fd, analytic)
+
+
+def test_mae_wrapper_passes_training_to_the_encoder():
+    """MAE.call(img, training=True) runs encoder.transformer(tokens, training=training) (mae.py:69): an encoder built with
+    dropout > 0 gives seed-dependent losses in training and the deterministic loss at inference."""
+    from vit_tensorflow import ViT
+    from vit_tensorflow.mae import MAE
+    enc = ViT(image_size=64, patch_size=16, num_classes=10, dim=64, depth=2, heads=2, mlp_dim=128, dim_head=32, dropout=0.3, compute="fp32", max_batch=2, seed=1)
+    mae = MAE(image_size=64, encoder=enc, decoder_dim=32, masking_ratio=0.5, decoder_depth=1, decoder_heads=2, decoder_dim_head=16, literal_loss=False)
+    img = np.random.default_rng(0).standard_normal((2, 64, 64, 3)).astype(np.float32)
+    idx = np.stack([np.random.default_rng(i).permutation(16) for i in range(2)]).astype(np.int32)
+    l_eval = [float(mae(img, training=False, indices=idx)) for _ in range(2)]
+    l_a, l_a2, l_b = (float(mae(img, training=True, indices=idx, seed=s)) for s in (5, 5, 6))
+    assert l_eval[0] == l_eval[1] and l_a == l_a2
+    assert abs(l_a - l_eval[0]) > 1e-4 and abs(l_a - l_b) > 1e-5

@@ -159,3 +159,34 @@ def test_hip_graph_replay_equals_eager_steps():
         outs.append(np.concatenate([w.reshape(-1) for w in m.get_weights()]))
     assert np.array_equal(outs[0], outs[1])
     assert not np.array_equal(outs[0], np.concatenate([np.asarray(P[n], np.float32).reshape(-1) for n, _, _ in m._table]))
+
+
+def test_optimizer_state_survives_a_handle_regrow(tmp_path):
+    """The AdamW moments and step count live in the device handle; a call with batch > max_batch rebuilds the handle.  Training at
+    b = 2, one evaluation at b = 4, then training again must continue exactly like an uninterrupted run."""
+    cfg = oracle_cfg("vit_small")
+    P = spec.init_params(cfg, 1, randomize_all=True)
+    img = np.random.default_rng(0).standard_normal((4, 64, 64, 3)).astype(np.float32)
+    dl = (np.random.default_rng(1).standard_normal((2, cfg["num_classes"])) / 2).astype(np.float32)
+
+    def run(interrupt):
+        m = make_engine_model("vit_small", "fp32", 2, P)
+        for step in range(4):
+            m(img[:2], training=False)
+            m.backward(dl)
+            m.apply_gradients("adamw", lr=1e-2, weight_decay=0.01)
+            if interrupt and step == 1:
+                m(img, training=False)          # b = 4 > max_batch = 2: the handle is rebuilt
+                assert m._cfg.max_batch == 4
+        return m.state_dict()
+
+    a, b = run(False), run(True)
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+    # save_weights / load_weights agree on the file name with or without the .npz suffix (np.savez appends it)
+    m = make_engine_model("vit_small", "fp32", 2, P)
+    for name in ("ckpt", "ckpt2.npz"):
+        m.save_weights(str(tmp_path / name))
+        m2 = make_engine_model("vit_small", "fp32", 2)
+        m2.load_weights(str(tmp_path / name))
+        assert all(np.array_equal(v, m2.state_dict()[k]) for k, v in m.state_dict().items())

@@ -43,7 +43,7 @@ def main():
         if w.decoder is not None:
             N.check(lib.vitx_params_changed(w.decoder._handle))
         N.check(lib.vitx_mim_params_changed(m))
-        N.check(lib.vitx_mim_forward_dev(m, C.c_void_p(img.data_ptr()), b, 224, 224, C.c_void_p(idx.data_ptr()), C.c_void_p(loss.data_ptr())))
+        N.check(lib.vitx_mim_forward_dev(m, C.c_void_p(img.data_ptr()), b, 224, 224, C.c_void_p(idx.data_ptr()), 1, 0, C.c_void_p(loss.data_ptr())))
         N.check(lib.vitx_mim_backward(m))
 
     for _ in range(3):

@@ -222,7 +222,7 @@ int32_t vitx_backward(vitx_handle h, const float* dlogits_host, float* dimg_host
   CAPI_CATCH
 }
 
-int32_t vitx_transformer_forward(vitx_handle h, const float* tokens_host, int32_t b, int32_t n, float* out_host) {
+int32_t vitx_transformer_forward(vitx_handle h, const float* tokens_host, int32_t b, int32_t n, int32_t training, uint64_t seed, float* out_host) {
   CAPI_TRY
   if (!h || !tokens_host || !out_host) return fail(VITX_ERR_INVALID, "null argument");
   if (b <= 0 || b > h->cfg.max_batch || n <= 0 || n > h->ntok_cap) return fail(VITX_ERR_INVALID, "transformer_forward: b or n out of range");
@@ -230,7 +230,7 @@ int32_t vitx_transformer_forward(vitx_handle h, const float* tokens_host, int32_
   float* tmp = h->g;   // [>= mp, d] fp32 scratch that no forward kernel touches
   CAPI_HIP(hipMemcpyAsync(tmp, tokens_host, bytes, hipMemcpyHostToDevice, h->stream));
   std::string err;
-  int rc = engine_transformer_forward(h, tmp, b, n, tmp, err);
+  int rc = engine_transformer_forward(h, tmp, b, n, training, seed, tmp, err);
   if (rc != VITX_OK) return fail(rc, err);
   CAPI_HIP(hipMemcpyAsync(out_host, tmp, bytes, hipMemcpyDeviceToHost, h->stream));
   CAPI_HIP(hipStreamSynchronize(h->stream));
@@ -264,13 +264,12 @@ int32_t vitx_patch_unfold(const float* img_host, int32_t b, int32_t H, int32_t W
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(VITX_ERR_HIP, "no HIP device available (no CPU fallback)");
   const size_t n = (size_t)b * H * W * C;
   float *din = nullptr, *dout = nullptr;
+  struct Free { float*& p; ~Free() { if (p) (void)hipFree(p); } } free_in{din}, free_out{dout};   // every exit path releases both
   CAPI_HIP(hipMalloc((void**)&din, n * 4));
   CAPI_HIP(hipMalloc((void**)&dout, n * 4));
   CAPI_HIP(hipMemcpy(din, img_host, n * 4, hipMemcpyHostToDevice));
   launch_unfold(din, dout, 0, b, H, W, C, ph, pw, (int64_t)ph * pw * C, nullptr);
   CAPI_HIP(hipMemcpy(out_host, dout, n * 4, hipMemcpyDeviceToHost));
-  (void)hipFree(din);
-  (void)hipFree(dout);
   return VITX_OK;
   CAPI_CATCH
 }
@@ -505,6 +504,42 @@ int32_t vitx_sgd_step(vitx_handle h, float lr, float momentum, float weight_deca
   if (momentum != 0.f) { int rc = ensure_opt_state(h, false); if (rc != VITX_OK) return rc; }
   launch_sgd(h->params, h->grads, momentum != 0.f ? h->opt_m : nullptr, h->n_arena, lr, momentum, weight_decay, h->stream);
   h->params_dirty = true;
+  return VITX_OK;
+  CAPI_CATCH
+}
+
+// Optimizer state (first / second moments in the parameter-arena layout, step count): lives only inside the handle, so whoever
+// rebuilds a handle (the Python front grows it when a larger batch arrives) carries it over with this pair.
+int32_t vitx_get_opt_state(vitx_handle h, float* m_host, float* v_host, int64_t n_elems, int64_t* step, int32_t* have_m, int32_t* have_v) {
+  CAPI_TRY
+  if (!h) return fail(VITX_ERR_INVALID, "null handle");
+  if (step) *step = h->opt_step;
+  if (have_m) *have_m = h->opt_m != nullptr;
+  if (have_v) *have_v = h->opt_v != nullptr;
+  if ((m_host || v_host) && n_elems != h->n_params) return fail(VITX_ERR_INVALID, "optimizer state size mismatch");
+  CAPI_HIP(hipStreamSynchronize(h->stream));
+  for (int which = 0; which < 2; ++which) {
+    float* dst = which ? v_host : m_host;
+    const float* src = which ? h->opt_v : h->opt_m;
+    if (!dst || !src) continue;
+    for (auto& p : h->table) CAPI_HIP(hipMemcpy(dst + p.offset, src + p.aoff, (size_t)p.count * 4, hipMemcpyDeviceToHost));
+  }
+  return VITX_OK;
+  CAPI_CATCH
+}
+int32_t vitx_set_opt_state(vitx_handle h, const float* m_host, const float* v_host, int64_t n_elems, int64_t step) {
+  CAPI_TRY
+  if (!h) return fail(VITX_ERR_INVALID, "null handle");
+  if ((m_host || v_host) && n_elems != h->n_params) return fail(VITX_ERR_INVALID, "optimizer state size mismatch");
+  if (m_host || v_host) { int rc = ensure_opt_state(h, v_host != nullptr); if (rc != VITX_OK) return rc; }
+  CAPI_HIP(hipStreamSynchronize(h->stream));
+  for (int which = 0; which < 2; ++which) {
+    const float* src = which ? v_host : m_host;
+    float* dst = which ? h->opt_v : h->opt_m;
+    if (!src || !dst) continue;
+    for (auto& p : h->table) CAPI_HIP(hipMemcpy(dst + p.aoff, src + p.offset, (size_t)p.count * 4, hipMemcpyHostToDevice));
+  }
+  h->opt_step = (int)step;
   return VITX_OK;
   CAPI_CATCH
 }

@@ -113,6 +113,24 @@ template <typename V> __device__ __forceinline__ V gelu_grad_fast(V x) {
   const V ex = vexp2(u0 * vsplat(x, -1.44269504088896340736f));
   return vfma(x * vsplat(x, 0.39894228040143267794f), ex, phi);
 }
+// gelu(x) and gelu'(x) from ONE evaluation of the erf polynomial (the bf16 forward epilogue of fc1 stores both: the backward
+// epilogue of the fc2 input gradient is then a single multiply by the stored derivative instead of a polynomial + exp2 per element)
+template <typename V> __device__ __forceinline__ void gelu_both_fast(V x, V& g, V& gd) {
+  V u0;
+  const V e = gelu_erf_fast(x, u0);
+  const V hx = x * vsplat(x, 0.5f);
+  g = vfma(hx, e, hx);
+  const V phi = vfma(e, vsplat(x, 0.5f), vsplat(x, 0.5f));
+  const V ex = vexp2(u0 * vsplat(x, -1.44269504088896340736f));
+  gd = vfma(x * vsplat(x, 0.39894228040143267794f), ex, phi);
+}
+__device__ __forceinline__ void gelu_both4(float4 x, float4& g, float4& gd) {
+  f32x2 ga, gb, da, db;
+  gelu_both_fast<f32x2>(f32x2{x.x, x.y}, ga, da);
+  gelu_both_fast<f32x2>(f32x2{x.z, x.w}, gb, db);
+  g = make_float4(ga.x, ga.y, gb.x, gb.y);
+  gd = make_float4(da.x, da.y, db.x, db.y);
+}
 template <typename T> __device__ __forceinline__ float gelu_t(float x) { return gelu_f(x); }
 template <> __device__ __forceinline__ float gelu_t<bf16_t>(float x) { return gelu_fast<float>(x); }
 template <typename T> __device__ __forceinline__ float gelu_grad_t(float x) { return gelu_grad_f(x); }

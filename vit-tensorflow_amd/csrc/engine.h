@@ -132,6 +132,8 @@ struct vitx_engine {
   bool have_fwd = false;
   bool have_tf = false;              // saved activations describe a transformer_forward(tokens) of [tf_b, tf_n, dim]
   int tf_b = 0, tf_n = 0;
+  float tf_drop = 0.f;               // dropout rate that transformer_forward applied (0 unless training) and the seed of its masks
+  uint64_t tf_seed = 0;
   bool have_embed = false, have_head = false;   // efficient.ViT shell: state of the last embed_forward / head_forward
   int shell_b = 0, shell_n = 0;
   float* shell_x = nullptr;          // [mp, dim] fp32 copy of the head's input (allocated on first use)
@@ -173,7 +175,7 @@ int engine_forward(vitx_engine* e, const float* img_dev, int b, int H, int W, in
 // d_distill_dev [b, dim]: cotangent of distill_out; d_token_out_dev [dim]: gradient of the distillation token
 int engine_backward(vitx_engine* e, const float* dlogits_dev, float* dimg_dev, std::string& err, const float* d_distill_dev = nullptr,
                     float* d_token_out_dev = nullptr);
-int engine_transformer_forward(vitx_engine* e, const float* tokens_dev, int b, int n, float* out_dev, std::string& err);
+int engine_transformer_forward(vitx_engine* e, const float* tokens_dev, int b, int n, int training, uint64_t seed, float* out_dev, std::string& err);
 int engine_transformer_backward(vitx_engine* e, const float* dout_dev, float* dtokens_dev, std::string& err);
 int engine_patch_tokens_forward(vitx_engine* e, const float* img_dev, int b, int H, int W, float* tokens_dev, float* patches_f32_dev_or_null,
                                 std::string& err);

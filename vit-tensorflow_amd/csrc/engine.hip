@@ -162,6 +162,8 @@ static void finalize_epi(EpiParams& ep) {
   ep.vec_ok = (ep.ldo % 4 == 0) && (ep.ldo2 % 4 == 0) && (ep.ldr % 4 == 0) && (ep.ldaux % 4 == 0) && al(ep.out) && al(ep.out2) &&
               al(ep.bias) && al(ep.resid) && al(ep.scale) && al(ep.aux) && al(ep.pos) && (ep.out_batch_stride % 4 == 0) &&
               (ep.out_head_stride % 4 == 0) && (ep.partial_stride % 4 == 0);
+  static const int wide_env = [] { const char* v = getenv("VITX_EPI_WIDE"); return v ? atoi(v) : 1; }();
+  ep.wide_ok = wide_env && ep.vec_ok && (ep.ldo % 8 == 0) && (ep.ldo2 % 8 == 0) && (ep.ldaux % 8 == 0);
 }
 
 static int dalloc(vitx_engine* e, void** p, size_t bytes, bool t_buffer, std::string& err) {
@@ -811,15 +813,16 @@ static int block_backward(vitx_engine* e, Stage& st, int si, int l, int b, int n
 // ------------------------------------------------------------------------------------------------
 static bool env_flag(const char* n) { const char* v = getenv(n); return v && v[0] && v[0] != '0'; }
 
-int engine_create(const vitx_config& cfg, vitx_engine** out, std::string& err) {
-  vitx_engine* e = new vitx_engine();
+// body of engine_create: on any failure the caller (engine_create) releases everything `e` owns so far
+void engine_destroy(vitx_engine* e);
+static int engine_create_body(vitx_engine* e, const vitx_config& cfg, std::string& err) {
   e->cfg = cfg;
   if (e->cfg.ln_eps <= 0.f) e->cfg.ln_eps = 1e-3f;
   if (e->cfg.channels <= 0) e->cfg.channels = 3;
   if (e->cfg.max_batch <= 0) e->cfg.max_batch = 1;
   const vitx_config& c = e->cfg;
   std::string perr = build_param_table(c, e->table);
-  if (!perr.empty()) { err = perr; delete e; return VITX_ERR_INVALID; }
+  if (!perr.empty()) { err = perr; return VITX_ERR_INVALID; }
   e->n_params = e->table.back().offset + e->table.back().count;
   e->n_arena = e->table.back().aoff + round_up(e->table.back().count, 4);
   e->bf16 = c.compute == VITX_COMPUTE_BF16;
@@ -832,13 +835,13 @@ int engine_create(const vitx_config& cfg, vitx_engine** out, std::string& err) {
   e->pd = c.patch_h * c.patch_w * c.channels;
   e->pd_k = (int)round_up(e->pd, 64);
   e->nc_k = (int)round_up(c.num_classes, 64);
-  if (c.dim % 4 != 0 || c.dim > 4096) { err = "dim must be a multiple of 4 and <= 4096"; delete e; return VITX_ERR_UNSUPPORTED; }
-  if (c.heads > 32 && c.variant != VITX_VARIANT_VIT) { err = "heads > 32 unsupported for DeepViT/CaiT"; delete e; return VITX_ERR_UNSUPPORTED; }
+  if (c.dim % 4 != 0 || c.dim > 4096) { err = "dim must be a multiple of 4 and <= 4096"; return VITX_ERR_UNSUPPORTED; }
+  if (c.heads > 32 && c.variant != VITX_VARIANT_VIT) { err = "heads > 32 unsupported for DeepViT/CaiT"; return VITX_ERR_UNSUPPORTED; }
   if (e->bf16 && (c.dim % 64 || e->inner % 64 || c.mlp_dim % 64)) {
     err = "BF16 compute needs dim, heads*dim_head and mlp_dim to be multiples of 64 (use FP32_PARITY otherwise)";
-    delete e; return VITX_ERR_UNSUPPORTED;
+    return VITX_ERR_UNSUPPORTED;
   }
-  if (cait && c.cls_depth < 0) { err = "cls_depth must be >= 0"; delete e; return VITX_ERR_INVALID; }
+  if (cait && c.cls_depth < 0) { err = "cls_depth must be >= 0"; return VITX_ERR_INVALID; }
   e->force_generic_gemm = env_flag("VITX_GENERIC_GEMM");
   e->force_generic_attn = env_flag("VITX_GENERIC_ATTN");
   if (const char* k = getenv("VITX_GEMM_KERNEL")) e->gemm_kernel = atoi(k);
@@ -1081,7 +1084,7 @@ int engine_create(const vitx_config& cfg, vitx_engine** out, std::string& err) {
                                     deepvit_point_bwd_ws_elems(c.heads)});
   DALLOC(e->red_ws, (size_t)e->red_elems * 4, false);
   HIPCHK(hipStreamSynchronize(e->stream));
-  *out = e;
+  
   return VITX_OK;
 }
 
@@ -1091,6 +1094,17 @@ void engine_destroy(vitx_engine* e) {
   for (void* p : e->allocs) (void)hipFree(p);
   if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
   delete e;
+}
+
+int engine_create(const vitx_config& cfg, vitx_engine** out, std::string& err) {
+  vitx_engine* e = new vitx_engine();
+  const int rc = engine_create_body(e, cfg, err);
+  if (rc != VITX_OK) {          // a failed hipMalloc half-way (e.g. out of memory at a larger max_batch) must not strand the buffers,
+    engine_destroy(e);          // the stream and the object allocated before it
+    return rc;
+  }
+  *out = e;
+  return VITX_OK;
 }
 
 // rows >= M of every T buffer must be zero (they are K-padding of the wgrad GEMMs): re-zero when the geometry changes
@@ -1459,7 +1473,10 @@ int engine_embed_backward(vitx_engine* e, const float* dtokens_dev, float* dimg_
   return VITX_OK;
 }
 
-int engine_transformer_forward(vitx_engine* e, const float* tokens_dev, int b, int n, float* out_dev, std::string& err) {
+// training != 0 with a dropout rate > 0 draws the Dropout masks of vit.py:41,43,64 from (seed, site, element) exactly as the full
+// forward does (the reference calls self.encoder.transformer(tokens, training=training), mae.py:69, simmim.py:116, efficient.py:47);
+// the backward below regenerates the same masks.
+int engine_transformer_forward(vitx_engine* e, const float* tokens_dev, int b, int n, int training, uint64_t seed, float* out_dev, std::string& err) {
   const vitx_config& c = e->cfg;
   if (c.variant == VITX_VARIANT_CAIT || c.variant == VITX_VARIANT_PATCH_MERGER) { err = "transformer_forward: ViT / DeepViT only"; return VITX_ERR_UNSUPPORTED; }
   if (b <= 0 || b > c.max_batch || n <= 0 || n > e->ntok_cap) { err = "transformer_forward: b or n out of range"; return VITX_ERR_INVALID; }
@@ -1470,11 +1487,12 @@ int engine_transformer_forward(vitx_engine* e, const float* tokens_dev, int b, i
   if (s0.depth == 0) { HIPCHK(hipMemcpyAsync(out_dev, tokens_dev, bytes, hipMemcpyDeviceToDevice, e->stream)); return VITX_OK; }
   HIPCHK(hipMemcpyAsync(s0.ba[0].x_in, tokens_dev, bytes, hipMemcpyDeviceToDevice, e->stream));
   int rc;
+  const float drop = training ? c.dropout : 0.f;
   for (int l = 0; l < s0.depth; ++l)
-    if ((rc = block_forward(e, s0, 0, l, b, n, 0, nullptr, 0.f, 0, err)) != VITX_OK) return rc;
+    if ((rc = block_forward(e, s0, 0, l, b, n, 0, nullptr, drop, seed, err)) != VITX_OK) return rc;
   HIPCHK(hipMemcpyAsync(out_dev, s0.ba[s0.depth - 1].x_out, bytes, hipMemcpyDeviceToDevice, e->stream));
   e->have_fwd = false;   // saved activations no longer describe a full model forward
-  e->have_tf = true; e->tf_b = b; e->tf_n = n;
+  e->have_tf = true; e->tf_b = b; e->tf_n = n; e->tf_drop = drop; e->tf_seed = seed;
   e->last_training = 0;
   return VITX_OK;
 }
@@ -1494,7 +1512,7 @@ int engine_transformer_backward(vitx_engine* e, const float* dout_dev, float* dt
   if (T) launch_convert(e->g, d, e->g_lp, 1, d, b * n, d, d, e->stream);
   int rc;
   for (int l = s0.depth - 1; l >= 0; --l)
-    if ((rc = block_backward(e, s0, 0, l, b, n, 0, 0.f, 0, err)) != VITX_OK) return rc;
+    if ((rc = block_backward(e, s0, 0, l, b, n, 0, e->tf_drop, e->tf_seed, err)) != VITX_OK) return rc;
   if (dtokens_dev) HIPCHK(hipMemcpyAsync(dtokens_dev, e->g, bytes, hipMemcpyDeviceToDevice, e->stream));
   return VITX_OK;
 }
@@ -1718,6 +1736,9 @@ int engine_bench_gemm(vitx_engine* e, int M, int N, int K, int kernel, int epilo
     mode = EPI_BIAS_GELU; ep.out = C2; ep.ldo = Np; ep.out2 = C2 + Mp * Np; ep.ldo2 = Np; ep.bias = bias;
   } else if (epilogue == 3) {     // plain bf16 store (QKV / dgrads)
     mode = EPI_STORE; ep.out = C2; ep.ldo = Np;
+  } else if (epilogue == 4) {     // fc2 input gradient: bf16 out = acc * stored gelu'(h), per-tile column sums (the fc1 bias gradient)
+    mode = EPI_GELU_BWD; ep.out = C2; ep.ldo = Np; ep.aux = C2 + Mp * Np; ep.ldaux = Np; ep.colsum = C; ep.ldcs = Np;
+    launch_fill_random_bf16(C2 + Mp * Np, Mp * Np, 3u, 1.0f, e->stream);
   } else {
     ep.out = C; ep.ldo = Np;
   }
@@ -1782,8 +1803,9 @@ int engine_bench_gemm(vitx_engine* e, int M, int N, int K, int kernel, int epilo
       HIPCHK(hipStreamSynchronize(e->stream));
     } else {
       if (int rc = fetch_bf16(C2, got)) return rc;
-      if (epilogue == 2) { if (int rc = fetch_bf16(C2 + Mp * Np, got2)) return rc; }
+      if (epilogue == 2 || epilogue == 4) { if (int rc = fetch_bf16(C2 + Mp * Np, got2)) return rc; }
     }
+    auto bf16r = [](float f) { uint32_t u; memcpy(&u, &f, 4); u += 0x7fffu + ((u >> 16) & 1u); u &= 0xffff0000u; memcpy(&f, &u, 4); return f; };
     float me = 0.f;
     for (int i = 0; i < M; ++i)
       for (int j = 0; j < N; ++j) {
@@ -1793,11 +1815,20 @@ int engine_bench_gemm(vitx_engine* e, int M, int N, int K, int kernel, int epilo
         if (epilogue == 2) want += hbias[j];
         float tol_scale = 1.f;
         if (epilogue >= 2) tol_scale = 1.f / (1.f + std::fabs(want));   // bf16 outputs: error relative to magnitude
-        me = std::max(me, std::fabs(got[o] - want) * tol_scale);
         if (epilogue == 2) {
-          const float h = got[o];   // GELU is evaluated on the stored (rounded) pre-activation
-          const float gl = 0.5f * h * (1.f + std::erf(h * 0.70710678f));
-          me = std::max(me, std::fabs(got2[o] - gl) / (1.f + std::fabs(gl)));
+          // bf16 mode stores gelu'(h) and gelu(h), both evaluated on h as bf16 would round it (epilogue.h: kStoreGeluGrad).  A one-ulp
+          // difference of that rounding between the two kernels' accumulation orders moves both by |dh| <= 2^-8 |h|: allow for it.
+          const float h = bf16r(want);
+          const float phi = 0.5f * (1.f + std::erf(h * 0.70710678f));
+          const float gl = h * phi, gd = phi + h * 0.39894228f * std::exp(-0.5f * h * h);
+          const float slack = 1.f / (1.f + 0.6f * std::fabs(h));
+          me = std::max(me, std::fabs(got[o] - gd) * 0.5f * slack);
+          me = std::max(me, std::fabs(got2[o] - gl) / (1.f + std::fabs(gl)) * slack);
+        } else if (epilogue == 4) {
+          want *= got2[o];
+          me = std::max(me, std::fabs(got[o] - want) / (1.f + std::fabs(want)));
+        } else {
+          me = std::max(me, std::fabs(got[o] - want) * tol_scale);
         }
       }
     *max_err = me;

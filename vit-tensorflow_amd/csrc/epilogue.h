@@ -6,12 +6,18 @@
 enum EpiMode {
   EPI_STORE = 0,      // out[T] = alpha*acc (+bias)                                  QKV, dgrads
   EPI_STORE_F32 = 1,  // out[f32] = alpha*acc (+bias)                                logits, scores
-  EPI_BIAS_GELU = 2,  // h = acc+bias; out[T] = h; out2[T] = gelu(h)                 fc1 (vit.py:39,34)
+  EPI_BIAS_GELU = 2,  // h = acc+bias; out2[T] = gelu(h); out[T] = h (T = float) or gelu'(h) (T = bf16: what the backward needs)   fc1 (vit.py:39,34)
   EPI_BIAS_RESID = 3, // f = acc+bias; out2[T] = f (iff scale); out[f32] = resid + f*scale   to_out / fc2 + residual (vit.py:101-102, cait.py:47-48)
   EPI_PATCH = 4,      // out[f32][img*ntok + tok_off + t] = acc + bias + pos[tok_off+t]   patch embed (vit.py:143,164-165)
-  EPI_GELU_BWD = 5,   // out[T] = acc * gelu'(aux[T])                                 fc2 dgrad
+  EPI_GELU_BWD = 5,   // out[T] = acc * gelu'(aux[T]) (T = float: aux = h) or acc * aux[T] (T = bf16: aux = the stored gelu'(h))   fc2 dgrad
   EPI_PARTIAL = 6,    // out[f32][z][row][col] = acc                                  split-K partial sums
 };
+
+// bf16 (throughput) mode: the fc1 epilogue stores gelu'(h) where parity mode stores h -- the only consumer of that buffer is the
+// fc2 input-gradient epilogue, which then multiplies instead of re-evaluating the derivative (same bytes, ~40 VALU slots less per
+// 4 elements in the backward epilogue; the forward pays one exp2 and three FMAs per element on top of the GELU it evaluates anyway)
+template <typename T> inline constexpr bool kStoreGeluGrad = false;
+template <> inline constexpr bool kStoreGeluGrad<bf16_t> = true;
 
 struct EpiParams {
   void* out = nullptr;
@@ -29,6 +35,7 @@ struct EpiParams {
   int M = 0, N = 0;        // valid extents (rows >= M are written as zero for T outputs, skipped for f32)
   int np = 1, ntok = 1, tok_off = 0;
   int vec_ok = 1;          // 0: some pointer / leading dimension is not 16-B friendly -> scalar accesses
+  int wide_ok = 0;         // 1: bf16 outputs / aux rows start 16-B aligned (leading dimensions % 8 == 0): eight-column epilogue form allowed
   int zero_pad = 0;        // 1: rows in [M, tile end) of T outputs are written as zeros (buffers are row-padded)
   float alpha = 1.0f;
 };
@@ -74,6 +81,7 @@ __device__ __forceinline__ float4 epilogue_apply4(const EpiParams& p, int row, i
       // GELU is evaluated on the value as stored (T-rounded) so that backward's gelu'(hpre) matches
       float hs = (float)(T)a[i];
       g[i] = row_ok ? gelu_t<T>(hs) : 0.f;
+      if (kStoreGeluGrad<T>) a[i] = row_ok ? gelu_grad_t<T>(hs) : 0.f;   // bf16 mode keeps gelu'(h) instead of h (see EPI_GELU_BWD)
     }
     if (full) { st4<T>(o, make_float4(a[0], a[1], a[2], a[3])); st4<T>(o2, make_float4(g[0], g[1], g[2], g[3])); }
     else for (int i = 0; i < 4 && col + i < p.N; ++i) { stf<T>(o + i, a[i]); stf<T>(o2 + i, g[i]); }
@@ -108,13 +116,20 @@ __device__ __forceinline__ float4 epilogue_apply4(const EpiParams& p, int row, i
     float g[4];
     if (full) {
       float4 hv = ld4<T>(h);
+      if (kStoreGeluGrad<T>) { g[0] = a[0] * hv.x; g[1] = a[1] * hv.y; g[2] = a[2] * hv.z; g[3] = a[3] * hv.w; }
+      else {
       g[0] = a[0] * gelu_grad_t<T>(hv.x); g[1] = a[1] * gelu_grad_t<T>(hv.y);
       g[2] = a[2] * gelu_grad_t<T>(hv.z); g[3] = a[3] * gelu_grad_t<T>(hv.w);
+      }
       if (!row_ok) g[0] = g[1] = g[2] = g[3] = 0.f;
       st4<T>(o, make_float4(g[0], g[1], g[2], g[3]));
     } else {
       g[0] = g[1] = g[2] = g[3] = 0.f;
-      for (int i = 0; i < 4 && col + i < p.N; ++i) { g[i] = row_ok ? a[i] * gelu_grad_t<T>(ldf<T>(h + i)) : 0.f; stf<T>(o + i, g[i]); }
+      for (int i = 0; i < 4 && col + i < p.N; ++i) {
+        const float hv = ldf<T>(h + i);
+        g[i] = row_ok ? a[i] * (kStoreGeluGrad<T> ? hv : gelu_grad_t<T>(hv)) : 0.f;
+        stf<T>(o + i, g[i]);
+      }
     }
     // what was stored (rounded to T): the fused column sums add exactly what a later pass over the output would read
     return make_float4((float)(T)g[0], (float)(T)g[1], (float)(T)g[2], (float)(T)g[3]);
@@ -142,9 +157,16 @@ __device__ __forceinline__ float4 epilogue_fast4(const EpiParams& p, int row, in
   } else if (MODE == EPI_STORE_F32 || MODE == EPI_PARTIAL) {
     *(float4*)((float*)p.out + out_off + (int64_t)row * p.ldo + col) = v;
   } else if (MODE == EPI_BIAS_GELU) {
-    st4<T>((T*)p.out + (int64_t)row * p.ldo + col, v);
-    const float4 g = gelu4_t<T>(make_float4((float)(T)v.x, (float)(T)v.y, (float)(T)v.z, (float)(T)v.w));   // on the value as stored
-    st4<T>((T*)p.out2 + (int64_t)row * p.ldo2 + col, g);
+    const float4 hs = make_float4((float)(T)v.x, (float)(T)v.y, (float)(T)v.z, (float)(T)v.w);   // GELU of the value as T would store it
+    if constexpr (kStoreGeluGrad<T>) {
+      float4 g, gd;
+      gelu_both4(hs, g, gd);
+      st4<T>((T*)p.out + (int64_t)row * p.ldo + col, gd);
+      st4<T>((T*)p.out2 + (int64_t)row * p.ldo2 + col, g);
+    } else {
+      st4<T>((T*)p.out + (int64_t)row * p.ldo + col, v);
+      st4<T>((T*)p.out2 + (int64_t)row * p.ldo2 + col, gelu4_t<T>(hs));
+    }
   } else if (MODE == EPI_BIAS_RESID) {
     if (HAS_SCALE) {
       if (p.out2) st4<T>((T*)p.out2 + (int64_t)row * p.ldo2 + col, v);
@@ -152,12 +174,53 @@ __device__ __forceinline__ float4 epilogue_fast4(const EpiParams& p, int row, in
     }
     *(float4*)((float*)p.out + (int64_t)row * p.ldo + col) = make_float4(x.x + v.x, x.y + v.y, x.z + v.z, x.w + v.w);
   } else if (MODE == EPI_GELU_BWD) {
-    const float4 gd = gelu_grad4_t<T>(x);
+    const float4 gd = kStoreGeluGrad<T> ? x : gelu_grad4_t<T>(x);
     const float4 gq = make_float4(v.x * gd.x, v.y * gd.y, v.z * gd.z, v.w * gd.w);
     st4<T>((T*)p.out + (int64_t)row * p.ldo + col, gq);
     return make_float4((float)(T)gq.x, (float)(T)gq.y, (float)(T)gq.z, (float)(T)gq.w);   // as stored (see epilogue_apply4)
   }
   return v;
+}
+// Eight consecutive columns per lane for the bf16-output epilogues (EPI_STORE, EPI_BIAS_GELU, EPI_GELU_BWD): ONE 16-byte global
+// access per lane and output row instead of two 8-byte ones.  The bf16 store tail of an MFMA epilogue is bound by the number of
+// store instructions, not by their bytes (MI355X: a 16 x dwordx2 tail takes twice as long as the same bytes as 8 x dwordx4), so
+// halving the instruction count is what shortens it.  Interior tiles only; same arithmetic as epilogue_fast4 on each half.
+__device__ __forceinline__ bf16x8 pack_bf16x8(float4 a, float4 b) {
+  bf16x8 o;
+  o[0] = (bf16_t)a.x; o[1] = (bf16_t)a.y; o[2] = (bf16_t)a.z; o[3] = (bf16_t)a.w;
+  o[4] = (bf16_t)b.x; o[5] = (bf16_t)b.y; o[6] = (bf16_t)b.z; o[7] = (bf16_t)b.w;
+  return o;
+}
+template <int MODE>
+__device__ __forceinline__ bf16x8 epilogue_wide_load(const EpiParams& p, int row, int col) {
+  if (MODE == EPI_GELU_BWD) return *(const bf16x8*)((const bf16_t*)p.aux + (int64_t)row * p.ldaux + col);
+  return bf16x8{};
+}
+// returns (as two float4 through lo / hi) what was stored, rounded to bf16 -- the fused column sums of EPI_GELU_BWD
+template <int MODE, bool HAS_BIAS>
+__device__ __forceinline__ void epilogue_wide8(const EpiParams& p, int row, int col, float4& lo, float4& hi, float4 b_lo, float4 b_hi, bf16x8 x,
+                                               int64_t out_off) {
+  if (HAS_BIAS && MODE != EPI_GELU_BWD) {
+    lo.x += b_lo.x; lo.y += b_lo.y; lo.z += b_lo.z; lo.w += b_lo.w;
+    hi.x += b_hi.x; hi.y += b_hi.y; hi.z += b_hi.z; hi.w += b_hi.w;
+  }
+  if (MODE == EPI_STORE) {
+    *(bf16x8*)((bf16_t*)p.out + out_off + (int64_t)row * p.ldo + col) = pack_bf16x8(lo, hi);
+  } else if (MODE == EPI_BIAS_GELU) {
+    const bf16x8 h = pack_bf16x8(lo, hi);       // GELU and its derivative of the pre-activation as bf16 would store it
+    float4 g0, d0, g1, d1;
+    gelu_both4(make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]), g0, d0);
+    gelu_both4(make_float4((float)h[4], (float)h[5], (float)h[6], (float)h[7]), g1, d1);
+    *(bf16x8*)((bf16_t*)p.out + (int64_t)row * p.ldo + col) = pack_bf16x8(d0, d1);
+    *(bf16x8*)((bf16_t*)p.out2 + (int64_t)row * p.ldo2 + col) = pack_bf16x8(g0, g1);
+  } else if (MODE == EPI_GELU_BWD) {
+    lo = make_float4(lo.x * (float)x[0], lo.y * (float)x[1], lo.z * (float)x[2], lo.w * (float)x[3]);
+    hi = make_float4(hi.x * (float)x[4], hi.y * (float)x[5], hi.z * (float)x[6], hi.w * (float)x[7]);
+    const bf16x8 o = pack_bf16x8(lo, hi);
+    *(bf16x8*)((bf16_t*)p.out + (int64_t)row * p.ldo + col) = o;
+    lo = make_float4((float)o[0], (float)o[1], (float)o[2], (float)o[3]);
+    hi = make_float4((float)o[4], (float)o[5], (float)o[6], (float)o[7]);
+  }
 }
 __device__ __forceinline__ bool epilogue_fast_ok(const EpiParams& p, int mode) {
   return p.vec_ok && p.alpha == 1.0f && mode != EPI_PATCH;

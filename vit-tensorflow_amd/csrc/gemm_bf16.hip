@@ -548,6 +548,17 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_pipe_kernel(Bf16Gem
       // alternately: ONE barrier per round -- the accumulator rows of round R+1 are written while round R is still being read and
       // stored (the round trip  barrier - LDS write - barrier - LDS read - global store  was the epilogue's critical path, not HBM).
       // Reuse of an area two rounds later is ordered by the barrier in between (every wave waits for its own reads first).
+      // bf16 outputs (WIDE): a lane takes EIGHT consecutive columns of a row (two staged 16-B chunks -> one 16-B global access per
+      // output, two rows per wave instruction): half the store instructions for the same bytes.  Even chunks of a staged row live
+      // in its first 512 B, odd chunks in the second, so both reads of a 16-lane group stay conflict-free.
+      // (256-row tiles only: in the 320-row variants the second code path costs the registers the accumulators need -- 44-116 B of scratch;
+      //  same-box A/B on fc1-shaped launches, profiles/r2/epilogue_wide_ab_r2d.log: +1.0..2.5 % plain store, +1 % GELU, +2.5 % GELU VJP)
+      constexpr bool WIDE = BM == 256 && (MODE == EPI_STORE || MODE == EPI_BIAS_GELU || MODE == EPI_GELU_BWD);
+      const bool wide = WIDE && interior && ep.wide_ok;
+      float4 cs2 = make_float4(0.f, 0.f, 0.f, 0.f);   // WIDE column sums: columns 4..7 of the lane's eight
+      const int cc = lane & 31, gcol8 = tile_n * BN + cc * 8;
+      float4 b8lo = make_float4(0.f, 0.f, 0.f, 0.f), b8hi = b8lo;
+      if (wide && has_bias && MODE != EPI_GELU_BWD) { b8lo = *(const float4*)(ep.bias + gcol8); b8hi = *(const float4*)(ep.bias + gcol8 + 4); }
 #pragma clang loop unroll(full)
       for (int R = 0; R < BM / 32; ++R) {
         const int wm_r = (R * 32) / WTM, i0 = ((R * 32) % WTM) / 32;
@@ -559,20 +570,48 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_pipe_kernel(Bf16Gem
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
               const int chunk = (wn * WTN + j * 32 + 8 * q + 4 * khalf) >> 2;
-              *(float4*)(sr + m * BN + ((chunk ^ (m & 7)) << 2)) =
+              const int pc = WIDE ? ((chunk >> 1) | ((chunk & 1) << 5)) : chunk;
+              *(float4*)(sr + m * BN + ((pc ^ (m & 7)) << 2)) =
                   make_float4(acc[i0][j][4 * q], acc[i0][j][4 * q + 1], acc[i0][j][4 * q + 2], acc[i0][j][4 * q + 3]);
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        const int grow0 = tile_m * BM + R * 32;
+        if constexpr (WIDE) {
+          if (wide) {
+            constexpr int RPW2 = 16 / NW;    // two rows per wave instruction, 16 instructions per 32-row round
+            float4 lo[RPW2], hi[RPW2];
+            bf16x8 x[RPW2];
+#pragma unroll
+            for (int k = 0; k < RPW2; ++k) {
+              const int r = (k * NW + wave) * 2 + (lane >> 5);
+              const int pc = cc ^ (r & 7);
+              lo[k] = *(const float4*)(sr + r * BN + (pc << 2));
+              hi[k] = *(const float4*)(sr + r * BN + ((pc + 32) << 2));
+              x[k] = epilogue_wide_load<MODE>(ep, grow0 + r, gcol8);
+            }
+#pragma unroll
+            for (int k = 0; k < RPW2; ++k) {
+              const int r = (k * NW + wave) * 2 + (lane >> 5);
+              if (has_bias) epilogue_wide8<MODE, true>(ep, grow0 + r, gcol8, lo[k], hi[k], b8lo, b8hi, x[k], out_off);
+              else epilogue_wide8<MODE, false>(ep, grow0 + r, gcol8, lo[k], hi[k], b8lo, b8hi, x[k], out_off);
+              if (MODE == EPI_GELU_BWD) {
+                cs.x += lo[k].x; cs.y += lo[k].y; cs.z += lo[k].z; cs.w += lo[k].w;
+                cs2.x += hi[k].x; cs2.y += hi[k].y; cs2.z += hi[k].z; cs2.w += hi[k].w;
+              }
+            }
+            continue;
+          }
+        }
         float4 v[RPW];
 #pragma unroll
         for (int k = 0; k < RPW; ++k) {
           const int r = k * NW + wave;
-          v[k] = *(const float4*)(sr + r * BN + ((lane ^ (r & 7)) << 2));
+          const int pc = WIDE ? (((lane >> 1) | ((lane & 1) << 5)) ^ (r & 7)) : (lane ^ (r & 7));
+          v[k] = *(const float4*)(sr + r * BN + (pc << 2));
         }
-        const int grow0 = tile_m * BM + R * 32;
         if (interior) {
           float4 x[RPW];
 #pragma unroll
@@ -593,14 +632,20 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_pipe_kernel(Bf16Gem
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        *(float4*)(st + wave * BN + lane * 4) = cs;
+        // per-tile column sums: partial rows through the staging buffer (one per wave; two per wave in the eight-column form)
+        const int nrows = wide ? 2 * NW : NW;
+        if (wide) {
+          *(float4*)(st + (wave * 2 + (lane >> 5)) * BN + cc * 8) = cs;
+          *(float4*)(st + (wave * 2 + (lane >> 5)) * BN + cc * 8 + 4) = cs2;
+        } else {
+          *(float4*)(st + wave * BN + lane * 4) = cs;
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if (tid < BN) {
           float a = 0.f;
-#pragma unroll
-          for (int w = 0; w < NW; ++w) a += st[w * BN + tid];
+          for (int w = 0; w < nrows; ++w) a += st[w * BN + tid];
           const int c = tile_n * BN + tid;
           if (c < ep.N) ep.colsum[(int64_t)tile_m * ep.ldcs + c] = a;
         }

@@ -244,7 +244,7 @@ void mim_destroy(vitx_mim* m) {
 
 // mae.py:47-92 / simmim.py:86-130 on device.  idx_dev: MAE int32 [b, np] = rand_indices (first num_masked columns are the masked
 // patches, mae.py:58-59); SimMIM int32 [b, num_masked] = masked_indices (simmim.py:108).
-int mim_forward(vitx_mim* m, const float* img_dev, int b, int H, int W, const int32_t* idx_dev, std::string& err) {
+int mim_forward(vitx_mim* m, const float* img_dev, int b, int H, int W, const int32_t* idx_dev, int training, uint64_t seed, std::string& err) {
   vitx_engine* e = m->enc;
   hipStream_t s = e->stream;
   if (m->dec) m->dec->stream = s;
@@ -268,11 +268,11 @@ int mim_forward(vitx_mim* m, const float* img_dev, int b, int H, int W, const in
   if (m->mae) {
     launch_index_inverse(idx_dev, np, b, 0, np, np, m->inv, s);
     launch_gather_rows(m->tok, (int64_t)np * d, idx_dev, np, nm, b, nu, d, m->sel, s);                      // mae.py:62
-    if ((rc = engine_transformer_forward(e, m->sel, b, nu, m->enc_out, err)) != VITX_OK) return rc;          // mae.py:69
+    if ((rc = engine_transformer_forward(e, m->sel, b, nu, training, seed, m->enc_out, err)) != VITX_OK) return rc;          // mae.py:69
     const float* proj = m->enc_out;
     if (m->project) { glue_fwd(m, m->ed, m->x_ed_T, m->enc_out, b * nu, d, P + m->w_ed, P + m->b_ed, dd, m->proj); proj = m->proj; }   // mae.py:72
     launch_mae_assemble(proj, P + m->mask_tok, P + m->dpos, idx_dev, b, np, nm, dd, m->dec_in, s);          // mae.py:75-82
-    if ((rc = engine_transformer_forward(m->dec, m->dec_in, b, np, m->dec_out, err)) != VITX_OK) return rc;  // mae.py:83
+    if ((rc = engine_transformer_forward(m->dec, m->dec_in, b, np, training, seed + 0x9e3779b97f4a7c15ull, m->dec_out, err)) != VITX_OK) return rc;  // mae.py:83
     HIPCHK(hipMemcpy2DAsync(m->rows_m, (size_t)nm * dd * 4, m->dec_out, (size_t)np * dd * 4, (size_t)nm * dd * 4, b, hipMemcpyDeviceToDevice, s));   // mae.py:86
     glue_fwd(m, m->px, m->x_px_T, m->rows_m, b * nm, dd, P + m->w_px, P + m->b_px, pd, m->pred);            // mae.py:87
     if (!m->cfg.literal_loss) {
@@ -284,7 +284,7 @@ int mim_forward(vitx_mim* m, const float* img_dev, int b, int H, int W, const in
   } else {
     launch_index_inverse(idx_dev, nm, b, 0, nm, np, m->inv, s);                                             // simmim.py:109-110 (the bool mask)
     launch_simmim_select(m->tok, m->inv, P + m->mask_tok, e->params + e->pos + d, b, np, d, s);             // simmim.py:102-113
-    if ((rc = engine_transformer_forward(e, m->tok, b, np, m->enc_out, err)) != VITX_OK) return rc;          // simmim.py:116
+    if ((rc = engine_transformer_forward(e, m->tok, b, np, training, seed, m->enc_out, err)) != VITX_OK) return rc;          // simmim.py:116
     launch_gather_rows(m->enc_out, (int64_t)np * d, idx_dev, nm, 0, b, nm, d, m->rows_m, s);                // simmim.py:119
     glue_fwd(m, m->px, m->x_px_T, m->rows_m, b * nm, d, P + m->w_px, P + m->b_px, pd, m->pred);             // simmim.py:122
     launch_gather_rows(m->patches, (int64_t)np * pd, idx_dev, nm, 0, b, nm, pd, m->target, s);              // simmim.py:125
@@ -459,17 +459,17 @@ int32_t vitx_mim_num_masked(vitx_mim_handle m, int32_t H, int32_t W, int32_t* nu
   return VITX_OK;
 }
 
-int32_t vitx_mim_forward_dev(vitx_mim_handle m, const float* img_dev, int32_t b, int32_t H, int32_t W, const int32_t* idx_dev, float* loss_dev) {
+int32_t vitx_mim_forward_dev(vitx_mim_handle m, const float* img_dev, int32_t b, int32_t H, int32_t W, const int32_t* idx_dev, int32_t training, uint64_t seed, float* loss_dev) {
   MIM_TRY
   if (!m || !img_dev || !idx_dev) return capi_fail(VITX_ERR_INVALID, "null argument");
   std::string err;
-  int rc = mim_forward(m, img_dev, b, H, W, idx_dev, err);
+  int rc = mim_forward(m, img_dev, b, H, W, idx_dev, training, seed, err);
   if (rc != VITX_OK) return capi_fail(rc, err);
   if (loss_dev) MIM_HIP(hipMemcpyAsync(loss_dev, m->loss, 4, hipMemcpyDeviceToDevice, m->enc->stream));
   return VITX_OK;
   MIM_CATCH
 }
-int32_t vitx_mim_forward(vitx_mim_handle m, const float* img_host, int32_t b, int32_t H, int32_t W, const int32_t* idx_host, float* loss_host) {
+int32_t vitx_mim_forward(vitx_mim_handle m, const float* img_host, int32_t b, int32_t H, int32_t W, const int32_t* idx_host, int32_t training, uint64_t seed, float* loss_host) {
   MIM_TRY
   if (!m || !img_host || !idx_host) return capi_fail(VITX_ERR_INVALID, "null argument");
   const vitx_config& c = m->enc->cfg;
@@ -483,7 +483,7 @@ int32_t vitx_mim_forward(vitx_mim_handle m, const float* img_host, int32_t b, in
   hipStream_t s = m->enc->stream;
   MIM_HIP(hipMemcpyAsync(m->img, img_host, (size_t)b * H * W * c.channels * 4, hipMemcpyHostToDevice, s));
   MIM_HIP(hipMemcpyAsync(m->idx, idx_host, (size_t)b * (m->mae ? np : nm) * 4, hipMemcpyHostToDevice, s));
-  rc = mim_forward(m, m->img, b, H, W, m->idx, err);
+  rc = mim_forward(m, m->img, b, H, W, m->idx, training, seed, err);
   if (rc != VITX_OK) return capi_fail(rc, err);
   if (loss_host) MIM_HIP(hipMemcpyAsync(loss_host, m->loss, 4, hipMemcpyDeviceToHost, s));
   MIM_HIP(hipStreamSynchronize(s));

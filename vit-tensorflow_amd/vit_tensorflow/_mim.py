@@ -178,8 +178,9 @@ class MimWrapper:
         idx = np.ascontiguousarray(np.asarray(indices, dtype=np.int32))
         self.last_indices = idx
         loss = np.zeros(1, dtype=np.float32)
+        seed = int(kwargs.get("seed", np.random.randint(0, 2 ** 31 - 1)))   # Dropout masks of the encoder (training=training, mae.py:69)
         N.check(N.lib().vitx_mim_forward(m, x.ctypes.data_as(C.c_void_p), b, H, W, idx.ctypes.data_as(C.c_void_p),
-                                         loss.ctypes.data_as(C.c_void_p)))
+                                         1 if training else 0, seed, loss.ctypes.data_as(C.c_void_p)))
         return loss[0]
 
     call = __call__

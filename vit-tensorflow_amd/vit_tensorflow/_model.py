@@ -59,8 +59,8 @@ class _TransformerProxy:
     def __init__(self, owner: "VitxModel"):
         self._owner = owner
 
-    def __call__(self, tokens, training=True, **_):
-        return self._owner._transformer_call(tokens, training)
+    def __call__(self, tokens, training=True, seed=None, **_):
+        return self._owner._transformer_call(tokens, training, seed)
 
     def backward(self, dout, want_dtokens: bool = True):
         """VJP of the last `transformer(tokens)` call: returns ({name: grad}, dtokens|None); gradients of parameters outside the
@@ -225,8 +225,10 @@ class VitxModel:
             return self._handle
         if self._borrowed:
             raise N.VitxError(N.ERR_INVALID, "batch must be in [1, max_batch] (this model's device plan belongs to its wrapper)")
-        if self._handle is not None:   # grow: keep the weights, rebuild the device plan
+        opt = None
+        if self._handle is not None:   # grow: keep the weights AND the optimizer state (both live in the handle), rebuild the device plan
             self._pull_params()
+            opt = self._pull_opt_state()
             N.check(l.vitx_destroy(self._handle))
             self._handle = None
         self._cfg.max_batch = max(int(batch), int(self._cfg.max_batch))
@@ -235,7 +237,24 @@ class VitxModel:
         self._handle = h
         self._handle_gen += 1
         self._push_params()
+        if opt is not None:
+            mom, var, step = opt
+            N.check(l.vitx_set_opt_state(h, mom.ctypes.data_as(C.c_void_p) if mom is not None else None,
+                                         var.ctypes.data_as(C.c_void_p) if var is not None else None, self._n, step))
         return h
+
+    def _pull_opt_state(self):
+        """(momentum | None, second moment | None, step) of the live handle; None when no optimizer step has run on it."""
+        l = N.lib()
+        step, hm, hv = C.c_int64(), C.c_int32(), C.c_int32()
+        N.check(l.vitx_get_opt_state(self._handle, None, None, self._n, C.byref(step), C.byref(hm), C.byref(hv)))
+        if not (hm.value or hv.value or step.value):
+            return None
+        mom = np.empty(self._n, dtype=np.float32) if hm.value else None
+        var = np.empty(self._n, dtype=np.float32) if hv.value else None
+        N.check(l.vitx_get_opt_state(self._handle, mom.ctypes.data_as(C.c_void_p) if mom is not None else None,
+                                     var.ctypes.data_as(C.c_void_p) if var is not None else None, self._n, C.byref(step), None, None))
+        return mom, var, int(step.value)
 
     def _push_params(self):
         if self._handle is not None:
@@ -289,11 +308,19 @@ class VitxModel:
     def load_state_dict(self, sd: Dict[str, np.ndarray]) -> None:
         self.set_weights([sd[n] for n, _, _ in self._table])
 
+    @staticmethod
+    def _npz_path(path: str) -> str:
+        path = str(path)
+        return path if path.endswith(".npz") else path + ".npz"    # np.savez appends the suffix: both directions agree on the name
+
     def save_weights(self, path: str) -> None:
-        np.savez(path, **self.state_dict())
+        """Weights by engine parameter name in one .npz (NOT the Keras TF-checkpoint / H5 the reference's inherited
+        Model.save_weights writes -- those formats need TensorFlow / h5py; `set_weights(list)` takes Keras' get_weights() order
+        for tensors exported elsewhere)."""
+        np.savez(self._npz_path(path), **self.state_dict())
 
     def load_weights(self, path: str) -> None:
-        with np.load(path) as z:
+        with np.load(self._npz_path(path)) as z:
             self.load_state_dict({k: z[k] for k in z.files})
 
     @property
@@ -374,13 +401,17 @@ class VitxModel:
     def _last_img_shape(self):
         return self._img_shape
 
-    def _transformer_call(self, tokens, training=True):
+    def _transformer_call(self, tokens, training=True, seed=None):
+        """Transformer.call(x, training=True) (vit.py:99-104): with training the Dropout layers inside the blocks are active
+        (masks from `seed`, drawn when None), exactly as in the full forward."""
         x, proto = self._as_host(tokens)
         assert x.ndim == 3 and x.shape[2] == self.dim, "expected tokens [b, n, dim]"
         b, n, _ = x.shape
         h = self._ensure_handle(b)
         out = np.empty_like(x)
-        N.check(N.lib().vitx_transformer_forward(h, x.ctypes.data_as(C.c_void_p), b, n, out.ctypes.data_as(C.c_void_p)))
+        seed = int(np.random.randint(0, 2 ** 31 - 1)) if seed is None else int(seed)
+        N.check(N.lib().vitx_transformer_forward(h, x.ctypes.data_as(C.c_void_p), b, n, 1 if training else 0, seed,
+                                                 out.ctypes.data_as(C.c_void_p)))
         return self._like(out, proto)
 
     def _transformer_backward(self, dout, want_dtokens=True):

@@ -88,7 +88,9 @@ SYMBOLS: List[Tuple[str, object, list]] = [
     ("vitx_forward_dev", C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_uint64, C.c_void_p]),
     ("vitx_backward", C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p]),
     ("vitx_backward_dev", C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p]),
-    ("vitx_transformer_forward", C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    ("vitx_get_opt_state", C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("vitx_set_opt_state", C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64]),
+    ("vitx_transformer_forward", C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_uint64, C.c_void_p]),
     ("vitx_transformer_backward", C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p]),
     ("vitx_patch_unfold", C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     ("vitx_embed_forward", C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
@@ -134,8 +136,8 @@ SYMBOLS: List[Tuple[str, object, list]] = [
     ("vitx_mim_params_dev", C.c_int32, [C.c_void_p, _P(C.c_void_p), _P(C.c_void_p), _P(C.c_int64)]),
     ("vitx_mim_params_changed", C.c_int32, [C.c_void_p]),
     ("vitx_mim_num_masked", C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, _P(C.c_int32), _P(C.c_int32)]),
-    ("vitx_mim_forward", C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
-    ("vitx_mim_forward_dev", C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    ("vitx_mim_forward", C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_uint64, C.c_void_p]),
+    ("vitx_mim_forward_dev", C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_uint64, C.c_void_p]),
     ("vitx_mim_backward", C.c_int32, [C.c_void_p]),
     ("vitx_mim_read", C.c_int32, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64, _P(C.c_int64)]),
     ("vitx_forward_distill", C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]),
