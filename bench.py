@@ -46,22 +46,21 @@ WORKLOADS = {
 
 
 def flops_per_image(kw) -> float:
-    from oracle import spec   # FLOP model only; no oracle compute in the timed path
+    from vit_tensorflow._model_math import flops_per_image as f   # the package's own closed form
     kw = dict(kw)
-    return spec.flops_per_image(spec.make_config(kw.pop("variant", "vit"), **kw))
+    return f(kw.pop("variant", "vit"), **kw)
 
 
-def cpu_baseline(kw, seconds: float, batch: int = 4):
-    """Reference-restatement CPU baseline (torch-CPU fp32, NOT TensorFlow: TF is absent from the image)."""
+def cpu_baseline(kw, seconds: float, batch: int = 32):
+    """Reference-restatement CPU baseline (torch-CPU fp32, NOT TensorFlow: TF is absent from the image): the oracle's op-for-op
+    restatement of vit.py, forward + autograd backward, batch 32, on the thread count that measures fastest on this host
+    (torch-CPU with hundreds of threads on a shared host oversubscribes badly; 16 / 32 / 64 are tried for one step each)."""
     from oracle import ref_torch, spec
     cfg = spec.make_config("vit", **kw)
     try:
         avail = len(os.sched_getaffinity(0))
     except Exception:
         avail = os.cpu_count() or 1
-    # a bounded thread count: torch-CPU with hundreds of threads on a shared host oversubscribes badly
-    ncores = max(1, min(avail, int(os.environ.get("VITX_CPU_BASELINE_THREADS", "16"))))
-    torch.set_num_threads(ncores)
     P = {k: torch.tensor(v, dtype=torch.float32, requires_grad=True) for k, v in spec.init_params(cfg, 1).items()}
     img = torch.randn(batch, *cfg["image_size"], 3)
     labels = torch.randint(0, cfg["num_classes"], (batch,))
@@ -72,31 +71,45 @@ def cpu_baseline(kw, seconds: float, batch: int = 4):
         logits = ref_torch.forward(cfg, P, img)
         torch.nn.functional.cross_entropy(logits, labels).backward()
 
-    step()   # warm-up
+    forced = os.environ.get("VITX_CPU_BASELINE_THREADS")
+    cands = [int(forced)] if forced else sorted({min(avail, t) for t in (16, 32, 64)})
+    torch.set_num_threads(cands[0])
+    step()   # warm-up (allocator, thread pool)
+    tried = {}
+    for t in cands:
+        torch.set_num_threads(t)
+        t0 = time.perf_counter()
+        step()
+        tried[t] = time.perf_counter() - t0
+    ncores = min(tried, key=tried.get)
+    torch.set_num_threads(ncores)
+    budget = max(0.0, seconds - sum(tried.values()))
     n, t0 = 0, time.perf_counter()
     while True:
         step()
         n += 1
         el = time.perf_counter() - t0
-        if el >= seconds or n >= 50:
+        if el >= budget or n >= 50:
             break
     return {"value": round(batch * n / el, 3), "unit": "images/sec", "cores": ncores, "host_cpus": avail, "kind": "port",
+            "threads_tried_s_per_step": {str(k): round(v, 2) for k, v in tried.items()},
             "sample": f"oracle/ref_torch.py (unfused torch-CPU fp32 restatement of vit.py, autograd backward), ViT-B/16 224 "
-                      f"batch {batch}, {n} fwd+bwd steps in {el:.1f} s; TensorFlow itself is not installable here"}
+                      f"batch {batch}, {n} fwd+bwd steps in {el:.1f} s on {ncores} threads; TensorFlow itself is not installable here"}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)    # ~2 s of GPU time at batch 256: long enough for a utilisation sampler to see it
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=256, help="images per GPU")
     ap.add_argument("--workload", default="vit_b16_224", choices=sorted(WORKLOADS))
     ap.add_argument("--compute", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--cpu-seconds", type=float, default=25.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--bucket-mb", type=float, default=48.0)
+    ap.add_argument("--grad-wire", default="fp32", choices=["fp32", "bf16"], help="dtype of the gradient all-reduce on the wire (N > 1)")
     args = ap.parse_args()
 
     # The contract is ONE JSON line on stdout.  Native libraries (RCCL prints a version banner through C stdio, flushed at exit)
@@ -154,7 +167,8 @@ def main():
         N.check(lib.vitx_set_stream(h, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
         broadcast_params(params_t, 0)
         N.check(lib.vitx_params_changed(h))
-        sync = GradSync(grads_t, bucket_elems=int(args.bucket_mb * (1 << 20) / 4), average=False, always_reduce=force_dp)
+        sync = GradSync(grads_t, bucket_elems=int(args.bucket_mb * (1 << 20) / 4), average=False, always_reduce=force_dp,
+                        wire_dtype=torch.bfloat16 if args.grad_wire == "bf16" else None)
         cb = N.GRAD_READY_FN(lambda _u, off, cnt: sync.on_ready(int(off), int(cnt)))
         N.check(lib.vitx_set_grad_ready_callback(h, cb, None))
     inv_global = 1.0 / float(b * world)   # dlogits carry 1/global_batch, so the all-reduce is a plain sum
@@ -201,7 +215,7 @@ def main():
         "dtype": "bf16" if args.compute == "bf16" else "f32", "data": "synthetic",
         "config": {"workload": f"{args.workload} fwd+bwd, batch {b}/GPU, N(0,1) NHWC images resident in HBM, random-init weights, "
                                f"softmax-CE cotangent, dropout 0", "global_batch": b * world,
-                   "parallelism": f"dp{world}", "compute": args.compute},
+                   "parallelism": f"dp{world}", "compute": args.compute, **({"grad_wire": args.grad_wire} if dp else {})},
         "path_mfma_frac": round(value / world * fpi / MFMA_BF16_PEAK, 4),
         "flops_per_image": fpi,
     }
@@ -240,13 +254,20 @@ def main():
                 ach = fl / (ms * 1e-3)
                 # HBM traffic of the family per launch: PMC counters cannot be collected from inside this process; the committed
                 # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE reduction of this very command (tools/pmc_traffic.py) is reported
+                # -- only when that profile was taken on the kernel sources this run is built from (it carries their digest)
                 traffic, traffic_src = None, None
                 try:
+                    from vit_tensorflow._model_math import kernel_source_id
                     tp = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")
                     if args.workload == "vit_b16_224" and b == 256 and os.path.exists(tp):
                         with open(tp) as f:
-                            traffic = json.load(f).get("gemm_family_hbm_bytes_per_launch")
-                        traffic_src = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this command)"
+                            prof = json.load(f)
+                        if prof.get("kernel_source_id") == kernel_source_id():
+                            traffic = prof.get("gemm_family_hbm_bytes_per_launch")
+                            traffic_src = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this command, same kernel sources)"
+                        else:
+                            traffic_src = (f"profiles/pmc_traffic.json is from other kernel sources ({prof.get('kernel_source_id')} vs "
+                                           f"{kernel_source_id()}): not quoted; re-run tools/gpu_round.sh <tag> pmc_bench")
                 except Exception:
                     traffic = None
                 out["roofline"] = {"bound": "mfma", "kernel": "+".join(s.name.decode() for s in fam), "achieved": round(ach / 1e12, 2),

@@ -1,0 +1,156 @@
+"""GPU tier: the data-parallel path with the ENGINE in the loop (tests/test_parallel.py covers the bucket logic on CPU with gloo and
+oracle gradients).  On a one-GPU box the RCCL group has one rank: that still runs the whole plumbing on hardware -- arenas bound to
+torch tensors, the engine on torch's stream, the gradient-ready callback firing per block, bucketed asynchronous ncclAllReduce
+(fp32 and bf16 on the wire), the native vitx_comm_* path -- and the result must equal the plain single-process gradient.  The
+two-rank test needs two visible GPUs and is skipped otherwise (the driver's multi-GPU node runs it)."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import ctypes as C, os, sys
+import numpy as np, torch, torch.distributed as dist
+root = sys.argv[1]; wire = sys.argv[2]; out = sys.argv[3]; gb = int(sys.argv[4])
+sys.path[:0] = [root, os.path.join(root, "vit-tensorflow_amd"), os.path.join(root, "tests")]
+from vit_tensorflow import ViT, _native as N
+from vit_tensorflow.parallel import GradSync, broadcast_params, init_from_env, shard_range
+rank, local, world = init_from_env(force=True)
+torch.cuda.set_device(local)
+dev = torch.device("cuda", local)
+kw = dict(image_size=64, patch_size=16, num_classes=10, dim=128, depth=3, heads=2, mlp_dim=256, dim_head=64)
+b = gb // world
+m = ViT(**kw, compute="bf16", max_batch=b, device=local, seed=1 + rank)      # different initial weights per rank: the broadcast must fix that
+m.build((b,))
+h, lib = m._handle, N.lib()
+stream = torch.cuda.Stream(device=dev); torch.cuda.set_stream(stream)
+n, p = C.c_int64(), C.c_void_p()
+N.check(lib.vitx_params_dev(h, C.byref(p), C.byref(n)))
+params = torch.empty(n.value, device=dev); grads = torch.zeros(n.value, device=dev)
+blob = np.empty(m._n, dtype=np.float32)
+N.check(lib.vitx_get_params(h, blob.ctypes.data_as(C.c_void_p), m._n))
+N.check(lib.vitx_bind_arenas(h, C.c_void_p(params.data_ptr()), C.c_void_p(grads.data_ptr())))
+N.check(lib.vitx_set_params(h, blob.ctypes.data_as(C.c_void_p), m._n))        # re-upload into the bound arena
+N.check(lib.vitx_set_stream(h, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+broadcast_params(params, 0); N.check(lib.vitx_params_changed(h))
+rng = np.random.Generator(np.random.PCG64(5))
+img_all = rng.standard_normal((gb, 64, 64, 3)).astype(np.float32)
+lab_all = rng.integers(0, 10, gb).astype(np.int32)
+idx = list(shard_range(gb, rank, world))
+img = torch.tensor(img_all[idx], device=dev); lab = torch.tensor(lab_all[idx], device=dev)
+sync = GradSync(grads, bucket_elems=1 << 16, average=False, always_reduce=True, wire_dtype=torch.bfloat16 if wire == "bf16" else None)
+fired = []
+cb = N.GRAD_READY_FN(lambda _u, off, cnt: (fired.append((int(off), int(cnt))), sync.on_ready(int(off), int(cnt)))[1])
+N.check(lib.vitx_set_grad_ready_callback(h, cb, None))
+for _ in range(2):
+    sync.begin()
+    N.check(lib.vitx_forward_dev(h, C.c_void_p(img.data_ptr()), b, 64, 64, 0, 0, None))
+    N.check(lib.vitx_ce_loss_grad_dev(h, C.c_void_p(lab.data_ptr()), 1.0 / gb, None))
+    N.check(lib.vitx_backward_dev(h, None, None))
+    sync.finish()
+torch.cuda.synchronize()
+assert len(fired) >= 2 * 3, fired                       # at least one report per block and step
+g = np.empty(m._n, dtype=np.float32)
+N.check(lib.vitx_get_grads(h, g.ctypes.data_as(C.c_void_p), m._n))
+np.save(os.path.join(out, f"grads_rank{rank}.npy"), g)
+if rank == 0:
+    w = np.empty(m._n, dtype=np.float32)
+    N.check(lib.vitx_get_params(h, w.ctypes.data_as(C.c_void_p), m._n))
+    np.save(os.path.join(out, "params.npy"), w); np.save(os.path.join(out, "img.npy"), img_all); np.save(os.path.join(out, "lab.npy"), lab_all)
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _single_process_gradient(tmp):
+    """The same global batch on ONE handle without any of the DP plumbing."""
+    import ctypes as C
+    from vit_tensorflow import ViT, _native as N
+    kw = dict(image_size=64, patch_size=16, num_classes=10, dim=128, depth=3, heads=2, mlp_dim=256, dim_head=64)
+    img, lab, w = np.load(tmp / "img.npy"), np.load(tmp / "lab.npy"), np.load(tmp / "params.npy")
+    gb = img.shape[0]
+    m = ViT(**kw, compute="bf16", max_batch=gb, seed=0)
+    m.build((gb,))
+    N.check(N.lib().vitx_set_params(m._handle, w.ctypes.data_as(C.c_void_p), m._n))
+    logits = np.asarray(m(img, training=False), np.float64)
+    p = np.exp(logits - logits.max(-1, keepdims=True))
+    p /= p.sum(-1, keepdims=True)
+    dl = ((p - np.eye(10)[lab]) / gb).astype(np.float32)
+    grads, _ = m.backward(dl)
+    return np.concatenate([grads[n].reshape(-1) for n, _, _ in m._table])
+
+
+def _launch(world, wire, tmp, gb=4):
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, "-c", WORKER, ROOT, wire, str(tmp), str(gb)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    for p in procs:
+        out, _ = p.communicate(timeout=600)
+        assert p.returncode == 0, out[-3000:]
+
+
+@pytest.mark.parametrize("wire", ["fp32", "bf16"])
+def test_engine_through_gradsync_on_rccl_group_of_one(wire, tmp_path):
+    _launch(1, wire, tmp_path)
+    got = np.load(tmp_path / "grads_rank0.npy")
+    ref = _single_process_gradient(tmp_path)
+    scale = np.abs(ref).max()
+    # same kernels on the same data; the DP run uses one-tile-per-workgroup GEMM variants (same K order: bit-identical sums) and the
+    # device-side CE gradient instead of a host-computed one (float32 rounding of softmax): 1e-5.  bf16 wire: one rounding per value.
+    tol = 1e-5 if wire == "fp32" else 2.0 ** -8
+    assert np.abs(got - ref).max() <= tol * scale, np.abs(got - ref).max() / scale
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two visible GPUs (the round-end multi-GPU node)")
+def test_engine_dp_two_ranks_equals_one_rank(tmp_path):
+    """Batch-sharded DP over RCCL: 2 ranks x 2 images, gradients summed (dlogits carry 1/global batch) == 1 rank x 4 images."""
+    _launch(2, "fp32", tmp_path)
+    g0, g1 = np.load(tmp_path / "grads_rank0.npy"), np.load(tmp_path / "grads_rank1.npy")
+    assert np.array_equal(g0, g1), "ranks must hold identical reduced gradients"
+    ref = _single_process_gradient(tmp_path)
+    assert np.abs(g0 - ref).max() <= 2e-2 * np.abs(ref).max()      # bf16 mode: shard sums round differently from the whole batch
+
+
+def test_native_comm_entry_points_group_of_one():
+    """vitx_comm_unique_id / vitx_comm_init / vitx_allreduce_grads (RCCL loaded with dlopen, for hosts without torch): a group of one
+    leaves the gradient arena unchanged (sum over one rank, x 1/1); calling the all-reduce without a communicator is a state error."""
+    import ctypes as C
+    from oracle import spec
+    from util import make_engine_model, oracle_cfg, rand_images
+    from vit_tensorflow import _native as N
+    cfg = oracle_cfg("vit_small")
+    m = make_engine_model("vit_small", "fp32", 2, spec.init_params(cfg, 1, randomize_all=True))
+    m(rand_images(cfg, 2), training=False)
+    dl = (np.random.default_rng(0).standard_normal((2, cfg["num_classes"])) / 2).astype(np.float32)
+    before, _ = m.backward(dl)
+    lib, h = N.lib(), m._handle
+    with pytest.raises(N.VitxError, match="vitx_comm_init"):
+        N.check(lib.vitx_allreduce_grads(h))
+    uid = (C.c_char * 128)()
+    N.check(lib.vitx_comm_unique_id(uid))
+    assert any(bytes(uid)), "ncclGetUniqueId returned an all-zero id"
+    N.check(lib.vitx_comm_init(h, 0, 1, uid))
+    N.check(lib.vitx_allreduce_grads(h))
+    N.check(lib.vitx_sync(h))
+    g = np.empty(m._n, dtype=np.float32)
+    N.check(lib.vitx_get_grads(h, g.ctypes.data_as(C.c_void_p), m._n))
+    for n, s, o in m._table:
+        assert np.array_equal(g[o:o + int(np.prod(s))].reshape(s), before[n]), n

@@ -190,3 +190,38 @@ def test_optimizer_state_survives_a_handle_regrow(tmp_path):
         m2 = make_engine_model("vit_small", "fp32", 2)
         m2.load_weights(str(tmp_path / name))
         assert all(np.array_equal(v, m2.state_dict()[k]) for k, v in m.state_dict().items())
+
+
+@pytest.mark.parametrize("name", ["vit_small", "deepvit_small", "cait_small", "cfg2_vit_b16"])
+def test_fp32_mfma_gemm_is_bit_identical_to_the_scalar_fma_gemm(name, monkeypatch):
+    """FP32_PARITY mode runs its GEMMs on the fp32 matrix pipe (v_mfma_f32_32x32x2_f32, gemm_f32_mfma.hip).  That instruction is a
+    k-ordered fmaf chain, i.e. the arithmetic of the scalar kernel it replaces: logits and every gradient must come out
+    bit-identical with VITX_F32_MFMA=0 (scalar FMA kernel) and =1 (matrix pipe) -- Dense layers, their VJPs (all three stride
+    patterns) and the batched attention products."""
+    from util import CONFIGS
+    kw = dict(CONFIGS[name][1])
+    if name == "cfg2_vit_b16":
+        kw["depth"] = 1
+    v = CONFIGS[name][0]
+    cfg = spec.make_config(v, **kw)
+    P = spec.init_params(cfg, 1, randomize_all=True)
+    img = rand_images(cfg, 2)
+    dl = (np.random.default_rng(5).standard_normal((2, cfg["num_classes"])) / 2).astype(np.float32)
+    outs = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("VITX_F32_MFMA", flag)
+        if v == "vit":
+            from vit_tensorflow import ViT as cls
+        elif v == "deepvit":
+            from vit_tensorflow.deepvit import DeepViT as cls
+        else:
+            from vit_tensorflow.cait import CaiT as cls
+        m = cls(**kw, compute="fp32", max_batch=2, seed=0)
+        m.load_state_dict({k: a.astype(np.float32) for k, a in P.items()})
+        lg = m(img, training=False)
+        g, dimg = m.backward(dl, want_dimg=True)
+        outs.append((lg, g, dimg))
+    assert np.array_equal(outs[0][0], outs[1][0])
+    assert np.array_equal(outs[0][2], outs[1][2])
+    for k in outs[0][1]:
+        assert np.array_equal(outs[0][1][k], outs[1][1][k]), k

@@ -27,7 +27,7 @@ def _flat(cfg, grads):
     return np.concatenate([grads[n].reshape(-1) for n, _, _ in spec.param_spec(cfg)])
 
 
-def _worker(rank, world, port, name, gb, out_dir):
+def _worker(rank, world, port, name, gb, out_dir, wire=None):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path[:0] = [root, os.path.join(root, "vit-tensorflow_amd"), os.path.join(root, "tests")]
@@ -50,7 +50,7 @@ def _worker(rank, world, port, name, gb, out_dir):
         k = int(np.prod(s))
         table.append((off, k))
         off += k
-    sync = GradSync(flat, bucket_elems=4096, average=True)
+    sync = GradSync(flat, bucket_elems=4096, average=True, wire_dtype=torch.bfloat16 if wire == "bf16" else None)
     sync.begin()
     for o, k in reversed(table):          # backward reports ranges from the head towards the embedding
         sync.on_ready(o, k)
@@ -77,6 +77,25 @@ def test_dp_equivalence_gloo_world2(name, tmp_path):
     r1 = np.load(tmp_path / "rank1.npy")
     assert np.array_equal(r0, r1), "ranks must hold identical reduced gradients"
     assert np.abs(r0 - ref).max() <= 1e-10 * max(1.0, np.abs(ref).max())
+
+
+def test_dp_equivalence_gloo_world2_bf16_wire(tmp_path):
+    """Gradient buckets sent as bf16 (half the xGMI bytes): both ranks end with IDENTICAL gradients, within bf16 rounding of the
+    single-process gradient (each addend rounded once to 2^-9 relative, the two-rank sum once more)."""
+    name, world, gb = "vit_small", 2, 4
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, name, gb, str(tmp_path), "bf16"), nprocs=world, join=True)
+    cfg = oracle_cfg(name)
+    P = spec.init_params(cfg, 1, randomize_all=True)
+    rng = np.random.Generator(np.random.PCG64(3))
+    img = rng.standard_normal((gb, *cfg["image_size"], 3))
+    dl = rng.standard_normal((gb, cfg["num_classes"])) / gb
+    _, grads, _ = ref_torch.forward_backward(cfg, P, img, dl)
+    ref = _flat(cfg, grads)
+    r0 = np.load(tmp_path / "rank0.npy")
+    r1 = np.load(tmp_path / "rank1.npy")
+    assert np.array_equal(r0, r1), "ranks must hold identical reduced gradients"
+    assert 0 < np.abs(r0 - ref).max() <= 2.0 ** -7 * np.abs(ref).max()   # bf16 on the wire: not exact, and bounded
 
 
 def test_gradsync_bucket_bookkeeping_single_process():

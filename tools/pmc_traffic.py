@@ -52,7 +52,9 @@ def main():
         for kv in sys.argv[2].split(","):
             k, v = kv.split("=")
             last[k] = int(v)
-    out = OrderedDict(source="rocprofv3 --pmc (separate passes) over bench.py --steps 1 --warmup 1, LAST step only",
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "vit-tensorflow_amd"))
+    from vit_tensorflow._model_math import kernel_source_id
+    out = OrderedDict(kernel_source_id=kernel_source_id(), source="rocprofv3 --pmc (separate passes) over bench.py --steps 1 --warmup 1, LAST step only",
                       corrections="fetch bytes = 2 x FETCH_SIZE x 1024 (gfx950 tallies 128-B requests at 64 B); WRITE_SIZE x 1024 as reported (uncalibrated)")
     fams = defaultdict(lambda: {"launches": 0, "fetch_bytes": 0.0, "write_bytes": 0.0})
     for counter, key, mult in (("FETCH_SIZE", "fetch_bytes", 2.0 * 1024.0), ("WRITE_SIZE", "write_bytes", 1024.0)):

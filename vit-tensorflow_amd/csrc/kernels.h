@@ -13,6 +13,11 @@ struct GenericGemmArgs {
   int64_t sAb = 0, sAh = 0, sBb = 0, sBh = 0;
 };
 void launch_gemm_generic(const GenericGemmArgs& g, const EpiParams& ep, int mode, int ta, int tb, int to, hipStream_t s);
+// ---------------------------------------------------------------- gemm_f32_mfma.hip
+// the same contract on v_mfma_f32_32x32x2_f32 for all-fp32 problems (bit-identical to the scalar kernel: a k-ordered fmaf chain);
+// launch_gemm_generic routes to it when supported (VITX_F32_MFMA=0 keeps the scalar kernel)
+bool gemm_f32_mfma_supported(const GenericGemmArgs& g, int ta, int tb, int to);
+void launch_gemm_f32_mfma(const GenericGemmArgs& g, const EpiParams& ep, int mode, hipStream_t s);
 
 // ---------------------------------------------------------------- attn_headchain.hip
 // fused head-axis chains (one wave per (image, query) row): CaiT talking heads, DeepViT re-attention, and their VJPs

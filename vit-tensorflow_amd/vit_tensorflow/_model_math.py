@@ -1,0 +1,45 @@
+"""Closed-form size figures of the models this package builds (no device work): algorithmic FLOPs per image and the identity of
+the kernel sources a measurement belongs to.  Used by bench.py and the tools; lives in the package so that the benchmark does not
+import anything from oracle/ (which is test infrastructure)."""
+from __future__ import annotations
+
+import hashlib
+import os
+from typing import Tuple, Union
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _pair(t) -> Tuple[int, int]:
+    return t if isinstance(t, tuple) else (t, t)
+
+
+def flops_per_image(variant: str = "vit", *, image_size: Union[int, Tuple[int, int]], patch_size: Union[int, Tuple[int, int]], num_classes: int,
+                    dim: int, depth: int, heads: int, mlp_dim: int, dim_head: int = 64, channels: int = 3, num_parallel_branches: int = 1,
+                    fwd_only: bool = False, **_ignored) -> float:
+    """Algorithmic FLOPs of one image: multiply-add = 2, backward = 2 x forward, no recomputation counted.
+        fwd = 2 Np pd d + L (2 N d 3I + 2 N^2 I + 2 N^2 I + 2 N I d + 4 N d m) + 2 d nc
+    with Np patches, N tokens (Np + 1; CaiT's patch stage: Np), I = heads x dim_head, pd = p1 p2 C, L = depth (x parallel branches).
+    ViT-B/16 at 224 px: 35.128 GFLOP forward, 105.383 GFLOP forward + backward."""
+    ih, iw = _pair(image_size)
+    ph, pw = _pair(patch_size)
+    np_ = (ih // ph) * (iw // pw)
+    pd = ph * pw * channels
+    inner = heads * dim_head
+    n = np_ if variant == "cait" else np_ + 1
+    layers = depth * max(1, int(num_parallel_branches))
+    fwd = 2 * np_ * pd * dim + layers * (2 * n * dim * 3 * inner + 4 * n * n * inner + 2 * n * inner * dim + 4 * n * dim * mlp_dim) + 2 * dim * num_classes
+    return float(fwd if fwd_only else 3 * fwd)
+
+
+def kernel_source_id() -> str:
+    """Digest of the HIP sources and the C header the library is built from: profiles that quote per-build counters (PMC traffic) carry
+    it, and bench.py refuses to quote a profile taken on other sources."""
+    h = hashlib.sha1()
+    root = os.path.join(_HERE, "..", "csrc")
+    files = sorted(os.path.join(root, f) for f in os.listdir(root) if f.endswith((".hip", ".h")))
+    files.append(os.path.join(_HERE, "..", "..", "include", "vitx.h"))
+    for f in files:
+        with open(f, "rb") as fh:
+            h.update(os.path.basename(f).encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]

@@ -20,8 +20,20 @@ import torch.distributed as dist
 
 
 class GradSync:
-    def __init__(self, grads: torch.Tensor, bucket_elems: int = 8 << 20, group=None, average: bool = True, always_reduce: bool = False):
+    """Bucketed asynchronous all-reduce of the flat fp32 gradient arena.
+
+    wire_dtype=torch.bfloat16 sends each bucket as bf16 (half the bytes over xGMI: 173 MB instead of 346 MB for ViT-B, 608 MB
+    instead of 1217 MB for ViT-L): the bucket is rounded to bf16 on the engine's stream, summed in bf16 by the collective and
+    widened back into the fp32 arena when the step finishes.  The rounding (2^-9 relative per addend) is the usual price of
+    compressed gradient exchange; the default keeps fp32 on the wire."""
+
+    def __init__(self, grads: torch.Tensor, bucket_elems: int = 8 << 20, group=None, average: bool = True, always_reduce: bool = False,
+                 wire_dtype: Optional[torch.dtype] = None):
         assert grads.dim() == 1 and grads.is_contiguous()
+        assert wire_dtype in (None, torch.float32, torch.bfloat16), "wire_dtype must be None / float32 / bfloat16"
+        self.wire = None if wire_dtype in (None, torch.float32) else wire_dtype
+        self._wire_buf = torch.empty(grads.numel(), dtype=self.wire, device=grads.device) if self.wire is not None else None
+        self._wired: List[int] = []
         self.grads = grads
         self.n = grads.numel()
         self.bucket = max(1, int(bucket_elems))
@@ -44,12 +56,18 @@ class GradSync:
         if self.world == 1 and not self.always_reduce:
             return
         sl = self.grads[i * self.bucket: i * self.bucket + self._size(i)]
+        if self.wire is not None:
+            wb = self._wire_buf[i * self.bucket: i * self.bucket + self._size(i)]
+            wb.copy_(sl)                      # fp32 -> bf16 on the current stream, ordered after the kernels that produced the bucket
+            self._wired.append(i)
+            sl = wb
         self._works.append(dist.all_reduce(sl, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def begin(self) -> None:
         self._covered = [0] * self.nb
         self._launched = [False] * self.nb
         self._works = []
+        self._wired = []
 
     def on_ready(self, offset: int, count: int) -> None:
         """Arena range [offset, offset+count) is final (all producing kernels enqueued on the current stream)."""
@@ -69,6 +87,10 @@ class GradSync:
         for w in self._works:
             w.wait()
         self._works = []
+        for i in self._wired:             # widen the reduced bf16 buckets back into the fp32 arena
+            lo, hi = i * self.bucket, i * self.bucket + self._size(i)
+            self.grads[lo:hi].copy_(self._wire_buf[lo:hi])
+        self._wired = []
         if self.average and self.world > 1:
             self.grads.mul_(1.0 / self.world)
 
