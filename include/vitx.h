@@ -126,6 +126,16 @@ int32_t vitx_forward_dev(vitx_handle h, const float* img_dev, int32_t b, int32_t
  * b; fills the gradient arena (overwrites, no accumulation).  dimg may be NULL (TF does not
  * differentiate w.r.t. an un-watched image). */
 int32_t vitx_backward(vitx_handle h, const float* dlogits_host, float* dimg_host_or_null);
+/* Forward from caller-supplied patch rows [b, np, patch_dim] (fp32) in place of the image + Rearrange: the first layer(s) of T2T-ViT's
+ * patch_embedding are a tokenizer pipeline (t2t.py:59-77) whose output feeds the same Dense, cls / position rows, transformer and head
+ * (t2t.py:99-121).  A backward after it returns d(patches) [b, np, patch_dim] through the dimg argument. */
+/* One shot: the NEXT host-pointer forward entry on this handle (vitx_forward, vitx_forward_distill, or vitx_distill_forward of a
+ * wrapper around it) reads its image argument as patch rows [b, np, patch_dim]; H / W are ignored there.  np = 0 clears it. */
+int32_t vitx_set_patch_input(vitx_handle h, int32_t np);
+int32_t vitx_forward_patches(vitx_handle h, const float* patches_host, int32_t b, int32_t np, int32_t training, uint64_t seed,
+                             float* logits_host);
+int32_t vitx_forward_patches_dev(vitx_handle h, const float* patches_dev, int32_t b, int32_t np, int32_t training, uint64_t seed,
+                                 float* logits_dev_or_null);
 int32_t vitx_backward_dev(vitx_handle h, const float* dlogits_dev, float* dimg_dev_or_null);
 
 /* ---- encoder.transformer(tokens, training=training) on arbitrary [b,n,dim] tokens (mae.py:69, simmim.py:116,
@@ -326,6 +336,9 @@ int32_t vitx_distill_forward_dev(vitx_distill_handle m, const float* img_dev, co
 /* VJP for the cotangent dloss [b] (NULL = ones: tape.gradient of a non-scalar target differentiates its sum): wrapper gradients
  * -> vitx_distill_get_grads, student gradients -> the student's arena. */
 int32_t vitx_distill_backward(vitx_distill_handle m, const float* dloss_host_or_null);
+/* the same, also returning d(loss)/d(input) of the student's forward: d(img) [b,H,W,C], or d(patches) [b,np,patch_dim] when that forward
+ * took patch rows (vitx_set_patch_input: a T2T-ViT student, whose tokenizer in front of the handle continues the chain) */
+int32_t vitx_distill_backward_input(vitx_distill_handle m, const float* dloss_host_or_null, float* dinput_host);
 /* "student_logits", "distill_logits" [b,num_classes], "distill_tokens" [b,dim] of the last forward */
 int32_t vitx_distill_read(vitx_distill_handle m, const char* which, float* out_host, int64_t cap_elems, int64_t* n_elems);
 

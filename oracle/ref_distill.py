@@ -1,4 +1,5 @@
-"""TEST INFRASTRUCTURE -- NOT PRODUCT CODE.  PARITY UNPINNED (see oracle/spec.py).
+"""TEST INFRASTRUCTURE -- NOT PRODUCT CODE.  Pinned by tests/golden/ref_distill_*.npz (the reference's own distill.py run under oracle/tf_shim;
+tests/test_ref_fixtures.py).
 
 Torch-CPU restatement (fp64, autograd) of vit_tensorflow/distill.py: DistillMixin.call (distill.py:16-44) and
 DistillWrapper.call (distill.py:107-134), with the Keras loss functions it calls written out:
@@ -47,11 +48,15 @@ def wrapper_param_spec(dim, num_classes):
             ("distill_mlp.kernel", (dim, num_classes)), ("distill_mlp.bias", (num_classes,))]
 
 
-def wrapper_loss(cfg, P, Wd, img, labels, teacher_logits, temperature=1.0, alpha=0.5, hard=False, literal_loss=True, q=None):
-    """DistillWrapper.call (distill.py:107-134): returns (loss [b], student_logits, distill_logits)."""
+def wrapper_loss(cfg, P, Wd, img, labels, teacher_logits, temperature=1.0, alpha=0.5, hard=False, literal_loss=True, q=None, student_fn=None):
+    """DistillWrapper.call (distill.py:107-134): returns (loss [b], student_logits, distill_logits).  student_fn(cfg, P, img, token)
+    replaces the DistillableViT forward (e.g. oracle.ref_t2t.student_forward for a DistillableT2TViT student, distill.py:60-72)."""
     T = temperature
     teacher_logits = teacher_logits.detach()                                                        # distill.py:114
-    student_logits, dtok = student_forward(cfg, P, img, Wd["distillation_token"], q)                # distill.py:116
+    if student_fn is not None:
+        student_logits, dtok = student_fn(cfg, P, img, Wd["distillation_token"])
+    else:
+        student_logits, dtok = student_forward(cfg, P, img, Wd["distillation_token"], q)            # distill.py:116
     yh = R.layer_norm(dtok, Wd["distill_mlp.norm.gamma"], Wd["distill_mlp.norm.beta"])
     distill_logits = yh @ Wd["distill_mlp.kernel"] + Wd["distill_mlp.bias"]                         # distill.py:117
     loss = -(labels * torch.log_softmax(student_logits, dim=-1)).sum(dim=-1)                        # distill.py:119

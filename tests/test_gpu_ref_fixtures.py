@@ -149,3 +149,78 @@ def test_ce_loss_gradient_matches_softmax_minus_onehot(compute):
     for n, s, o in m._table:
         a = g[o:o + int(np.prod(s))].reshape(s)
         assert np.abs(a - ref[n]).max() <= 1e-5 * np.abs(ref[n]).max() + 1e-9, n
+
+
+@pytest.mark.parametrize("case", list(G.T2T_CASES))
+def test_fp32_t2t_vit_matches_reference_source(case):
+    """T2TViT (t2t.py:49-122) against the reference's own t2t.py run under the shim: the unfold tokenizer, the tokenizer's
+    transformers at widths that are not multiples of 4 (27 / 243 and 147: the any-width LayerNorm and scalar epilogue paths), the
+    Dense on caller-supplied patch rows (vitx_forward_patches), and the whole VJP chain back to the image."""
+    from oracle import ref_t2t
+    from vit_tensorflow.t2t import T2TViT
+    kw = G.T2T_CASES[case]
+    z = np.load(os.path.join(GOLDEN_DIR, f"ref_{case}.npz"))
+    cfg = ref_t2t.make_config(**kw)
+    P = ref_t2t.init_params(cfg, seed=int(z["param_seed"]))
+    assert abs(sum(float(np.abs(v).sum()) for v in P.values()) - float(z["param_checksum"])) < 1e-6
+    m = T2TViT(**kw, compute="fp32", max_batch=2, seed=0)
+    assert [n for n, _, _, _ in m._name_map()] == [n for n, _, _ in ref_t2t.param_spec(cfg)]
+    m.load_state_dict({k: v.astype(np.float32) for k, v in P.items()})
+    logits = m(z["img"], training=True)
+    err = float(np.abs(logits - z["logits"]).max())
+    assert err <= FP32_LOGIT_TOL, err
+    grads, dimg = m.backward(z["dlogits"], want_dimg=True)
+    worst = ("", 0.0)
+    for n, _, _ in ref_t2t.param_spec(cfg):
+        e = rel_max_err(grads[n], z["grad/" + n])
+        worst = max(worst, (n, e), key=lambda t: t[1])
+        assert e <= FP32_GRAD_RTOL, f"{case}: grad {n} rel err {e:.3e}"
+    assert rel_max_err(dimg, z["dimg"]) <= FP32_GRAD_RTOL
+    print(f"[ref:{case}] fp32 max|dlogit| {err:.3e}, worst grad rel err {worst[1]:.3e} ({worst[0]})")
+
+
+@pytest.mark.parametrize("case", list(G.DISTILL_CASES))
+def test_fp32_distill_matches_reference_source(case):
+    """distill.py run under the shim vs the engine: Distillable{ViT,T2TViT}.call(img, distill_token) -> (logits, distill_tokens)
+    with its VJP, and DistillWrapper((img, labels)) -> per-image loss (soft mode exactly as written) with every gradient."""
+    from oracle import ref_distill, ref_t2t
+    from vit_tensorflow.distill import DistillableT2TViT, DistillableViT, DistillWrapper
+    kind, kw, wkw = G.DISTILL_CASES[case]
+    z = np.load(os.path.join(GOLDEN_DIR, f"ref_{case}.npz"))
+    if kind == "vit":
+        cfg = spec.make_config("vit", **kw)
+        P = spec.init_params(cfg, seed=1, randomize_all=True)
+        stu = DistillableViT(**kw, compute="fp32", max_batch=2, seed=0)
+    else:
+        cfg = ref_t2t.make_config(**kw)
+        P = ref_t2t.init_params(cfg, seed=1)
+        stu = DistillableT2TViT(**kw, compute="fp32", max_batch=2, seed=0)
+    assert abs(sum(float(np.abs(v).sum()) for v in P.values()) - float(z["param_checksum"])) < 1e-6
+    stu.load_state_dict({k: v.astype(np.float32) for k, v in P.items()})
+    logits, dtok = stu(z["img"], distill_token=z["call/token"].astype(np.float32), training=True)
+    assert np.abs(logits - z["call/logits"]).max() <= FP32_LOGIT_TOL
+    assert np.abs(dtok - z["call/distill_tokens"]).max() <= FP32_LOGIT_TOL
+    grads, dt = stu.backward_distill(z["call/dlogits"], z["call/d_distill_tokens"])
+    assert rel_max_err(dt.reshape(-1), z["call/grad_token"].reshape(-1)) <= FP32_GRAD_RTOL
+    for n in P:
+        assert rel_max_err(grads[n], z["call/grad/" + n]) <= FP32_GRAD_RTOL, n
+    # the wrapper: a teacher that returns the fixture's logits
+    w = DistillWrapper(teacher=lambda im, training=True: z["wrap/teacher_logits"], student=stu, hard=False, literal_loss=True, seed=0, **wkw)
+    w.load_state_dict({n: z["wrap/param/" + n].astype(np.float32) for n, _ in ref_distill.wrapper_param_spec(cfg["dim"], cfg["num_classes"])})
+    loss = w((z["img"], z["wrap/labels"]), training=True)
+    assert np.abs(loss - z["wrap/loss"]).max() <= 1e-4 * np.abs(z["wrap/loss"]).max()
+    g = w.backward()
+    for n, _ in ref_distill.wrapper_param_spec(cfg["dim"], cfg["num_classes"]):
+        ref = z["wrap/grad/" + n]
+        assert np.abs(g[n] - ref).max() <= FP32_GRAD_RTOL * np.abs(ref).max() + 1e-7, n     # distill_mlp.*: exactly zero in this mode
+    for n in P:
+        assert rel_max_err(g["student." + n], z["wrap/grad/student." + n]) <= FP32_GRAD_RTOL, n
+
+
+def test_distillable_efficient_vit_fails_like_the_reference():
+    """distill.py:74-85: DistillMixin.call reaches self.dropout, which efficient.ViT never defines -- the reference's class raises
+    AttributeError on its first call; the drop-in constructs and raises the same."""
+    from vit_tensorflow.distill import DistillableEfficientViT
+    m = DistillableEfficientViT(image_size=32, patch_size=8, num_classes=7, dim=32, transformer=lambda t, training=True: t)
+    with pytest.raises(AttributeError, match="dropout"):
+        m(np.zeros((1, 32, 32, 3), np.float32))

@@ -85,3 +85,69 @@ def test_committed_fixture_is_what_the_reference_source_produces(case):
 
 def test_shim_does_not_leak_into_this_process():
     assert "tensorflow" not in sys.modules or not getattr(sys.modules["tensorflow"], "__vitx_shim__", False)
+
+
+@pytest.mark.parametrize("case", list(G.T2T_CASES))
+def test_t2t_oracle_reproduces_reference_fixture(case):
+    """oracle/ref_t2t.py (T2TViT, t2t.py:49-122) against the fixture the reference's own t2t.py produced under the shim."""
+    from oracle import ref_t2t
+    z = _load(case)
+    cfg = ref_t2t.make_config(**G.T2T_CASES[case])
+    P = ref_t2t.init_params(cfg, seed=int(z["param_seed"]))
+    assert abs(sum(float(np.abs(v).sum()) for v in P.values()) - float(z["param_checksum"])) < 1e-6
+    logits, grads, dimg = ref_t2t.forward_backward(cfg, P, z["img"], z["dlogits"])
+    assert np.abs(logits - z["logits"]).max() <= F64_TOL
+    for n, _, _ in ref_t2t.param_spec(cfg):
+        ref = z["grad/" + n]
+        assert np.abs(ref).max() > 0, n
+        assert np.abs(grads[n] - ref).max() <= F64_TOL * max(1.0, np.abs(ref).max()), n
+    assert np.abs(dimg - z["dimg"]).max() <= F64_TOL * max(1.0, np.abs(z["dimg"]).max())
+
+
+def _distill_oracle(case):
+    """(cfg, P, student_fn) of a distill fixture's student, in the oracle's terms."""
+    from oracle import ref_distill, ref_t2t
+    kind, kw, _ = G.DISTILL_CASES[case]
+    if kind == "vit":
+        cfg = spec.make_config("vit", **kw)
+        return cfg, spec.init_params(cfg, seed=1, randomize_all=True), (lambda c, P, im, tok: ref_distill.student_forward(c, P, im, tok))
+    cfg = ref_t2t.make_config(**kw)
+    return cfg, ref_t2t.init_params(cfg, seed=1), ref_t2t.student_forward
+
+
+@pytest.mark.parametrize("case", list(G.DISTILL_CASES))
+def test_distill_oracle_reproduces_reference_fixture(case):
+    """oracle/ref_distill.py (+ ref_t2t.student_forward) against what the reference's own distill.py produced under the shim:
+    Distillable*.call(img, distill_token) with its VJP, and DistillWrapper's per-image loss (soft mode, as written: Keras'
+    KLDivergence clips the log-probabilities it is handed) with d(sum loss)/d(every variable)."""
+    import torch
+    from oracle import ref_distill
+    z = _load(case)
+    cfg, P, student_fn = _distill_oracle(case)
+    assert abs(sum(float(np.abs(v).sum()) for v in P.values()) - float(z["param_checksum"])) < 1e-6
+    Pt = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in P.items()}
+    img = torch.tensor(z["img"].astype(np.float64))
+    tok = torch.tensor(z["call/token"], requires_grad=True)
+    logits, dt = student_fn(cfg, Pt, img, tok)
+    assert np.abs(logits.detach().numpy() - z["call/logits"]).max() <= F64_TOL
+    assert np.abs(dt.detach().numpy() - z["call/distill_tokens"]).max() <= F64_TOL
+    ((logits * torch.tensor(z["call/dlogits"].astype(np.float64))).sum() + (dt * torch.tensor(z["call/d_distill_tokens"].astype(np.float64))).sum()).backward()
+    assert np.abs(tok.grad.numpy() - z["call/grad_token"]).max() <= F64_TOL * max(1.0, np.abs(z["call/grad_token"]).max())
+    for n, v in Pt.items():
+        ref = z["call/grad/" + n]
+        assert np.abs(v.grad.numpy() - ref).max() <= F64_TOL * max(1.0, np.abs(ref).max()), n
+    # the wrapper
+    Pt = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in P.items()}
+    Wd = {n: torch.tensor(z["wrap/param/" + n], dtype=torch.float64, requires_grad=True) for n, _ in ref_distill.wrapper_param_spec(cfg["dim"], cfg["num_classes"])}
+    loss, _, _ = ref_distill.wrapper_loss(cfg, Pt, Wd, img, torch.tensor(z["wrap/labels"].astype(np.float64)),
+                                          torch.tensor(z["wrap/teacher_logits"].astype(np.float64)), temperature=float(z["wrap/temperature"]),
+                                          alpha=float(z["wrap/alpha"]), hard=False, literal_loss=True, student_fn=student_fn)
+    assert np.abs(loss.detach().numpy() - z["wrap/loss"]).max() <= 1e-10 * np.abs(z["wrap/loss"]).max()
+    loss.sum().backward()
+    for n, v in Wd.items():
+        ref = z["wrap/grad/" + n]
+        g = v.grad.numpy() if v.grad is not None else np.zeros_like(ref)
+        assert np.abs(g - ref).max() <= F64_TOL * max(1.0, np.abs(ref).max()), n
+    for n, v in Pt.items():
+        ref = z["wrap/grad/student." + n]
+        assert np.abs(v.grad.numpy() - ref).max() <= 1e-11 * max(1.0, np.abs(ref).max()), n

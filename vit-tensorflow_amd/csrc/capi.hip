@@ -175,16 +175,64 @@ int32_t vitx_forward_dev(vitx_handle h, const float* img_dev, int32_t b, int32_t
   CAPI_CATCH
 }
 
+int32_t vitx_set_patch_input(vitx_handle h, int32_t np) {
+  if (!h) return fail(VITX_ERR_INVALID, "null handle");
+  if (np < 0 || np > h->np_max) return fail(VITX_ERR_INVALID, "set_patch_input: np must be in [0, num_patches]");
+  h->next_patch_np = np;
+  return VITX_OK;
+}
+
 int32_t vitx_forward(vitx_handle h, const float* img_host, int32_t b, int32_t H, int32_t W, int32_t training, uint64_t seed,
                      float* logits_host) {
   CAPI_TRY
   if (!h || !img_host || !logits_host) return fail(VITX_ERR_INVALID, "null argument");
+  if (h->next_patch_np > 0) {   // one-shot: img_host holds patch rows [b, np, patch_dim]
+    const int np = h->next_patch_np;
+    h->next_patch_np = 0;
+    return vitx_forward_patches(h, img_host, b, np, training, seed, logits_host);
+  }
   if (b <= 0 || b > h->cfg.max_batch) return fail(VITX_ERR_INVALID, "batch must be in [1, max_batch]");
   if (H <= 0 || W <= 0 || H > h->cfg.image_h || W > h->cfg.image_w)
     return fail(VITX_ERR_INVALID, "image larger than the configured image_size");
   CAPI_HIP(hipMemcpyAsync(h->img_dev, img_host, (size_t)b * H * W * h->cfg.channels * 4, hipMemcpyHostToDevice, h->stream));
   std::string err;
   int rc = engine_forward(h, h->img_dev, b, H, W, training, seed, nullptr, err);
+  if (rc != VITX_OK) return fail(rc, err);
+  CAPI_HIP(hipMemcpy2DAsync(logits_host, (size_t)h->cfg.num_classes * 4, h->logits, (size_t)h->nc_k * 4, (size_t)h->cfg.num_classes * 4,
+                            (size_t)b, hipMemcpyDeviceToHost, h->stream));
+  CAPI_HIP(hipStreamSynchronize(h->stream));
+  return VITX_OK;
+  CAPI_CATCH
+}
+
+// Forward from caller-supplied patch rows [b, np, patch_dim] (fp32) instead of an image: the patch Dense, cls / position rows, the
+// transformer and the head run as usual.  vitx_backward(_dev) after it returns d(patches) [b, np, patch_dim] where it would return
+// d(img).  T2T-ViT's patch_embedding is a tokenizer pipeline that ends in this Dense (t2t.py:59-77).
+int32_t vitx_forward_patches_dev(vitx_handle h, const float* patches_dev, int32_t b, int32_t np, int32_t training, uint64_t seed,
+                                 float* logits_dev) {
+  CAPI_TRY
+  if (!h || !patches_dev) return fail(VITX_ERR_INVALID, "null argument");
+  h->fwd_patches = patches_dev;
+  h->fwd_np = np;
+  std::string err;
+  int rc = engine_forward(h, nullptr, b, 0, 0, training, seed, logits_dev, err);
+  h->fwd_patches = nullptr;
+  if (rc != VITX_OK) return fail(rc, err);
+  return VITX_OK;
+  CAPI_CATCH
+}
+int32_t vitx_forward_patches(vitx_handle h, const float* patches_host, int32_t b, int32_t np, int32_t training, uint64_t seed,
+                             float* logits_host) {
+  CAPI_TRY
+  if (!h || !patches_host || !logits_host) return fail(VITX_ERR_INVALID, "null argument");
+  if (b <= 0 || b > h->cfg.max_batch) return fail(VITX_ERR_INVALID, "batch must be in [1, max_batch]");
+  if (np <= 0 || np > h->np_max) return fail(VITX_ERR_INVALID, "forward_patches: np must be in [1, num_patches]");
+  CAPI_HIP(hipMemcpyAsync(h->img_dev, patches_host, (size_t)b * np * h->pd * 4, hipMemcpyHostToDevice, h->stream));
+  h->fwd_patches = h->img_dev;
+  h->fwd_np = np;
+  std::string err;
+  int rc = engine_forward(h, nullptr, b, 0, 0, training, seed, nullptr, err);
+  h->fwd_patches = nullptr;
   if (rc != VITX_OK) return fail(rc, err);
   CAPI_HIP(hipMemcpy2DAsync(logits_host, (size_t)h->cfg.num_classes * 4, h->logits, (size_t)h->nc_k * 4, (size_t)h->cfg.num_classes * 4,
                             (size_t)b, hipMemcpyDeviceToHost, h->stream));

@@ -223,7 +223,7 @@ int distill_forward(vitx_distill* m, const float* img_dev, const float* labels_d
 }
 
 // dloss_host [b] or null (= ones: tf's tape.gradient of a non-scalar target differentiates its sum)
-int distill_backward(vitx_distill* m, const float* dloss_host, std::string& err) {
+int distill_backward(vitx_distill* m, const float* dloss_host, std::string& err, float* dinput_dev = nullptr) {
   if (!m->have_fwd) { err = "backward requires a preceding forward"; return VITX_ERR_STATE; }
   vitx_engine* e = m->stu;
   hipStream_t s = e->stream;
@@ -259,7 +259,7 @@ int distill_backward(vitx_distill* m, const float* dloss_host, std::string& err)
   }
   launch_layernorm_bwd(m->g_yh, 0, d, m->dtok, d, m->mean, m->rstd, P + m->ln_g, nullptr, 0, m->g_dtok, d, nullptr, 0, m->ws, G + m->ln_g, G + m->ln_b,
                        nullptr, b, d, s);
-  return engine_backward(e, m->g_slog, nullptr, err, m->g_dtok, G + m->tok);
+  return engine_backward(e, m->g_slog, dinput_dev, err, m->g_dtok, G + m->tok);
 }
 
 }  // namespace
@@ -293,12 +293,16 @@ int32_t vitx_forward_distill(vitx_handle h, const float* img_host, int32_t b, in
   D_TRY
   if (!h || !img_host || !distill_token_host || !logits_host || !distill_tokens_host) return capi_fail(VITX_ERR_INVALID, "null argument");
   if (b <= 0 || b > h->cfg.max_batch) return capi_fail(VITX_ERR_INVALID, "batch must be in [1, max_batch]");
-  if (H <= 0 || W <= 0 || H > h->cfg.image_h || W > h->cfg.image_w) return capi_fail(VITX_ERR_INVALID, "image larger than the configured image_size");
+  const int np_in = h->next_patch_np;   // > 0: img_host holds patch rows [b, np, patch_dim] (vitx_set_patch_input, one shot)
+  h->next_patch_np = 0;
+  if (!np_in && (H <= 0 || W <= 0 || H > h->cfg.image_h || W > h->cfg.image_w)) return capi_fail(VITX_ERR_INVALID, "image larger than the configured image_size");
   const int d = h->cfg.dim, nc = h->cfg.num_classes;
   hipStream_t s = h->stream;
   float* tok = distill_scratch(h);   // row 0 = the token, rows 1.. = the returned per-image tokens
   if (!tok) return capi_fail(VITX_ERR_HIP, "hipMalloc failed");
-  D_HIP(hipMemcpyAsync(h->img_dev, img_host, (size_t)b * H * W * h->cfg.channels * 4, hipMemcpyHostToDevice, s));
+  const size_t in_elems = np_in ? (size_t)b * np_in * h->pd : (size_t)b * H * W * h->cfg.channels;
+  D_HIP(hipMemcpyAsync(h->img_dev, img_host, in_elems * 4, hipMemcpyHostToDevice, s));
+  if (np_in) { h->fwd_patches = h->img_dev; h->fwd_np = np_in; }
   D_HIP(hipMemcpyAsync(tok, distill_token_host, (size_t)d * 4, hipMemcpyHostToDevice, s));
   std::string err;
   int rc = engine_forward(h, h->img_dev, b, H, W, training, seed, nullptr, err, tok, tok + d);
@@ -404,9 +408,13 @@ int32_t vitx_distill_forward(vitx_distill_handle m, const float* img_host, const
   if (!m || !img_host || !labels_host || !teacher_logits_host) return capi_fail(VITX_ERR_INVALID, "null argument");
   const vitx_config& c = m->stu->cfg;
   if (b <= 0 || b > c.max_batch) return capi_fail(VITX_ERR_INVALID, "batch must be in [1, max_batch]");
-  if (H <= 0 || W <= 0 || H > c.image_h || W > c.image_w) return capi_fail(VITX_ERR_INVALID, "image larger than the configured image_size");
+  const int np_in = m->stu->next_patch_np;   // > 0: img_host holds patch rows [b, np, patch_dim] (vitx_set_patch_input on the student, one shot)
+  m->stu->next_patch_np = 0;
+  if (!np_in && (H <= 0 || W <= 0 || H > c.image_h || W > c.image_w)) return capi_fail(VITX_ERR_INVALID, "image larger than the configured image_size");
   hipStream_t s = m->stu->stream;
-  D_HIP(hipMemcpyAsync(m->img, img_host, (size_t)b * H * W * c.channels * 4, hipMemcpyHostToDevice, s));
+  const size_t in_elems = np_in ? (size_t)b * np_in * m->stu->pd : (size_t)b * H * W * c.channels;
+  D_HIP(hipMemcpyAsync(m->img, img_host, in_elems * 4, hipMemcpyHostToDevice, s));
+  if (np_in) { m->stu->fwd_patches = m->img; m->stu->fwd_np = np_in; }
   D_HIP(hipMemcpyAsync(m->labels, labels_host, (size_t)b * m->nc * 4, hipMemcpyHostToDevice, s));
   D_HIP(hipMemcpyAsync(m->teacher, teacher_logits_host, (size_t)b * m->nc * 4, hipMemcpyHostToDevice, s));
   std::string err;
@@ -434,6 +442,20 @@ int32_t vitx_distill_backward(vitx_distill_handle m, const float* dloss_host_or_
   std::string err;
   int rc = distill_backward(m, dloss_host_or_null, err);
   if (rc != VITX_OK) return capi_fail(rc, err);
+  return VITX_OK;
+  D_CATCH
+}
+// the same, also returning d(loss)/d(input) of the student's forward: d(img) [b, H, W, C], or d(patches) [b, np, patch_dim] when that
+// forward took patch rows (a T2T-ViT student: the tokenizer in front of the handle needs it to continue the chain)
+int32_t vitx_distill_backward_input(vitx_distill_handle m, const float* dloss_host_or_null, float* dinput_host) {
+  D_TRY
+  if (!m || !dinput_host) return capi_fail(VITX_ERR_INVALID, "null argument");
+  std::string err;
+  int rc = distill_backward(m, dloss_host_or_null, err, m->img);
+  if (rc != VITX_OK) return capi_fail(rc, err);
+  vitx_engine* e = m->stu;
+  D_HIP(hipMemcpyAsync(dinput_host, m->img, (size_t)e->last_b * e->last_H * e->last_W * e->cfg.channels * 4, hipMemcpyDeviceToHost, e->stream));
+  D_HIP(hipStreamSynchronize(e->stream));
   return VITX_OK;
   D_CATCH
 }

@@ -128,6 +128,79 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
   }
 }
 
+// Any-width forms (d % 4 != 0, or rows that do not start 16-B aligned: T2T-ViT's 147- and 1323-wide token transformers, t2t.py:62-70):
+// one wave per row, one element per lane and step.  Same arithmetic as the vector kernels (two-pass statistics, biased variance).
+template <typename TO>
+__global__ __launch_bounds__(256) void layernorm_fwd_any_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, TO* __restrict__ y, int64_t ldy,
+                                                                float* __restrict__ mean, float* __restrict__ rstd, int rows, int d, float eps) {
+  const int row = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* xr = x + (int64_t)row * ldx;
+  float s = 0.f;
+  for (int c = lane; c < d; c += 64) s += xr[c];
+  const float mu = wave_sum(s) / (float)d;
+  float q = 0.f;
+  for (int c = lane; c < d; c += 64) { const float a = xr[c] - mu; q += a * a; }
+  const float rs = rsqrtf(wave_sum(q) / (float)d + eps);
+  if (lane == 0) {
+    if (mean) mean[row] = mu;
+    if (rstd) rstd[row] = rs;
+  }
+  TO* yr = y + (int64_t)row * ldy;
+  for (int c = lane; c < d; c += 64) stf<TO>(yr + c, (xr[c] - mu) * rs * gamma[c] + beta[c]);
+}
+// dx (+ g_in) -> g_out / g_lp per row; the column reductions (dgamma, dbeta, column sums of g_in) are a second, column-parallel kernel
+template <typename TD, typename TL>
+__global__ __launch_bounds__(256) void layernorm_bwd_any_rows_kernel(const TD* __restrict__ dy, int64_t lddy, const float* __restrict__ x, int64_t ldx,
+                                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                     const float* __restrict__ gamma, const float* g_in, int64_t ldgi, float* g_out,
+                                                                     int64_t ldgo, TL* g_lp, int64_t ldglp, int rows, int d) {
+  const int row = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float mu = mean[row], rs = rstd[row];
+  const float* xr = x + (int64_t)row * ldx;
+  const TD* dr = dy + (int64_t)row * lddy;
+  float s1 = 0.f, s2 = 0.f;
+  for (int c = lane; c < d; c += 64) {
+    const float gg = ldf<TD>(dr + c) * gamma[c];
+    s1 += gg;
+    s2 += gg * ((xr[c] - mu) * rs);
+  }
+  const float invd = 1.0f / (float)d;
+  s1 = wave_sum(s1) * invd;
+  s2 = wave_sum(s2) * invd;
+  for (int c = lane; c < d; c += 64) {
+    const float xh = (xr[c] - mu) * rs;
+    float dx = rs * (ldf<TD>(dr + c) * gamma[c] - s1 - xh * s2);
+    if (g_in) dx += g_in[(int64_t)row * ldgi + c];
+    g_out[(int64_t)row * ldgo + c] = dx;
+    if (g_lp) stf<TL>(g_lp + (int64_t)row * ldglp + c, dx);
+  }
+}
+// partial[chunk][0][c] = sum_rows dy*xhat, [1] = sum_rows dy, [2] = sum_rows g_in (rows of the chunk in ascending order: fixed order)
+template <typename TD>
+__global__ __launch_bounds__(256) void layernorm_bwd_any_cols_kernel(const TD* __restrict__ dy, int64_t lddy, const float* __restrict__ x, int64_t ldx,
+                                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                     const float* g_in, int64_t ldgi, float* __restrict__ partial, int rows, int d,
+                                                                     int want_gsum) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= d) return;
+  const int per = (rows + gridDim.y - 1) / gridDim.y;
+  const int r0 = blockIdx.y * per, r1 = min(rows, r0 + per);
+  float ag = 0.f, ab = 0.f, as = 0.f;
+  for (int r = r0; r < r1; ++r) {
+    const float dv = ldf<TD>(dy + (int64_t)r * lddy + c);
+    ab += dv;
+    ag += dv * ((x[(int64_t)r * ldx + c] - mean[r]) * rstd[r]);
+    if (want_gsum) as += g_in[(int64_t)r * ldgi + c];
+  }
+  float* p = partial + (int64_t)blockIdx.y * 3 * d;
+  p[c] = ag; p[d + c] = ab; p[2 * d + c] = as;
+}
+
 constexpr int LNB_BLOCKS = 512;
 constexpr int LNB_THREADS = 512;   // 8 waves per block: 4096 waves in flight with only 512 partial rows to reduce
 
@@ -642,10 +715,23 @@ void launch_cls_pos_row(float* x, const float* cls, const float* pos, int b, int
     else { CALL(16); }                                  \
   } while (0)
 
+// the four-columns-per-lane LayerNorm kernels need d % 4 == 0 and 16-B aligned rows everywhere; anything else takes the any-width forms
+static bool ln_vec_ok(int d, std::initializer_list<int64_t> lds, std::initializer_list<const void*> ptrs) {
+  if (d % 4) return false;
+  for (int64_t l : lds) if (l % 4) return false;
+  for (const void* p : ptrs) if (((uintptr_t)p) % 16) return false;
+  return true;
+}
+
 void launch_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, void* y, int y_bf16, int64_t ldy,
                           float* mean, float* rstd, int rows, int d, float eps, hipStream_t s) {
   if (rows == 0) return;
   dim3 grid((unsigned)ceil_div(rows, 4)), block(256);
+  if (!ln_vec_ok(d, {ldx, ldy}, {x, gamma, beta, y})) {
+    if (y_bf16) hipLaunchKernelGGL(layernorm_fwd_any_kernel<bf16_t>, grid, block, 0, s, x, ldx, gamma, beta, (bf16_t*)y, ldy, mean, rstd, rows, d, eps);
+    else hipLaunchKernelGGL(layernorm_fwd_any_kernel<float>, grid, block, 0, s, x, ldx, gamma, beta, (float*)y, ldy, mean, rstd, rows, d, eps);
+    return;
+  }
 #define CALL(V)                                                                                                             \
   if (y_bf16) hipLaunchKernelGGL((layernorm_fwd_kernel<bf16_t, V>), grid, block, 0, s, x, ldx, gamma, beta, (bf16_t*)y, ldy, \
                                  mean, rstd, rows, d, eps);                                                                 \
@@ -661,6 +747,23 @@ void launch_layernorm_bwd(const void* dy, int dy_bf16, int64_t lddy, const float
                           float* partial_ws, float* dgamma, float* dbeta, float* gsum, int rows, int d, hipStream_t s) {
   if (rows == 0) return;
   const int want_gsum = (gsum != nullptr && g_in != nullptr) ? 1 : 0;
+  if (!ln_vec_ok(d, {lddy, ldx, g_in ? ldgi : 0, ldgo, g_lp ? ldglp : 0}, {dy, x, gamma, g_in, g_out, g_lp})) {
+    dim3 rgrid((unsigned)ceil_div(rows, 4)), block(256);
+    const int chunks = (int)std::max<int64_t>(1, std::min<int64_t>(LNB_BLOCKS, ceil_div(rows, 64)));
+    dim3 cgrid((unsigned)ceil_div(d, 256), (unsigned)chunks);
+    if (dy_bf16) {
+      hipLaunchKernelGGL((layernorm_bwd_any_cols_kernel<bf16_t>), cgrid, block, 0, s, (const bf16_t*)dy, lddy, x, ldx, mean, rstd, g_in, ldgi, partial_ws, rows, d, want_gsum);
+      hipLaunchKernelGGL((layernorm_bwd_any_rows_kernel<bf16_t, bf16_t>), rgrid, block, 0, s, (const bf16_t*)dy, lddy, x, ldx, mean, rstd, gamma, g_in, ldgi, g_out, ldgo,
+                         (bf16_t*)g_lp, ldglp, rows, d);
+    } else {
+      hipLaunchKernelGGL((layernorm_bwd_any_cols_kernel<float>), cgrid, block, 0, s, (const float*)dy, lddy, x, ldx, mean, rstd, g_in, ldgi, partial_ws, rows, d, want_gsum);
+      hipLaunchKernelGGL((layernorm_bwd_any_rows_kernel<float, float>), rgrid, block, 0, s, (const float*)dy, lddy, x, ldx, mean, rstd, gamma, g_in, ldgi, g_out, ldgo,
+                         (float*)g_lp, ldglp, rows, d);
+    }
+    // (the column kernel runs FIRST: g_out may alias g_in, which it reads)
+    launch_reduce_partials3(partial_ws, chunks, (int64_t)3 * d, d, want_gsum ? 3 : 2, dgamma, dbeta, gsum, partial_ws + (int64_t)LNB_BLOCKS * 3 * d, 1.0f, s);
+    return;
+  }
   const int nblk = (int)std::min<int64_t>(LNB_BLOCKS, ceil_div(rows, 8));
   dim3 grid(nblk), block(LNB_THREADS);
   const size_t shm = (size_t)(LNB_THREADS / 64) * d * sizeof(float);

@@ -131,6 +131,10 @@ struct vitx_engine {
   // state of the last forward
   bool have_fwd = false;
   bool have_tf = false;              // saved activations describe a transformer_forward(tokens) of [tf_b, tf_n, dim]
+  int next_patch_np = 0;                // vitx_set_patch_input: the next host-pointer forward entry reads patch rows [b, np, pd] (one shot)
+  const float* fwd_patches = nullptr;   // set by the forward_patches entry points for the next engine_forward (consumed there)
+  int fwd_np = 0;
+  bool last_from_patches = false;
   int tf_b = 0, tf_n = 0;
   float tf_drop = 0.f;               // dropout rate that transformer_forward applied (0 unless training) and the seed of its masks
   uint64_t tf_seed = 0;

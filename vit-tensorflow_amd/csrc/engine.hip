@@ -835,7 +835,7 @@ static int engine_create_body(vitx_engine* e, const vitx_config& cfg, std::strin
   e->pd = c.patch_h * c.patch_w * c.channels;
   e->pd_k = (int)round_up(e->pd, 64);
   e->nc_k = (int)round_up(c.num_classes, 64);
-  if (c.dim % 4 != 0 || c.dim > 4096) { err = "dim must be a multiple of 4 and <= 4096"; return VITX_ERR_UNSUPPORTED; }
+  if (c.dim > 4096) { err = "dim must be <= 4096"; return VITX_ERR_UNSUPPORTED; }   // (any width: rows that are not multiples of 4 floats take the scalar-tail kernels)
   if (c.heads > 32 && c.variant != VITX_VARIANT_VIT) { err = "heads > 32 unsupported for DeepViT/CaiT"; return VITX_ERR_UNSUPPORTED; }
   if (e->bf16 && (c.dim % 64 || e->inner % 64 || c.mlp_dim % 64)) {
     err = "BF16 compute needs dim, heads*dim_head and mlp_dim to be multiples of 64 (use FP32_PARITY otherwise)";
@@ -1251,7 +1251,14 @@ int engine_forward(vitx_engine* e, const float* img_dev, int b, int H, int W, in
   const int extra = distill_token_dev ? 1 : 0;
   if (extra && c.variant == VITX_VARIANT_CAIT) { err = "distillation token: ViT / DeepViT only"; return VITX_ERR_UNSUPPORTED; }
   if (b <= 0 || b > c.max_batch) { err = "batch must be in [1, max_batch]"; return VITX_ERR_INVALID; }
-  if (H <= 0 || W <= 0 || H > c.image_h || W > c.image_w || H % c.patch_h || W % c.patch_w) {
+  // caller-supplied patch rows [b, np, pd] instead of an image (engine_forward_patches: T2T-ViT's tokenizer output feeding the
+  // patch Dense, t2t.py:74-75,106): the unfold is skipped, everything else is the ordinary forward
+  const float* patches_in = e->fwd_patches;
+  e->fwd_patches = nullptr;
+  if (patches_in) {
+    if (e->fwd_np <= 0 || e->fwd_np > e->np_max) { err = "forward_patches: np must be in [1, num_patches]"; return VITX_ERR_INVALID; }
+    H = e->fwd_np * c.patch_h; W = c.patch_w;      // np x 1 patches: keeps b * H * W * C == b * np * pd for the staging buffers
+  } else if (H <= 0 || W <= 0 || H > c.image_h || W > c.image_w || H % c.patch_h || W % c.patch_w) {
     err = "Image dimensions must be divisible by the patch size.";            // and fit the configured pos_embedding (vit.py:165)
     return VITX_ERR_INVALID;
   }
@@ -1266,10 +1273,13 @@ int engine_forward(vitx_engine* e, const float* img_dev, int b, int H, int W, in
   Stage& s0 = e->stages[0];
   float* x0 = s0.depth > 0 ? s0.ba[0].x_in : e->tmp_f32;
   prepare_patch_rows(e, (int64_t)b * np);
-  {
+  if (patches_in) {
+    launch_convert(patches_in, e->pd, e->patches, T, e->pd_k, b * np, e->pd, e->pd_k, e->stream);
+  } else {
     Prof pr(e, "patch_unfold", 0, (double)b * H * W * c.channels * 4 + (double)b * np * e->pd_k * e->esz);
     launch_unfold(img_dev, e->patches, T, b, H, W, c.channels, c.patch_h, c.patch_w, e->pd_k, e->stream);   // vit.py:142
   }
+  e->last_from_patches = patches_in != nullptr;
   if (!no_cls) {
     Prof pr(e, "cls_pos_row", 0, 0);
     launch_cls_pos_row(x0, e->params + e->cls, e->params + e->pos, b, ntok, d, d, e->stream);              // vit.py:163-165
@@ -1686,8 +1696,12 @@ int engine_backward(vitx_engine* e, const float* dlogits_dev, float* dimg_dev, s
   if (dimg_dev) {
     EpiParams ep; ep.out = e->tmp_f32; ep.ldo = e->pd;
     dense_dgrad(e, e->d_y, d, b * np, e->patch, EPI_STORE_F32, ep);
-    Prof pr(e, "patch_fold", 0, 0);
-    launch_fold_add(e->tmp_f32, e->pd, dimg_dev, b, e->last_H, e->last_W, c.channels, c.patch_h, c.patch_w, e->stream);
+    if (e->last_from_patches) {   // the forward took patch rows: d(patches) [b, np, pd] goes out as it is
+      HIPCHK(hipMemcpyAsync(dimg_dev, e->tmp_f32, (size_t)b * np * e->pd * 4, hipMemcpyDeviceToDevice, e->stream));
+    } else {
+      Prof pr(e, "patch_fold", 0, 0);
+      launch_fold_add(e->tmp_f32, e->pd, dimg_dev, b, e->last_H, e->last_W, c.channels, c.patch_h, c.patch_w, e->stream);
+    }
   }
   if (e->grad_cb) e->grad_cb(e->grad_cb_user, 0, e->stages[0].depth > 0 ? e->stages[0].bp[0].p_begin : e->head_g);
   return VITX_OK;

@@ -158,7 +158,7 @@ class VitxModel:
 
     def _init_common(self, *, image_size, patch_size, num_classes, dim, depth, heads, mlp_dim, pool, dim_head, dropout,
                      emb_dropout, layer_dropout=0.0, cls_depth=0, num_parallel_branches=1, patch_merge_layer=None, patch_merge_num_tokens=8,
-                     compute="fp32", max_batch=None, device=0, seed=None):
+                     compute="fp32", max_batch=None, device=0, seed=None, channels=3):
         ih, iw = pair(image_size)
         ph, pw = pair(patch_size)
         assert ih % ph == 0 and iw % pw == 0, 'Image dimensions must be divisible by the patch size.'
@@ -169,7 +169,7 @@ class VitxModel:
         self.num_classes = num_classes
         cfg = N.Config()
         cfg.variant = self._variant
-        cfg.image_h, cfg.image_w, cfg.patch_h, cfg.patch_w, cfg.channels = ih, iw, ph, pw, 3
+        cfg.image_h, cfg.image_w, cfg.patch_h, cfg.patch_w, cfg.channels = ih, iw, ph, pw, int(channels)
         cfg.num_classes, cfg.dim, cfg.depth, cfg.cls_depth = num_classes, dim, depth, cls_depth
         cfg.heads, cfg.dim_head, cfg.mlp_dim = heads, dim_head, mlp_dim
         cfg.pool = N.POOL_MEAN if pool == 'mean' else N.POOL_CLS
@@ -366,6 +366,19 @@ class VitxModel:
 
     call = __call__
     predict = lambda self, img, **kw: self(img, training=False, **kw)
+
+    def forward_patches(self, patches, training=True, seed=None):
+        """The model from its patch Dense onwards, on caller-supplied patch rows [b, np, patch_dim] instead of an image (T2T-ViT's
+        tokenizer output, t2t.py:74,100-115).  `backward(dlogits, want_dimg=True)` afterwards returns d(patches) as its second result."""
+        x, proto = self._as_host(patches)
+        assert x.ndim == 3, "expected patch rows [b, np, patch_dim]"
+        b, n, pd = x.shape
+        h = self._ensure_handle(b)
+        self._img_shape = (b, n, pd)
+        out = np.empty((b, self.num_classes), dtype=np.float32)
+        seed = int(np.random.randint(0, 2 ** 31 - 1)) if seed is None else int(seed)
+        N.check(N.lib().vitx_forward_patches(h, x.ctypes.data_as(C.c_void_p), b, n, 1 if training else 0, seed, out.ctypes.data_as(C.c_void_p)))
+        return self._like(out, proto)
 
     def backward(self, dlogits, want_dimg: bool = False):
         """VJP for the last forward (what tf.GradientTape.gradient would return, README.md:746-749).

@@ -88,6 +88,10 @@ SYMBOLS: List[Tuple[str, object, list]] = [
     ("vitx_forward_dev", C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_uint64, C.c_void_p]),
     ("vitx_backward", C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p]),
     ("vitx_backward_dev", C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("vitx_set_patch_input", C.c_int32, [C.c_void_p, C.c_int32]),
+    ("vitx_distill_backward_input", C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("vitx_forward_patches", C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_uint64, C.c_void_p]),
+    ("vitx_forward_patches_dev", C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_uint64, C.c_void_p]),
     ("vitx_get_opt_state", C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("vitx_set_opt_state", C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64]),
     ("vitx_transformer_forward", C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_uint64, C.c_void_p]),

@@ -11,6 +11,7 @@ import numpy as np
 
 from . import _native as N
 from ._model import VitxModel, _Weight
+from .t2t import T2TViT
 from .vit import ViT
 
 
@@ -63,12 +64,94 @@ class DistillableViT(ViT):
         return {n: g[o:o + int(np.prod(s))].reshape(s) for n, s, o in self._table}, dt.reshape(1, 1, -1)
 
 
+class DistillableT2TViT(T2TViT):
+    """distill.py:60-72: a T2TViT whose call accepts a distillation token.  The tokenizer runs as in T2TViT; the token joins the
+    sequence on the main engine handle, which reads the tokenizer's output as patch rows (vitx_set_patch_input)."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.args = args
+        self.kwargs = kwargs
+
+    # what DistillWrapper needs from a student: the handle that carries the distillation token is the main one
+    @property
+    def _handle(self):
+        return self._main._handle
+
+    @property
+    def _cfg(self):
+        return self._main._cfg
+
+    @property
+    def _handle_gen(self):
+        return self._main._handle_gen
+
+    def _ensure_handle(self, b):
+        return self._main._ensure_handle(b)
+
+    def __call__(self, img, distill_token=None, training=True, **kw):
+        if not exists(distill_token):
+            return super().__call__(img, training=training, **kw)
+        x, proto = VitxModel._as_host(img)
+        tok_in = self._tokenize(x, training, kw.get("seed"))                       # [b, n, last layer_dim]
+        b, n, _ = tok_in.shape
+        tok = np.ascontiguousarray(np.asarray(distill_token, dtype=np.float32).reshape(-1))
+        assert tok.size == self.dim, "distill_token must have shape [1, 1, dim]"
+        m = self._main
+        h = m._ensure_handle(b)
+        m._img_shape = (b, n, tok_in.shape[2])
+        logits = np.empty((b, self.num_classes), dtype=np.float32)
+        dtok = np.empty((b, self.dim), dtype=np.float32)
+        a = np.ascontiguousarray(tok_in, dtype=np.float32)
+        N.check(N.lib().vitx_set_patch_input(h, n))
+        N.check(N.lib().vitx_forward_distill(h, a.ctypes.data_as(C.c_void_p), b, 0, 0, 1 if training else 0, self._last_seed,
+                                             tok.ctypes.data_as(C.c_void_p), logits.ctypes.data_as(C.c_void_p), dtok.ctypes.data_as(C.c_void_p)))
+        return VitxModel._like(logits, proto), VitxModel._like(dtok, proto)
+
+    call = __call__
+
+    def backward_distill(self, dlogits, d_distill_tokens=None):
+        """VJP of the last `model(img, distill_token=tok)`: ({name: grad}, d(distill_token) [1, 1, dim])."""
+        m = self._main
+        d, _ = VitxModel._as_host(dlogits)
+        dd = None if d_distill_tokens is None else VitxModel._as_host(d_distill_tokens)[0]
+        dt = np.empty(self.dim, dtype=np.float32)
+        dpat = np.empty(m._img_shape, dtype=np.float32)
+        N.check(N.lib().vitx_backward_distill(m._handle, d.ctypes.data_as(C.c_void_p), None if dd is None else dd.ctypes.data_as(C.c_void_p),
+                                              dt.ctypes.data_as(C.c_void_p), dpat.ctypes.data_as(C.c_void_p)))
+        g = np.empty(m._n, dtype=np.float32)
+        N.check(N.lib().vitx_get_grads(m._handle, g.ctypes.data_as(C.c_void_p), m._n))
+        gm = {n: g[o:o + int(np.prod(s))].reshape(s) for n, s, o in m._table}
+        return self._chain_tokenizer(gm, dpat, False)[0], dt.reshape(1, 1, -1)
+
+
+class DistillableEfficientViT:
+    """distill.py:74-85.  The reference's class cannot run: DistillMixin.call reaches `self.dropout` through `_attend`
+    (distill.py:83), an attribute efficient.ViT never defines (efficient.py:13-36), so every call raises AttributeError there.
+    The drop-in keeps that behaviour: it constructs (the shell is vit_tensorflow.efficient.ViT) and fails on call with the
+    reference's own error."""
+
+    def __init__(self, *args, **kwargs):
+        from .efficient import ViT as EfficientViT
+        self._shell = EfficientViT(*args, **kwargs)
+        self.args, self.kwargs = args, kwargs
+        self.dim, self.num_classes = kwargs['dim'], kwargs['num_classes']
+
+    def __call__(self, img, distill_token=None, training=True):
+        raise AttributeError("'DistillableEfficientViT' object has no attribute 'dropout'")
+
+    call = __call__
+
+
 class DistillWrapper:
     def __init__(self, teacher, student, temperature=1.0, alpha=0.5, hard=False, *, literal_loss=True, seed=None):
         """Same arguments as the reference (distill.py:88).  Engine-only keyword extras: literal_loss (soft mode) -- True keeps
         the distillation term exactly as distill.py:122-129 computes it (Keras' KLDivergence clips the LOG-probabilities it is
         handed to 1e-7, which makes the term constant in the student), False computes the intended KL divergence; seed."""
-        assert isinstance(student, DistillableViT), 'student must be a vision transformer'        # distill.py:91
+        assert isinstance(student, (DistillableViT, DistillableT2TViT, DistillableEfficientViT)), 'student must be a vision transformer'   # distill.py:91
+        if isinstance(student, DistillableEfficientViT):
+            student()   # raises what the reference raises on its first call (see the class)
+        self._t2t = isinstance(student, DistillableT2TViT)
         self.teacher, self.student = teacher, student
         self.temperature, self.alpha, self.hard = temperature, alpha, hard
         cfg = N.DistillConfig()
@@ -167,12 +250,17 @@ class DistillWrapper:
         x, _ = VitxModel._as_host(img)
         y, _ = VitxModel._as_host(labels)
         b, H, W, _c = x.shape
+        seed = int(kwargs.get("seed", np.random.randint(0, 2 ** 31 - 1)))
         assert y.shape == (b, self.student.num_classes), "labels must be [b, num_classes] (one-hot or soft)"
         t, _ = VitxModel._as_host(self.teacher(img, training=training) if not isinstance(self.teacher, np.ndarray) else self.teacher)   # distill.py:114
         assert t.shape == y.shape, "teacher must return logits [b, num_classes]"
         h = self._ensure(b)
         loss = np.empty(b, dtype=np.float32)
-        seed = int(kwargs.get("seed", np.random.randint(0, 2 ** 31 - 1)))
+        if self._t2t:   # the student's tokenizer runs in front of its main handle, which then reads patch rows
+            x = np.ascontiguousarray(self.student._tokenize(x, training, seed), dtype=np.float32)
+            self.student._main._img_shape = x.shape
+            N.check(N.lib().vitx_set_patch_input(self.student._handle, x.shape[1]))
+            H = W = 0
         N.check(N.lib().vitx_distill_forward(h, x.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p), t.ctypes.data_as(C.c_void_p), b, H, W,
                                              1 if training else 0, seed, -1.0 if temperature is None else float(temperature),
                                              -1.0 if alpha is None else float(alpha), loss.ctypes.data_as(C.c_void_p)))
@@ -187,10 +275,23 @@ class DistillWrapper:
             raise N.VitxError(N.ERR_STATE, "backward requires a preceding forward")
         l = N.lib()
         dl = None if dloss is None else np.ascontiguousarray(np.asarray(dloss, dtype=np.float32))
-        N.check(l.vitx_distill_backward(self._h, None if dl is None else dl.ctypes.data_as(C.c_void_p)))
+        dpat = None
+        if self._t2t:
+            dpat = np.empty(self.student._main._img_shape, dtype=np.float32)
+            N.check(l.vitx_distill_backward_input(self._h, None if dl is None else dl.ctypes.data_as(C.c_void_p), dpat.ctypes.data_as(C.c_void_p)))
+        else:
+            N.check(l.vitx_distill_backward(self._h, None if dl is None else dl.ctypes.data_as(C.c_void_p)))
         g = np.empty(self._n, dtype=np.float32)
         N.check(l.vitx_distill_get_grads(self._h, g.ctypes.data_as(C.c_void_p), self._n))
         out = {n: g[o:o + int(np.prod(s))].reshape(s) for n, s, o in self._table}
+        if self._t2t:
+            m = self.student._main
+            sg = np.empty(m._n, dtype=np.float32)
+            N.check(l.vitx_get_grads(m._handle, sg.ctypes.data_as(C.c_void_p), m._n))
+            gm = {n: sg[o:o + int(np.prod(s))].reshape(s) for n, s, o in m._table}
+            for n, a in self.student._chain_tokenizer(gm, dpat, False)[0].items():
+                out["student." + n] = a
+            return out
         stu = self.student
         sg = np.empty(stu._n, dtype=np.float32)
         N.check(l.vitx_get_grads(stu._handle, sg.ctypes.data_as(C.c_void_p), stu._n))
