@@ -1713,6 +1713,10 @@ int engine_backward(vitx_engine* e, const float* dlogits_dev, float* dimg_dev, s
 int engine_bench_gemm(vitx_engine* e, int M, int N, int K, int kernel, int epilogue, int iters, float* avg_ms, float* max_err,
                       std::string& err) {
   if (K % 64 || M <= 0 || N <= 0) { err = "bench_gemm: K must be a multiple of 64"; return VITX_ERR_INVALID; }
+  // bits 4..7 of `kernel` reach the kernels' `stagger` field, whose low bits double as timing-experiment switches (no DMA wait /
+  // no DMA issue: WRONG results, faster launches).  A sweep that packs anything else into those bits measures the switch, not its
+  // own parameter (profiles/r2/gemm_tile_band_README.txt), so they are refused unless the caller says it wants the experiment.
+  if (((kernel >> 4) & 3) && !getenv("VITX_GEMM_XP")) { err = "vitx_bench_gemm: kernel bits 4-5 are timing-experiment switches (results invalid); set VITX_GEMM_XP=1 to use them"; return VITX_ERR_INVALID; }
   const int64_t Mp = round_up(M, 1280), Np = round_up(N, 256);
   bf16_t *A, *B; float *C, *R, *bias; bf16_t* C2;
   HIPCHK(hipMalloc((void**)&A, (size_t)Mp * K * 2));
