@@ -125,7 +125,6 @@ __global__ __launch_bounds__(256) void deepvit_point_fwd_kernel(float* __restric
       for (int hh = 0; hh < h; ++hh) a = fmaf(y[hh], w[hh * h + gg], a);
       v[gg] = a;
       mu += a;
-      if (keep) mixed[(bi * h + gg) * plane + ij] = a;
     }
     mu /= (float)h;
     float var = 0.f;
@@ -328,7 +327,7 @@ __global__ __launch_bounds__(256) void headmix_bwd_mfma_kernel(const float* __re
 // matrix pipe, see headmix_bwd_mfma_kernel).  d(A2) in `da` -> d(A0) written back; the softmax VJP follows as its own (row) kernel.
 // Per-wave partials: [dW (H*H) | dgamma (H) | dbeta (H)].
 template <int H>
-__global__ __launch_bounds__(256) void deepvit_point_bwd_kernel(const float* __restrict__ a0, const float* __restrict__ mixed,
+__global__ __launch_bounds__(256) void deepvit_point_bwd_kernel(const float* __restrict__ a0,
                                                                 float* __restrict__ da, const float* __restrict__ w,
                                                                 const float* __restrict__ gamma, float* __restrict__ partial, int b,
                                                                 int64_t plane, int64_t nvalid_per_row, int64_t ld, float eps) {
@@ -351,10 +350,19 @@ __global__ __launch_bounds__(256) void deepvit_point_bwd_kernel(const float* __r
     float av[H], xh[H], dm[H];
     float mu = 0.f;
 #pragma unroll
-    for (int g = 0; g < H; ++g) {
-      av[g] = valid ? a0[(bi * H + g) * plane + ij] : 0.f;
-      xh[g] = valid ? mixed[(bi * H + g) * plane + ij] : 0.f;
-      mu += xh[g];
+    for (int g = 0; g < H; ++g) av[g] = valid ? a0[(bi * H + g) * plane + ij] : 0.f;
+    {
+      // the mixed scores (deepvit.py:83) are recomputed from the softmax instead of being kept by the forward: 256 FMAs per point
+      // against a [b, h, n, n] fp32 tensor written and read back; same FMA order as the forward kernels, i.e. the same bits
+      const float* wm = w + opaque_zero();
+#pragma unroll
+      for (int g = 0; g < H; ++g) {
+        float a = 0.f;
+#pragma unroll
+        for (int hh = 0; hh < H; ++hh) a = fmaf(av[hh], wm[hh * H + g], a);
+        xh[g] = a;
+        mu += a;
+      }
     }
     mu /= (float)H;
     float var = 0.f;
@@ -602,11 +610,11 @@ void launch_softmax_bwd_rows(const float* p, float* dp, int64_t rows, int n, int
 }
 // DeepViT backward chain: fused point kernel (LayerNorm-over-heads VJP + mix VJP), then the row softmax VJP
 int64_t deepvit_point_bwd_ws_elems(int h) { return (int64_t)(HMM_BLOCKS * 4 + 40) * (h * h + 2 * h); }
-void launch_deepvit_point_bwd(const float* a0, const float* mixed, float* da_inout, const float* w, const float* gamma, float* ws, float* dw,
+void launch_deepvit_point_bwd(const float* a0, float* da_inout, const float* w, const float* gamma, float* ws, float* dw,
                               float* dgamma, float* dbeta, int b, int h, int nq, int nk, int64_t ld, float eps, hipStream_t s) {
   const int64_t plane = (int64_t)nq * ld;
   const int nb = (int)std::max<int64_t>(1, std::min<int64_t>(HMM_BLOCKS, ceil_div((int64_t)b * plane, 256)));
-#define CALLB(HT) hipLaunchKernelGGL(deepvit_point_bwd_kernel<HT>, dim3(nb), dim3(256), 0, s, a0, mixed, da_inout, w, gamma, ws, b, plane, (int64_t)nk, ld, eps)
+#define CALLB(HT) hipLaunchKernelGGL(deepvit_point_bwd_kernel<HT>, dim3(nb), dim3(256), 0, s, a0, da_inout, w, gamma, ws, b, plane, (int64_t)nk, ld, eps)
   if (h == 16) { CALLB(16); } else if (h == 12) { CALLB(12); } else if (h == 8) { CALLB(8); } else { CALLB(4); }
 #undef CALLB
   const int nparts = nb * 4;

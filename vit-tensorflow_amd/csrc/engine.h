@@ -56,6 +56,7 @@ struct BlockActs {
   int64_t sc_keep_elems = 0;        // 0: not tried yet, -1: over the budget (this block recomputes), else elements per buffer
   int64_t sc_geom = -1;             // (b, nq, nk) the kept tensors describe
   int sc_pi = 0;                    // index of the tensor that multiplies V
+  bool sc_no_mixed = false;         // kept by the one-kernel DeepViT forward: sc_keep[1] (the mixed scores) was not written
   int par_first = 0, par_last = 0;   // backward order inside a group of parallel half-blocks: first / last one processed (1 + 1 = alone)
 };
 
@@ -157,6 +158,7 @@ struct vitx_engine {
   // env switches
   bool force_generic_gemm = false, force_generic_attn = false, wgrad_via_transpose = true;
   int gemm_kernel = 0;
+  bool deepvit_fused = true;         // VITX_DEEPVIT_FUSED=0: DeepViT attention forward as batched GEMMs + head-axis kernels (A/B reference)
   bool unfused_headops = false;      // VITX_UNFUSED_HEADOPS=1: separate mix / softmax / LayerNorm-over-heads kernels (A/B reference)
   int gemm_stagger = 0;
 

@@ -475,8 +475,19 @@ static void attn_generic_fwd(vitx_engine* e, const BlockParams& bp, const AttnVi
   const int64_t ld = round_up(a.nk, 4);
   const int64_t hs = (int64_t)a.nq * ld, bs = (int64_t)h * hs;
   float* const* sc = keep ? keep->sc_keep : e->sc;
+  if (T && e->cfg.variant == VITX_VARIANT_DEEPVIT && e->deepvit_fused && !e->unfused_headops && !e->force_generic_gemm &&
+      deepvit_attn_fused_supported(h, dh, a.nq, a.nk)) {
+    // deepvit.py:79-88 in one kernel; the three score tensors only leave the chip when this block's backward will read them
+    const double pts = (double)b * h * a.nq * a.nk;
+    Prof pr(e, "attn_deepvit_fused_fwd", 4.0 * pts * dh + 2.0 * pts * h, ((double)b * a.nq * 3 * h * dh + (double)b * a.nq * h * dh) * 2 + (keep ? 8.0 * pts : 0.0));
+    launch_deepvit_attn_fwd((const bf16_t*)a.q, (const bf16_t*)a.k, (const bf16_t*)a.v, a.ldq, a.ldk, a.ldv, a.qb, a.kb, a.vb, (bf16_t*)a.o,
+                            a.ldo, a.ob, e->params + bp.re_w, e->params + bp.re_g, e->params + bp.re_b, sc[0], sc[2], keep != nullptr,
+                            b, h, a.nq, a.nk, ld, 1.0f / std::sqrt((float)dh), e->cfg.ln_eps, (const bf16_t*)e->zero_page, e->stream);
+    if (keep) { keep->sc_geom = score_geom(b, a.nq, a.nk); keep->sc_pi = 2; keep->sc_no_mixed = true; }
+    return;
+  }
   const int pi = attn_generic_scores(e, bp, a, b, keep != nullptr, sc);
-  if (keep) { keep->sc_geom = score_geom(b, a.nq, a.nk); keep->sc_pi = pi; }
+  if (keep) { keep->sc_geom = score_geom(b, a.nq, a.nk); keep->sc_pi = pi; keep->sc_no_mixed = false; }
   // out = attn v   (vit.py:81, deepvit.py:87, cait.py:127)
   bgemm(e, sc[pi], 0, ld, 1, bs, hs, a.v, T, a.ldv, 1, a.vb, dh, a.nq, dh, a.nk, b, h, EPI_STORE, T, a.o, a.ldo, a.ob, dh, 1.0f);
 }
@@ -501,7 +512,8 @@ static void attn_generic_bwd(vitx_engine* e, const BlockParams& bp, const AttnVi
   // d(attn) = dO v^T ; dV = attn^T dO
   bgemm(e, gr.d_o, T, gr.ldo, 1, gr.ob, dh, a.v, T, 1, a.ldv, a.vb, dh, a.nq, a.nk, dh, b, h, EPI_STORE_F32, 0, dA, ld, bs, hs, 1.0f);
   bgemm(e, sc[pi], 0, 1, ld, bs, hs, gr.d_o, T, gr.ldo, 1, gr.ob, dh, a.nk, dh, a.nq, b, h, EPI_STORE, T, gr.dv, gr.lddv, gr.dvb, dh, 1.0f);
-  const bool chain = !e->unfused_headops && headchain_supported(h, a.nk);
+  // (the row-per-wave DeepViT chain reads the mixed scores; tensors kept by the one-kernel forward go to the point kernel, which recomputes them)
+  const bool chain = !e->unfused_headops && headchain_supported(h, a.nk) && !(kept && keep->sc_no_mixed);
   if (chain && e->cfg.variant == VITX_VARIANT_CAIT) {
     Prof pr(e, "attn_headchain", 0, 0);
     launch_cait_chain_bwd(sc[0], sc[1], dA, e->params + bp.mix_pre, e->params + bp.mix_post, e->red_ws, e->grads + bp.mix_pre,
@@ -512,7 +524,7 @@ static void attn_generic_bwd(vitx_engine* e, const BlockParams& bp, const AttnVi
                              e->grads + bp.re_b, b, h, a.nq, a.nk, ld, e->cfg.ln_eps, e->stream);
   } else if (!e->unfused_headops && e->cfg.variant == VITX_VARIANT_DEEPVIT && deepvit_point_fwd_supported(h, a.nk)) {
     Prof pr(e, "attn_headchain", 0, 0);     // LayerNorm-over-heads VJP + mix VJP in one point kernel, then the softmax VJP
-    launch_deepvit_point_bwd(sc[0], sc[1], dA, e->params + bp.re_w, e->params + bp.re_g, e->red_ws, e->grads + bp.re_w,
+    launch_deepvit_point_bwd(sc[0], dA, e->params + bp.re_w, e->params + bp.re_g, e->red_ws, e->grads + bp.re_w,
                              e->grads + bp.re_g, e->grads + bp.re_b, b, h, a.nq, a.nk, ld, e->cfg.ln_eps, e->stream);
   } else {
     Prof pr(e, "attn_generic_headops", 0, 0);
@@ -844,6 +856,7 @@ static int engine_create_body(vitx_engine* e, const vitx_config& cfg, std::strin
   if (cait && c.cls_depth < 0) { err = "cls_depth must be >= 0"; return VITX_ERR_INVALID; }
   e->force_generic_gemm = env_flag("VITX_GENERIC_GEMM");
   e->force_generic_attn = env_flag("VITX_GENERIC_ATTN");
+  if (const char* k = getenv("VITX_DEEPVIT_FUSED")) e->deepvit_fused = atoi(k) != 0;
   if (const char* k = getenv("VITX_GEMM_KERNEL")) e->gemm_kernel = atoi(k);
   if (const char* k = getenv("VITX_UNFUSED_HEADOPS")) e->unfused_headops = atoi(k) != 0;
   e->wgrad_via_transpose = env_flag("VITX_WGRAD_TRANSPOSE");

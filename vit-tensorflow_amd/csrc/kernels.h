@@ -118,8 +118,14 @@ void launch_softmax_rows(float* sc, int64_t rows, int n, int64_t ld, hipStream_t
 void launch_softmax_bwd_rows(const float* p, float* dp_inout, int64_t rows, int n, int64_t ld, hipStream_t s);
 // DeepViT forward chain (softmax -> re-attention mix -> LayerNorm over heads) as row statistics + one fused point kernel
 int64_t deepvit_point_bwd_ws_elems(int h);
-void launch_deepvit_point_bwd(const float* a0, const float* mixed, float* da_inout, const float* w, const float* gamma, float* ws, float* dw,
+void launch_deepvit_point_bwd(const float* a0, float* da_inout, const float* w, const float* gamma, float* ws, float* dw,
                               float* dgamma, float* dbeta, int b, int h, int nq, int nk, int64_t ld, float eps, hipStream_t s);
+// attn_deepvit_fused.hip: the whole Re-attention forward (deepvit.py:79-88) in one kernel, bf16 mode, nk <= 80
+bool deepvit_attn_fused_supported(int h, int dim_head, int nq, int nk);
+void launch_deepvit_attn_fwd(const bf16_t* q, const bf16_t* k, const bf16_t* v, int64_t ldq, int64_t ldk, int64_t ldv, int64_t qb,
+                             int64_t kb, int64_t vb, bf16_t* o, int64_t ldo, int64_t ob, const float* w, const float* gamma,
+                             const float* beta, float* p_keep, float* a2_keep, int keep, int b, int h, int nq,
+                             int nk, int64_t ld, float scale, float eps, const bf16_t* zero_page, hipStream_t s);
 bool deepvit_point_fwd_supported(int h, int nk);
 int64_t deepvit_point_ws_elems(int b, int h, int nq);
 void launch_deepvit_point_fwd(float* s0_inout, float* stats_ws, const float* w, const float* gamma, const float* beta, float* mixed, float* a2,
