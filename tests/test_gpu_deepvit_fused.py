@@ -58,6 +58,20 @@ def test_fused_reattention_matches_oracle_and_unfused_path(case, monkeypatch):
     assert d_g[0] <= FUSED_VS_UNFUSED_GRAD, d_g
 
 
+@pytest.mark.parametrize("cpi", ["1", "2"])
+def test_workgroup_walking_several_query_tiles(cpi, monkeypatch):
+    """At the benchmark batch one workgroup walks all query tiles of an image (K fragments held, Q prefetched, V re-staged); small
+    test batches get one tile per workgroup unless told otherwise.  Same bits either way: the tiles are independent."""
+    kw, b = CASES["h16_n65"]
+    monkeypatch.setenv("VITX_DV_CPI", "99")
+    _, _, _, _, lg_a, g_a = _run(kw, b, True, monkeypatch)
+    monkeypatch.setenv("VITX_DV_CPI", cpi)
+    _, _, _, _, lg_b, g_b = _run(kw, b, True, monkeypatch)
+    assert np.array_equal(lg_a, lg_b)
+    for k in g_a:
+        assert np.array_equal(g_a[k], g_b[k]), k
+
+
 def test_fused_kernel_is_the_one_that_runs(monkeypatch):
     """The profile of one forward + backward names the fused kernels, and none of the launch-per-op classes they replace."""
     import ctypes as C

@@ -31,49 +31,64 @@ template <int H>
 __global__ __launch_bounds__(DV_THREADS) void deepvit_attn_fwd_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, int64_t ldq, int64_t ldk, int64_t ldv,
     int64_t qb, int64_t kb, int64_t vb, bf16_t* __restrict__ o, int64_t ldo, int64_t ob, const float* __restrict__ w,
-    const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ p_keep, float* __restrict__ a2_keep, int keep, int nq, int nk, int64_t ld, float scale, float eps, const bf16_t* __restrict__ zero_page,
-    int ntile, int xp) {
+    const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ p_keep, float* __restrict__ a2_keep, int keep,
+    int nq, int nk, int64_t ld, float scale, float eps, const bf16_t* __restrict__ zero_page, int ntile, int cpi, int xp) {
   constexpr int HPW = (H + 7) / 8;                     // heads per wave
   constexpr int R0 = (H * 16 * DV_PP * 4 > 8 * DV_VBYTES) ? H * 16 * DV_PP * 4 : 8 * DV_VBYTES;
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   float* Pl = (float*)smem;                            // [H][16][DV_PP] fp32; dead after stage 2, reused as the V images
   bf16_t* Al = (bf16_t*)(smem + R0);                   // [H][16][DV_AP] bf16
-  // Workgroup ids go round-robin over the 8 XCDs, each with its own L2, and the query tiles of one image all read that image's
-  // whole K and V: the logical index is made contiguous per XCD so that they meet in ONE L2 (id order: 5 tiles of an image on 5
-  // XCDs, K and V fetched from HBM five times -- 540 MB per launch instead of 274 at the BASELINE.json shape).
+  // A workgroup owns `ntile / cpi` consecutive query tiles of ONE image (cpi = 1 at the BASELINE.json batch: one image per CU, no
+  // partial last round of workgroups): its K fragments stay in registers for all of them, the next tile's Q fragments are
+  // requested while the current tile is in stage 2, and V is re-staged from an L2 that already holds it.  Workgroup ids go
+  // round-robin over the 8 XCDs, each with its own L2; the logical index is made contiguous per XCD so that the chunks of one
+  // image (cpi > 1) meet in one L2.
   const int xcd = blockIdx.x & 7, per = gridDim.x >> 3, rem = gridDim.x & 7;
   const int logical = xcd * per + min(xcd, rem) + (int)(blockIdx.x >> 3);
-  const int bi = logical / ntile, tile = logical - bi * ntile;
+  const int bi = logical / cpi, chunk = logical - bi * cpi;
+  const int t_begin = chunk * ntile / cpi, t_end = (chunk + 1) * ntile / cpi;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int qi = lane & 15, g = lane >> 4;
-  const int q0 = tile * 16;
   const int nt = (nk + 15) >> 4, nu = (nk + 31) >> 5;
   const int64_t plane = (int64_t)nq * ld;
 
-  // ---------------------------------------------------------------- stage 1: S^T, softmax (deepvit.py:79-80)
-  {
-    const int qrow = min(q0 + qi, nq - 1);
-    // every fragment of this wave's heads is requested before the first MFMA: one memory latency, not one per head
-    bf16x8 qf[HPW][2], kf[HPW][DV_NT][2];
+  // key columns nk .. 32 nu - 1 of the normalised scores multiply zero rows of V: zero them once (stage 2 never touches them)
+  for (int idx = tid; idx < H * 16 * (DV_AP / 4); idx += DV_THREADS)
+    *(bf16x4*)(Al + idx * 4) = bf16x4{(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+
+  // K fragments of this wave's heads: S^T = K Q^T takes K as the A operand, lane (key qi of tile t, 16-B chunk g)
+  bf16x8 kf[HPW][DV_NT][2], qf[HPW][2];
+#pragma unroll
+  for (int s = 0; s < HPW; ++s) {
+    const int head = min(wave * HPW + s, H - 1);
+#pragma unroll
+    for (int t = 0; t < DV_NT; ++t) {
+      const int krow = min(16 * t + qi, nk - 1);
+      const bf16_t* kp = k + (int64_t)bi * kb + (int64_t)krow * ldk + head * DH;
+      if (t < nt) {
+        kf[s][t][0] = *(const bf16x8*)(kp + g * 8);
+        kf[s][t][1] = *(const bf16x8*)(kp + (g + 4) * 8);
+      } else {
+        kf[s][t][0] = zero8(); kf[s][t][1] = zero8();
+      }
+    }
+  }
+  auto load_q = [&](int tile, bf16x8 (&dst)[HPW][2]) {
+    const int qrow = min(tile * 16 + qi, nq - 1);
 #pragma unroll
     for (int s = 0; s < HPW; ++s) {
       const int head = min(wave * HPW + s, H - 1);
       const bf16_t* qp = q + (int64_t)bi * qb + (int64_t)qrow * ldq + head * DH;
-      qf[s][0] = *(const bf16x8*)(qp + g * 8);
-      qf[s][1] = *(const bf16x8*)(qp + (g + 4) * 8);
-#pragma unroll
-      for (int t = 0; t < DV_NT; ++t) {
-        const int krow = min(16 * t + qi, nk - 1);
-        const bf16_t* kp = k + (int64_t)bi * kb + (int64_t)krow * ldk + head * DH;
-        if (t < nt) {
-          kf[s][t][0] = *(const bf16x8*)(kp + g * 8);
-          kf[s][t][1] = *(const bf16x8*)(kp + (g + 4) * 8);
-        } else {
-          kf[s][t][0] = zero8(); kf[s][t][1] = zero8();
-        }
-      }
+      dst[s][0] = *(const bf16x8*)(qp + g * 8);
+      dst[s][1] = *(const bf16x8*)(qp + (g + 4) * 8);
     }
+  };
+  load_q(t_begin, qf);
+
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    const int q0 = tile * 16;
+    // ---------------------------------------------------------------- stage 1: S^T, softmax (deepvit.py:79-80)
 #pragma unroll
     for (int s = 0; s < HPW; ++s) {
       const int head = wave * HPW + s;
@@ -120,94 +135,95 @@ __global__ __launch_bounds__(DV_THREADS) void deepvit_attn_fwd_kernel(
         }
       }
     }
-  }
-  __syncthreads();
+    if (tile + 1 < t_end) load_q(tile + 1, qf);         // in flight during stages 2 and 3
+    __syncthreads();
 
-  // ---------------------------------------------------------------- stage 2: re-attention mix + LayerNorm over heads (deepvit.py:83-84)
-  // one thread per (query, 4 consecutive keys): 16-B LDS reads, 8-B LDS writes, 16-B global stores of the kept tensor
-  {
-    const int ngrp = 8 * nu;                 // 4-key groups per query row: the 32 nu key columns the A V product reads
-    for (int p = tid; p < ((xp & 2) ? 0 : 16 * ngrp); p += DV_THREADS) {
-      const int i = p / ngrp, j0 = 4 * (p - i * ngrp);
-      if (j0 >= nk) {
+    // -------------------------------------------------------------- stage 2: re-attention mix + LayerNorm over heads (deepvit.py:83-84)
+    // one thread per (query, key) point, exactly the 16 nk valid ones: the VALU work (H^2 FMAs per point) is spread evenly over
+    // the waves; with 4-key groups and padded columns it took two waves on one SIMD 5 us per tile
+    for (int p = tid; p < ((xp & 2) ? 0 : 16 * nk); p += DV_THREADS) {
+      const int i = p / nk, j = p - i * nk;
+      float y[H], vv[H];
 #pragma unroll
-        for (int gg = 0; gg < H; ++gg) *(bf16x4*)(Al + (gg * 16 + i) * DV_AP + j0) = bf16x4{(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
-        continue;
-      }
-      float4 y[H];
-      float vv[H][4];
+      for (int hh = 0; hh < H; ++hh) y[hh] = Pl[(hh * 16 + i) * DV_PP + j];
+      // vv[g] = sum_h y[h] W[h][g], accumulated over h in ascending order for every g (the FMA chain of the backward's
+      // recomputation in deepvit_point_bwd_kernel: same bits).  W is read with wave-uniform addresses (scalar loads, SGPR operands)
+      // one ROW at a time, the next row requested before the current one is used; the scheduling barriers keep the compiler from
+      // requesting all H rows at once -- H^2 SGPRs do not exist and it parks them in VGPR lanes (2231 v_readlane per point).
+      const float* wm = w + opaque_zero();
 #pragma unroll
-      for (int hh = 0; hh < H; ++hh) y[hh] = *(const float4*)(Pl + (hh * 16 + i) * DV_PP + j0);
-      float mu[4] = {0.f, 0.f, 0.f, 0.f};
+      for (int gg = 0; gg < H; ++gg) vv[gg] = 0.f;
+      float wc[H], wn[H];
 #pragma unroll
-      for (int gg = 0; gg < H; ++gg) {        // column-wise: W[hh][gg] with wave-uniform addresses (scalar loads), same FMA order as the
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;   // backward's recomputation (deepvit_point_bwd_kernel)
+      for (int gg = 0; gg < H; ++gg) wc[gg] = wm[gg];
 #pragma unroll
-        for (int hh = 0; hh < H; ++hh) {
-          const float ww = w[hh * H + gg];
-          a0 = fmaf(y[hh].x, ww, a0); a1 = fmaf(y[hh].y, ww, a1); a2 = fmaf(y[hh].z, ww, a2); a3 = fmaf(y[hh].w, ww, a3);
+      for (int hh = 0; hh < H; ++hh) {
+        if (hh + 1 < H) {
+#pragma unroll
+          for (int gg = 0; gg < H; ++gg) wn[gg] = wm[(hh + 1) * H + gg];
         }
-        vv[gg][0] = a0; vv[gg][1] = a1; vv[gg][2] = a2; vv[gg][3] = a3;
-        mu[0] += a0; mu[1] += a1; mu[2] += a2; mu[3] += a3;
-      }
-      float rs[4];
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int e2 = 0; e2 < 4; ++e2) {
-        mu[e2] /= (float)H;
-        float var = 0.f;
+        for (int gg = 0; gg < H; ++gg) vv[gg] = fmaf(y[hh], wc[gg], vv[gg]);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int gg = 0; gg < H; ++gg) var += (vv[gg][e2] - mu[e2]) * (vv[gg][e2] - mu[e2]);
-        rs[e2] = rsqrtf(var / (float)H + eps);
+        for (int gg = 0; gg < H; ++gg) wc[gg] = wn[gg];
       }
-      const bool st = keep && (q0 + i) < nq && j0 < ld;
-      float* arow = a2_keep + (int64_t)bi * H * plane + (int64_t)(q0 + i) * ld + j0;
+      float mu = 0.f;
+#pragma unroll
+      for (int gg = 0; gg < H; ++gg) mu += vv[gg];
+      mu /= (float)H;
+      float var = 0.f;
+#pragma unroll
+      for (int gg = 0; gg < H; ++gg) var += (vv[gg] - mu) * (vv[gg] - mu);
+      const float rs = rsqrtf(var / (float)H + eps);
+      const bool st = keep && (q0 + i) < nq;
+      float* arow = a2_keep + (int64_t)bi * H * plane + (int64_t)(q0 + i) * ld + j;
 #pragma unroll
       for (int gg = 0; gg < H; ++gg) {
-        const float ga = gamma[gg], be = beta[gg];
-        float r4[4];
-#pragma unroll
-        for (int e2 = 0; e2 < 4; ++e2) r4[e2] = (j0 + e2) < nk ? (vv[gg][e2] - mu[e2]) * rs[e2] * ga + be : 0.f;   // padded keys multiply V rows of zeros: keep them finite and zero
-        *(bf16x4*)(Al + (gg * 16 + i) * DV_AP + j0) = bf16x4{(bf16_t)r4[0], (bf16_t)r4[1], (bf16_t)r4[2], (bf16_t)r4[3]};
-        if (st) *(float4*)(arow + gg * plane) = make_float4(r4[0], r4[1], r4[2], r4[3]);
+        const float a2 = (vv[gg] - mu) * rs * gamma[gg] + beta[gg];
+        Al[(gg * 16 + i) * DV_AP + j] = (bf16_t)a2;
+        if (st) arow[gg * plane] = a2;
       }
     }
-  }
-  __syncthreads();
+    __syncthreads();
 
-  // ---------------------------------------------------------------- stage 3: out = attn' v, merged heads (deepvit.py:87-88)
-  {
-    char* vbuf = smem + wave * DV_VBYTES;
+    // -------------------------------------------------------------- stage 3: out = attn' v, merged heads (deepvit.py:87-88)
+    {
+      char* vbuf = smem + wave * DV_VBYTES;
 #pragma unroll
-    for (int s = 0; s < HPW; ++s) {
-      const int head = wave * HPW + s;
-      if (head >= H || (xp & 4)) break;
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the previous head's transpose reads have returned
-      stage_head_dma(v + (int64_t)bi * vb + head * DH, ldv, nk, 32 * nu, vbuf, zero_page, 0, lane, 1);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      f32x4 oacc[4];
+      for (int s = 0; s < HPW; ++s) {
+        const int head = wave * HPW + s;
+        if (head >= H || (xp & 4)) break;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the previous head's transpose reads have returned
+        stage_head_dma(v + (int64_t)bi * vb + head * DH, ldv, nk, 32 * nu, vbuf, zero_page, 0, lane, 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        f32x4 oacc[4];
 #pragma unroll
-      for (int c = 0; c < 4; ++c) oacc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-      for (int u = 0; u < nu; ++u) {
-        // B operand: k-slot (g, e) <-> key 32u + 4g + e (e < 4), 32u + 16 + 4g + (e - 4): the permutation frag_trr applies to V
-        const bf16_t* ar = Al + (head * 16 + qi) * DV_AP + 32 * u + 4 * g;
-        const bf16x4 lo = *(const bf16x4*)ar, hi = *(const bf16x4*)(ar + 16);
-        bf16x8 pf;
+        for (int c = 0; c < 4; ++c) oacc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int u = 0; u < nu; ++u) {
+          // B operand: k-slot (g, e) <-> key 32u + 4g + e (e < 4), 32u + 16 + 4g + (e - 4): the permutation frag_trr applies to V
+          const bf16_t* ar = Al + (head * 16 + qi) * DV_AP + 32 * u + 4 * g;
+          const bf16x4 lo = *(const bf16x4*)ar, hi = *(const bf16x4*)(ar + 16);
+          bf16x8 pf;
 #pragma unroll
-        for (int e2 = 0; e2 < 4; ++e2) { pf[e2] = lo[e2]; pf[4 + e2] = hi[e2]; }
+          for (int e2 = 0; e2 < 4; ++e2) { pf[e2] = lo[e2]; pf[4 + e2] = hi[e2]; }
 #pragma unroll
-        for (int c = 0; c < 4; ++c) oacc[c] = mfma16(frag_trr(vbuf, c, u, lane), pf, oacc[c]);
-      }
-      if (q0 + qi < nq) {
-        bf16_t* op = o + (int64_t)bi * ob + (int64_t)(q0 + qi) * ldo + head * DH;
+          for (int c = 0; c < 4; ++c) oacc[c] = mfma16(frag_trr(vbuf, c, u, lane), pf, oacc[c]);
+        }
+        if (q0 + qi < nq) {
+          bf16_t* op = o + (int64_t)bi * ob + (int64_t)(q0 + qi) * ldo + head * DH;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          bf16x4 ov;
+          for (int c = 0; c < 4; ++c) {
+            bf16x4 ov;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) ov[r] = (bf16_t)oacc[c][r];
-          *(bf16x4*)(op + 16 * c + 4 * g) = ov;
+            for (int r = 0; r < 4; ++r) ov[r] = (bf16_t)oacc[c][r];
+            *(bf16x4*)(op + 16 * c + 4 * g) = ov;
+          }
         }
       }
     }
+    __syncthreads();   // the V images overlay the P buffer of the next tile
   }
 }
 
@@ -236,14 +252,17 @@ void launch_deepvit_attn_fwd(const bf16_t* q, const bf16_t* k, const bf16_t* v, 
                              const float* beta, float* p_keep, float* a2_keep, int keep, int b, int h, int nq,
                              int nk, int64_t ld, float scale, float eps, const bf16_t* zero_page, hipStream_t s) {
   const int ntile = (nq + 15) / 16;
+  // chunks per image: one workgroup per image once the batch alone fills the chip, otherwise enough chunks to cover the 256 CUs
+  int cpi = b >= 192 ? 1 : std::max(1, std::min(ntile, (256 + b - 1) / b));
+  if (const char* e = getenv("VITX_DV_CPI")) cpi = std::max(1, std::min(ntile, atoi(e)));   // tests: the multi-tile loop at small batches
   static const int xp = [] { const char* e = getenv("VITX_DV_XP"); return e ? atoi(e) : 0; }();   // timing experiments: 1 = no kept tensors, 2 = no stage 2, 4 = no stage 3 (WRONG results)
   if (xp & 1) keep = 0;
 #define CALL(HT)                                                                                                                  \
   {                                                                                                                               \
     dv_set_smem(deepvit_attn_fwd_kernel<HT>, dv_fwd_smem<HT>());                                                                  \
-    hipLaunchKernelGGL(deepvit_attn_fwd_kernel<HT>, dim3(b * ntile), dim3(DV_THREADS), dv_fwd_smem<HT>(), s, q, k, v, ldq, ldk,   \
+    hipLaunchKernelGGL(deepvit_attn_fwd_kernel<HT>, dim3(b * cpi), dim3(DV_THREADS), dv_fwd_smem<HT>(), s, q, k, v, ldq, ldk,   \
                        ldv, qb, kb, vb, o, ldo, ob, w, gamma, beta, p_keep, a2_keep, keep, nq, nk, ld, scale, eps,   \
-                       zero_page, ntile, xp);                                                                                     \
+                       zero_page, ntile, cpi, xp);                                                                                \
   }
   if (h == 4) CALL(4) else if (h == 8) CALL(8) else if (h == 12) CALL(12) else CALL(16)
 #undef CALL
