@@ -1,4 +1,4 @@
-"""TEST INFRASTRUCTURE -- NOT PRODUCT CODE.  PARITY UNPINNED (see oracle/spec.py).
+"""TEST INFRASTRUCTURE -- NOT PRODUCT CODE.  Fixtures of the ORACLE (bisecting aids: per-block activations); the files that pin it to the reference are tests/golden/ref_*.npz (oracle/gen_ref_fixtures.py).
 
 Writes the small golden fixtures under tests/golden/ from the ORACLE (the reference itself cannot be
 imported here: TensorFlow is absent from the image and there is no network).  They freeze the oracle's

@@ -5,8 +5,10 @@
 * the T2T tokenizer (/root/reference/vit_tensorflow/t2t.py:39-47): tf.image.extract_patches(sizes k, strides s, rates 1,
   padding 'SAME') between two rearranges.
 
-Parity unpinned: TensorFlow cannot be installed here and the reference holds no golden vectors.
-extract_patches follows TensorFlow's documented SAME rule (out = ceil(in / stride); pad_total = max((out - 1) * stride + k - in, 0);
+Pinned through the reference's own source run under oracle/tf_shim: efficient.py with the reference's vit.Transformer in the middle
+(tests/golden/ref_efficient_vit*.npz) is reproduced by the ViT restatement this shell is the depth-0 case of, and t2t.py
+(tests/golden/ref_t2t_*.npz; the shim's extract_patches is an independent pad + unfold formulation) by oracle/ref_t2t.py, which
+calls extract_patches below.  extract_patches follows TensorFlow's documented SAME rule (out = ceil(in / stride); pad_total = max((out - 1) * stride + k - in, 0);
 pad_before = pad_total // 2, the odd pixel goes after; taps outside the image read 0; output depth ordered (row, col, channel));
 the loop form below is checked against an independent formulation (explicit zero padding + torch.nn.functional.unfold) in
 tests/test_efficient_t2t.py.

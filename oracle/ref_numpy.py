@@ -1,4 +1,4 @@
-"""TEST INFRASTRUCTURE -- NOT PRODUCT CODE.  PARITY UNPINNED (see oracle/spec.py).
+"""TEST INFRASTRUCTURE -- NOT PRODUCT CODE.  Pinned against the reference's own source run under oracle/tf_shim (tests/golden/ref_*.npz, tests/test_ref_fixtures.py).
 
 fp64 numpy restatement, op for op, of the reference's forward pass:
   vit_tensorflow/vit.py:14-177, deepvit.py:46-157, cait.py:17-194.

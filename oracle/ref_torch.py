@@ -1,4 +1,4 @@
-"""TEST INFRASTRUCTURE -- NOT PRODUCT CODE.  PARITY UNPINNED (see oracle/spec.py).
+"""TEST INFRASTRUCTURE -- NOT PRODUCT CODE.  Pinned against the reference's own source run under oracle/tf_shim (tests/golden/ref_*.npz, tests/test_ref_fixtures.py).
 
 Independent torch-CPU twin of oracle/ref_numpy.py (plain reshape/permute instead of einops)
 with autograd, used as the gradient oracle (the reference has no backward code: gradients are

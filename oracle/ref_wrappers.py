@@ -1,4 +1,5 @@
-"""TEST INFRASTRUCTURE -- NOT PRODUCT CODE.  PARITY UNPINNED (see oracle/spec.py).
+"""TEST INFRASTRUCTURE -- NOT PRODUCT CODE.  Pinned: tests/test_ref_fixtures.py checks this module against tests/golden/ref_mae_*.npz and
+ref_simmim_vit.npz, produced by the reference's own mae.py / simmim.py under oracle/tf_shim (oracle/gen_ref_fixtures.py:make_mim).
 
 Torch-CPU restatement (fp64 by default, autograd) of the two masked-image-modelling wrappers that call
 `encoder.transformer(tokens)` on something other than the full token sequence:

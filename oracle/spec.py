@@ -4,9 +4,11 @@ Parameter specification (names, shapes, order, initialisers) shared by the two
 oracle twins (ref_numpy / ref_torch).  Only tests/, __graft_entry__.smoke() and
 bench.py's cpu_baseline leg may import anything under oracle/.
 
-PARITY UNPINNED: the reference (taki0112/vit-tensorflow) ships no tests, golden
-vectors or seeds, and TensorFlow is not installable here, so this restatement
-cannot be checked against outputs of the reference itself.
+Pinned (round 2): the reference ships no tests or golden vectors and TensorFlow is not
+installable here, but its source files run unmodified under oracle/tf_shim;
+oracle/gen_ref_fixtures.py loads THESE parameters into the reference's own layer objects
+and commits what they compute (tests/golden/ref_*.npz); tests/test_ref_fixtures.py holds
+the oracle twins to those files at float64 rounding.
 
 Shapes follow the Keras conventions the reference relies on:
   Dense kernel [in, out] (+ bias [out])              vit.py:39,42,59,63,143,156

@@ -61,6 +61,21 @@ class _T(torch.Tensor):
     def ndim_(self):
         return self.dim()
 
+    # EagerTensor (op) ndarray is a tensor on the tape (simmim.py:128: pred - patches.numpy()[...]); torch would hand the pair to
+    # NumPy, which detaches.  The ndarray operand becomes a constant tensor instead.
+    def _lift(self, other):
+        return _t(other) if isinstance(other, np.ndarray) else other
+
+    def __add__(self, o): return torch.Tensor.__add__(self, self._lift(o))
+    def __radd__(self, o): return torch.Tensor.__radd__(self, self._lift(o))
+    def __sub__(self, o): return torch.Tensor.__sub__(self, self._lift(o))
+    def __rsub__(self, o): return torch.Tensor.__rsub__(self, self._lift(o))
+    def __mul__(self, o): return torch.Tensor.__mul__(self, self._lift(o))
+    def __rmul__(self, o): return torch.Tensor.__rmul__(self, self._lift(o))
+    def __truediv__(self, o): return torch.Tensor.__truediv__(self, self._lift(o))
+    def __rtruediv__(self, o): return torch.Tensor.__rtruediv__(self, self._lift(o))
+    __array_priority__ = 1000          # ndarray (op) tensor defers to the tensor as well
+
 
 def _t(x, dtype=None) -> torch.Tensor:
     if isinstance(x, torch.Tensor):
@@ -268,7 +283,7 @@ class Layer:
 
     def __call__(self, *args, **kwargs):
         if not self.built:
-            if args and isinstance(args[0], torch.Tensor):
+            if args and getattr(args[0], "shape", None) is not None:     # tensors and NumPy arrays alike (simmim.py:122 hands one over)
                 self.build(tuple(args[0].shape))
             self.built = True
         if "training" in kwargs and not _accepts(self.call, "training"):

@@ -1,6 +1,6 @@
 """CPU tier: the oracle against itself (numpy fp64 vs torch fp64 twins), against the committed golden
 fixtures, against the real `einops` for the patch-index arithmetic, and finite-difference checks of the
-gradient oracle.  PARITY UNPINNED: the reference has no golden vectors."""
+gradient oracle.  (What pins the oracle to the reference itself is tests/test_ref_fixtures.py.)"""
 import os
 
 import numpy as np

@@ -151,3 +151,38 @@ def test_distill_oracle_reproduces_reference_fixture(case):
     for n, v in Pt.items():
         ref = z["wrap/grad/student." + n]
         assert np.abs(v.grad.numpy() - ref).max() <= 1e-11 * max(1.0, np.abs(ref).max()), n
+
+
+@pytest.mark.parametrize("case", list(G.MIM_CASES))
+def test_mim_oracle_reproduces_reference_fixture(case):
+    """oracle/ref_wrappers.py (MAE.call mae.py:47-92, SimMIM.call simmim.py:86-130) against what the reference's own mae.py /
+    simmim.py produced under the shim on the indices the reference itself drew: the loss as written (mae.py:90 squares the
+    prediction alone), every variable's gradient, and the tape cut of the `.numpy()` indexing (mae.py:62, simmim.py:119) --
+    variables upstream of it have NO gradient in the reference, which `detach_like_reference=True` reproduces."""
+    from oracle import ref_wrappers as RW
+    z = _load(case)
+    kind, ekw, wkw = G.MIM_CASES[case]
+    ecfg = spec.make_config("vit", **ekw)
+    E = spec.init_params(ecfg, int(z["enc_seed"]), randomize_all=True)
+    Wp = G.mim_wrapper_params(kind, ecfg, wkw, int(z["wrap_seed"]))
+    if kind == "mae":
+        dcfg = G.mim_decoder_cfg(ekw, wkw)
+        D = spec.init_params(dcfg, int(z["dec_seed"]), randomize_all=True)
+        loss, _, ge, gd, gw = RW.mae_forward_backward(ecfg, dcfg, E, D, Wp, z["img"], z["indices"], float(z["masking_ratio"]),
+                                                      literal_loss=True, detach_like_reference=True)
+        got = {**{"encoder." + k: v for k, v in ge.items()}, **{"decoder." + k: v for k, v in gd.items() if k.startswith("transformer.")}, **gw}
+    else:
+        loss, _, ge, gw = RW.simmim_forward_backward(ecfg, E, Wp, z["img"], z["indices"], float(z["masking_ratio"]), detach_like_reference=True)
+        got = {**{"encoder." + k: v for k, v in ge.items()}, **gw}
+    assert abs(loss - float(z["loss"])) <= F64_TOL * abs(float(z["loss"]))
+    names = [k[5:] for k in z.files if k.startswith("grad/")]
+    assert sorted(names) == sorted(got), sorted(set(names) ^ set(got))
+    with_grad = 0
+    for n in names:
+        ref = z["grad/" + n]
+        if not bool(z["has_grad/" + n]):
+            assert not np.asarray(got[n]).any(), n          # cut off from the tape in the reference: the oracle must agree
+            continue
+        with_grad += 1
+        assert np.abs(got[n] - ref).max() <= F64_TOL * max(1.0, np.abs(ref).max()), n
+    assert with_grad == {"mae_vit": 39, "mae_same_dim": 48, "simmim_vit": 2}[case]
