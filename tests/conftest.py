@@ -23,3 +23,14 @@ def _built_library():
         import build as _b   # vit-tensorflow_amd/build.py (hipcc cross-compiles without a GPU)
         _b.build()
     yield
+
+
+@pytest.fixture(autouse=True)
+def _print_observed_gate_errors():
+    """After each test: the worst error each bf16-sized gate saw (tests/util.py:gate)."""
+    yield
+    try:
+        from util import report_gates
+        report_gates()
+    except Exception:
+        pass

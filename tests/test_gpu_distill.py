@@ -26,10 +26,11 @@ def _student(compute, pool, b, seed=1):
     return cfg, P, m
 
 
-def _close(a, ref, tol, what):
+def _close(a, ref, tol, what, group=None):
+    from util import gate
     ref = np.asarray(ref)
     err = np.abs(np.asarray(a, np.float64).reshape(ref.shape) - ref).max()
-    assert err <= tol * max(1e-6, np.abs(ref).max()) + 1e-7, f"{what}: err {err:.3e} vs max {np.abs(ref).max():.3e}"
+    gate((err - 1e-7) / max(1e-6, np.abs(ref).max()), tol, what, group or ("values" if what in ("logits", "distill_tokens", "plain logits", "loss", "student_logits", "distill_logits", "loss with overrides") else "gradients"))
 
 
 @pytest.mark.parametrize("compute,pool", [("fp32", "cls"), ("fp32", "mean"), ("bf16", "cls"), ("bf16", "mean")])
@@ -48,8 +49,8 @@ def test_distillable_vit_call_and_vjp(compute, pool):
     tt = torch.tensor(tok.astype(np.float64), requires_grad=True)
     rl, rd = RD.student_forward(cfg, Pt, torch.tensor(img, dtype=torch.float64), tt, q)
     (rl * torch.tensor(dlogits, dtype=torch.float64)).sum().add((rd * torch.tensor(ddt, dtype=torch.float64)).sum()).backward()
-    tol = 1e-4 if compute == "fp32" else 3e-2
-    gtol = 1e-4 if compute == "fp32" else 6e-2
+    tol = 1e-4 if compute == "fp32" else 1e-2   # bf16 gates: ~2x the worst error observed on MI355X (profiles/r2/pytest_gpu_gates_observed_r2x.log): values 3.2e-3, gradients 8.3e-3
+    gtol = 1e-4 if compute == "fp32" else 2e-2
     _close(logits, rl.detach().numpy(), tol, "logits")
     _close(dtok, rd.detach().numpy(), tol, "distill_tokens")
     _close(dtoken, tt.grad.numpy(), gtol, "d(distill_token)")
@@ -88,8 +89,8 @@ def test_distill_wrapper_matches_the_oracle(compute, kw):
     rl, rsl, rdl, gP, gW = RD.wrapper_forward_backward(cfg, P, {k: v.astype(np.float64) for k, v in sd.items()}, img, labels, teacher_logits,
                                                      dloss=dloss, temperature=kw["temperature"], alpha=kw["alpha"], hard=kw["hard"],
                                                      literal_loss=kw["literal_loss"], q=q)
-    tol = 1e-4 if compute == "fp32" else 3e-2
-    gtol = 1e-4 if compute == "fp32" else 6e-2
+    tol = 1e-4 if compute == "fp32" else 1e-2   # bf16 gates: ~2x the worst error observed on MI355X (profiles/r2/pytest_gpu_gates_observed_r2x.log): values 3.2e-3, gradients 8.3e-3
+    gtol = 1e-4 if compute == "fp32" else 2e-2
     _close(loss, rl, tol, "loss")
     _close(w.read("student_logits"), rsl, tol, "student_logits")
     _close(w.read("distill_logits"), rdl, tol, "distill_logits")

@@ -5,13 +5,13 @@ import numpy as np
 import pytest
 
 from oracle import ref_numpy, ref_torch, spec
-from util import make_engine_model, oracle_cfg, rand_images
+from util import gate, make_engine_model, oracle_cfg, rand_images
 from vit_tensorflow import _native as N
 
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("name,compute,tol", [("vit_small", "fp32", 1e-4), ("vit_bf16_small", "bf16", 8e-2), ("cait_small", "fp32", 1e-4)])
+@pytest.mark.parametrize("name,compute,tol", [("vit_small", "fp32", 1e-4), ("vit_bf16_small", "bf16", 6e-3), ("cait_small", "fp32", 1e-4)])
 def test_batch_geometry_changes_on_one_handle(name, compute, tol):
     """b = 4 -> 1 -> 3 on the same handle: each call must match the oracle (stale rows of the larger batch must not leak in)."""
     cfg = oracle_cfg(name)
@@ -22,7 +22,7 @@ def test_batch_geometry_changes_on_one_handle(name, compute, tol):
         got = m(img, training=False)
         ref = ref_numpy.forward(cfg, P, img)
         assert got.shape == ref.shape
-        assert np.abs(got - ref).max() <= tol * max(1.0, np.abs(ref).max()), (b, np.abs(got - ref).max())
+        gate(np.abs(got - ref).max() / max(1.0, np.abs(ref).max()), tol, f"logits at b={b}", "logits")
         # backward on the changed geometry as well
         dl = np.random.default_rng(b).standard_normal(ref.shape).astype(np.float32) / b
         grads, _ = m.backward(dl)
@@ -99,8 +99,8 @@ def test_gemm_variant_choice_does_not_change_results(monkeypatch):
         assert np.array_equal(outs[0], o)
 
 
-@pytest.mark.parametrize("name,compute,tol", [("deepvit_82tok", "fp32", 2e-4), ("cait_82tok", "fp32", 2e-4), ("deepvit_82tok", "bf16", 6e-2),
-                                              ("cait_82tok", "bf16", 6e-2)])
+@pytest.mark.parametrize("name,compute,tol", [("deepvit_82tok", "fp32", 2e-4), ("cait_82tok", "fp32", 2e-4), ("deepvit_82tok", "bf16", 2e-2),
+                                              ("cait_82tok", "bf16", 2e-2)])   # bf16 (against the oracle with the same rounding points): observed logits 2.4e-3, gradients 9.1e-3
 def test_head_axis_chains_beyond_64_keys(name, compute, tol):
     """Rows with more than 64 keys take the multi-sweep fused head-axis kernels (softmax / head mixing / LayerNorm over heads and
     their VJPs): logits and every gradient against the autograd twin."""
@@ -113,9 +113,9 @@ def test_head_axis_chains_beyond_64_keys(name, compute, tol):
     grads, _ = m.backward(dl)
     q = ref_torch.bf16_round if compute == "bf16" else None
     ref_logits, ref_grads, _ = ref_torch.forward_backward(cfg, P, img, dl, q=q)
-    assert np.abs(logits - ref_logits).max() <= tol * max(1.0, np.abs(ref_logits).max())
+    gate(np.abs(logits - ref_logits).max() / max(1.0, np.abs(ref_logits).max()), tol, "logits", "logits")
     for k, r in ref_grads.items():
-        assert np.abs(grads[k] - r).max() <= tol * np.abs(r).max() + 1e-6, (k, np.abs(grads[k] - r).max(), np.abs(r).max())
+        gate((np.abs(grads[k] - r).max() - 1e-6) / np.abs(r).max(), tol, k, "gradients")
 
 
 def test_hip_graph_replay_equals_eager_steps():

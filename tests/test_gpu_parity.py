@@ -11,7 +11,7 @@ import torch
 from einops import rearrange
 
 from oracle import ref_numpy, ref_torch, spec
-from util import CONFIGS, make_engine_model, oracle_cfg, rand_images, rel_max_err
+from util import CONFIGS, gate, make_engine_model, oracle_cfg, rand_images, rel_max_err
 from vit_tensorflow import _native as N
 
 pytestmark = pytest.mark.gpu
@@ -214,9 +214,9 @@ def test_bf16_fused_attention_equals_materialised_path(monkeypatch):
         lg = m(img, training=False)
         g, _ = m.backward(dl)
         outs.append((lg, g))
-    assert np.abs(outs[0][0] - outs[1][0]).max() <= 2e-2
+    gate(np.abs(outs[0][0] - outs[1][0]).max(), 1.2e-2, "logits", "fused vs materialised logits")          # observed 5.8e-3
     for k in outs[0][1]:
-        assert rel_max_err(outs[0][1][k], outs[1][1][k].astype(np.float64)) <= 4e-2, k
+        gate(rel_max_err(outs[0][1][k], outs[1][1][k].astype(np.float64)), 1.6e-2, k, "fused vs materialised gradients")   # observed 7.9e-3
 
 
 def test_bf16_mfma_gemm_equals_fp32_fma_gemm():
@@ -265,7 +265,7 @@ def test_full_size_properties_vit_b16_bf16():
         gh, _ = m.backward(dl[half])          # dl already carries 1/b, so halves simply add up
         acc = gh if acc is None else {k: acc[k] + gh[k] for k in gh}
     for k in ("transformer.0.attn.to_qkv.kernel", "transformer.5.mlp.fc1.bias", "cls_token", "mlp_head.bias"):
-        assert rel_max_err(acc[k], g1[k].astype(np.float64)) <= 3e-2, k
+        gate(rel_max_err(acc[k], g1[k].astype(np.float64)), 3e-2, k, "two half batches vs one batch")
 
 
 def test_optimizer_steps_match_numpy():

@@ -43,11 +43,13 @@ def _randomize(model, seed):
 def _close(a, ref, tol, what, norm=False):
     ref = np.asarray(ref)
     diff = np.asarray(a, np.float64).reshape(ref.shape) - ref
+    from util import gate
+    grp = "values" if what in ("pred_pixel_values",) else "gradients"
     if norm:   # gradients of an L1 loss are sums of sign() terms: a bf16-sized change of pred flips a few of them outright
-        assert np.linalg.norm(diff) <= tol * np.linalg.norm(ref) + 1e-7, f"{what}: |diff| {np.linalg.norm(diff):.3e} vs |ref| {np.linalg.norm(ref):.3e}"
+        gate((np.linalg.norm(diff) - 1e-7) / max(1e-30, np.linalg.norm(ref)), tol, what, grp + " (L2)")
         return
     err = np.abs(diff).max()
-    assert err <= tol * max(1e-6, np.abs(ref).max()) + 1e-7, f"{what}: err {err:.3e} vs max {np.abs(ref).max():.3e}"
+    gate((err - 1e-7) / max(1e-6, np.abs(ref).max()), tol, what, grp)
 
 
 def _images(cfg, b, seed=7):
@@ -81,10 +83,10 @@ def test_mae_matches_the_oracle(compute, literal, same_dim):
     grads = mae.backward()
     q = ref_torch.bf16_round if compute == "bf16" else None
     rl, rpred, ge, gd, gw = RW.mae_forward_backward(ecfg, dcfg, E, D, Wm, img, perm, 0.75, literal_loss=literal, q=q)
-    tol = 1e-4 if compute == "fp32" else 3e-2     # bf16: same rounding points, different accumulation order, bf16 P in attention
+    tol = 1e-4 if compute == "fp32" else 1e-2     # bf16: same rounding points, different accumulation order, bf16 P in attention; observed 4.5e-3
     assert abs(loss - rl) <= tol * abs(rl), (loss, rl)
     _close(mae.read("pred"), rpred, tol, "pred_pixel_values")
-    gtol = tol if compute == "fp32" else 6e-2
+    gtol = tol if compute == "fp32" else 2e-2     # observed 4.7e-3 (profiles/r2/pytest_gpu_gates_observed_r2x.log)
     for k, r in gw.items():
         _close(grads[k], r, gtol, k)
     for k, r in ge.items():
@@ -112,10 +114,10 @@ def test_simmim_matches_the_oracle(key, variant):
     grads = mim.backward()
     q = ref_torch.bf16_round if compute == "bf16" else None
     rl, rpred, ge, gw = RW.simmim_forward_backward(ecfg, E, Ws, img, midx, 0.5, q=q)
-    tol = 1e-4 if compute == "fp32" else 3e-2
+    tol = 1e-4 if compute == "fp32" else 1e-2     # observed 3.6e-3
     assert abs(loss - rl) <= tol * abs(rl), (loss, rl)
     _close(mim.read("pred"), rpred, tol, "pred_pixel_values")
-    gtol, nrm = (tol, False) if compute == "fp32" else (8e-2, True)   # bf16: relative L2 error per tensor (see _close)
+    gtol, nrm = (tol, False) if compute == "fp32" else (8e-2, True)   # bf16: relative L2 error per tensor (see _close); observed 3.5e-2 .. 5.5e-2
     for k, r in gw.items():
         _close(grads[k], r, gtol, k, nrm)
     for k, r in ge.items():

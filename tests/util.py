@@ -52,3 +52,22 @@ def rand_images(cfg: dict, b: int, seed: int = 0, hw=None) -> np.ndarray:
 
 def rel_max_err(a: np.ndarray, ref: np.ndarray) -> float:
     return float(np.abs(np.asarray(a, np.float64) - ref).max() / (np.abs(ref).max() + 1e-30))
+
+
+_OBSERVED = {}
+
+
+def gate(err: float, tol: float, what: str, group: str = "") -> None:
+    """assert err <= tol, and remember the worst err / tol ratio per group: `report_gates()` prints them (pytest -rA shows the
+    output), which is how the bf16 gates of the GPU tier are kept at about twice what MI355X actually produces."""
+    if tol >= 5e-3:
+        w = _OBSERVED.setdefault(group or what, (0.0, tol, what))
+        if err > w[0]:
+            _OBSERVED[group or what] = (float(err), tol, what)
+    assert err <= tol, f"{what}: {err:.3e} > {tol:.1e}"
+
+
+def report_gates() -> None:
+    for k, (e, t, what) in sorted(_OBSERVED.items()):
+        print(f"[gate] {k}: worst observed {e:.3e} (gate {t:.1e}, at {what})")
+    _OBSERVED.clear()
