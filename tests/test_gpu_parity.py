@@ -219,6 +219,26 @@ def test_bf16_fused_attention_equals_materialised_path(monkeypatch):
         gate(rel_max_err(outs[0][1][k], outs[1][1][k].astype(np.float64)), 1.6e-2, k, "fused vs materialised gradients")   # observed 7.9e-3
 
 
+def test_one_launch_attention_backward_equals_two_launches(monkeypatch):
+    """attn_bwd_fused_kernel runs the dQ pass and the dK / dV pass of one (image, head) back to back in one workgroup (the second
+    pass finds q, k, v, dO in L2; D stays in LDS): the arithmetic is the two-kernel form's, so every gradient has the same bits."""
+    cfg = oracle_cfg("cfg2_vit_b16")
+    kw = dict(CONFIGS["cfg2_vit_b16"][1], depth=2)
+    from vit_tensorflow import ViT
+    img = rand_images(cfg, 3)
+    dl = (np.random.default_rng(5).standard_normal((3, 1000)) / 2).astype(np.float32)
+    m = ViT(**kw, compute="bf16", max_batch=3, seed=2)
+    got = []
+    for split in ("0", "1"):
+        monkeypatch.setenv("VITX_ATTN_BWD_SPLIT", split)
+        m(img, training=False)
+        g, dimg = m.backward(dl, want_dimg=True)
+        got.append((g, dimg))
+    for k in got[0][0]:
+        assert np.array_equal(got[0][0][k], got[1][0][k]), k
+    assert np.array_equal(got[0][1], got[1][1])
+
+
 def test_bf16_mfma_gemm_equals_fp32_fma_gemm():
     """gemm_bf16.hip (MFMA, swizzled LDS, all tile variants) vs the k-ordered fp32 FMA kernel on the same bf16 operands."""
     m = make_engine_model("vit_bf16_small", "bf16", 1)
