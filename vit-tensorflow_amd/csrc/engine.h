@@ -158,6 +158,7 @@ struct vitx_engine {
   // env switches
   bool force_generic_gemm = false, force_generic_attn = false, wgrad_via_transpose = true;
   int gemm_kernel = 0;
+  bool mlp_bwd_consumers_first = true;   // VITX_MLP_BWD_ORDER=0: fc2 weight gradient between the producer and the consumers of d hpre
   bool deepvit_fused = true;         // VITX_DEEPVIT_FUSED=0: DeepViT attention forward as batched GEMMs + head-axis kernels (A/B reference)
   bool unfused_headops = false;      // VITX_UNFUSED_HEADOPS=1: separate mix / softmax / LayerNorm-over-heads kernels (A/B reference)
   int gemm_stagger = 0;

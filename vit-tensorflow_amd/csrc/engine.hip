@@ -716,15 +716,22 @@ static int block_backward(vitx_engine* e, Stage& st, int si, int l, int b, int n
       launch_dropout(e->d_h, T, (int64_t)rows * m, drop, seed, site0 + 2, e->stream);   // mask of the post-GELU dropout (commutes)
     }
   }
-  dense_wgrad(e, ba.act, m, dbranch, d, rows, bp.fc2);
+  // Order: the two consumers of d hpre (310 MB at ViT-B/16, just written) run right behind its producer; the fc2 weight gradient,
+  // which reads other tensors (act, the branch gradient), follows them instead of sitting in between and pushing d hpre out of the
+  // memory-side cache.  VITX_MLP_BWD_ORDER=0: fc2 weight gradient first (the order of round 1; same results either way).
   const bool fc2_bias_in_ln = dbranch != e->d_br && !grouped;   // db_fc2 = column sums of g: fused into the LayerNorm backward pass below
-  if (!fc2_bias_in_ln) bias_grad(e, dbranch == e->d_br ? (const void*)e->d_br : (const void*)e->g, dbranch == e->d_br ? T : 0, d, rows, bp.fc2);
+  auto fc2_param_grads = [&]() {
+    dense_wgrad(e, ba.act, m, dbranch, d, rows, bp.fc2);
+    if (!fc2_bias_in_ln) bias_grad(e, dbranch == e->d_br ? (const void*)e->d_br : (const void*)e->g, dbranch == e->d_br ? T : 0, d, rows, bp.fc2);
+  };
+  if (!e->mlp_bwd_consumers_first) fc2_param_grads();
   {
     EpiParams ep; ep.out = e->d_y; ep.ldo = d;
     dense_dgrad(e, e->d_h, m, rows, bp.fc1, EPI_STORE, ep);
   }
   dense_wgrad(e, ba.y2, d, e->d_h, m, rows, bp.fc1);
   if (!fc1_bias_fused) bias_grad(e, e->d_h, T, m, rows, bp.fc1);
+  if (e->mlp_bwd_consumers_first) fc2_param_grads();
   {
     Prof pr(e, "layernorm_bwd", 0, lnb);
     launch_layernorm_bwd(e->d_y, T, d, ba.ln2_src ? ba.ln2_src : ba.x_mid, d, ba.mean2, ba.rstd2, e->params + bp.ln2_g, ln_gin, d, ln_gout, d, ln_glp, d,
@@ -857,6 +864,7 @@ static int engine_create_body(vitx_engine* e, const vitx_config& cfg, std::strin
   e->force_generic_gemm = env_flag("VITX_GENERIC_GEMM");
   e->force_generic_attn = env_flag("VITX_GENERIC_ATTN");
   if (const char* k = getenv("VITX_DEEPVIT_FUSED")) e->deepvit_fused = atoi(k) != 0;
+  if (const char* k = getenv("VITX_MLP_BWD_ORDER")) e->mlp_bwd_consumers_first = atoi(k) != 0;
   if (const char* k = getenv("VITX_GEMM_KERNEL")) e->gemm_kernel = atoi(k);
   if (const char* k = getenv("VITX_UNFUSED_HEADOPS")) e->unfused_headops = atoi(k) != 0;
   e->wgrad_via_transpose = env_flag("VITX_WGRAD_TRANSPOSE");
