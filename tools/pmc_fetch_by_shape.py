@@ -1,3 +1,5 @@
+"""Per-dispatch FETCH_SIZE of the NT GEMM launches of the last step, grouped by kernel instance and fetch volume:
+    python tools/pmc_fetch_by_shape.py <rocprofv3 --pmc FETCH_SIZE counter_collection.csv>   (fetch bytes = 2 x FETCH_SIZE x 1024 on gfx950)"""
 import csv, collections, re, sys
 rows=list(csv.DictReader(open(sys.argv[1])))
 nt=[r for r in rows if 'gemm_bf16_nt' in r['Kernel_Name']][-99:]
