@@ -158,6 +158,9 @@ struct vitx_engine {
   // env switches
   bool force_generic_gemm = false, force_generic_attn = false, wgrad_via_transpose = true;
   int gemm_kernel = 0;
+  int nt_mask = 1;                       // VITX_NT=bits: non-temporal hints.  1: the fc1 epilogue's gelu'(h) store (read again only by the backward).
+                                         // (Measured and dropped: the same hint on the fc2-dgrad epilogue's read of it -- no effect -- and on the
+                                         // weight-gradient operand loads -- 10.8 -> 11.25 ms per step.)
   bool mlp_bwd_consumers_first = true;   // VITX_MLP_BWD_ORDER=0: fc2 weight gradient between the producer and the consumers of d hpre
   bool deepvit_fused = true;         // VITX_DEEPVIT_FUSED=0: DeepViT attention forward as batched GEMMs + head-axis kernels (A/B reference)
   bool unfused_headops = false;      // VITX_UNFUSED_HEADOPS=1: separate mix / softmax / LayerNorm-over-heads kernels (A/B reference)

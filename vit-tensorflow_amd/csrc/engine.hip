@@ -643,6 +643,7 @@ static int block_forward(vitx_engine* e, Stage& st, int si, int l, int b, int nq
   }
   {
     EpiParams ep; ep.out = ba.hpre; ep.ldo = m; ep.out2 = ba.act; ep.ldo2 = m;
+    ep.nt_out = e->nt_mask & 1;
     dense_fwd(e, ba.y2, d, rows, bp.fc1, EPI_BIAS_GELU, ep);                  // vit.py:39,34
   }
   if (drop > 0.f) {
@@ -865,6 +866,7 @@ static int engine_create_body(vitx_engine* e, const vitx_config& cfg, std::strin
   e->force_generic_attn = env_flag("VITX_GENERIC_ATTN");
   if (const char* k = getenv("VITX_DEEPVIT_FUSED")) e->deepvit_fused = atoi(k) != 0;
   if (const char* k = getenv("VITX_MLP_BWD_ORDER")) e->mlp_bwd_consumers_first = atoi(k) != 0;
+  if (const char* k = getenv("VITX_NT")) e->nt_mask = atoi(k);
   if (const char* k = getenv("VITX_GEMM_KERNEL")) e->gemm_kernel = atoi(k);
   if (const char* k = getenv("VITX_UNFUSED_HEADOPS")) e->unfused_headops = atoi(k) != 0;
   e->wgrad_via_transpose = env_flag("VITX_WGRAD_TRANSPOSE");
