@@ -94,3 +94,31 @@ def test_fused_kernel_is_the_one_that_runs(monkeypatch):
     assert names.get("attn_deepvit_fused_fwd") == kw["depth"], names
     for gone in FUSED_AWAY:
         assert gone not in names, (gone, names)
+
+
+@pytest.mark.parametrize("name", ["deepvit_bf16_small", "cait_bf16_small", "cfg4_deepvit"])
+def test_paired_batched_products_equal_separate_launches(name, monkeypatch):
+    """The materialised attention backward runs its batched products in pairs that share an operand (dA = dO V^T with dV = A^T dO,
+    dQ = dS K with dK = dS^T Q): one launch per pair, the same workgroup doing both.  Same arithmetic as four launches: same bits."""
+    from oracle import spec as S
+    from util import CONFIGS, make_engine_model, oracle_cfg, rand_images
+    cfg = oracle_cfg(name)
+    if name == "cfg4_deepvit":
+        cfg = S.make_config("deepvit", **dict(CONFIGS[name][1], depth=2))
+    P = S.init_params(cfg, 1, randomize_all=True)
+    img = rand_images(cfg, 2, seed=4)
+    dl = (np.random.default_rng(6).standard_normal((2, cfg["num_classes"])) / 2).astype(np.float32)
+    got = []
+    for pairs in ("1", "0"):
+        monkeypatch.setenv("VITX_BGEMM_PAIRS", pairs)
+        if name == "cfg4_deepvit":
+            from vit_tensorflow.deepvit import DeepViT
+            m = DeepViT(**dict(CONFIGS[name][1], depth=2), compute="bf16", max_batch=2, seed=0)
+            m.load_state_dict({k: np.asarray(v, np.float32) for k, v in P.items()})
+        else:
+            m = make_engine_model(name, "bf16", 2, P)
+        m(img, training=True)
+        g, _ = m.backward(dl)
+        got.append(g)
+    for k in got[0]:
+        assert np.array_equal(got[0][k], got[1][k]), k

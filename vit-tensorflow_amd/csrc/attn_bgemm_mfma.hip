@@ -69,8 +69,7 @@ __device__ __forceinline__ void stage_canonical(const T* src, int64_t sr, int64_
 }
 
 template <typename TA, typename TO>
-__global__ __launch_bounds__(256) void bgemm_mfma_kernel(GenericGemmArgs g, EpiParams ep, int Mp, int Np, int Kp) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ __forceinline__ void bgemm_mfma_body(const GenericGemmArgs& g, const EpiParams& ep, int Mp, int Np, int Kp, char* smem) {
   const int pitch = Kp + PAD;
   bf16_t* As = (bf16_t*)smem;
   bf16_t* Bs = As + Mp * pitch;
@@ -107,6 +106,24 @@ __global__ __launch_bounds__(256) void bgemm_mfma_kernel(GenericGemmArgs g, EpiP
   }
 }
 
+template <typename TA, typename TO>
+__global__ __launch_bounds__(256) void bgemm_mfma_kernel(GenericGemmArgs g, EpiParams ep, int Mp, int Np, int Kp) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bgemm_mfma_body<TA, TO>(g, ep, Mp, Np, Kp, smem);
+}
+
+// Two products of the same (image, head) in one launch, run back to back by the same workgroup: the attention backward's pairs
+// (dA = dO V^T, dV = A^T dO) and (dQ = dS K, dK = dS^T Q) share an operand -- dO, resp. the [b, h, n, n] fp32 dS -- which the second
+// product then finds in L2 instead of fetching it from HBM again (same idea as attn_bwd_fused_kernel), and a launch is saved.
+template <typename TA1, typename TO1, typename TA2, typename TO2>
+__global__ __launch_bounds__(256) void bgemm_mfma_pair_kernel(GenericGemmArgs g1, EpiParams ep1, int Mp1, int Np1, int Kp1, GenericGemmArgs g2,
+                                                              EpiParams ep2, int Mp2, int Np2, int Kp2) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bgemm_mfma_body<TA1, TO1>(g1, ep1, Mp1, Np1, Kp1, smem);
+  __syncthreads();                     // every wave is done reading the first product's LDS images
+  bgemm_mfma_body<TA2, TO2>(g2, ep2, Mp2, Np2, Kp2, smem);
+}
+
 }  // namespace
 
 bool bgemm_mfma_supported(const GenericGemmArgs& g, int ta, int tb, int to, int mode) {
@@ -114,6 +131,26 @@ bool bgemm_mfma_supported(const GenericGemmArgs& g, int ta, int tb, int to, int 
   if (tb != 1) return false;                                           // B operand: bf16 q / k / v / dO head slices
   if (!((ta == 1 && to == 0 && mode == EPI_STORE_F32) || (ta == 0 && to == 1 && mode == EPI_STORE))) return false;
   return true;
+}
+
+void launch_bgemm_mfma_pair(const GenericGemmArgs& g1, const EpiParams& ep1, int ta1, const GenericGemmArgs& g2, const EpiParams& ep2, int ta2,
+                            hipStream_t s) {
+  const int Mp1 = (int)round_up(g1.M, 16), Np1 = (int)round_up(g1.N, 16), Kp1 = (int)round_up(g1.K, 32);
+  const int Mp2 = (int)round_up(g2.M, 16), Np2 = (int)round_up(g2.N, 16), Kp2 = (int)round_up(g2.K, 32);
+  const size_t smem = std::max((size_t)(Mp1 + Np1) * (Kp1 + PAD) * 2, (size_t)(Mp2 + Np2) * (Kp2 + PAD) * 2);
+  dim3 grid((unsigned)(g1.nb * g1.nh)), block(256);
+#define VITX_PAIR(T1, O1, T2, O2)                                                                                                  \
+  {                                                                                                                                \
+    auto kern = bgemm_mfma_pair_kernel<T1, O1, T2, O2>;                                                                            \
+    static bool set = false;                                                                                                       \
+    if (!set) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); set = true; } \
+    hipLaunchKernelGGL(kern, grid, block, smem, s, g1, ep1, Mp1, Np1, Kp1, g2, ep2, Mp2, Np2, Kp2);                                \
+  }
+  if (ta1 && !ta2) VITX_PAIR(bf16_t, float, float, bf16_t)
+  else if (!ta1 && !ta2) VITX_PAIR(float, bf16_t, float, bf16_t)
+  else if (ta1 && ta2) VITX_PAIR(bf16_t, float, bf16_t, float)
+  else VITX_PAIR(float, bf16_t, bf16_t, float)
+#undef VITX_PAIR
 }
 
 void launch_bgemm_mfma(const GenericGemmArgs& g, const EpiParams& ep, int ta, hipStream_t s) {

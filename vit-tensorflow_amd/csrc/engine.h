@@ -158,6 +158,7 @@ struct vitx_engine {
   // env switches
   bool force_generic_gemm = false, force_generic_attn = false, wgrad_via_transpose = true;
   int gemm_kernel = 0;
+  bool bgemm_pairs = true;               // VITX_BGEMM_PAIRS=0: the four batched products of the materialised attention backward as four launches
   int nt_mask = 1;                       // VITX_NT=bits: non-temporal hints.  1: the fc1 epilogue's gelu'(h) store (read again only by the backward).
                                          // (Measured and dropped: the same hint on the fc2-dgrad epilogue's read of it -- no effect -- and on the
                                          // weight-gradient operand loads -- 10.8 -> 11.25 ms per step.)

@@ -397,6 +397,37 @@ static int ensure_scores(vitx_engine* e, int count, int64_t elems, std::string& 
   return VITX_OK;
 }
 
+struct BgemmCall {   // one batched small product, as bgemm() takes it
+  const void* A; int ta; int64_t sam, sak, sAb, sAh; const void* B; int tb; int64_t sbk, sbn, sBb, sBh; int M, N, K, nb, nh, mode, to; void* out;
+  int64_t ldo, ob, oh; float alpha;
+};
+static void bgemm_fill(const BgemmCall& c, GenericGemmArgs& g, EpiParams& ep) {
+  g.A = c.A; g.B = c.B; g.M = c.M; g.N = c.N; g.K = c.K;
+  g.sam = c.sam; g.sak = c.sak; g.sbk = c.sbk; g.sbn = c.sbn;
+  g.nb = c.nb; g.nh = c.nh; g.sAb = c.sAb; g.sAh = c.sAh; g.sBb = c.sBb; g.sBh = c.sBh;
+  ep.out = c.out; ep.ldo = c.ldo; ep.out_batch_stride = c.ob; ep.out_head_stride = c.oh; ep.alpha = c.alpha;
+  ep.M = c.M; ep.N = c.N;
+  finalize_epi(ep);
+}
+static void bgemm(vitx_engine* e, const void* A, int ta, int64_t sam, int64_t sak, int64_t sAb, int64_t sAh, const void* B, int tb,
+                  int64_t sbk, int64_t sbn, int64_t sBb, int64_t sBh, int M, int N, int K, int nb, int nh, int mode, int to, void* out,
+                  int64_t ldo, int64_t ob, int64_t oh, float alpha);
+// two products of the same (image, head) that share an operand: one launch when both fit the MFMA kernel (attn_bgemm_mfma.hip)
+static void bgemm_pair(vitx_engine* e, const BgemmCall& c1, const BgemmCall& c2) {
+  GenericGemmArgs g1, g2;
+  EpiParams ep1, ep2;
+  bgemm_fill(c1, g1, ep1);
+  bgemm_fill(c2, g2, ep2);
+  if (e->bf16 && !e->force_generic_gemm && e->bgemm_pairs && c1.nb == c2.nb && c1.nh == c2.nh && bgemm_mfma_supported(g1, c1.ta, c1.tb, c1.to, c1.mode) &&
+      bgemm_mfma_supported(g2, c2.ta, c2.tb, c2.to, c2.mode)) {
+    Prof pr(e, "attn_bgemm_mfma", 2.0 * c1.nb * c1.nh * ((double)c1.M * c1.N * c1.K + (double)c2.M * c2.N * c2.K), 0);
+    launch_bgemm_mfma_pair(g1, ep1, c1.ta, g2, ep2, c2.ta, e->stream);
+    return;
+  }
+  for (const BgemmCall* c : {&c1, &c2})
+    bgemm(e, c->A, c->ta, c->sam, c->sak, c->sAb, c->sAh, c->B, c->tb, c->sbk, c->sbn, c->sBb, c->sBh, c->M, c->N, c->K, c->nb, c->nh, c->mode, c->to, c->out,
+          c->ldo, c->ob, c->oh, c->alpha);
+}
 static void bgemm(vitx_engine* e, const void* A, int ta, int64_t sam, int64_t sak, int64_t sAb, int64_t sAh, const void* B, int tb,
                   int64_t sbk, int64_t sbn, int64_t sBb, int64_t sBh, int M, int N, int K, int nb, int nh, int mode, int to, void* out,
                   int64_t ldo, int64_t ob, int64_t oh, float alpha) {
@@ -510,8 +541,8 @@ static void attn_generic_bwd(vitx_engine* e, const BlockParams& bp, const AttnVi
   const int pi = kept ? keep->sc_pi : attn_generic_scores(e, bp, a, b, true, e->sc);
   float* dA = e->sc[3];
   // d(attn) = dO v^T ; dV = attn^T dO
-  bgemm(e, gr.d_o, T, gr.ldo, 1, gr.ob, dh, a.v, T, 1, a.ldv, a.vb, dh, a.nq, a.nk, dh, b, h, EPI_STORE_F32, 0, dA, ld, bs, hs, 1.0f);
-  bgemm(e, sc[pi], 0, 1, ld, bs, hs, gr.d_o, T, gr.ldo, 1, gr.ob, dh, a.nk, dh, a.nq, b, h, EPI_STORE, T, gr.dv, gr.lddv, gr.dvb, dh, 1.0f);
+  bgemm_pair(e, BgemmCall{gr.d_o, T, gr.ldo, 1, gr.ob, dh, a.v, T, 1, a.ldv, a.vb, dh, a.nq, a.nk, dh, b, h, EPI_STORE_F32, 0, dA, ld, bs, hs, 1.0f},
+             BgemmCall{sc[pi], 0, 1, ld, bs, hs, gr.d_o, T, gr.ldo, 1, gr.ob, dh, a.nk, dh, a.nq, b, h, EPI_STORE, T, gr.dv, gr.lddv, gr.dvb, dh, 1.0f});
   // (the row-per-wave DeepViT chain reads the mixed scores; tensors kept by the one-kernel forward go to the point kernel, which recomputes them)
   const bool chain = !e->unfused_headops && headchain_supported(h, a.nk) && !(kept && keep->sc_no_mixed);
   if (chain && e->cfg.variant == VITX_VARIANT_CAIT) {
@@ -542,8 +573,8 @@ static void attn_generic_bwd(vitx_engine* e, const BlockParams& bp, const AttnVi
     }
   }
   // dQ = scale dS k ; dK = scale dS^T q
-  bgemm(e, dA, 0, ld, 1, bs, hs, a.k, T, a.ldk, 1, a.kb, dh, a.nq, dh, a.nk, b, h, EPI_STORE, T, gr.dq, gr.lddq, gr.dqb, dh, scale);
-  bgemm(e, dA, 0, 1, ld, bs, hs, a.q, T, a.ldq, 1, a.qb, dh, a.nk, dh, a.nq, b, h, EPI_STORE, T, gr.dk, gr.lddk, gr.dkb, dh, scale);
+  bgemm_pair(e, BgemmCall{dA, 0, ld, 1, bs, hs, a.k, T, a.ldk, 1, a.kb, dh, a.nq, dh, a.nk, b, h, EPI_STORE, T, gr.dq, gr.lddq, gr.dqb, dh, scale},
+             BgemmCall{dA, 0, 1, ld, bs, hs, a.q, T, a.ldq, 1, a.qb, dh, a.nk, dh, a.nq, b, h, EPI_STORE, T, gr.dk, gr.lddk, gr.dkb, dh, scale});
 }
 
 static bool use_fused_attn(const vitx_engine* e, int n) {
@@ -867,6 +898,7 @@ static int engine_create_body(vitx_engine* e, const vitx_config& cfg, std::strin
   if (const char* k = getenv("VITX_DEEPVIT_FUSED")) e->deepvit_fused = atoi(k) != 0;
   if (const char* k = getenv("VITX_MLP_BWD_ORDER")) e->mlp_bwd_consumers_first = atoi(k) != 0;
   if (const char* k = getenv("VITX_NT")) e->nt_mask = atoi(k);
+  if (const char* k = getenv("VITX_BGEMM_PAIRS")) e->bgemm_pairs = atoi(k) != 0;
   if (const char* k = getenv("VITX_GEMM_KERNEL")) e->gemm_kernel = atoi(k);
   if (const char* k = getenv("VITX_UNFUSED_HEADOPS")) e->unfused_headops = atoi(k) != 0;
   e->wgrad_via_transpose = env_flag("VITX_WGRAD_TRANSPOSE");

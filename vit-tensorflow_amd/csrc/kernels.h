@@ -36,6 +36,8 @@ void launch_deepvit_chain_bwd(const float* a0, const float* mixed, float* da_ino
 // batched small GEMM (M, N, K <= 128 per (image, head)) on MFMA for the materialised attention path in bf16 mode
 bool bgemm_mfma_supported(const GenericGemmArgs& g, int ta, int tb, int to, int mode);
 void launch_bgemm_mfma(const GenericGemmArgs& g, const EpiParams& ep, int ta, hipStream_t s);
+void launch_bgemm_mfma_pair(const GenericGemmArgs& g1, const EpiParams& ep1, int ta1, const GenericGemmArgs& g2, const EpiParams& ep2, int ta2,
+                            hipStream_t s);   // two products of the same (image, head) back to back in one launch (same nb, nh)
 
 // ---------------------------------------------------------------- gemm_bf16.hip
 // C[M,N] = A[M,K] * B[N,K]^T, bf16 operands (K contiguous), fp32 MFMA accumulation.
