@@ -108,6 +108,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=25.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="replay the step as one HIP graph (single GPU; the default launches kernel by kernel)")
     ap.add_argument("--bucket-mb", type=float, default=48.0)
     ap.add_argument("--grad-wire", default="fp32", choices=["fp32", "bf16"], help="dtype of the gradient all-reduce on the wire (N > 1)")
     args = ap.parse_args()
@@ -196,9 +197,20 @@ def main():
     for _ in range(args.warmup + priming):
         step()
     full_sync()
+    run_step = step
+    if args.graph and not dp:
+        # vitx_graph_*: the whole step (operand refresh, forward, CE gradient, backward) recorded once and replayed as ONE launch
+        N.check(lib.vitx_graph_capture_begin(h))
+        step()
+        graph = C.c_void_p()
+        N.check(lib.vitx_graph_capture_end(h, C.byref(graph)))
+        run_step = lambda: N.check(lib.vitx_graph_launch(h, graph))
+        for _ in range(2):
+            run_step()
+        full_sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        run_step()
     full_sync()
     el = time.perf_counter() - t0
     if dist.is_initialized():
@@ -215,7 +227,7 @@ def main():
         "dtype": "bf16" if args.compute == "bf16" else "f32", "data": "synthetic",
         "config": {"workload": f"{args.workload} fwd+bwd, batch {b}/GPU, N(0,1) NHWC images resident in HBM, random-init weights, "
                                f"softmax-CE cotangent, dropout 0", "global_batch": b * world,
-                   "parallelism": f"dp{world}", "compute": args.compute, **({"grad_wire": args.grad_wire} if dp else {})},
+                   "parallelism": f"dp{world}", "compute": args.compute, **({"launch": "hip_graph"} if (args.graph and not dp) else {}), **({"grad_wire": args.grad_wire} if dp else {})},
         "path_mfma_frac": round(value / world * fpi / MFMA_BF16_PEAK, 4),
         "flops_per_image": fpi,
     }
