@@ -219,6 +219,27 @@ def test_bf16_fused_attention_equals_materialised_path(monkeypatch):
         gate(rel_max_err(outs[0][1][k], outs[1][1][k].astype(np.float64)), 1.6e-2, k, "fused vs materialised gradients")   # observed 7.9e-3
 
 
+@pytest.mark.parametrize("image,patch", [(256, 16), (96, 16), (160, 16)])
+def test_bf16_fused_attention_at_other_token_counts(image, patch):
+    """The fused attention kernels are instantiated for 64 / 96 / 224 / 288 padded keys: 257 tokens (north_star's 256 x 256 images at
+    patch 16: the 288-key instance), 37 tokens (64) and 101 tokens (the 224-key instance with most tile pairs empty), logits and every
+    gradient against the autograd oracle with bf16 rounding at the same points."""
+    kw = dict(image_size=image, patch_size=patch, num_classes=10, dim=128, depth=2, heads=2, mlp_dim=256, dim_head=64)
+    cfg = spec.make_config("vit", **kw)
+    P = spec.init_params(cfg, 1, randomize_all=True)
+    from vit_tensorflow import ViT
+    m = ViT(**kw, compute="bf16", max_batch=2, seed=0)
+    m.load_state_dict({k: v.astype(np.float32) for k, v in P.items()})
+    img = rand_images(cfg, 2, seed=3)
+    dl = (np.random.default_rng(5).standard_normal((2, 10)) / 2).astype(np.float32)
+    logits = m(img, training=False)
+    grads, _ = m.backward(dl)
+    ref_logits, ref_grads, _ = ref_torch.forward_backward(cfg, P, img, dl, q=ref_torch.bf16_round)
+    gate(float(np.abs(logits - ref_logits).max()), 1.2e-2, "logits", "logits")       # observed 4.0e-3 .. 6.1e-3
+    for k, r in ref_grads.items():
+        gate(rel_max_err(grads[k], r), 1.8e-2, k, "gradients")                        # observed 7.0e-3 .. 8.9e-3
+
+
 def test_one_launch_attention_backward_equals_two_launches(monkeypatch):
     """attn_bwd_fused_kernel runs the dQ pass and the dK / dV pass of one (image, head) back to back in one workgroup (the second
     pass finds q, k, v, dO in L2; D stays in LDS): the arithmetic is the two-kernel form's, so every gradient has the same bits."""
