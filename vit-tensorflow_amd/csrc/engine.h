@@ -159,7 +159,9 @@ struct vitx_engine {
   bool force_generic_gemm = false, force_generic_attn = false, wgrad_via_transpose = true;
   int gemm_kernel = 0;
   bool bgemm_pairs = true;               // VITX_BGEMM_PAIRS=0: the four batched products of the materialised attention backward as four launches
-  int nt_mask = 1;                       // VITX_NT=bits: non-temporal hints.  1: the fc1 epilogue's gelu'(h) store (read again only by the backward).
+  int nt_mask = 17;                      // VITX_NT=bits: non-temporal hints.  1: the fc1 epilogue's gelu'(h) store (read again only by the backward);
+                                         // 16: the fc1- and qkv-dgrad outputs d(y), read by the LayerNorm backward only after the weight gradient that
+                                         // re-reads d(hpre) / d(qkv) (TN class -0.25 ms per step).
                                          // (Measured and dropped: the same hint on the fc2-dgrad epilogue's read of it -- no effect -- and on the
                                          // weight-gradient operand loads -- 10.8 -> 11.25 ms per step.)
   bool mlp_bwd_consumers_first = true;   // VITX_MLP_BWD_ORDER=0: fc2 weight gradient between the producer and the consumers of d hpre

@@ -759,6 +759,7 @@ static int block_backward(vitx_engine* e, Stage& st, int si, int l, int b, int n
   if (!e->mlp_bwd_consumers_first) fc2_param_grads();
   {
     EpiParams ep; ep.out = e->d_y; ep.ldo = d;
+    ep.nt_out = (e->nt_mask >> 4) & 1;   // d(y2) is read by the LayerNorm backward only after both weight gradients: keep d(hpre) cached instead
     dense_dgrad(e, e->d_h, m, rows, bp.fc1, EPI_STORE, ep);
   }
   dense_wgrad(e, ba.y2, d, e->d_h, m, rows, bp.fc1);
@@ -847,6 +848,7 @@ static int block_backward(vitx_engine* e, Stage& st, int si, int l, int b, int n
       attn_generic_bwd(e, bp, av, ag, b, &ba);
     }
     EpiParams ep; ep.out = e->d_y; ep.ldo = d;
+    ep.nt_out = (e->nt_mask >> 4) & 1;
     dense_dgrad(e, e->d_qkv, 3 * inner, rows, bp.qkv, EPI_STORE, ep);
     dense_wgrad(e, ba.y1, d, e->d_qkv, 3 * inner, rows, bp.qkv);
   }

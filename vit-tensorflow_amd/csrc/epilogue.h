@@ -36,8 +36,9 @@ struct EpiParams {
   int np = 1, ntok = 1, tok_off = 0;
   int vec_ok = 1;          // 0: some pointer / leading dimension is not 16-B friendly -> scalar accesses
   int wide_ok = 0;         // 1: bf16 outputs / aux rows start 16-B aligned (leading dimensions % 8 == 0): eight-column epilogue form allowed
-  int nt_out = 0;          // EPI_BIAS_GELU: 1 = `out` (gelu', read again only by the backward) is written with non-temporal stores: it does not push
-                           //   `out2` (the activation the next GEMM reads) out of the 256 MB memory-side cache (-0.3 ms per ViT-B/16 step)
+  int nt_out = 0;          // EPI_BIAS_GELU / EPI_STORE (bf16): 1 = `out` is written with non-temporal stores.  For tensors nothing reads soon
+                           //   (gelu' of the fc1 epilogue: read by the backward; d(y) of the fc1 / qkv dgrad: read after the next weight gradient)
+                           //   so that they do not push what the NEXT kernel reads out of the 256 MB memory-side cache (-0.3 and -0.13 ms per step)
   int zero_pad = 0;        // 1: rows in [M, tile end) of T outputs are written as zeros (buffers are row-padded)
   float alpha = 1.0f;
 };
@@ -155,6 +156,14 @@ template <int MODE, typename T, bool HAS_BIAS, bool HAS_SCALE>
 __device__ __forceinline__ float4 epilogue_fast4(const EpiParams& p, int row, int col, float4 v, float4 b4, float4 s4, float4 x, int64_t out_off) {
   if (HAS_BIAS && MODE != EPI_GELU_BWD && MODE != EPI_PARTIAL) { v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w; }
   if (MODE == EPI_STORE) {
+    if constexpr (sizeof(T) == 2) {
+      if (p.nt_out) {
+        bf16x4 o4;
+        o4[0] = (bf16_t)v.x; o4[1] = (bf16_t)v.y; o4[2] = (bf16_t)v.z; o4[3] = (bf16_t)v.w;
+        __builtin_nontemporal_store(o4, (bf16x4*)((bf16_t*)p.out + out_off + (int64_t)row * p.ldo + col));
+        return v;
+      }
+    }
     st4<T>((T*)p.out + out_off + (int64_t)row * p.ldo + col, v);
   } else if (MODE == EPI_STORE_F32 || MODE == EPI_PARTIAL) {
     *(float4*)((float*)p.out + out_off + (int64_t)row * p.ldo + col) = v;
@@ -213,7 +222,8 @@ __device__ __forceinline__ void epilogue_wide8(const EpiParams& p, int row, int 
     hi.x += b_hi.x; hi.y += b_hi.y; hi.z += b_hi.z; hi.w += b_hi.w;
   }
   if (MODE == EPI_STORE) {
-    *(bf16x8*)((bf16_t*)p.out + out_off + (int64_t)row * p.ldo + col) = pack_bf16x8(lo, hi);
+    if (p.nt_out) __builtin_nontemporal_store(pack_bf16x8(lo, hi), (bf16x8*)((bf16_t*)p.out + out_off + (int64_t)row * p.ldo + col));
+    else *(bf16x8*)((bf16_t*)p.out + out_off + (int64_t)row * p.ldo + col) = pack_bf16x8(lo, hi);
   } else if (MODE == EPI_BIAS_GELU) {
     const bf16x8 h = pack_bf16x8(lo, hi);       // GELU and its derivative of the pre-activation as bf16 would store it
     float4 g0, d0, g1, d1;
