@@ -57,12 +57,12 @@ constexpr int QB_BWD = 1;   // backward: QB = 2 costs a workgroup of occupancy (
 
 template <int NTP>
 __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o, float* __restrict__ lse,
-                                                       int n, int h, float scale, const bf16_t* __restrict__ zero_page) {
+                                                       int n, int h, float scale, const bf16_t* __restrict__ zero_page, int reverse) {
   constexpr int NKP = 16 * NTP, QB = QB_FWD;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* k_rm = smem;                                   // [NKP][128 B] swizzled
   char* v_rm = smem + NKP * ROWB;                      // [NKP][128 B] swizzled (read through the hardware transpose)
-  const int bh = blockIdx.x, bi = bh / h, hi = bh - bi * h;
+  const int bh = reverse ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x, bi = bh / h, hi = bh - bi * h;   // reverse: newest qkv rows first (memory-side cache)
   const int inner = h * DH;
   const int64_t tok_stride = 3 * (int64_t)inner;
   const bf16_t* qbase = qkv + (int64_t)bi * n * tok_stride + hi * DH;
@@ -621,7 +621,10 @@ void launch_attn_bf16_fwd(const bf16_t* qkv, bf16_t* o, float* lse, int b, int n
   const int ntp = pick_ntp(n);
   const int nkp = 16 * ntp;
   const int smem = 2 * nkp * ROWB;
-#define CALL(NTP) { set_smem(attn_fwd_kernel<NTP>, smem); hipLaunchKernelGGL(attn_fwd_kernel<NTP>, dim3(b * h), dim3(att_threads(n)), smem, s, qkv, o, lse, n, h, scale, zero_page); }
+  // (image, head) tasks from the last to the first: qkv (232 MB at ViT-B/16, written front to back by the GEMM before) is read newest rows
+  // first, while they are still in the 256 MB memory-side cache (1.24 -> 1.15 ms per step); VITX_REVERSE without bit 4 restores id order
+  static const int reverse = [] { const char* e = getenv("VITX_REVERSE"); return e ? (atoi(e) >> 2) & 1 : 1; }();
+#define CALL(NTP) { set_smem(attn_fwd_kernel<NTP>, smem); hipLaunchKernelGGL(attn_fwd_kernel<NTP>, dim3(b * h), dim3(att_threads(n)), smem, s, qkv, o, lse, n, h, scale, zero_page, reverse); }
   VITX_NTP_DISPATCH(ntp, CALL);
 #undef CALL
 }

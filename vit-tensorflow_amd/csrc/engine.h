@@ -158,6 +158,8 @@ struct vitx_engine {
   // env switches
   bool force_generic_gemm = false, force_generic_attn = false, wgrad_via_transpose = true;
   int gemm_kernel = 0;
+  int reverse_mask = 7;                  // VITX_REVERSE=bits: 1 forward GEMMs, 2 dgrad GEMMs walk their row tiles last-to-first when the A operand exceeds
+  int64_t reverse_min_bytes = 200ll << 20;   //   VITX_REVERSE_MIN_MB (default 200 MB), see decode_tile (gemm_bf16.hip); 4: the fused attention forward (attn_bf16.hip)
   bool bgemm_pairs = true;               // VITX_BGEMM_PAIRS=0: the four batched products of the materialised attention backward as four launches
   int nt_mask = 17;                      // VITX_NT=bits: non-temporal hints.  1: the fc1 epilogue's gelu'(h) store (read again only by the backward);
                                          // 16: the fc1- and qkv-dgrad outputs d(y), read by the LayerNorm backward only after the weight gradient that

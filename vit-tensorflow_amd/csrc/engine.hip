@@ -235,6 +235,7 @@ static void dense_fwd(vitx_engine* e, const void* X, int64_t ldx, int rows, cons
     g.A = (const bf16_t*)X; g.lda = ldx;
     g.B = w.wt; g.ldb = w.in_k;
     g.M = rows; g.N = w.out; g.K = w.in_k; g.kernel = e->gemm_kernel;
+    g.reverse_m = (e->reverse_mask & 1) && (int64_t)rows * w.in_k * 2 > e->reverse_min_bytes;   // A larger than the memory-side cache, just written
     g.stagger = (mode == EPI_BIAS_GELU || mode == EPI_BIAS_RESID || mode == EPI_PATCH) ? e->gemm_stagger : 0;
     ep.zero_pad = 1;
     finalize_epi(ep);
@@ -264,6 +265,7 @@ static void dense_dgrad(vitx_engine* e, const void* dY, int64_t ldy, int rows, c
     g.A = (const bf16_t*)dY; g.lda = ldy;
     g.B = w.wn; g.ldb = w.out_k;
     g.M = rows; g.N = w.in; g.K = w.out_k; g.kernel = e->gemm_kernel;
+    g.reverse_m = (e->reverse_mask & 2) && (int64_t)rows * w.out_k * 2 > e->reverse_min_bytes;
     g.stagger = (mode == EPI_GELU_BWD) ? e->gemm_stagger : 0;
     ep.zero_pad = 1;
     finalize_epi(ep);
@@ -901,6 +903,8 @@ static int engine_create_body(vitx_engine* e, const vitx_config& cfg, std::strin
   if (const char* k = getenv("VITX_MLP_BWD_ORDER")) e->mlp_bwd_consumers_first = atoi(k) != 0;
   if (const char* k = getenv("VITX_NT")) e->nt_mask = atoi(k);
   if (const char* k = getenv("VITX_BGEMM_PAIRS")) e->bgemm_pairs = atoi(k) != 0;
+  if (const char* k = getenv("VITX_REVERSE")) e->reverse_mask = atoi(k);
+  if (const char* k = getenv("VITX_REVERSE_MIN_MB")) e->reverse_min_bytes = (int64_t)atoi(k) << 20;
   if (const char* k = getenv("VITX_GEMM_KERNEL")) e->gemm_kernel = atoi(k);
   if (const char* k = getenv("VITX_UNFUSED_HEADOPS")) e->unfused_headops = atoi(k) != 0;
   e->wgrad_via_transpose = env_flag("VITX_WGRAD_TRANSPOSE");

@@ -47,7 +47,16 @@ template <int V> using ic = std::integral_constant<int, V>;
 // logical tile index -> (tile_m, tile_n).  Wide outputs (>= 8 column tiles) are walked in bands of 4 row tiles, column-major inside a
 // band, so the ~32 consecutive tiles an XCD works on at any time form a 4 x 8 block: 12 operand panels in flight instead of 2.7 + 12
 // (PMC: the row-major order re-fetched the A panel of fc1 5.5x and of qkv 3.7x through the XCD's 4 MiB L2; 8192^3 +12 %).
+__device__ __forceinline__ void decode_tile_fwd(int L, int tiles_m, int tiles_n, int gm, int& tm, int& tn);
+// gm < 0: the same walk with the row tiles taken from the LAST to the first.  For a GEMM whose A operand was just written, front to back,
+// by the previous kernel and is larger than the 256 MB memory-side cache (act for fc2, d(hpre) for the fc1 dgrad: 310 MB): the cache holds
+// the most recently written rows, and a reader that starts at row 0 misses, allocates, and evicts exactly the rows it needs next; starting
+// at the end it hits on everything that is still there.
 __device__ __forceinline__ void decode_tile(int L, int tiles_m, int tiles_n, int gm, int& tm, int& tn) {
+  if (gm < 0) { decode_tile_fwd(L, tiles_m, tiles_n, -gm, tm, tn); tm = tiles_m - 1 - tm; return; }
+  decode_tile_fwd(L, tiles_m, tiles_n, gm, tm, tn);
+}
+__device__ __forceinline__ void decode_tile_fwd(int L, int tiles_m, int tiles_n, int gm, int& tm, int& tn) {
   if (gm == 1) { tm = L / tiles_n; tn = L - tm * tiles_n; return; }
   const int group = gm * tiles_n;
   const int gid = L / group, first = gid * gm;
@@ -127,7 +136,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_kernel(Bf16GemmArgs
   int it = 0;                                   // running K-tile counter: LDS buffer = it & 1 (continues across output tiles)
   int logical = logical0;
   if (logical >= total_tiles) return;
-  const int gm = tiles_n >= 8 ? 4 : 1;
+  const int gm = (tiles_n >= 8 ? 4 : 1) * (g.reverse_m ? -1 : 1);
   int tile_m, tile_n;
   decode_tile(logical, tiles_m, tiles_n, gm, tile_m, tile_n);
   const bf16_t* Ag = g.A + (int64_t)tile_m * BM * g.lda + (int64_t)kt0 * BK;
@@ -382,7 +391,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_pipe_kernel(Bf16Gem
     offB[i] = (uint32_t)(row * (int)g.ldb + (((lane & 7) ^ ((row >> 1) & 7)) << 3)) * 2u;
   }
 
-  const int gm = (tiles_n >= 8 && g.stagger != 8) ? 4 : 1;   // (stagger 8: row-major order, A/B switch of the micro-benchmark)
+  const int gm = ((tiles_n >= 8 && g.stagger != 8) ? 4 : 1) * (g.reverse_m ? -1 : 1);   // (stagger 8: row-major order, A/B switch of the micro-benchmark)
   // ---- issue cursor over this workgroup's K-tile stream (tile, kt); LDS buffer of stream item i = i & 1
   int i_logical = logical0, i_k = 0, issued = 0;
   bool i_more = nk > 0;
