@@ -160,5 +160,27 @@ __device__ __forceinline__ int opaque_zero() {
   return z;
 }
 
+// ---- LDS-DMA hidden from the compiler's s_waitcnt bookkeeping.
+// hipcc (ROCm 7.2) treats every LDS-DMA builtin as a pending LDS write that any later ds_read may alias: in the pipelined GEMM loops it put
+// `s_waitcnt vmcnt(0)` in front of the fragment reads of the k-step that follows each DMA piece (NT kernel: once per K-tile, weight-gradient
+// kernel: before EVERY k-step), i.e. the MFMA waves waited for pieces they had issued a few hundred cycles earlier and the "prefetch" was
+// drained three times per K-tile.  Issued from inline asm the pieces are invisible to that pass; the only waits left are the explicit
+// `s_waitcnt vmcnt(N)` of the schedule (issuing wave) + the workgroup barrier in front of the first read of the buffer.  Ordinary loads and
+// stores the compiler counts itself only become more conservative (hidden pieces add to the hardware counter, never to the compiler's).
+//   dst  = wave-uniform LDS byte address (lane i lands at dst + 16 i);  rsrc = buffer resource of the operand (kernel-argument pointer);
+//   voff = per-lane byte offset;  soff = wave-uniform byte offset.  M0 is written inside the statement (the compiler does not preserve it
+//   around asm) and nothing else in these kernels uses M0 once the builtins are gone.
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ i32x4 vitx_make_rsrc(const void* p) {
+  const uint64_t a = (uint64_t)p;
+  return i32x4{(int)(uint32_t)a, (int)((uint32_t)(a >> 32) & 0xffffu), 0x7fffffff, 0x00020000};
+}
+__device__ __forceinline__ uint32_t vitx_lds_addr(const void* p) {
+  return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
+}
+__device__ __forceinline__ void vitx_dma16(i32x4 rsrc, uint32_t dst, uint32_t voff, uint32_t soff) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(dst), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
+
 static inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }

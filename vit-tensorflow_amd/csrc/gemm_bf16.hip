@@ -398,8 +398,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_pipe_kernel(Bf16Gem
   // DMA addressing: buffer_load ... lds with one resource per operand (SGPRs), the tile / K offset in the scalar offset and a
   // loop-invariant 32-bit lane offset -- no per-piece VALU address arithmetic and one address dword per lane instead of two
   // (the flat global_load_lds form needs a 64-bit address per lane).  Operands are < 4 GiB (checked by the launcher).
-  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)g.A, 0, 0x7fffffff, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)g.B, 0, 0x7fffffff, 0x00020000);
+  // The pieces are issued from inline asm (vitx_dma16, common.h): as builtins the compiler drained them with vmcnt(0) in front of the
+  // next k-step's fragment reads.
+  const i32x4 rsA = vitx_make_rsrc(g.A), rsB = vitx_make_rsrc(g.B);
+  const uint32_t lds_w = vitx_lds_addr(smem) + (uint32_t)wave * 1024u;   // this wave's 1-KiB slot inside an 8-KiB piece row
   uint32_t a_soff = 0, b_soff = 0;       // byte offset of the cursor tile's first K-tile inside A / B
   auto i_set_tile = [&]() {
     int tm, tn;
@@ -417,13 +419,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_pipe_kernel(Bf16Gem
   constexpr int N1 = P - N3 - N0;
   bool pending = false;                  // pieces of the cursor's K-tile still to be issued
   const int xp = g.stagger;   // timing experiments only (results are wrong): 1 = no DMA wait, 2 = no DMA issue in the K loop
-  auto issue_piece = [&](char* base, auto p_c) {
+  auto issue_piece = [&](uint32_t base, auto p_c) {   // base = LDS byte offset of the target stage
     constexpr int p = decltype(p_c)::value;
-    if constexpr (p < A_INSTR)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void_t*)(base + (p * NW + wave) * 1024), 16, (int)offA[p], (int)(a_soff + i_k * (BK * 2)), 0, 0);
-    else
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void_t*)(base + A_BYTES + ((p - A_INSTR) * NW + wave) * 1024), 16,
-                                               (int)offB[p - A_INSTR], (int)(b_soff + i_k * (BK * 2)), 0, 0);
+    if constexpr (p < A_INSTR) vitx_dma16(rsA, lds_w + base + p * NW * 1024, offA[p], a_soff + i_k * (BK * 2));
+    else vitx_dma16(rsB, lds_w + base + A_BYTES + (p - A_INSTR) * NW * 1024, offB[p - A_INSTR], b_soff + i_k * (BK * 2));
   };
   auto i_advance = [&]() {
     ++issued;
@@ -436,7 +435,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_pipe_kernel(Bf16Gem
   };
   auto issue = [&]() {
     if (!i_more) return;
-    char* base = smem + (issued & 1) * STAGE;
+    const uint32_t base = (issued & 1) * STAGE;
     static_for<P>([&](auto p_c) { issue_piece(base, p_c); });
     i_advance();
   };
@@ -463,9 +462,12 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_pipe_kernel(Bf16Gem
       acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[CUR][j], fa[CUR][i], acc[i][j], 0, 0, 0);
     });
   };
+  // The wait is the BUILTIN, not asm: the compiler models it, so its own scoreboard is empty from here on.  With an asm wait it kept the
+  // epilogue's global loads "pending" around the whole K loop and protected the registers they had written with `s_waitcnt vmcnt(1)` /
+  // `vmcnt(0)` in front of the first fragment reads of every K-tile -- which, at run time, waited for the DMA pieces issued a few MFMAs earlier.
   auto handover = [&]() {   // every wave's reads of the older buffer are in registers, the younger buffer has landed
-    if (xp & 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    if (xp & 1) __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
+    else __builtin_amdgcn_s_waitcnt(0x0070);          // vmcnt(0) lgkmcnt(0)
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
   };
@@ -478,10 +480,14 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_pipe_kernel(Bf16Gem
   load_frags(fa[0], fb[0], smem, 0);
   int it = 0;   // consumed K-tile counter of the stream
   int tile_idx = 0;
+  constexpr bool kStamps = false;   // cycle stamps of the tile phases (diagnostic build only: the stores leave VMEM state pending across the K loop)
   auto stamp = [&](int k) {
-    if (g.stamps && tid == 0 && bid < 256 && tile_idx < 16) g.stamps[((int64_t)bid * 16 + tile_idx) * 4 + k] = __builtin_readcyclecounter();
+    if constexpr (kStamps)
+      if (g.stamps && tid == 0 && bid < 256 && tile_idx < 16) g.stamps[((int64_t)bid * 16 + tile_idx) * 4 + k] = __builtin_readcyclecounter();
   };
-  for (int logical = logical0; logical < total_tiles; logical += nwg, ++tile_idx) {
+  // (the ONLY back edge of this loop runs through handover(): on any other path the compiler's scoreboard would carry the epilogue's
+  //  bias / residual loads into the K loop as "pending" and protect their registers with vmcnt waits there -- see handover())
+  for (int logical = logical0;; logical += nwg, ++tile_idx) {
     int tile_m, tile_n;
     decode_tile(logical, tiles_m, tiles_n, gm, tile_m, tile_n);
     const bool has_next = persistent && logical + nwg < total_tiles;
@@ -521,7 +527,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_pipe_kernel(Bf16Gem
         }
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (NP > 0) {
-          char* ibase = smem + (issued & 1) * STAGE;
+          const uint32_t ibase = (issued & 1) * STAGE;
           static_for<NP>([&](auto d_c) {
             constexpr int d = decltype(d_c)::value;
             mfma_range(ic<CUR>{}, ic<(2 + d < Q ? 2 + d : Q)>{}, ic<(3 + d < Q ? 3 + d : Q)>{});
@@ -661,11 +667,13 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_pipe_kernel(Bf16Gem
       }
     }
     stamp(2);
-    if (has_next) {
-      handover();                                   // staging reads done everywhere
-      issue();                                      // deferred refill of the staging buffer: stream item it+1
-      load_frags(fa[0], fb[0], smem + (it & 1) * STAGE, 0);
-    }
+    // modelled wait on EVERY path out of the epilogue (the structurizer routes the `break` through the block that is also the loop latch, so a
+    // wait on the continue path alone leaves the epilogue's loads pending at the loop header in the compiler's view)
+    __builtin_amdgcn_s_waitcnt(0x0F70);           // vmcnt(0): the epilogue's stores have left the wave
+    if (!has_next) break;
+    handover();                                   // staging reads done everywhere
+    issue();                                      // deferred refill of the staging buffer: stream item it+1
+    load_frags(fa[0], fb[0], smem + (it & 1) * STAGE, 0);
     stamp(3);
   }
 }
@@ -767,17 +775,15 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_tn_kernel(Bf16GemmArgs
   // pieces of K-tile kt+2 are issued in k-step 3 of tile kt (after the hand-over) and k-steps 0, 1 of tile kt+1 -- see the NT kernel
   constexpr int N3 = (P + 2) / 3, N0 = (P + 1) / 3, N1 = P - N3 - N0;
   // buffer-addressed DMA (see the NT pipe kernel): resource per operand, K-tile offset in the scalar offset
-  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)Ag, 0, 0x7fffffff, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)Bg, 0, 0x7fffffff, 0x00020000);
+  // issued from inline asm (vitx_dma16, common.h): as builtins the compiler put `s_waitcnt vmcnt(0)` in front of EVERY k-step's transpose reads
+  const i32x4 rsA = vitx_make_rsrc(Ag), rsB = vitx_make_rsrc(Bg);
+  const uint32_t lds_w = vitx_lds_addr(smem) + (uint32_t)wave * 1024u;
   const uint32_t a_kstep = (uint32_t)(BK * g.lda * 2), b_kstep = (uint32_t)(BK * g.ldb * 2);   // bytes per K-tile (64 token rows)
   auto issue_piece = [&](int buf, int kt, auto p_c) {
     constexpr int p = decltype(p_c)::value;
-    char* base = smem + buf * STAGE;
-    if constexpr (p < INSTR)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void_t*)(base + (p * NW + wave) * 1024), 16, (int)offA[p], (int)(kt * a_kstep), 0, 0);
-    else
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void_t*)(base + OP_BYTES + ((p - INSTR) * NW + wave) * 1024), 16, (int)offB[p - INSTR],
-                                               (int)(kt * b_kstep), 0, 0);
+    const uint32_t base = lds_w + (uint32_t)buf * STAGE;
+    if constexpr (p < INSTR) vitx_dma16(rsA, base + p * NW * 1024, offA[p], (uint32_t)kt * a_kstep);
+    else vitx_dma16(rsB, base + OP_BYTES + (p - INSTR) * NW * 1024, offB[p - INSTR], (uint32_t)kt * b_kstep);
   };
   auto stage = [&](int buf, int kt) { static_for<P>([&](auto p_c) { issue_piece(buf, kt, p_c); }); };
 
