@@ -240,6 +240,13 @@ int32_t vitx_debug_read(vitx_handle h, const char* which, int32_t layer, float* 
  * random data), returns the average ms over `iters` launches; `kernel` selects the tile variant */
 int32_t vitx_bench_gemm(vitx_handle h, int32_t M, int32_t N, int32_t K, int32_t kernel,
                         int32_t epilogue, int32_t iters, float* avg_ms, float* max_abs_err);
+/* full-size self-check of the bf16 MFMA GEMM launches, compared on the device with the k-ordered fp32-FMA kernel on the same bf16 operands
+ * (test hook; the Dense layers of vit.py:39,42,59,63 at the benchmarked row count).  kind 0: C[M,N] = A[M,K] B[N,K]^T with fused epilogue
+ * `epilogue` (codes of vitx_bench_gemm) on tile variant `kernel`; kind 1: the weight-gradient form dW[M=in, N=out] over K token rows with the
+ * engine's split-K rule and slice reduction.  errs2[0] = max |got - want| / (1 + |want|); errs2[1] = the same for the second output
+ * (epilogue 2) / the fused column sums (epilogue 4), the number of K slices (kind 1), else -1. */
+int32_t vitx_check_gemm(vitx_handle h, int32_t kind, int32_t M, int32_t N, int32_t K, int32_t kernel,
+                        int32_t epilogue, float* errs2);
 
 /* ---- masked-image-modelling wrappers around a built encoder ("next" row f2 of SURVEY.md section 8):
  *   MAE(image_size, encoder, decoder_dim, masking_ratio, decoder_depth, decoder_heads, decoder_dim_head)   mae.py:17-45

@@ -18,9 +18,9 @@ FP32_LOGIT_TOL = 1e-3
 FP32_GRAD_RTOL = 1e-3
 # bf16 mode vs the exact (float64) reference: operands rounded to bf16 (2^-9 relative) at every GEMM / attention input.
 # Gates = 2x what was observed on MI355X (profiles/r2/pytest_gpu_ref_fixtures_r2a.log): (max|dlogit| / logit std, worst gradient digest error)
-#   vit_b16_depth2 0.96e-2 / 0.58e-2, deepvit_cfg4_depth2 1.6e-2 / 0.78e-2, cait_cfg5_depth2 2.9e-2 / 4.4e-2 (the class-attention
+#   vit_b16_depth2 0.96e-2 / 0.58e-2, vit_l16_depth2 1.09e-2 / 0.58e-2 (round 3, profiles/r3/pytest_gpu_full_size_r3f.log), deepvit_cfg4_depth2 1.6e-2 / 0.78e-2, cait_cfg5_depth2 2.9e-2 / 4.4e-2 (the class-attention
 #   stage has ONE query per image: its 16 x 16 head-mixing gradients sum b x 65 bf16-rounded terms, nothing averages out)
-BF16_GATES = {"vit_b16_depth2": (2.0e-2, 1.2e-2), "deepvit_cfg4_depth2": (3.3e-2, 1.6e-2), "cait_cfg5_depth2": (6.0e-2, 8.8e-2)}
+BF16_GATES = {"vit_b16_depth2": (2.0e-2, 1.2e-2), "vit_l16_depth2": (2.2e-2, 1.2e-2), "deepvit_cfg4_depth2": (3.3e-2, 1.6e-2), "cait_cfg5_depth2": (6.0e-2, 8.8e-2)}
 
 
 def _model(case, compute, b, P):

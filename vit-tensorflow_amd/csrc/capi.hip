@@ -815,6 +815,16 @@ int32_t vitx_debug_read(vitx_handle h, const char* which, int32_t layer, float* 
   CAPI_CATCH
 }
 
+int32_t vitx_check_gemm(vitx_handle h, int32_t kind, int32_t M, int32_t N, int32_t K, int32_t kernel, int32_t epilogue, float* errs2) {
+  CAPI_TRY
+  if (!h || !errs2) return fail(VITX_ERR_INVALID, "null argument");
+  std::string err;
+  int rc = engine_check_gemm(h, kind, M, N, K, kernel, epilogue, errs2, err);
+  if (rc != VITX_OK) return fail(rc, err);
+  return VITX_OK;
+  CAPI_CATCH
+}
+
 int32_t vitx_bench_gemm(vitx_handle h, int32_t M, int32_t N, int32_t K, int32_t kernel, int32_t epilogue, int32_t iters, float* avg_ms,
                         float* max_abs_err) {
   CAPI_TRY

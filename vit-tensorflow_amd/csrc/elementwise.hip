@@ -882,6 +882,26 @@ void launch_fill_zero(void* p, int64_t bytes, hipStream_t s) {
   if (bytes <= 0) return;
   hipLaunchKernelGGL(fill_zero_kernel, dim3(grid_for(bytes / 16)), dim3(256), 0, s, (float4*)p, bytes / 16);
 }
+// max over rows < `rows`, cols < `cols` of |a - b| / (1 + |b|), as the bit pattern of a non-negative float (atomicMax on uint32 keeps the order)
+template <typename T>
+__global__ __launch_bounds__(256) void max_rel_diff_kernel(const T* a, const T* b, int64_t rows, int cols, int64_t lda, int64_t ldb, unsigned* out) {
+  float m = 0.f;
+  const int64_t n = rows * cols;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / cols;
+    const int c = (int)(i - r * cols);
+    const float x = ldf<T>(a + r * lda + c), y = ldf<T>(b + r * ldb + c);
+    const float d = fabsf(x - y) / (1.f + fabsf(y));
+    m = fmaxf(m, (d == d) ? d : INFINITY);   // NaN anywhere -> inf
+  }
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) atomicMax(out, __builtin_bit_cast(unsigned, m));
+}
+void launch_max_rel_diff(const void* a, const void* b, int is_bf16, int64_t rows, int cols, int64_t lda, int64_t ldb, float* out_max, hipStream_t s) {
+  const unsigned grid = (unsigned)std::min<int64_t>(4096, std::max<int64_t>(1, ceil_div(rows * cols, 256)));
+  if (is_bf16) hipLaunchKernelGGL(max_rel_diff_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)a, (const bf16_t*)b, rows, cols, lda, ldb, (unsigned*)out_max);
+  else hipLaunchKernelGGL(max_rel_diff_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)a, (const float*)b, rows, cols, lda, ldb, (unsigned*)out_max);
+}
 void launch_fill_random_bf16(bf16_t* p, int64_t n, uint32_t seed, float scale, hipStream_t s) {
   hipLaunchKernelGGL(fill_random_bf16_kernel, dim3(grid_for(n)), dim3(256), 0, s, p, n, seed, scale);
 }

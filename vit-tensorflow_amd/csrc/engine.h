@@ -209,6 +209,7 @@ void engine_ext_dense_refresh(vitx_engine* e, const Dense& w);
 void engine_ext_dense_fwd(vitx_engine* e, const void* X, int64_t ldx, int rows, const Dense& w, float* y);
 void engine_ext_dense_bwd(vitx_engine* e, const void* X, int64_t ldx, const void* dY, int64_t ldy, const float* dY_f32, int rows, const Dense& w,
                           float* dx_or_null);
+int engine_check_gemm(vitx_engine* e, int kind, int M, int N, int K, int kernel, int epilogue, float* errs, std::string& err);
 int engine_bench_gemm(vitx_engine* e, int M, int N, int K, int kernel, int epilogue, int iters, float* avg_ms, float* max_err,
                       std::string& err);
 int prof_class(vitx_engine* e, const char* name);

@@ -1771,13 +1771,115 @@ int engine_backward(vitx_engine* e, const float* dlogits_dev, float* dimg_dev, s
 // ------------------------------------------------------------------------------------------------
 // raw GEMM micro-benchmark (random bf16 operands), checked against the generic fp32-FMA kernel
 // ------------------------------------------------------------------------------------------------
+// Full-size self-check of the bf16 MFMA GEMMs, everything on the device (the launches of the benchmarked step have 50k rows: too large for the
+// host-side comparison of engine_bench_gemm).  kind 0: the NT kernel `kernel` with fused epilogue `epilogue` (codes of engine_bench_gemm) against the
+// k-ordered fp32-FMA kernel running the SAME epilogue functor on the same bf16 operands; kind 1: the weight-gradient (TN) kernel with the engine's
+// split-K rule + the fixed-order slice reduction against the fp32-FMA kernel (M = in, N = out, K = token rows).
+// err[0] = max |got - want| / (1 + |want|) over every output element, err[1] = the same for the second output / the fused column sums (or -1).
+int engine_check_gemm(vitx_engine* e, int kind, int M, int N, int K, int kernel, int epilogue, float* errs, std::string& err) {
+  if (K % 64 || M <= 0 || N <= 0 || kind < 0 || kind > 1 || epilogue < 0 || epilogue > 4) { err = "check_gemm: bad arguments (K must be a multiple of 64)"; return VITX_ERR_INVALID; }
+  float* dmax;
+  HIPCHK(hipMalloc((void**)&dmax, 16));
+  HIPCHK(hipMemsetAsync(dmax, 0, 16, e->stream));
+  errs[0] = errs[1] = -1.f;
+  std::vector<void*> bufs;
+  auto alloc = [&](void** p, size_t bytes) -> hipError_t { hipError_t r = hipMalloc(p, bytes + 8192); if (r == hipSuccess) { bufs.push_back(*p); r = hipMemsetAsync(*p, 0, bytes + 8192, e->stream); } return r; };
+  auto cleanup = [&]() { for (void* b : bufs) (void)hipFree(b); (void)hipFree(dmax); };
+  if (kind == 0) {
+    const int64_t Mp = round_up(M, 1280), Np = round_up(N, 256);
+    bf16_t *A, *B, *T1[2], *T2[2], *aux; float *F[2], *bias, *R, *cs[2];
+    if (alloc((void**)&A, (size_t)Mp * K * 2) || alloc((void**)&B, (size_t)Np * K * 2) || alloc((void**)&bias, (size_t)Np * 4) || alloc((void**)&R, (size_t)Mp * Np * 4) ||
+        alloc((void**)&aux, (size_t)Mp * Np * 2) || alloc((void**)&cs[0], (size_t)(Mp / 256 + 8) * Np * 4) || alloc((void**)&cs[1], (size_t)Np * 4 * 64)) { cleanup(); err = "check_gemm: out of memory"; return VITX_ERR_HIP; }
+    for (int i = 0; i < 2; ++i)
+      if (alloc((void**)&T1[i], (size_t)Mp * Np * 2) || alloc((void**)&T2[i], (size_t)Mp * Np * 2) || alloc((void**)&F[i], (size_t)Mp * Np * 4)) { cleanup(); err = "check_gemm: out of memory"; return VITX_ERR_HIP; }
+    launch_fill_random_bf16(A, (int64_t)M * K, 11u, 1.0f, e->stream);          // rows >= M stay zero (row padding invariant)
+    launch_fill_random_bf16(B, (int64_t)N * K, 12u, 1.0f / 16.f, e->stream);   // |acc| ~ sqrt(K) / 16: pre-activations of a sensible size for the GELU forms
+    launch_fill_random_bf16(aux, (int64_t)M * Np, 13u, 1.0f, e->stream);
+    {   // bias, residual: random bf16 patterns widened to fp32
+      bf16_t* t;
+      if (alloc((void**)&t, (size_t)Mp * Np * 2)) { cleanup(); err = "check_gemm: out of memory"; return VITX_ERR_HIP; }
+      launch_fill_random_bf16(t, (int64_t)M * Np, 14u, 2.0f, e->stream);
+      launch_to_f32(t, 1, Np, R, Np, M, (int)Np, e->stream);
+      launch_fill_random_bf16(t, Np, 15u, 0.5f, e->stream);
+      launch_to_f32(t, 1, Np, bias, Np, 1, (int)Np, e->stream);
+    }
+    Bf16GemmArgs g;
+    g.A = A; g.lda = K; g.B = B; g.ldb = K; g.M = M; g.N = N; g.K = K; g.kernel = kernel & (15 | 256 | 512);
+    GenericGemmArgs gg;
+    gg.A = A; gg.B = B; gg.M = M; gg.N = N; gg.K = K; gg.sam = K; gg.sak = 1; gg.sbk = 1; gg.sbn = K;
+    int mode = EPI_STORE_F32;
+    auto params = [&](int i) {
+      EpiParams ep;
+      ep.M = M; ep.N = N; ep.zero_pad = 1;
+      if (epilogue == 1) { mode = EPI_BIAS_RESID; ep.out = F[i]; ep.ldo = Np; ep.resid = R; ep.ldr = Np; ep.bias = bias; }
+      else if (epilogue == 2) { mode = EPI_BIAS_GELU; ep.out = T1[i]; ep.ldo = Np; ep.out2 = T2[i]; ep.ldo2 = Np; ep.bias = bias; }
+      else if (epilogue == 3) { mode = EPI_STORE; ep.out = T1[i]; ep.ldo = Np; }
+      else if (epilogue == 4) { mode = EPI_GELU_BWD; ep.out = T1[i]; ep.ldo = Np; ep.aux = aux; ep.ldaux = Np; if (i == 0) { ep.colsum = cs[0]; ep.ldcs = Np; } }
+      else { ep.out = F[i]; ep.ldo = Np; }
+      finalize_epi(ep);
+      return ep;
+    };
+    const EpiParams ep0 = params(0), ep1 = params(1);
+    launch_gemm_bf16(g, ep0, mode, e->stream);
+    launch_gemm_generic(gg, ep1, mode, 1, 1, 1, e->stream);
+    if (epilogue == 0 || epilogue == 1) launch_max_rel_diff(F[0], F[1], 0, M, N, Np, Np, dmax, e->stream);
+    else launch_max_rel_diff(T1[0], T1[1], 1, M, N, Np, Np, dmax, e->stream);
+    if (epilogue == 2) launch_max_rel_diff(T2[0], T2[1], 1, M, N, Np, Np, dmax + 1, e->stream);
+    if (epilogue == 4) {   // fused column sums (one partial row per M-tile of the launch) against the column sums of the reference output
+      const int tm = gemm_bf16_tile_m(g.kernel, M, N);
+      const int nt = (int)ceil_div(M, tm);
+      float* ws;
+      if (alloc((void**)&ws, (size_t)std::max<int64_t>(colsum_ws_elems(N), (int64_t)nt * Np) * 4)) { cleanup(); err = "check_gemm: out of memory"; return VITX_ERR_HIP; }
+      if (g.kernel == 0) { cleanup(); err = "check_gemm: epilogue 4 needs an explicit kernel variant (the column-sum rows follow its tile height)"; return VITX_ERR_INVALID; }
+      launch_reduce_partials(cs[0], nt, Np, N, cs[1], 1.0f, e->stream);
+      launch_colsum(T1[1], 1, Np, M, N, ws, cs[1] + Np, e->stream);
+      launch_max_rel_diff(cs[1], cs[1] + Np, 0, 1, N, Np, Np, dmax + 1, e->stream);
+    }
+  } else {
+    const int in = M, out = N, tokens = K;
+    bf16_t *X, *dY; float *dW[2], *part;
+    const int tile = gemm_bf16_tn_tile(kernel, in, out);
+    const int64_t tiles = ceil_div(in, tile) * ceil_div(out, tile);
+    const int nk = tokens / 64;
+    const int split = (int)std::max<int64_t>(1, std::min<int64_t>(ceil_div(nk, 4), std::max<int64_t>(1, 256 / tiles)));   // dense_wgrad's rule
+    const int slices = gemm_bf16_num_slices(tokens, split);
+    const int64_t ldx = round_up(in, 256), ldy = round_up(out, 256);
+    if (alloc((void**)&X, (size_t)(tokens + 64) * ldx * 2) || alloc((void**)&dY, (size_t)(tokens + 64) * ldy * 2) || alloc((void**)&dW[0], (size_t)in * out * 4) ||
+        alloc((void**)&dW[1], (size_t)in * out * 4) || alloc((void**)&part, (size_t)slices * in * out * 4)) { cleanup(); err = "check_gemm: out of memory"; return VITX_ERR_HIP; }
+    launch_fill_random_bf16(X, (int64_t)tokens * ldx, 21u, 1.0f, e->stream);
+    launch_fill_random_bf16(dY, (int64_t)tokens * ldy, 22u, 1.0f / 16.f, e->stream);
+    Bf16GemmArgs g;
+    g.A = X; g.lda = ldx; g.B = dY; g.ldb = ldy; g.M = in; g.N = out; g.K = tokens; g.kernel = kernel; g.split_k = split;
+    EpiParams ep;
+    ep.out = slices == 1 ? dW[0] : part; ep.ldo = out; ep.partial_stride = (int64_t)in * out; ep.M = in; ep.N = out;
+    finalize_epi(ep);
+    launch_gemm_bf16_tn(g, ep, e->stream);
+    if (slices > 1) launch_reduce_partials(part, slices, (int64_t)in * out, (int64_t)in * out, dW[0], 1.0f, e->stream);
+    GenericGemmArgs gg;
+    gg.A = X; gg.B = dY; gg.M = in; gg.N = out; gg.K = tokens; gg.sam = 1; gg.sak = ldx; gg.sbk = ldy; gg.sbn = 1;
+    EpiParams e2; e2.out = dW[1]; e2.ldo = out; e2.M = in; e2.N = out;
+    finalize_epi(e2);
+    launch_gemm_generic(gg, e2, EPI_STORE_F32, 1, 1, 0, e->stream);
+    launch_max_rel_diff(dW[0], dW[1], 0, in, out, out, out, dmax, e->stream);
+    errs[1] = (float)slices;
+  }
+  float h[2] = {0.f, 0.f};
+  hipError_t rc = hipMemcpyAsync(h, dmax, 8, hipMemcpyDeviceToHost, e->stream);
+  if (rc == hipSuccess) rc = hipStreamSynchronize(e->stream);
+  cleanup();
+  if (rc != hipSuccess) { err = std::string("check_gemm: ") + hipGetErrorString(rc); return VITX_ERR_HIP; }
+  errs[0] = h[0];
+  if (kind == 0 && (epilogue == 2 || epilogue == 4)) errs[1] = h[1];
+  return VITX_OK;
+}
+
 int engine_bench_gemm(vitx_engine* e, int M, int N, int K, int kernel, int epilogue, int iters, float* avg_ms, float* max_err,
                       std::string& err) {
   if (K % 64 || M <= 0 || N <= 0) { err = "bench_gemm: K must be a multiple of 64"; return VITX_ERR_INVALID; }
   // bits 4..7 of `kernel` reach the kernels' `stagger` field, whose low bits double as timing-experiment switches (no DMA wait /
   // no DMA issue: WRONG results, faster launches).  A sweep that packs anything else into those bits measures the switch, not its
   // own parameter (profiles/r2/gemm_tile_band_README.txt), so they are refused unless the caller says it wants the experiment.
-  if (((kernel >> 4) & 3) && !getenv("VITX_GEMM_XP")) { err = "vitx_bench_gemm: kernel bits 4-5 are timing-experiment switches (results invalid); set VITX_GEMM_XP=1 to use them"; return VITX_ERR_INVALID; }
+  if (((kernel >> 4) & 7) && !getenv("VITX_GEMM_XP")) { err = "vitx_bench_gemm: kernel bits 4-5 are timing-experiment switches (results invalid); set VITX_GEMM_XP=1 to use them"; return VITX_ERR_INVALID; }
   const int64_t Mp = round_up(M, 1280), Np = round_up(N, 256);
   bf16_t *A, *B; float *C, *R, *bias; bf16_t* C2;
   HIPCHK(hipMalloc((void**)&A, (size_t)Mp * K * 2));

@@ -1,0 +1,456 @@
+// Software-pipelined persistent NT kernel of the bf16 MFMA GEMM family (see gemm_bf16.hip for the family's design notes).
+#include "gemm_bf16_common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// Software-pipelined persistent NT kernel (the default for N >= 256).  Same tile / wave decomposition, LDS image and swizzle as
+// gemm_bf16_nt_kernel, but
+//   * the MFMA fragments are double-buffered in registers: the ds_reads of k-step s+1 are issued before the MFMAs of k-step s,
+//     so the LDS latency (8 exposed lgkmcnt(0) waits per K-tile in the plain loop, taken by both waves of a SIMD at the same time)
+//     disappears from the critical path; PMC on the plain loop: 38 % of wave cycles parked in s_waitcnt, MFMA pipe 54 % busy;
+//   * the K-tile hand-over (vmcnt(0) + barrier + DMA issue for the tile after next + first fragments of the next tile) sits in
+//     front of the LAST k-step's MFMAs instead of between two tiles;
+//   * workgroups are persistent and their K-tile stream runs across output tiles (the next tile's first K-tile is in LDS before
+//     the epilogue of the current one starts).
+template <int BM, int BN, int WM, int WN, int MODE, int PAT>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_pipe_kernel(Bf16GemmArgs g, EpiParams ep, int tiles_m, int tiles_n,
+                                                                         int kt_per_split) {
+  constexpr int NW = WM * WN;
+  constexpr int WTM = BM / WM, WTN = BN / WN;
+  constexpr int MT = WTM / 32, NT = WTN / 32;
+  constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
+  constexpr int A_INSTR = BM / 8 / NW, B_INSTR = BN / 8 / NW;
+  constexpr int SROW = BN + 4;                     // epilogue staging row (floats); +16 B keeps ds_write_b128 groups conflict-free
+  static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile rows must split evenly over the waves");
+  static_assert(BN == 256 && 2 * 32 * BN * 4 <= STAGE, "two 32-row epilogue staging areas must fit one pipeline buffer");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
+  const int logical0 = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int total_tiles = tiles_m * tiles_n;
+  if (logical0 >= total_tiles) return;
+  const int z = blockIdx.y;
+  const int kt0 = z * kt_per_split;
+  const int nk = min(kt_per_split, g.K / BK - kt0);
+  const bool persistent = gridDim.y == 1;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave - wm * WN;
+
+  if (g.phase > 0 && persistent) {   // de-phase the workgroups of an XCD: their store-heavy epilogues stop coinciding
+    const int ph = (bid >> 3) & 7;
+    for (int i = 0; i < ph * g.phase; ++i) __builtin_amdgcn_s_sleep(64);
+  }
+
+  // per-lane DMA source offsets in BYTES, unsigned: address = uniform 64-bit base (SGPR pair) + zero-extended 32-bit lane offset,
+  // which selects the saddr form of global_load_lds (one address dword per lane, no per-piece VALU address arithmetic)
+  uint32_t offA[A_INSTR], offB[B_INSTR];
+#pragma unroll
+  for (int i = 0; i < A_INSTR; ++i) {
+    const int row = (i * NW + wave) * 8 + (lane >> 3);
+    offA[i] = (uint32_t)(row * (int)g.lda + (((lane & 7) ^ ((row >> 1) & 7)) << 3)) * 2u;
+  }
+#pragma unroll
+  for (int i = 0; i < B_INSTR; ++i) {
+    const int row = (i * NW + wave) * 8 + (lane >> 3);
+    offB[i] = (uint32_t)(row * (int)g.ldb + (((lane & 7) ^ ((row >> 1) & 7)) << 3)) * 2u;
+  }
+
+  const int gm = ((tiles_n >= 8 && g.stagger != 8) ? 4 : 1) * (g.reverse_m ? -1 : 1);   // (stagger 8: row-major order, A/B switch of the micro-benchmark)
+  // ---- issue cursor over this workgroup's K-tile stream (tile, kt); LDS buffer of stream item i = i & 1
+  int i_logical = logical0, i_k = 0, issued = 0;
+  bool i_more = nk > 0;
+  // DMA addressing: buffer_load ... lds with one resource per operand (SGPRs), the tile / K offset in the scalar offset and a
+  // loop-invariant 32-bit lane offset -- no per-piece VALU address arithmetic and one address dword per lane instead of two
+  // (the flat global_load_lds form needs a 64-bit address per lane).  Operands are < 4 GiB (checked by the launcher).
+  // The pieces are issued from inline asm (vitx_dma16, common.h): as builtins the compiler drained them with vmcnt(0) in front of the
+  // next k-step's fragment reads.
+  const i32x4 rsA = vitx_make_rsrc(g.A), rsB = vitx_make_rsrc(g.B);
+  const uint32_t lds_w = vitx_lds_addr(smem) + (uint32_t)wave * 1024u;   // this wave's 1-KiB slot inside an 8-KiB piece row
+  uint32_t a_soff = 0, b_soff = 0;       // byte offset of the cursor tile's first K-tile inside A / B
+  auto i_set_tile = [&]() {
+    int tm, tn;
+    decode_tile(i_logical, tiles_m, tiles_n, gm, tm, tn);
+    a_soff = (uint32_t)(((int64_t)tm * BM * g.lda + (int64_t)kt0 * BK) * 2);
+    b_soff = (uint32_t)(((int64_t)tn * BN * g.ldb + (int64_t)kt0 * BK) * 2);
+  };
+  i_set_tile();
+  constexpr int P = A_INSTR + B_INSTR;   // DMA pieces (1 KiB each) per K-tile per wave
+  // where the P pieces of K-tile it+2 are issued: k-step 3 of tile it (after the hand-over), k-steps 0 and 1 of tile it+1.
+  // 64 pieces issued by 8 waves at the same moment queue up behind one address unit (~50 cycles each, all waves blocked);
+  // spread over the tile each one costs ~18 cycles and hides under an MFMA.
+  constexpr int N3 = PAT == 0 ? P : (PAT == 1 ? (P + 1) / 2 : (P + 2) / 3);
+  constexpr int N0 = PAT == 0 ? 0 : (PAT == 1 ? P / 2 : (P + 1) / 3);
+  constexpr int N1 = P - N3 - N0;
+  bool pending = false;                  // pieces of the cursor's K-tile still to be issued
+  const int xp = g.stagger;   // timing experiments only (results are wrong): 1 = no DMA wait, 2 = no DMA issue in the K loop, 4 = no fragment reads in the K loop
+  auto issue_piece = [&](uint32_t base, auto p_c) {   // base = LDS byte offset of the target stage
+    constexpr int p = decltype(p_c)::value;
+    if constexpr (p < A_INSTR) vitx_dma16(rsA, lds_w + base + p * NW * 1024, offA[p], a_soff + i_k * (BK * 2));
+    else vitx_dma16(rsB, lds_w + base + A_BYTES + (p - A_INSTR) * NW * 1024, offB[p - A_INSTR], b_soff + i_k * (BK * 2));
+  };
+  auto i_advance = [&]() {
+    ++issued;
+    if (++i_k == nk) {
+      i_k = 0;
+      i_logical += nwg;
+      i_more = persistent && i_logical < total_tiles;
+      if (i_more) i_set_tile();
+    }
+  };
+  auto issue = [&]() {
+    if (!i_more) return;
+    const uint32_t base = (issued & 1) * STAGE;
+    static_for<P>([&](auto p_c) { issue_piece(base, p_c); });
+    i_advance();
+  };
+
+  // fragment addressing: row = tile row of this lane (lane&31), chunk = (ks*2 + (lane>>5)) ^ swz(row)
+  const int sw = ((lane & 31) >> 1) & 7;
+  const int a_row_byte = (wm * WTM + (lane & 31)) * 128;
+  const int b_row_byte = A_BYTES + (wn * WTN + (lane & 31)) * 128;
+  const int khalf = lane >> 5;
+  bf16x8 fa[2][MT], fb[2][NT];
+  auto load_frags = [&](bf16x8(&af)[MT], bf16x8(&bfr)[NT], const char* base, int ks) {
+    const int cb = ((ks * 2 + khalf) ^ sw) << 4;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) af[i] = *(const bf16x8*)(base + a_row_byte + i * 32 * 128 + cb);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) bfr[j] = *(const bf16x8*)(base + b_row_byte + j * 32 * 128 + cb);
+  };
+  // one fragment of k-step `ks` (r-th in the order the next k-step's MFMAs first need them: b0, a0, b1, a1, a2, ...)
+  auto load_frag_one = [&](bf16x8(&af)[MT], bf16x8(&bfr)[NT], const char* base, int ks, auto r_c) {
+    constexpr int r = decltype(r_c)::value;
+    static_assert(NT == 2, "fragment order assumes two column fragments per wave");
+    const int cb = ((ks * 2 + khalf) ^ sw) << 4;
+    if constexpr (r == 0) bfr[0] = *(const bf16x8*)(base + b_row_byte + cb);
+    else if constexpr (r == 1) af[0] = *(const bf16x8*)(base + a_row_byte + cb);
+    else if constexpr (r == 2) bfr[1] = *(const bf16x8*)(base + b_row_byte + 32 * 128 + cb);
+    else af[r - 2] = *(const bf16x8*)(base + a_row_byte + (r - 2) * 32 * 128 + cb);
+  };
+  constexpr int Q = MT * NT;             // MFMAs per k-step per wave
+  // PAT >= 3, the uniform schedule: every MFMA of the K loop is followed by AT MOST ONE memory instruction.  A wave's P pieces of the pending
+  // K-tile go behind every SP-th MFMA of the three k-steps after the hand-over, and the waves' slots are staggered (phase = wave % SP; the two
+  // waves of a SIMD, w and w + 4, always differ), so the CU's address unit sees ~one piece per 24 cycles instead of eight in the same cycle;
+  // PAT 4 also takes the next k-step's fragment reads one per MFMA (behind MFMAs 1 .. MT+NT) instead of as a block of six.
+  // Measured on the previous schedule (8192^3, timing switches): 1284 TFLOP/s as built, 1570 without the pieces, 1452 without the fragment
+  // reads, 1808 with neither -- the memory instructions cost by arriving in bursts from all eight waves at the same slots.
+  constexpr int SP = (3 * Q) / P;
+  const int phi = wave % (SP > 0 ? SP : 1);
+  f32x16 acc[MT][NT];
+  auto mfma_range = [&](auto cur_c, auto first_c, auto last_c) {   // MFMAs [first, last) of a k-step, fragments set `cur`
+    constexpr int CUR = decltype(cur_c)::value, FIRST = decltype(first_c)::value, LAST = decltype(last_c)::value;
+    static_for<(LAST > FIRST ? LAST - FIRST : 0)>([&](auto d) {
+      constexpr int idx = FIRST + decltype(d)::value, i = idx / NT, j = idx % NT;
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[CUR][j], fa[CUR][i], acc[i][j], 0, 0, 0);
+    });
+  };
+  // The wait is the BUILTIN, not asm: the compiler models it, so its own scoreboard is empty from here on.  With an asm wait it kept the
+  // epilogue's global loads "pending" around the whole K loop and protected the registers they had written with `s_waitcnt vmcnt(1)` /
+  // `vmcnt(0)` in front of the first fragment reads of every K-tile -- which, at run time, waited for the DMA pieces issued a few MFMAs earlier.
+  auto handover = [&]() {   // every wave's reads of the older buffer are in registers, the younger buffer has landed
+    if (xp & 1) __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
+    else __builtin_amdgcn_s_waitcnt(0x0070);          // vmcnt(0) lgkmcnt(0)
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+  const bool has_bias = ep.bias != nullptr, has_scale = ep.scale != nullptr;
+  const int64_t out_off = (int64_t)z * ep.partial_stride;
+
+  issue();      // stream items 0 and 1
+  issue();
+  handover();
+  load_frags(fa[0], fb[0], smem, 0);
+  int it = 0;   // consumed K-tile counter of the stream
+  int tile_idx = 0;
+  constexpr bool kStamps = false;   // cycle stamps of the tile phases (diagnostic build only: the stores leave VMEM state pending across the K loop)
+  auto stamp = [&](int k) {
+    if constexpr (kStamps)
+      if (g.stamps && tid == 0 && bid < 256 && tile_idx < 16) g.stamps[((int64_t)bid * 16 + tile_idx) * 4 + k] = __builtin_readcyclecounter();
+  };
+  // (the ONLY back edge of this loop runs through handover(): on any other path the compiler's scoreboard would carry the epilogue's
+  //  bias / residual loads into the K loop as "pending" and protect their registers with vmcnt waits there -- see handover())
+  for (int logical = logical0;; logical += nwg, ++tile_idx) {
+    int tile_m, tile_n;
+    decode_tile(logical, tiles_m, tiles_n, gm, tile_m, tile_n);
+    const bool has_next = persistent && logical + nwg < total_tiles;
+    stamp(0);
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    for (int kt = 0; kt < nk; ++kt) {
+      const char* base = smem + (it & 1) * STAGE;
+      if constexpr (PAT >= 3) {
+        static_for<BK / 16>([&](auto ks_c) {
+          constexpr int ks = decltype(ks_c)::value, CUR = ks & 1;
+          constexpr int ORD = ks == 3 ? 0 : (ks == 0 ? 1 : (ks == 1 ? 2 : -1));   // place of this k-step in the issue window of the pending K-tile
+          const char* rbase = base;
+          bool reads = true;
+          if constexpr (ks == 3) {
+            handover();                                   // K-tile it+1 landed; buffer it&1 fully read by every wave
+            rbase = smem + ((it + 1) & 1) * STAGE;
+            reads = kt + 1 < nk;                          // at the last K-tile of an output tile the first fragments are loaded after the epilogue
+            pending = i_more && kt + 1 < nk && !(xp & 2);
+          }
+          constexpr int rks = (ks + 1) % (BK / 16);
+          const uint32_t ibase = (issued & 1) * STAGE;
+          static_for<Q>([&](auto q_c) {
+            constexpr int q = decltype(q_c)::value;
+            mfma_range(ic<CUR>{}, ic<q>{}, ic<q + 1>{});
+            if constexpr (PAT == 3) {
+              if constexpr (q == 1) { if (reads && !(xp & 4)) load_frags(fa[CUR ^ 1], fb[CUR ^ 1], rbase, rks); }
+            } else if constexpr (q >= 1 && q - 1 < MT + NT) {
+              if (reads) load_frag_one(fa[CUR ^ 1], fb[CUR ^ 1], rbase, rks, ic<q - 1>{});
+            }
+            if constexpr (ORD >= 0) {
+              constexpr int u = ORD * Q + q;
+              if constexpr (u / SP < P) { if (pending && phi == u % SP) issue_piece(ibase, ic<u / SP>{}); }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          });
+          if constexpr (ks == 1) {
+            if (pending) i_advance();
+            pending = false;
+          }
+        });
+        ++it;
+        continue;
+      }
+      static_for<BK / 16>([&](auto ks_c) {
+        constexpr int ks = decltype(ks_c)::value, CUR = ks & 1;
+        // Order is pinned with sched_barrier(0): two MFMAs, then the ds_reads of the NEXT k-step, then the remaining MFMAs with
+        // this k-step's share of the DMA pieces between them (the reads are >= Q-2 MFMAs old when their consumer arrives; left
+        // alone, the scheduler sinks them to just before use).
+        constexpr int NP = ks == 3 ? N3 : (ks == 0 ? N0 : (ks == 1 ? N1 : 0));   // DMA pieces issued in this k-step
+        constexpr int FP = ks == 3 ? 0 : (ks == 0 ? N3 : N3 + N0);              // first of them
+        if constexpr (ks + 1 < BK / 16) {
+          mfma_range(ic<CUR>{}, ic<0>{}, ic<2>{});
+          __builtin_amdgcn_sched_barrier(0);
+          if (!(xp & 4)) load_frags(fa[CUR ^ 1], fb[CUR ^ 1], base, ks + 1);
+        } else {
+          // K-tile hand-over in front of the last k-step's MFMAs (ONE instruction stream for every case -- branching the MFMA
+          // sequence makes the allocator copy accumulators): K-tile it+1 has landed, buffer it&1 is fully read by every wave.
+          handover();
+          mfma_range(ic<CUR>{}, ic<0>{}, ic<2>{});
+          __builtin_amdgcn_sched_barrier(0);
+          // first fragments of the next K-tile; at the last K-tile of an output tile they are loaded AFTER the epilogue instead
+          // (kept live across it they cost the 320-row variants their last free registers)
+          if (kt + 1 < nk && !(xp & 4)) load_frags(fa[0], fb[0], smem + ((it + 1) & 1) * STAGE, 0);
+          // K-tile it+2 goes into the buffer just released; at the last K-tile of an output tile the refill is deferred until
+          // after the epilogue, which stages through that buffer.
+          pending = i_more && kt + 1 < nk && !(xp & 2);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (NP > 0) {
+          const uint32_t ibase = (issued & 1) * STAGE;
+          static_for<NP>([&](auto d_c) {
+            constexpr int d = decltype(d_c)::value;
+            mfma_range(ic<CUR>{}, ic<(2 + d < Q ? 2 + d : Q)>{}, ic<(3 + d < Q ? 3 + d : Q)>{});
+            if (pending) issue_piece(ibase, ic<FP + d>{});
+            __builtin_amdgcn_sched_barrier(0);
+          });
+          mfma_range(ic<CUR>{}, ic<(2 + NP < Q ? 2 + NP : Q)>{}, ic<Q>{});
+          if constexpr (FP + NP == P) {
+            if (pending) i_advance();
+            pending = false;
+          }
+        } else {
+          mfma_range(ic<CUR>{}, ic<2>{}, ic<Q>{});
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      ++it;
+    }
+
+    // ---- epilogue: 32 output rows per round through the buffer of the last K-tile (its refill is deferred until after the epilogue)
+    stamp(1);
+    {
+      const bool interior = epilogue_fast_ok(ep, MODE) && (tile_m + 1) * BM <= ep.M && (tile_n + 1) * BN <= ep.N;
+      float* st = (float*)(smem + ((it + 1) & 1) * STAGE);
+      const int gcol = tile_n * BN + lane * 4;
+      float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f), s4 = make_float4(1.f, 1.f, 1.f, 1.f);
+      if (interior && has_bias) b4 = *(const float4*)(ep.bias + gcol);
+      if (interior && has_scale) s4 = *(const float4*)(ep.scale + gcol);
+      constexpr int RPW = 32 / NW;   // rows per wave per round (one 1-KiB row per wave instruction)
+      float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);   // EPI_GELU_BWD: column sums of what this lane stores (fused bias gradient)
+      auto cs_add = [&](float4 r) { if (MODE == EPI_GELU_BWD) { cs.x += r.x; cs.y += r.y; cs.z += r.z; cs.w += r.w; } };
+      // Two 32-row staging areas ([32][BN] fp32 = 32 KiB each, 16-B chunks swizzled chunk ^= row & 7 instead of padded rows) used
+      // alternately: ONE barrier per round -- the accumulator rows of round R+1 are written while round R is still being read and
+      // stored (the round trip  barrier - LDS write - barrier - LDS read - global store  was the epilogue's critical path, not HBM).
+      // Reuse of an area two rounds later is ordered by the barrier in between (every wave waits for its own reads first).
+      // bf16 outputs (WIDE): a lane takes EIGHT consecutive columns of a row (two staged 16-B chunks -> one 16-B global access per
+      // output, two rows per wave instruction): half the store instructions for the same bytes.  Even chunks of a staged row live
+      // in its first 512 B, odd chunks in the second, so both reads of a 16-lane group stay conflict-free.
+      // (256-row tiles only: in the 320-row variants the second code path costs the registers the accumulators need -- 44-116 B of scratch;
+      //  same-box A/B on fc1-shaped launches, profiles/r2/epilogue_wide_ab_r2d.log: +1.0..2.5 % plain store, +1 % GELU, +2.5 % GELU VJP)
+      constexpr bool WIDE = BM == 256 && (MODE == EPI_STORE || MODE == EPI_BIAS_GELU || MODE == EPI_GELU_BWD);
+      const bool wide = WIDE && interior && ep.wide_ok;
+      float4 cs2 = make_float4(0.f, 0.f, 0.f, 0.f);   // WIDE column sums: columns 4..7 of the lane's eight
+      const int cc = lane & 31, gcol8 = tile_n * BN + cc * 8;
+      float4 b8lo = make_float4(0.f, 0.f, 0.f, 0.f), b8hi = b8lo;
+      if (wide && has_bias && MODE != EPI_GELU_BWD) { b8lo = *(const float4*)(ep.bias + gcol8); b8hi = *(const float4*)(ep.bias + gcol8 + 4); }
+#pragma clang loop unroll(full)
+      for (int R = 0; R < BM / 32; ++R) {
+        const int wm_r = (R * 32) / WTM, i0 = ((R * 32) % WTM) / 32;
+        float* sr = st + (R & 1) * (32 * BN);
+        if (wm == wm_r) {
+          const int m = lane & 31;
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int chunk = (wn * WTN + j * 32 + 8 * q + 4 * khalf) >> 2;
+              const int pc = WIDE ? ((chunk >> 1) | ((chunk & 1) << 5)) : chunk;
+              *(float4*)(sr + m * BN + ((pc ^ (m & 7)) << 2)) =
+                  make_float4(acc[i0][j][4 * q], acc[i0][j][4 * q + 1], acc[i0][j][4 * q + 2], acc[i0][j][4 * q + 3]);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const int grow0 = tile_m * BM + R * 32;
+        if constexpr (WIDE) {
+          if (wide) {
+            constexpr int RPW2 = 16 / NW;    // two rows per wave instruction, 16 instructions per 32-row round
+            float4 lo[RPW2], hi[RPW2];
+            bf16x8 x[RPW2];
+#pragma unroll
+            for (int k = 0; k < RPW2; ++k) {
+              const int r = (k * NW + wave) * 2 + (lane >> 5);
+              const int pc = cc ^ (r & 7);
+              lo[k] = *(const float4*)(sr + r * BN + (pc << 2));
+              hi[k] = *(const float4*)(sr + r * BN + ((pc + 32) << 2));
+              x[k] = epilogue_wide_load<MODE>(ep, grow0 + r, gcol8);
+            }
+#pragma unroll
+            for (int k = 0; k < RPW2; ++k) {
+              const int r = (k * NW + wave) * 2 + (lane >> 5);
+              if (has_bias) epilogue_wide8<MODE, true>(ep, grow0 + r, gcol8, lo[k], hi[k], b8lo, b8hi, x[k], out_off);
+              else epilogue_wide8<MODE, false>(ep, grow0 + r, gcol8, lo[k], hi[k], b8lo, b8hi, x[k], out_off);
+              if (MODE == EPI_GELU_BWD) {
+                cs.x += lo[k].x; cs.y += lo[k].y; cs.z += lo[k].z; cs.w += lo[k].w;
+                cs2.x += hi[k].x; cs2.y += hi[k].y; cs2.z += hi[k].z; cs2.w += hi[k].w;
+              }
+            }
+            continue;
+          }
+        }
+        float4 v[RPW];
+#pragma unroll
+        for (int k = 0; k < RPW; ++k) {
+          const int r = k * NW + wave;
+          const int pc = WIDE ? (((lane >> 1) | ((lane & 1) << 5)) ^ (r & 7)) : (lane ^ (r & 7));
+          v[k] = *(const float4*)(sr + r * BN + (pc << 2));
+        }
+        if (interior) {
+          float4 x[RPW];
+#pragma unroll
+          for (int k = 0; k < RPW; ++k) x[k] = epilogue_fast_load<MODE, bf16_t>(ep, grow0 + k * NW + wave, gcol);
+          if (has_bias) {
+#pragma unroll
+            for (int k = 0; k < RPW; ++k) cs_add(epilogue_fast4<MODE, bf16_t, true, false>(ep, grow0 + k * NW + wave, gcol, v[k], b4, s4, x[k], out_off));
+          } else {
+#pragma unroll
+            for (int k = 0; k < RPW; ++k) cs_add(epilogue_fast4<MODE, bf16_t, false, false>(ep, grow0 + k * NW + wave, gcol, v[k], b4, s4, x[k], out_off));
+          }
+        } else {
+#pragma unroll
+          for (int k = 0; k < RPW; ++k) cs_add(epilogue_apply4<MODE, bf16_t>(ep, grow0 + k * NW + wave, gcol, v[k], out_off));
+        }
+      }
+      if (MODE == EPI_GELU_BWD && ep.colsum != nullptr) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        // per-tile column sums: partial rows through the staging buffer (one per wave; two per wave in the eight-column form)
+        const int nrows = wide ? 2 * NW : NW;
+        if (wide) {
+          *(float4*)(st + (wave * 2 + (lane >> 5)) * BN + cc * 8) = cs;
+          *(float4*)(st + (wave * 2 + (lane >> 5)) * BN + cc * 8 + 4) = cs2;
+        } else {
+          *(float4*)(st + wave * BN + lane * 4) = cs;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (tid < BN) {
+          float a = 0.f;
+          for (int w = 0; w < nrows; ++w) a += st[w * BN + tid];
+          const int c = tile_n * BN + tid;
+          if (c < ep.N) ep.colsum[(int64_t)tile_m * ep.ldcs + c] = a;
+        }
+      }
+    }
+    stamp(2);
+    // modelled wait on EVERY path out of the epilogue (the structurizer routes the `break` through the block that is also the loop latch, so a
+    // wait on the continue path alone leaves the epilogue's loads pending at the loop header in the compiler's view)
+    __builtin_amdgcn_s_waitcnt(0x0F70);           // vmcnt(0): the epilogue's stores have left the wave
+    if (!has_next) break;
+    handover();                                   // staging reads done everywhere
+    issue();                                      // deferred refill of the staging buffer: stream item it+1
+    load_frags(fa[0], fb[0], smem + (it & 1) * STAGE, 0);
+    stamp(3);
+  }
+}
+
+template <int BM, int BN, int WM, int WN, int MODE, int PAT = 0>
+void launch_pipe(const Bf16GemmArgs& g, const EpiParams& ep, hipStream_t s) {
+  constexpr int SMEM = 2 * (BM + BN) * BK * 2;
+  // buffer-addressed DMA: 31-bit byte offsets inside each operand; larger operands take the flat-addressed persistent kernel
+  if (((int64_t)ceil_div(g.M, BM) * BM * g.lda + g.K) * 2 >= (1LL << 31) || ((int64_t)ceil_div(g.N, BN) * BN * g.ldb + g.K) * 2 >= (1LL << 31)) {
+    launch_gemm_bf16_persistent_lockstep(BM, MODE, g, ep, s);
+    return;
+  }
+  auto kern = gemm_bf16_nt_pipe_kernel<BM, BN, WM, WN, MODE, PAT>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    attr_set = true;
+  }
+  const int tiles_m = (int)ceil_div(g.M, BM), tiles_n = (int)ceil_div(g.N, BN);
+  const int nk = g.K / BK;
+  const int split = g.split_k > 1 ? g.split_k : 1;
+  const int per = (int)ceil_div(nk, split);
+  const int zs = (int)ceil_div(nk, per);
+  static const int phase_env = [] { const char* v = getenv("VITX_GEMM_PHASE"); return v ? atoi(v) : 0; }();
+  Bf16GemmArgs gp = g;
+  if (gp.phase == 0) gp.phase = phase_env;
+  static const int grid_cap = [] { const char* v = getenv("VITX_GEMM_GRID"); return v ? atoi(v) : 256; }();   // experiment: fewer persistent workgroups
+  const unsigned gx = zs == 1 ? (unsigned)std::min(tiles_m * tiles_n, grid_cap) : (unsigned)(tiles_m * tiles_n);
+  dim3 grid(gx, (unsigned)zs), block(WM * WN * 64);
+  hipLaunchKernelGGL(kern, grid, block, SMEM, s, gp, ep, tiles_m, tiles_n, per);
+}
+
+template <int MODE>
+void pipe_mode(int variant, const Bf16GemmArgs& g, const EpiParams& ep, hipStream_t s) {
+  switch (variant) {
+    case 13: launch_pipe<256, 256, 2, 4, MODE, 4>(g, ep, s); break;   // uniform schedule, fragment reads one per MFMA
+    case 11: launch_pipe<320, 256, 2, 4, MODE, 4>(g, ep, s); break;
+    case 14: launch_pipe<256, 256, 2, 4, MODE, 2>(g, ep, s); break;   // pieces behind MFMAs 2..4 of three k-steps, all waves at once
+    case 15: launch_pipe<320, 256, 2, 4, MODE, 2>(g, ep, s); break;
+    case 10: launch_pipe<320, 256, 2, 4, MODE, 3>(g, ep, s); break;   // uniform schedule for the pieces, fragment reads as a block
+    default: launch_pipe<256, 256, 2, 4, MODE, 3>(g, ep, s); break;   // 9
+  }
+}
+
+}  // namespace
+
+void launch_gemm_bf16_pipe(int variant, int mode, const Bf16GemmArgs& g, const EpiParams& ep, hipStream_t s) {
+  switch (mode) {
+    case EPI_STORE: pipe_mode<EPI_STORE>(variant, g, ep, s); break;
+    case EPI_STORE_F32: pipe_mode<EPI_STORE_F32>(variant, g, ep, s); break;
+    case EPI_BIAS_GELU: pipe_mode<EPI_BIAS_GELU>(variant, g, ep, s); break;
+    case EPI_BIAS_RESID: pipe_mode<EPI_BIAS_RESID>(variant, g, ep, s); break;
+    case EPI_PATCH: pipe_mode<EPI_PATCH>(variant, g, ep, s); break;
+    case EPI_GELU_BWD: pipe_mode<EPI_GELU_BWD>(variant, g, ep, s); break;
+    case EPI_PARTIAL: pipe_mode<EPI_PARTIAL>(variant, g, ep, s); break;
+    default: break;
+  }
+}

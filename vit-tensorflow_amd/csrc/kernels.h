@@ -109,6 +109,8 @@ void launch_adamw(float* p, const float* g, float* m, float* v, int64_t n, float
 void launch_sgd(float* p, const float* g, float* m, int64_t n, float lr, float mom, float wd, hipStream_t s);   // m may be null (plain SGD)
 void launch_fill_zero(void* p, int64_t bytes, hipStream_t s);   // bytes multiple of 16
 void launch_fill_random_bf16(bf16_t* p, int64_t n, uint32_t seed, float scale, hipStream_t s);
+// *out_max (zero it first) = max(*out_max, max |a - b| / (1 + |b|)) over [rows, cols]; +inf when a NaN is met (GEMM self-checks at full size)
+void launch_max_rel_diff(const void* a, const void* b, int is_bf16, int64_t rows, int cols, int64_t lda, int64_t ldb, float* out_max, hipStream_t s);
 void launch_dropout(void* x, int is_bf16, int64_t n, float rate, uint64_t seed, uint32_t site, hipStream_t s);
 void launch_axpy_resid(const float* resid, const float* f, const float* scale, float* out, void* keep, int keep_bf16, int64_t rows, int d,
                        hipStream_t s);   // out = resid + f*scale[col]; keep[T] = f

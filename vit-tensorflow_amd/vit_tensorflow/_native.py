@@ -129,6 +129,7 @@ SYMBOLS: List[Tuple[str, object, list]] = [
     ("vitx_workspace_bytes", C.c_int32, [C.c_void_p, _P(C.c_int64)]),
     ("vitx_debug_read", C.c_int32, [C.c_void_p, C.c_char_p, C.c_int32, C.c_void_p, C.c_int64, _P(C.c_int64)]),
     ("vitx_bench_gemm", C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P(C.c_float), _P(C.c_float)]),
+    ("vitx_check_gemm", C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P(C.c_float)]),
     ("vitx_mim_create", C.c_int32, [C.c_void_p, _P(MimConfig), _P(C.c_void_p)]),
     ("vitx_mim_destroy", C.c_int32, [C.c_void_p]),
     ("vitx_mim_decoder", C.c_void_p, [C.c_void_p]),
