@@ -305,6 +305,10 @@ void launch_mode(const Bf16GemmArgs& g, const EpiParams& ep, hipStream_t s) {
   const bool bf16_out = (MODE == EPI_STORE || MODE == EPI_BIAS_GELU || MODE == EPI_GELU_BWD);
   // (8-B per-lane pieces) are staged; with 32-row staging rounds (variants 5-8) staging wins for fp32 outputs too.
   const bool direct = (g.kernel & 256) ? true : ((g.kernel & 512) ? false : (!bf16_out && k < 5));
+  if (k == 12) {   // wave-group ping-pong kernel (gemm_bf16_pp.hip); problems it does not take go to the pipelined 256 x 256 kernel
+    if (launch_gemm_bf16_pp(g, ep, MODE, s)) return;
+    k = 14;
+  }
   if (k == 9 || k == 10 || k == 11 || k == 13 || k == 14 || k == 15) { launch_gemm_bf16_pipe(k, MODE, g, ep, s); return; }   // gemm_bf16_pipe.hip
   if (direct) {
     if (k == 1) launch_variant<128, 128, 2, 2, MODE, false>(g, ep, s);
@@ -344,7 +348,7 @@ int gemm_bf16_tile_m(int kernel, int M, int N) {
 int gemm_bf16_tile_n(int kernel, int M, int N) {
   kernel &= 15;
   if (kernel == 0) kernel = gemm_bf16_pick(M, N);
-  return (kernel == 1 || kernel == 3) ? 128 : 256;
+  return (kernel == 1 || kernel == 3 || kernel == 12) ? 128 : 256;   // (12: the ping-pong kernel when it takes the problem; its fall-back is 256 wide)
 }
 void gemm_bf16_allow_320(int on) { g_allow_320 = on; }
 void gemm_bf16_set_shared_gpu(int on) { g_shared_gpu = on; }
@@ -399,7 +403,7 @@ void launch_gemm_bf16(const Bf16GemmArgs& g0, const EpiParams& ep, int mode, hip
   }
   Bf16GemmArgs g = g0;
   if (best < 0) {
-    static const int cand[] = {6, 9, 13, 14, 2, 7, 10, 11, 15, 5, 3, 1};   // 256x256 variants first, then 320x256 (only when allowed), then small tiles
+    static const int cand[] = {6, 9, 13, 14, 12, 2, 7, 10, 11, 15, 5, 3, 1};   // 256x256 variants first, then 320x256 (only when allowed), then small tiles
     // 256x128 / 128x128 tiles only compete when 256x256 tiles cannot give every CU two of them (token subsets: MAE's encoder
     // sees 49 of 196 patches, M = 12544 -> 147 tiles for a 768-wide output)
     const bool small_m = ceil_div(g0.M, 256) * ceil_div(g0.N, 256) < 512;
@@ -414,6 +418,7 @@ void launch_gemm_bf16(const Bf16GemmArgs& g0, const EpiParams& ep, int mode, hip
       const bool is320 = c == 5 || c == 7 || c == 10 || c == 11 || c == 15;
       if (is320 && !g_allow_320) continue;
       if ((c == 1 || c == 3) && !small_m) continue;
+      if (c == 12 && !gemm_bf16_pp_eligible(g0, ep, mode)) continue;
       if (g_shared_gpu && c != 2 && c != 5 && c != 1 && c != 3) continue;   // no persistent variants beside collectives (see gemm_bf16_set_shared_gpu)
       g.kernel = c;
       dispatch_gemm_bf16(g, ep, mode, s);   // warm-up (first-use attribute setup, instruction cache)
