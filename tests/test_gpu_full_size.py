@@ -48,6 +48,19 @@ def test_dense_launches_of_the_benchmarked_step_match_the_fp32_fma_kernel(N_, K,
                 gate(errs[1], COLSUM_TOL, what + " (fused column sums)", "gemm_full_size_colsum")
 
 
+def test_ping_pong_variant_matches_the_fp32_fma_kernel():
+    """Variant 12 (gemm_bf16_pp.hip: two wave groups alternating K loop / epilogue + operand feed; a measured-slower experiment that stays
+    callable): single tile, one pair, odd tile counts, several tiles per workgroup, the ViT-B launch shapes."""
+    N, m = _handle()
+    errs = (C.c_float * 2)()
+    for (M, N_, K) in [(256, 128, 768), (256, 256, 768), (768, 128, 768), (768, 384, 1024), (256 * 33, 128 * 5, 640), (M_TOKENS, 3072, 768), (M_TOKENS, 768, 3072)]:
+        for epi in (3, 2):
+            N.check(N.lib().vitx_check_gemm(m._handle, 0, M, N_, K, 12, epi, errs))
+            gate(errs[0], BF16_OUT_TOL, f"ping-pong M {M} N {N_} K {K} epilogue {epi}", "gemm_pingpong")
+            if epi == 2:
+                gate(errs[1], GELU_OUT2_TOL, f"ping-pong M {M} N {N_} K {K} epilogue 2 (second output)", "gemm_pingpong_out2")
+
+
 @pytest.mark.parametrize("in_, out", [(768, 3072), (3072, 768), (768, 768), (768, 2304), (1024, 4096)])
 def test_weight_gradient_launches_at_full_token_count_match_the_fp32_fma_kernel(in_, out):
     N, m = _handle()

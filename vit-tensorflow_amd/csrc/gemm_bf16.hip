@@ -403,7 +403,9 @@ void launch_gemm_bf16(const Bf16GemmArgs& g0, const EpiParams& ep, int mode, hip
   }
   Bf16GemmArgs g = g0;
   if (best < 0) {
-    static const int cand[] = {6, 9, 13, 14, 12, 2, 7, 10, 11, 15, 5, 3, 1};   // 256x256 variants first, then 320x256 (only when allowed), then small tiles
+    // (variant 12, the wave-group ping-pong kernel, is not a candidate: its 256 x 128 tile streams need 1.5x the operand bytes per FLOP and it measured
+    //  slower than the 256 x 256 kernels on every shape -- gemm_bf16_pp.hip, profiles/r3/pingpong_*; it stays callable and tested)
+    static const int cand[] = {6, 9, 13, 14, 2, 7, 10, 11, 15, 5, 3, 1};   // 256x256 variants first, then 320x256 (only when allowed), then small tiles
     // 256x128 / 128x128 tiles only compete when 256x256 tiles cannot give every CU two of them (token subsets: MAE's encoder
     // sees 49 of 196 patches, M = 12544 -> 147 tiles for a 768-wide output)
     const bool small_m = ceil_div(g0.M, 256) * ceil_div(g0.N, 256) < 512;
@@ -418,7 +420,6 @@ void launch_gemm_bf16(const Bf16GemmArgs& g0, const EpiParams& ep, int mode, hip
       const bool is320 = c == 5 || c == 7 || c == 10 || c == 11 || c == 15;
       if (is320 && !g_allow_320) continue;
       if ((c == 1 || c == 3) && !small_m) continue;
-      if (c == 12 && !gemm_bf16_pp_eligible(g0, ep, mode)) continue;
       if (g_shared_gpu && c != 2 && c != 5 && c != 1 && c != 3) continue;   // no persistent variants beside collectives (see gemm_bf16_set_shared_gpu)
       g.kernel = c;
       dispatch_gemm_bf16(g, ep, mode, s);   // warm-up (first-use attribute setup, instruction cache)

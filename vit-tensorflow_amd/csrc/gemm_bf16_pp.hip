@@ -21,6 +21,14 @@
 //   the consumer, which therefore waits for them (vmcnt(6), vmcnt(0) -- it has nothing else in flight) before its first two barriers.
 // All DMA goes through vitx_dma16 (inline asm, invisible to the compiler's waitcnt pass); the waits are the modelled builtin.
 //
+// RESULT (MI355X, round 3): correct on every shape (tests/test_gpu_full_size.py, tools/pp_check.py) but SLOWER than the 256 x 256 kernels:
+// 928 vs 1268-1306 TFLOP/s at 8192^3, fc1 + GELU 431 vs 376 us.  The consumer loop alone runs at 1447-1496 TFLOP/s (timing switch 2); what
+// binds is the operand feed: 24 KiB per 16 MFMAs per SIMD = ~28 B/clk/CU at 1300 TFLOP/s, while a CU gets 35 (4 issuing waves) - 49 B/clk
+// through the LDS-DMA from an L2-RESIDENT source with full-line pieces, ~30 with the half-line pieces of BK = 32, and only 14 B/clk (7.5 TB/s
+// for the whole chip) for whatever misses L2 (tools/probe_feed.hip, profiles/r3/probe_feed_paths_r3j.log).  A variant that staged the operands
+// through the producer's registers (buffer_load -> ds_write_b128) was slower still (737).  The structure hides the epilogue but pays 1.5x the
+// operand bytes per FLOP for it, which this memory system does not have to give.  Kept as a tested variant (12), not an autotune candidate.
+//
 // Eligible (launch_gemm_bf16_pp returns false otherwise and the caller takes another variant): interior-only problems (M % 256 == 0,
 // N % 128 == 0), K % 32 == 0 with at least PP_MIN_NK K-tiles, 16-B aligned rows, alpha == 1, no LayerScale, no split-K, operands < 2 GiB;
 // epilogues EPI_STORE (no bias), EPI_BIAS_GELU (bf16 form: act + stored gelu'), EPI_BIAS_RESID, EPI_GELU_BWD (bf16 form, fused column sums).
