@@ -292,6 +292,14 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_pipe_kernel(Bf16Gem
       //  same-box A/B on fc1-shaped launches, profiles/r2/epilogue_wide_ab_r2d.log: +1.0..2.5 % plain store, +1 % GELU, +2.5 % GELU VJP)
       constexpr bool WIDE = BM == 256 && (MODE == EPI_STORE || MODE == EPI_BIAS_GELU || MODE == EPI_GELU_BWD);
       const bool wide = WIDE && interior && ep.wide_ok;
+      // Global stores the LAST staging round of each path issues behind its last global load: only the epilogue's LOADS have to be back before
+      // the next tile (bias / residual / stored gelu' -- their registers are reused); the last stores may drain under the next tile's K loop.
+      // Memory operations of a wave retire in order, so "all but the S youngest" = every load.  The wait sits INSIDE each path, behind its last
+      // store, where the compiler's scoreboard knows which operations are the youngest (one merged wait after the paths made it keep loads
+      // "pending" and re-insert waits at the tile loop's header).  With vmcnt(0) every tile waited 1.5-3k cycles for its stores to reach L2.
+      constexpr int S_WIDE = (16 / NW) * (MODE == EPI_BIAS_GELU ? 2 : 1);    // rows per wave per round x outputs
+      constexpr int S_NARROW = (32 / NW) * (MODE == EPI_BIAS_GELU ? 2 : 1);
+      constexpr int vm_wide = (S_WIDE & 15) | 0x0F70, vm_narrow = (S_NARROW & 15) | 0x0F70;
       float4 cs2 = make_float4(0.f, 0.f, 0.f, 0.f);   // WIDE column sums: columns 4..7 of the lane's eight
       const int cc = lane & 31, gcol8 = tile_n * BN + cc * 8;
       float4 b8lo = make_float4(0.f, 0.f, 0.f, 0.f), b8hi = b8lo;
@@ -315,6 +323,14 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_pipe_kernel(Bf16Gem
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        if (R == 0) {
+          // the bias values are loaded for both epilogue forms but each path uses one set: a dummy use retires the other set's loads in the
+          // compiler's scoreboard (left "pending" they were protected with vmcnt waits at the tile loop's header, which at run time wait for the
+          // refill DMA and the last stores)
+          asm volatile("" ::"v"(b4.x), "v"(b4.y), "v"(b4.z), "v"(b4.w));
+          if constexpr (MODE == EPI_BIAS_RESID) asm volatile("" ::"v"(s4.x), "v"(s4.y), "v"(s4.z), "v"(s4.w));
+          if constexpr (WIDE) asm volatile("" ::"v"(b8lo.x), "v"(b8lo.y), "v"(b8lo.z), "v"(b8lo.w), "v"(b8hi.x), "v"(b8hi.y), "v"(b8hi.z), "v"(b8hi.w));
+        }
         const int grow0 = tile_m * BM + R * 32;
         if constexpr (WIDE) {
           if (wide) {
@@ -339,6 +355,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_pipe_kernel(Bf16Gem
                 cs2.x += hi[k].x; cs2.y += hi[k].y; cs2.z += hi[k].z; cs2.w += hi[k].w;
               }
             }
+            if (R == BM / 32 - 1) __builtin_amdgcn_s_waitcnt(vm_wide);
             continue;
           }
         }
@@ -360,9 +377,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_pipe_kernel(Bf16Gem
 #pragma unroll
             for (int k = 0; k < RPW; ++k) cs_add(epilogue_fast4<MODE, bf16_t, false, false>(ep, grow0 + k * NW + wave, gcol, v[k], b4, s4, x[k], out_off));
           }
+          if (R == BM / 32 - 1) __builtin_amdgcn_s_waitcnt(vm_narrow);
         } else {
 #pragma unroll
           for (int k = 0; k < RPW; ++k) cs_add(epilogue_apply4<MODE, bf16_t>(ep, grow0 + k * NW + wave, gcol, v[k], out_off));
+          if (R == BM / 32 - 1) __builtin_amdgcn_s_waitcnt(0x0F70);
         }
       }
       if (MODE == EPI_GELU_BWD && ep.colsum != nullptr) {
@@ -389,11 +408,13 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_pipe_kernel(Bf16Gem
       }
     }
     stamp(2);
-    // modelled wait on EVERY path out of the epilogue (the structurizer routes the `break` through the block that is also the loop latch, so a
-    // wait on the continue path alone leaves the epilogue's loads pending at the loop header in the compiler's view)
-    __builtin_amdgcn_s_waitcnt(0x0F70);           // vmcnt(0): the epilogue's stores have left the wave
+    // (every path out of the epilogue has waited for its loads -- see S_WIDE / S_NARROW above; the structurizer routes the `break` through the
+    //  block that is also the loop latch, so a path that left loads pending would show up as waits at the loop header)
     if (!has_next) break;
-    handover();                                   // staging reads done everywhere
+    // staging reads done everywhere (no DMA piece is in flight here: the refill is issued below, the prefetched K-tile landed before the epilogue)
+    __builtin_amdgcn_s_waitcnt(0xC07F);           // lgkmcnt(0)
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
     issue();                                      // deferred refill of the staging buffer: stream item it+1
     load_frags(fa[0], fb[0], smem + (it & 1) * STAGE, 0);
     stamp(3);
