@@ -245,21 +245,37 @@ def main():
                 N.check(lib.vitx_forward_dev(h, C.c_void_p(img.data_ptr()), b, H, W, 0, 0, None))
                 N.check(lib.vitx_ce_loss_grad_dev(h, C.c_void_p(labels.data_ptr()), inv_global, None))
                 N.check(lib.vitx_backward_dev(h, None, None))
-            stats = (N.KernelStat * 64)()
+            stats = (N.KernelStat * 160)()
             ns = C.c_int32()
-            N.check(lib.vitx_profile_end(h, stats, 64, C.byref(ns)))
-            classes = {}
+            N.check(lib.vitx_profile_end(h, stats, 160, C.byref(ns)))
+            classes, shapes = {}, []
+            epi_names = {0: "bf16 store", 1: "fp32 store", 2: "bias+GELU (act, gelu')", 3: "bias+fp32 residual", 4: "patch embed",
+                         5: "x gelu' + column sums", 6: "split-K partials"}
             for i in range(ns.value):
                 s = stats[i]
-                classes[s.name.decode()] = {"launches_per_step": s.launches // psteps, "ms_per_step": round(s.total_ms / psteps, 4),
-                                            "tflops": round(s.flops / max(s.total_ms, 1e-9) / 1e9, 1) if s.flops else None,
-                                            "gbps": round(s.bytes / max(s.total_ms, 1e-9) / 1e6, 1) if s.bytes else None}
+                name = s.name.decode()
+                if name.startswith("shape "):
+                    # per-shape rows of the dominant family ("shape nt e<epilogue> MxNxK" / "shape tn s<slices> MxNxK"; the same launches
+                    # are also booked under gemm_bf16_mfma / gemm_bf16_mfma_tn)
+                    _, form, tag, dims = name.split()
+                    M_, N_, K_ = (int(v) for v in dims.split("x"))
+                    us = 1e3 * s.total_ms / max(s.launches, 1)
+                    shapes.append({"form": form, "M": M_, "N": N_, "K": K_,
+                                   "epilogue": epi_names.get(int(tag[1:]), tag) if form == "nt" else f"fp32 partials, {tag[1:]} K slices",
+                                   "launches_per_step": s.launches // psteps, "us": round(us, 1),
+                                   "tflops": round(s.flops / max(s.total_ms, 1e-9) / 1e9, 1), "frac": round(s.flops / max(s.total_ms, 1e-9) / 1e-3 / MFMA_BF16_PEAK, 3)})
+                    continue
+                classes[name] = {"launches_per_step": s.launches // psteps, "ms_per_step": round(s.total_ms / psteps, 4),
+                                 "tflops": round(s.flops / max(s.total_ms, 1e-9) / 1e9, 1) if s.flops else None,
+                                 "gbps": round(s.bytes / max(s.total_ms, 1e-9) / 1e6, 1) if s.bytes else None}
             out["kernel_classes"] = classes
+            if shapes:
+                out["gemm_shapes"] = sorted(shapes, key=lambda r: -r["us"] * r["launches_per_step"])
             # dominant kernel family = the bf16 MFMA GEMM (NT form for forward/dgrad, TN form for the weight gradients)
             fam = [stats[i] for i in range(ns.value) if stats[i].name.decode().startswith("gemm_bf16_mfma")]
             peak = MFMA_BF16_PEAK
-            if not fam:
-                fam = [stats[i] for i in range(ns.value) if stats[i].name.decode() == "gemm_generic_fma"]
+            if not fam:   # fp32 parity mode: the exact-fp32 matrix-pipe kernel (+ the scalar kernel for small / strided problems)
+                fam = [stats[i] for i in range(ns.value) if stats[i].name.decode() in ("gemm_f32_mfma", "gemm_generic_fma")]
                 peak = 157.3e12
             if fam:
                 fl = sum(s.flops for s in fam); ms = sum(s.total_ms for s in fam); ln = sum(s.launches for s in fam)

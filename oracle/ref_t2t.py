@@ -44,6 +44,16 @@ def _inner_cfg(ld: int) -> dict:
 
 
 def param_spec(cfg: dict) -> List[Tuple[str, Tuple[int, ...], str]]:
+    """Keras' `Model.weights` order for t2t.py:49-122: a layer's OWN variables first (pos_embedding, cls_token: the tf.Variables the model
+    assigns to itself, t2t.py:77-78), then its sublayers in attribute order (patch_embedding Sequential, transformer, mlp_head) -- the same rule
+    the engine's ViT table follows (pos_embedding, cls_token, patch_embedding.*).  `init_params` draws the random values in `_draw_order`, the
+    order of this file's first version, so that the committed reference fixtures (tests/golden/ref_t2t_*.npz) keep their weights."""
+    d = _draw_order(cfg)
+    own = [e for e in d if e[0] in ("pos_embedding", "cls_token")]
+    return own + [e for e in d if e[0] not in ("pos_embedding", "cls_token")]
+
+
+def _draw_order(cfg: dict) -> List[Tuple[str, Tuple[int, ...], str]]:
     out = []
     add = lambda n, s, k: out.append((n, tuple(s), k))
     L = len(cfg["t2t_layers"])
@@ -76,7 +86,7 @@ def param_spec(cfg: dict) -> List[Tuple[str, Tuple[int, ...], str]]:
 def init_params(cfg: dict, seed: int = 1, randomize_all: bool = True) -> Dict[str, np.ndarray]:
     rng = np.random.Generator(np.random.PCG64(seed))
     out = {}
-    for name, shape, kind in param_spec(cfg):
+    for name, shape, kind in _draw_order(cfg):
         if kind == "normal":
             a = rng.standard_normal(shape)
         elif kind == "glorot":

@@ -224,6 +224,11 @@ def test_distillable_efficient_vit_fails_like_the_reference():
     m = DistillableEfficientViT(image_size=32, patch_size=8, num_classes=7, dim=32, transformer=lambda t, training=True: t)
     with pytest.raises(AttributeError, match="dropout"):
         m(np.zeros((1, 32, 32, 3), np.float32))
+    # the wrapper around it CONSTRUCTS (as the reference's does) and fails on the first call, inside the student's call (distill.py:116)
+    from vit_tensorflow.distill import DistillWrapper
+    w = DistillWrapper(teacher=lambda im, training=True: np.zeros((1, 7), np.float32), student=m)
+    with pytest.raises(AttributeError, match="dropout"):
+        w((np.zeros((1, 32, 32, 3), np.float32), np.eye(7, dtype=np.float32)[:1]))
 
 
 @pytest.mark.parametrize("case", list(G.MIM_CASES))

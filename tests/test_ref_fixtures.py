@@ -186,3 +186,36 @@ def test_mim_oracle_reproduces_reference_fixture(case):
         with_grad += 1
         assert np.abs(got[n] - ref).max() <= F64_TOL * max(1.0, np.abs(ref).max()), n
     assert with_grad == {"mae_vit": 39, "mae_same_dim": 48, "simmim_vit": 2}[case]
+
+
+@pytest.mark.skipif(not os.path.isdir(G.REF), reason="/root/reference is not present on this machine (GPU box)")
+def test_t2t_weight_order_follows_keras_own_variables_then_sublayers():
+    """Keras lists a Model's weights as its OWN tf.Variables first, then its sublayers' in attribute-creation order (Layer.weights =
+    own trainable weights + children's).  Derived from the reference's source, not from the oracle: the order in which T2TViT.__init__
+    (t2t.py:49-95) assigns its attributes, with tf.Variable attributes moved to the front."""
+    import ast
+    from oracle import ref_t2t
+    src = open(os.path.join(G.REF, "t2t.py")).read()
+    cls = next(n for n in ast.parse(src).body if isinstance(n, ast.ClassDef) and n.name == "T2TViT")
+    init = next(n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name == "__init__")
+    attrs = []
+    for st in ast.walk(init):
+        if isinstance(st, ast.Assign) and len(st.targets) == 1 and isinstance(st.targets[0], ast.Attribute) and getattr(st.targets[0].value, "id", "") == "self":
+            is_var = isinstance(st.value, ast.Call) and ast.unparse(st.value.func).endswith("Variable")
+            attrs.append((st.lineno, st.targets[0].attr, is_var))
+    attrs.sort()
+    own = [a for _, a, v in attrs if v]
+    layers = list(dict.fromkeys(a for _, a, v in attrs if not v))   # (self.transformer is assigned in both arms of an if)
+    assert own == ["pos_embedding", "cls_token"], own
+    cfg = ref_t2t.make_config(image_size=32, num_classes=7, dim=32, depth=2, heads=2, mlp_dim=64, dim_head=16, t2t_layers=((3, 2), (3, 2), (3, 2)))
+    groups = []
+    for n, _, _ in ref_t2t.param_spec(cfg):
+        g = n.split(".")[0]
+        if not groups or groups[-1] != g:
+            groups.append(g)
+    expect = own + [a for a in layers if a in ("patch_embedding", "transformer", "mlp_head")]
+    assert groups == expect, (groups, expect)
+    # and the random draw behind the committed fixtures did not move with the listing order
+    P = ref_t2t.init_params(cfg, seed=1)
+    z = np.load(os.path.join(GOLDEN_DIR, "ref_t2t_small.npz"))
+    assert abs(sum(float(np.abs(v).sum()) for v in P.values()) - float(z["param_checksum"])) < 1e-6

@@ -617,13 +617,13 @@ bool attn_bf16_supported(int n, int dim_head) { return dim_head == DH && n >= 1 
 #define VITX_NTP_DISPATCH(ntp, CALL) \
   do { if ((ntp) == 4) { CALL(4); } else if ((ntp) == 6) { CALL(6); } else if ((ntp) == 14) { CALL(14); } else { CALL(18); } } while (0)
 
-void launch_attn_bf16_fwd(const bf16_t* qkv, bf16_t* o, float* lse, int b, int n, int h, float scale, const bf16_t* zero_page, hipStream_t s) {
+void launch_attn_bf16_fwd(const bf16_t* qkv, bf16_t* o, float* lse, int b, int n, int h, float scale, const bf16_t* zero_page, int reverse, hipStream_t s) {
   const int ntp = pick_ntp(n);
   const int nkp = 16 * ntp;
   const int smem = 2 * nkp * ROWB;
   // (image, head) tasks from the last to the first: qkv (232 MB at ViT-B/16, written front to back by the GEMM before) is read newest rows
-  // first, while they are still in the 256 MB memory-side cache (1.24 -> 1.15 ms per step); VITX_REVERSE without bit 4 restores id order
-  static const int reverse = [] { const char* e = getenv("VITX_REVERSE"); return e ? (atoi(e) >> 2) & 1 : 1; }();
+  // first, while they are still in the 256 MB memory-side cache (1.24 -> 1.15 ms per step); `reverse` = bit 4 of the engine's reverse_mask
+  // (VITX_REVERSE, read once per handle)
 #define CALL(NTP) { set_smem(attn_fwd_kernel<NTP>, smem); hipLaunchKernelGGL(attn_fwd_kernel<NTP>, dim3(b * h), dim3(att_threads(n)), smem, s, qkv, o, lse, n, h, scale, zero_page, reverse); }
   VITX_NTP_DISPATCH(ntp, CALL);
 #undef CALL

@@ -185,12 +185,12 @@ int32_t vitx_set_patch_input(vitx_handle h, int32_t np) {
 int32_t vitx_forward(vitx_handle h, const float* img_host, int32_t b, int32_t H, int32_t W, int32_t training, uint64_t seed,
                      float* logits_host) {
   CAPI_TRY
+  // the one-shot vitx_set_patch_input state is consumed FIRST: a call that fails validation must not leave the handle armed (the next ordinary
+  // forward would read its image as patch rows)
+  const int np_once = h ? h->next_patch_np : 0;
+  if (h) h->next_patch_np = 0;
   if (!h || !img_host || !logits_host) return fail(VITX_ERR_INVALID, "null argument");
-  if (h->next_patch_np > 0) {   // one-shot: img_host holds patch rows [b, np, patch_dim]
-    const int np = h->next_patch_np;
-    h->next_patch_np = 0;
-    return vitx_forward_patches(h, img_host, b, np, training, seed, logits_host);
-  }
+  if (np_once > 0) return vitx_forward_patches(h, img_host, b, np_once, training, seed, logits_host);   // img_host holds patch rows [b, np, patch_dim]
   if (b <= 0 || b > h->cfg.max_batch) return fail(VITX_ERR_INVALID, "batch must be in [1, max_batch]");
   if (H <= 0 || W <= 0 || H > h->cfg.image_h || W > h->cfg.image_w)
     return fail(VITX_ERR_INVALID, "image larger than the configured image_size");
@@ -741,6 +741,13 @@ int32_t vitx_profile_end(vitx_handle h, vitx_kernel_stat* out, int32_t cap, int3
     s.total_ms += ms;
     s.flops += pe.flops;
     s.bytes += pe.bytes;
+    if (pe.cls2 >= 0) {
+      auto& s2 = stats[(size_t)pe.cls2];
+      s2.launches += 1;
+      s2.total_ms += ms;
+      s2.flops += pe.flops;
+      s2.bytes += pe.bytes;
+    }
     (void)hipEventDestroy(pe.e0);
     (void)hipEventDestroy(pe.e1);
   }

@@ -291,10 +291,10 @@ extern "C" {
 int32_t vitx_forward_distill(vitx_handle h, const float* img_host, int32_t b, int32_t H, int32_t W, int32_t training, uint64_t seed,
                              const float* distill_token_host, float* logits_host, float* distill_tokens_host) {
   D_TRY
+  const int np_in = h ? h->next_patch_np : 0;   // > 0: img_host holds patch rows [b, np, patch_dim] (vitx_set_patch_input, one shot: consumed
+  if (h) h->next_patch_np = 0;                  //   before any validation can fail, so that a rejected call does not leave the handle armed)
   if (!h || !img_host || !distill_token_host || !logits_host || !distill_tokens_host) return capi_fail(VITX_ERR_INVALID, "null argument");
   if (b <= 0 || b > h->cfg.max_batch) return capi_fail(VITX_ERR_INVALID, "batch must be in [1, max_batch]");
-  const int np_in = h->next_patch_np;   // > 0: img_host holds patch rows [b, np, patch_dim] (vitx_set_patch_input, one shot)
-  h->next_patch_np = 0;
   if (!np_in && (H <= 0 || W <= 0 || H > h->cfg.image_h || W > h->cfg.image_w)) return capi_fail(VITX_ERR_INVALID, "image larger than the configured image_size");
   const int d = h->cfg.dim, nc = h->cfg.num_classes;
   hipStream_t s = h->stream;
@@ -302,10 +302,11 @@ int32_t vitx_forward_distill(vitx_handle h, const float* img_host, int32_t b, in
   if (!tok) return capi_fail(VITX_ERR_HIP, "hipMalloc failed");
   const size_t in_elems = np_in ? (size_t)b * np_in * h->pd : (size_t)b * H * W * h->cfg.channels;
   D_HIP(hipMemcpyAsync(h->img_dev, img_host, in_elems * 4, hipMemcpyHostToDevice, s));
-  if (np_in) { h->fwd_patches = h->img_dev; h->fwd_np = np_in; }
   D_HIP(hipMemcpyAsync(tok, distill_token_host, (size_t)d * 4, hipMemcpyHostToDevice, s));
   std::string err;
+  if (np_in) { h->fwd_patches = h->img_dev; h->fwd_np = np_in; }   // set right before the call that consumes it: no error exit in between
   int rc = engine_forward(h, h->img_dev, b, H, W, training, seed, nullptr, err, tok, tok + d);
+  h->fwd_patches = nullptr;
   if (rc != VITX_OK) return capi_fail(rc, err);
   D_HIP(hipMemcpy2DAsync(logits_host, (size_t)nc * 4, h->logits, (size_t)h->nc_k * 4, (size_t)nc * 4, (size_t)b, hipMemcpyDeviceToHost, s));
   D_HIP(hipMemcpyAsync(distill_tokens_host, tok + d, (size_t)b * d * 4, hipMemcpyDeviceToHost, s));
@@ -405,20 +406,21 @@ int32_t vitx_distill_get_grads(vitx_distill_handle m, float* host_blob, int64_t 
 int32_t vitx_distill_forward(vitx_distill_handle m, const float* img_host, const float* labels_host, const float* teacher_logits_host, int32_t b,
                              int32_t H, int32_t W, int32_t training, uint64_t seed, float temperature, float alpha, float* loss_host) {
   D_TRY
+  const int np_in = (m && m->stu) ? m->stu->next_patch_np : 0;   // > 0: img_host holds patch rows [b, np, patch_dim] (vitx_set_patch_input on the
+  if (m && m->stu) m->stu->next_patch_np = 0;                    //   student, one shot: consumed before any validation can fail)
   if (!m || !img_host || !labels_host || !teacher_logits_host) return capi_fail(VITX_ERR_INVALID, "null argument");
   const vitx_config& c = m->stu->cfg;
   if (b <= 0 || b > c.max_batch) return capi_fail(VITX_ERR_INVALID, "batch must be in [1, max_batch]");
-  const int np_in = m->stu->next_patch_np;   // > 0: img_host holds patch rows [b, np, patch_dim] (vitx_set_patch_input on the student, one shot)
-  m->stu->next_patch_np = 0;
   if (!np_in && (H <= 0 || W <= 0 || H > c.image_h || W > c.image_w)) return capi_fail(VITX_ERR_INVALID, "image larger than the configured image_size");
   hipStream_t s = m->stu->stream;
   const size_t in_elems = np_in ? (size_t)b * np_in * m->stu->pd : (size_t)b * H * W * c.channels;
   D_HIP(hipMemcpyAsync(m->img, img_host, in_elems * 4, hipMemcpyHostToDevice, s));
-  if (np_in) { m->stu->fwd_patches = m->img; m->stu->fwd_np = np_in; }
   D_HIP(hipMemcpyAsync(m->labels, labels_host, (size_t)b * m->nc * 4, hipMemcpyHostToDevice, s));
   D_HIP(hipMemcpyAsync(m->teacher, teacher_logits_host, (size_t)b * m->nc * 4, hipMemcpyHostToDevice, s));
   std::string err;
+  if (np_in) { m->stu->fwd_patches = m->img; m->stu->fwd_np = np_in; }   // set right before the call that consumes it
   int rc = distill_forward(m, m->img, m->labels, m->teacher, b, H, W, training, seed, temperature, alpha, err);
+  m->stu->fwd_patches = nullptr;                                          // (also when distill_forward failed before reaching the engine)
   if (rc != VITX_OK) return capi_fail(rc, err);
   if (loss_host) D_HIP(hipMemcpyAsync(loss_host, m->loss, (size_t)b * 4, hipMemcpyDeviceToHost, s));
   D_HIP(hipStreamSynchronize(s));

@@ -70,6 +70,7 @@ struct Stage {
 
 struct ProfEvent {
   int cls;
+  int cls2 = -1;   // optional second class the same launch is booked under ("shape ..." rows: one per GEMM shape x epilogue)
   hipEvent_t e0, e1;
   double flops, bytes;
 };

@@ -135,9 +135,10 @@ struct Prof {
   vitx_engine* e;
   ProfEvent pe;
   bool on;
-  Prof(vitx_engine* e_, const char* name, double flops, double bytes) : e(e_), on(e_->profiling) {
+  Prof(vitx_engine* e_, const char* name, double flops, double bytes, const char* name2 = nullptr) : e(e_), on(e_->profiling) {
     if (!on) return;
     pe.cls = prof_class(e, name);
+    pe.cls2 = name2 ? prof_class(e, name2) : -1;
     pe.flops = flops;
     pe.bytes = bytes;
     (void)hipEventCreate(&pe.e0);
@@ -239,7 +240,9 @@ static void dense_fwd(vitx_engine* e, const void* X, int64_t ldx, int rows, cons
     g.stagger = (mode == EPI_BIAS_GELU || mode == EPI_BIAS_RESID || mode == EPI_PATCH) ? e->gemm_stagger : 0;
     ep.zero_pad = 1;
     finalize_epi(ep);
-    Prof pr(e, "gemm_bf16_mfma", flops, bytes);
+    char shape[48];
+    if (e->profiling) snprintf(shape, sizeof shape, "shape nt e%d %dx%dx%d", mode, g.M, g.N, g.K);   // per-shape row of bench.py's gemm_shapes table
+    Prof pr(e, "gemm_bf16_mfma", flops, bytes, e->profiling ? shape : nullptr);
     launch_gemm_bf16(g, ep, mode, e->stream);
   } else {
     GenericGemmArgs g;
@@ -248,7 +251,7 @@ static void dense_fwd(vitx_engine* e, const void* X, int64_t ldx, int rows, cons
     g.sam = ldx; g.sak = 1; g.sbk = w.out; g.sbn = 1;
     ep.zero_pad = 1;
     finalize_epi(ep);
-    Prof pr(e, "gemm_generic_fma", flops, bytes);
+    Prof pr(e, gemm_f32_mfma_supported(g, e->bf16, 0, e->bf16) ? "gemm_f32_mfma" : "gemm_generic_fma", flops, bytes);   // the class of the kernel that runs
     launch_gemm_generic(g, ep, mode, e->bf16, 0, e->bf16, e->stream);
   }
 }
@@ -269,7 +272,9 @@ static void dense_dgrad(vitx_engine* e, const void* dY, int64_t ldy, int rows, c
     g.stagger = (mode == EPI_GELU_BWD) ? e->gemm_stagger : 0;
     ep.zero_pad = 1;
     finalize_epi(ep);
-    Prof pr(e, "gemm_bf16_mfma", flops, bytes);
+    char shape[48];
+    if (e->profiling) snprintf(shape, sizeof shape, "shape nt e%d %dx%dx%d", mode, g.M, g.N, g.K);
+    Prof pr(e, "gemm_bf16_mfma", flops, bytes, e->profiling ? shape : nullptr);
     launch_gemm_bf16(g, ep, mode, e->stream);
   } else {
     GenericGemmArgs g;
@@ -278,7 +283,7 @@ static void dense_dgrad(vitx_engine* e, const void* dY, int64_t ldy, int rows, c
     g.sam = ldy; g.sak = 1; g.sbk = 1; g.sbn = w.out;
     ep.zero_pad = 1;
     finalize_epi(ep);
-    Prof pr(e, "gemm_generic_fma", flops, bytes);
+    Prof pr(e, gemm_f32_mfma_supported(g, e->bf16, 0, e->bf16) ? "gemm_f32_mfma" : "gemm_generic_fma", flops, bytes);   // the class of the kernel that runs
     launch_gemm_generic(g, ep, mode, e->bf16, 0, e->bf16, e->stream);
   }
 }
@@ -321,7 +326,9 @@ static void dense_wgrad(vitx_engine* e, const void* X, int64_t ldx, const void* 
     ep.M = w.in; ep.N = w.out;
     finalize_epi(ep);
     {
-      Prof pr(e, e->wgrad_via_transpose ? "gemm_bf16_mfma" : "gemm_bf16_mfma_tn", flops, bytes);
+      char shape[48];
+      if (e->profiling) snprintf(shape, sizeof shape, "shape tn s%d %dx%dx%d", slices, g.M, g.N, g.K);   // dW[in, out] over K token rows
+      Prof pr(e, e->wgrad_via_transpose ? "gemm_bf16_mfma" : "gemm_bf16_mfma_tn", flops, bytes, e->profiling ? shape : nullptr);
       if (e->wgrad_via_transpose) launch_gemm_bf16(g, ep, EPI_PARTIAL, e->stream);
       else launch_gemm_bf16_tn(g, ep, e->stream);
     }
@@ -337,7 +344,7 @@ static void dense_wgrad(vitx_engine* e, const void* X, int64_t ldx, const void* 
     EpiParams ep;
     ep.out = dW; ep.ldo = w.out; ep.M = w.in; ep.N = w.out;
     finalize_epi(ep);
-    Prof pr(e, "gemm_generic_fma", flops, bytes);
+    Prof pr(e, gemm_f32_mfma_supported(g, e->bf16, e->bf16, 0) ? "gemm_f32_mfma" : "gemm_generic_fma", flops, bytes);   // the class of the kernel that runs
     launch_gemm_generic(g, ep, EPI_STORE_F32, e->bf16, e->bf16, 0, e->stream);
   }
 }
@@ -628,7 +635,7 @@ static int block_forward(vitx_engine* e, Stage& st, int si, int l, int b, int nq
   }
   if (use_fused_attn(e, nq)) {
     Prof pr(e, "attn_bf16_fwd", 4.0 * b * c.heads * (double)nq * nq * c.dim_head, (double)rows * inner * 4 * esz);
-    launch_attn_bf16_fwd((const bf16_t*)ba.qkv, (bf16_t*)ba.o, ba.lse, b, nq, c.heads, 1.0f / std::sqrt((float)c.dim_head), (const bf16_t*)e->zero_page, e->stream);
+    launch_attn_bf16_fwd((const bf16_t*)ba.qkv, (bf16_t*)ba.o, ba.lse, b, nq, c.heads, 1.0f / std::sqrt((float)c.dim_head), (const bf16_t*)e->zero_page, (e->reverse_mask >> 2) & 1, e->stream);
   } else {
     const int need = c.variant == VITX_VARIANT_VIT ? 1 : 3;
     if (e->keep_scores && ba.sc_keep_elems == 0) {   // first use: this block's own score buffers, sized for the largest call
@@ -904,6 +911,7 @@ static int engine_create_body(vitx_engine* e, const vitx_config& cfg, std::strin
   if (const char* k = getenv("VITX_NT")) e->nt_mask = atoi(k);
   if (const char* k = getenv("VITX_BGEMM_PAIRS")) e->bgemm_pairs = atoi(k) != 0;
   if (const char* k = getenv("VITX_REVERSE")) e->reverse_mask = atoi(k);
+  gemm_f32_mfma_read_env();
   if (const char* k = getenv("VITX_REVERSE_MIN_MB")) e->reverse_min_bytes = (int64_t)atoi(k) << 20;
   if (const char* k = getenv("VITX_GEMM_KERNEL")) e->gemm_kernel = atoi(k);
   if (const char* k = getenv("VITX_UNFUSED_HEADOPS")) e->unfused_headops = atoi(k) != 0;

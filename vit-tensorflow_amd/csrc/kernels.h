@@ -18,6 +18,7 @@ void launch_gemm_generic(const GenericGemmArgs& g, const EpiParams& ep, int mode
 // launch_gemm_generic routes to it when supported (VITX_F32_MFMA=0 keeps the scalar kernel)
 bool gemm_f32_mfma_supported(const GenericGemmArgs& g, int ta, int tb, int to);
 void launch_gemm_f32_mfma(const GenericGemmArgs& g, const EpiParams& ep, int mode, hipStream_t s);
+void gemm_f32_mfma_read_env();   // VITX_F32_MFMA, read once per engine handle (not per launch)
 
 // ---------------------------------------------------------------- attn_headchain.hip
 // fused head-axis chains (one wave per (image, query) row): CaiT talking heads, DeepViT re-attention, and their VJPs
@@ -66,7 +67,8 @@ int gemm_bf16_tn_tile(int kernel, int M, int N);
 // ---------------------------------------------------------------- attn_bf16.hip
 // fused multi-head self-attention (vit.py:73-82) on packed qkv [b, n, 3, h, 64] bf16.
 bool attn_bf16_supported(int n, int dim_head);
-void launch_attn_bf16_fwd(const bf16_t* qkv, bf16_t* o, float* lse, int b, int n, int h, float scale, const bf16_t* zero_page, hipStream_t s);   // zero_page: >= 128 B of zeros
+void launch_attn_bf16_fwd(const bf16_t* qkv, bf16_t* o, float* lse, int b, int n, int h, float scale, const bf16_t* zero_page, int reverse,
+                          hipStream_t s);   // zero_page: >= 128 B of zeros; reverse: 1 = (image, head) tasks from the last to the first
 void launch_attn_bf16_bwd(const bf16_t* qkv, const bf16_t* o, const bf16_t* d_o, const float* lse, float* dsum_ws,
                           bf16_t* dqkv, int b, int n, int h, float scale, const bf16_t* zero_page, hipStream_t s);
 

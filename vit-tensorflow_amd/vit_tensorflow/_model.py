@@ -373,6 +373,8 @@ class VitxModel:
         x, proto = self._as_host(patches)
         assert x.ndim == 3, "expected patch rows [b, np, patch_dim]"
         b, n, pd = x.shape
+        want = self._cfg.patch_h * self._cfg.patch_w * self._cfg.channels     # the C side copies b * np * patch_dim floats from this pointer
+        assert pd == want, f"expected patches of {want} features (patch_h * patch_w * channels), got {pd}"
         h = self._ensure_handle(b)
         self._img_shape = (b, n, pd)
         out = np.empty((b, self.num_classes), dtype=np.float32)

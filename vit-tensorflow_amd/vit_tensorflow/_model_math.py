@@ -33,12 +33,12 @@ def flops_per_image(variant: str = "vit", *, image_size: Union[int, Tuple[int, i
 
 
 def kernel_source_id() -> str:
-    """Digest of the sources of the bf16 MFMA GEMM family (the kernels `roofline` is about: gemm_bf16.hip with its epilogues and
+    """Digest of the sources of the bf16 MFMA GEMM family (the kernels `roofline` is about: gemm_bf16*.hip with their epilogues and
     device helpers): profiles that quote per-build counters of that family (PMC traffic) carry it, and bench.py refuses to quote a
     profile taken on other GEMM sources.  Changes to other kernels (attention, LayerNorm, the DeepViT / CaiT paths) do not move it."""
     h = hashlib.sha1()
     root = os.path.join(_HERE, "..", "csrc")
-    files = [os.path.join(root, f) for f in ("common.h", "epilogue.h", "gemm_bf16.hip")]
+    files = [os.path.join(root, f) for f in ("common.h", "epilogue.h", "gemm_bf16_common.h", "gemm_bf16.hip", "gemm_bf16_pipe.hip", "gemm_bf16_tn.hip")]
     for f in files:
         with open(f, "rb") as fh:
             h.update(os.path.basename(f).encode() + b"\0" + fh.read())

@@ -149,11 +149,15 @@ class DistillWrapper:
         the distillation term exactly as distill.py:122-129 computes it (Keras' KLDivergence clips the LOG-probabilities it is
         handed to 1e-7, which makes the term constant in the student), False computes the intended KL divergence; seed."""
         assert isinstance(student, (DistillableViT, DistillableT2TViT, DistillableEfficientViT)), 'student must be a vision transformer'   # distill.py:91
-        if isinstance(student, DistillableEfficientViT):
-            student()   # raises what the reference raises on its first call (see the class)
         self._t2t = isinstance(student, DistillableT2TViT)
         self.teacher, self.student = teacher, student
         self.temperature, self.alpha, self.hard = temperature, alpha, hard
+        # a DistillableEfficientViT student: the reference CONSTRUCTS the wrapper and fails on its first call, inside the student's call, with
+        # AttributeError('dropout') (distill.py:83 / the class above) -- same here: nothing engine-side is built, __call__ invokes the student
+        self._unrunnable = isinstance(student, DistillableEfficientViT)
+        if self._unrunnable:
+            self._h = None
+            return
         cfg = N.DistillConfig()
         cfg.temperature, cfg.alpha, cfg.hard, cfg.literal_loss = float(temperature), float(alpha), 1 if hard else 0, 1 if literal_loss else 0
         self._dcfg = cfg
@@ -247,6 +251,8 @@ class DistillWrapper:
     def __call__(self, inputs, temperature=None, alpha=None, training=True, **kwargs):
         """DistillWrapper.call((img, labels), temperature, alpha, training) (distill.py:107): the per-image loss [b]."""
         img, labels = inputs
+        if self._unrunnable:   # distill.py:116: student(img, distill_token=..., training=...) -> AttributeError('dropout') inside the student's call
+            return self.student(img, distill_token=None, training=training)
         x, _ = VitxModel._as_host(img)
         y, _ = VitxModel._as_host(labels)
         b, H, W, _c = x.shape

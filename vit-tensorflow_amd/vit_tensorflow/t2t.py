@@ -95,6 +95,29 @@ def exists(val):
     return val is not None
 
 
+class _RenamedWeight:
+    """A weight handle of one of the composed engine handles under its T2TViT name."""
+
+    def __init__(self, w, name):
+        self._w, self.name = w, name
+
+    @property
+    def shape(self):
+        return self._w.shape
+
+    def numpy(self):
+        return self._w.numpy()
+
+    def assign(self, value):
+        self._w.assign(value)
+
+    def __array__(self, dtype=None):
+        return self._w.__array__(dtype)
+
+    def __getitem__(self, idx):
+        return self._w[idx]
+
+
 class T2TViT:
     """Drop-in for vit_tensorflow/t2t.py:49-122.  Same constructor and `model(img, training=True)`.
 
@@ -155,9 +178,11 @@ class T2TViT:
         for n, s, _ in self._main._table:
             nn = {"patch_embedding.kernel": f"patch_embedding.{L}.kernel", "patch_embedding.bias": f"patch_embedding.{L}.bias"}.get(n, n)
             out.append((nn, self._main, n, tuple(s)))
-        # the reference's order: patch_embedding.* first, then pos_embedding, cls_token, transformer.*, mlp_head.*
+        # Keras' Model.weights order: the model's own tf.Variables first (pos_embedding, cls_token: t2t.py:77-78), then the sublayers in
+        # attribute order -- patch_embedding.{i}.*, patch_embedding.{L}.kernel / .bias, transformer.*, mlp_head.* (as the engine's ViT table)
+        own = [e for e in out if e[0] in ("pos_embedding", "cls_token")]
         pe = [e for e in out if e[0].startswith("patch_embedding.")]
-        return pe + [e for e in out if not e[0].startswith("patch_embedding.")]
+        return own + pe + [e for e in out if e[0] not in ("pos_embedding", "cls_token") and not e[0].startswith("patch_embedding.")]
 
     def state_dict(self):
         sds = {id(m): m.state_dict() for m in self._inner + [self._main]}
@@ -183,6 +208,31 @@ class T2TViT:
 
     def count_params(self):
         return int(sum(int(np.prod(s)) for _, _, _, s in self._name_map()))
+
+    @property
+    def weights(self):
+        """Keras-order list of weight handles (name / shape / numpy()), spanning the tokenizer's handles and the main one."""
+        per = {id(m): {w.name: w for w in m.weights} for m in self._inner + [self._main]}
+        out = []
+        for nn, m, n, _ in self._name_map():
+            w = per[id(m)][n]
+            out.append(_RenamedWeight(w, nn))
+        return out
+
+    trainable_variables = weights
+    trainable_weights = weights
+
+    @staticmethod
+    def _npz_path(path):
+        return path if str(path).endswith(".npz") else str(path) + ".npz"
+
+    def save_weights(self, path):
+        """Weights by name in one .npz (same format and caveat as the ViT classes' save_weights)."""
+        np.savez(self._npz_path(path), **self.state_dict())
+
+    def load_weights(self, path):
+        with np.load(self._npz_path(path)) as z:
+            self.load_state_dict({k: z[k] for k in z.files})
 
     @property
     def pos_embedding(self):
