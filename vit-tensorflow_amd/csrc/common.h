@@ -182,5 +182,16 @@ __device__ __forceinline__ void vitx_dma16(i32x4 rsrc, uint32_t dst, uint32_t vo
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(dst), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
 }
 
+// Continuation piece: M0 as the previous vitx_dma16 of this wave left it, LDS destination = M0 + IMM (+ 16 lane), global address = ... + IMM as
+// well (the instruction's offset field feeds both), so the caller passes voff - IMM.  Writing M0 for every piece serialises a wave's pieces
+// on the M0 dependency (the next s_mov m0 waits until the address path has consumed the previous value); a wave's pieces of one operand are
+// therefore laid out back to back in LDS (<= 4 KiB: the 12-bit offset field) and share one M0 value.  Nothing else in the kernels that use
+// this touches M0 between the pieces of a group (checked in the ISA).
+template <int IMM>
+__device__ __forceinline__ void vitx_dma16_cont(i32x4 rsrc, uint32_t voff_minus_imm, uint32_t soff) {
+  static_assert(IMM > 0 && IMM < 4096, "12-bit unsigned offset field");
+  asm volatile("buffer_load_dwordx4 %0, %1, %2 offen offset:%3 lds" ::"v"(voff_minus_imm), "s"(rsrc), "s"(soff), "i"(IMM) : "memory");
+}
+
 static inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }

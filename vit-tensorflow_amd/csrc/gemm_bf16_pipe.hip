@@ -49,14 +49,16 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_pipe_kernel(Bf16Gem
   // which selects the saddr form of global_load_lds (one address dword per lane, no per-piece VALU address arithmetic)
   uint32_t offA[A_INSTR], offB[B_INSTR];
 #pragma unroll
+  // wave w moves rows [8 w A_INSTR, 8 (w + 1) A_INSTR) of the A tile: its pieces are back to back in LDS, so that groups of four share ONE M0
+  // value and differ in the instruction's immediate offset (vitx_dma16_cont; the offset also shifts the global address, hence the - (i & 3) KiB)
   for (int i = 0; i < A_INSTR; ++i) {
-    const int row = (i * NW + wave) * 8 + (lane >> 3);
-    offA[i] = (uint32_t)(row * (int)g.lda + (((lane & 7) ^ ((row >> 1) & 7)) << 3)) * 2u;
+    const int row = (wave * A_INSTR + i) * 8 + (lane >> 3);
+    offA[i] = (uint32_t)(row * (int)g.lda + (((lane & 7) ^ ((row >> 1) & 7)) << 3)) * 2u - (uint32_t)((i & 3) * 1024);
   }
 #pragma unroll
   for (int i = 0; i < B_INSTR; ++i) {
-    const int row = (i * NW + wave) * 8 + (lane >> 3);
-    offB[i] = (uint32_t)(row * (int)g.ldb + (((lane & 7) ^ ((row >> 1) & 7)) << 3)) * 2u;
+    const int row = (wave * B_INSTR + i) * 8 + (lane >> 3);
+    offB[i] = (uint32_t)(row * (int)g.ldb + (((lane & 7) ^ ((row >> 1) & 7)) << 3)) * 2u - (uint32_t)((i & 3) * 1024);
   }
 
   const int gm = ((tiles_n >= 8 && g.stagger != 8) ? 4 : 1) * (g.reverse_m ? -1 : 1);   // (stagger 8: row-major order, A/B switch of the micro-benchmark)
@@ -69,7 +71,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_pipe_kernel(Bf16Gem
   // The pieces are issued from inline asm (vitx_dma16, common.h): as builtins the compiler drained them with vmcnt(0) in front of the
   // next k-step's fragment reads.
   const i32x4 rsA = vitx_make_rsrc(g.A), rsB = vitx_make_rsrc(g.B);
-  const uint32_t lds_w = vitx_lds_addr(smem) + (uint32_t)wave * 1024u;   // this wave's 1-KiB slot inside an 8-KiB piece row
+  const uint32_t lds_wa = vitx_lds_addr(smem) + (uint32_t)wave * (A_INSTR * 1024u);             // this wave's A pieces (contiguous)
+  const uint32_t lds_wb = vitx_lds_addr(smem) + A_BYTES + (uint32_t)wave * (B_INSTR * 1024u);   // this wave's B pieces
   uint32_t a_soff = 0, b_soff = 0;       // byte offset of the cursor tile's first K-tile inside A / B
   auto i_set_tile = [&]() {
     int tm, tn;
@@ -89,8 +92,14 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_pipe_kernel(Bf16Gem
   const int xp = g.stagger;   // timing experiments only (results are wrong): 1 = no DMA wait, 2 = no DMA issue in the K loop, 4 = no fragment reads in the K loop
   auto issue_piece = [&](uint32_t base, auto p_c) {   // base = LDS byte offset of the target stage
     constexpr int p = decltype(p_c)::value;
-    if constexpr (p < A_INSTR) vitx_dma16(rsA, lds_w + base + p * NW * 1024, offA[p], a_soff + i_k * (BK * 2));
-    else vitx_dma16(rsB, lds_w + base + A_BYTES + (p - A_INSTR) * NW * 1024, offB[p - A_INSTR], b_soff + i_k * (BK * 2));
+    if constexpr (p < A_INSTR) {
+      if constexpr ((p & 3) == 0) vitx_dma16(rsA, lds_wa + base + p * 1024, offA[p], a_soff + i_k * (BK * 2));
+      else vitx_dma16_cont<(p & 3) * 1024>(rsA, offA[p], a_soff + i_k * (BK * 2));
+    } else {
+      constexpr int q = p - A_INSTR;
+      if constexpr ((q & 3) == 0) vitx_dma16(rsB, lds_wb + base + q * 1024, offB[q], b_soff + i_k * (BK * 2));
+      else vitx_dma16_cont<(q & 3) * 1024>(rsB, offB[q], b_soff + i_k * (BK * 2));
+    }
   };
   auto i_advance = [&]() {
     ++issued;

@@ -60,12 +60,14 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_tn_kernel(Bf16GemmArgs
   // per-lane DMA source offsets in bytes (unsigned 32-bit: uniform 64-bit base + zero-extended lane offset)
   uint32_t offA[INSTR], offB[INSTR];
 #pragma unroll
+  // wave w moves token rows [w INSTR RPI, (w + 1) INSTR RPI) of each operand: its pieces are back to back in LDS, so that groups of four
+  // share ONE M0 value and differ in the instruction's immediate offset (vitx_dma16_cont, common.h; the offset also shifts the global address)
   for (int i = 0; i < INSTR; ++i) {
-    const int row = (i * NW + wave) * RPI + lane / LPR;
+    const int row = (wave * INSTR + i) * RPI + lane / LPR;
     const int pc = lane % LPR;
     const int c = ((((pc >> 1) ^ (2 * (row & 3))) << 1) | (pc & 1));   // logical 16-B chunk stored at physical chunk pc
-    offA[i] = (uint32_t)(row * (int)g.lda + c * 8) * 2u;
-    offB[i] = (uint32_t)(row * (int)g.ldb + c * 8) * 2u;
+    offA[i] = (uint32_t)(row * (int)g.lda + c * 8) * 2u - (uint32_t)((i & 3) * 1024);
+    offB[i] = (uint32_t)(row * (int)g.ldb + c * 8) * 2u - (uint32_t)((i & 3) * 1024);
   }
   constexpr int P = 2 * INSTR;           // DMA pieces (1 KiB) per K-tile per wave: A pieces, then B pieces
   constexpr int Q = MT * NT;             // MFMAs per k-step per wave
@@ -74,13 +76,19 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_tn_kernel(Bf16GemmArgs
   // buffer-addressed DMA (see the NT pipe kernel): resource per operand, K-tile offset in the scalar offset
   // issued from inline asm (vitx_dma16, common.h): as builtins the compiler put `s_waitcnt vmcnt(0)` in front of EVERY k-step's transpose reads
   const i32x4 rsA = vitx_make_rsrc(Ag), rsB = vitx_make_rsrc(Bg);
-  const uint32_t lds_w = vitx_lds_addr(smem) + (uint32_t)wave * 1024u;
+  const uint32_t lds_w = vitx_lds_addr(smem) + (uint32_t)wave * (INSTR * 1024u);
   const uint32_t a_kstep = (uint32_t)(BK * g.lda * 2), b_kstep = (uint32_t)(BK * g.ldb * 2);   // bytes per K-tile (64 token rows)
   auto issue_piece = [&](int buf, int kt, auto p_c) {
     constexpr int p = decltype(p_c)::value;
     const uint32_t base = lds_w + (uint32_t)buf * STAGE;
-    if constexpr (p < INSTR) vitx_dma16(rsA, base + p * NW * 1024, offA[p], (uint32_t)kt * a_kstep);
-    else vitx_dma16(rsB, base + OP_BYTES + (p - INSTR) * NW * 1024, offB[p - INSTR], (uint32_t)kt * b_kstep);
+    if constexpr (p < INSTR) {
+      if constexpr ((p & 3) == 0) vitx_dma16(rsA, base + p * 1024, offA[p], (uint32_t)kt * a_kstep);
+      else vitx_dma16_cont<(p & 3) * 1024>(rsA, offA[p], (uint32_t)kt * a_kstep);
+    } else {
+      constexpr int q = p - INSTR;
+      if constexpr ((q & 3) == 0) vitx_dma16(rsB, base + OP_BYTES + q * 1024, offB[q], (uint32_t)kt * b_kstep);
+      else vitx_dma16_cont<(q & 3) * 1024>(rsB, offB[q], (uint32_t)kt * b_kstep);
+    }
   };
   auto stage = [&](int buf, int kt) { static_for<P>([&](auto p_c) { issue_piece(buf, kt, p_c); }); };
 
