@@ -21,7 +21,7 @@ if "--no-check" not in sys.argv:
               (50432, 768, 768), (50432, 3072, 768), (50432, 768, 3072), (50432, 2304, 768)]
     for (M, Nn, K) in shapes:
         for epi in epis:
-            N.check(N.lib().vitx_check_gemm(m._handle, 0, M, Nn, K, 12, epi, errs))
+            N.check(N.lib().vitx_check_gemm(m._handle, 0, M, Nn, K, int(os.environ.get("PP_CHECK_VARIANT", "12")), epi, errs))
             ok = errs[0] <= 1.1e-2 and (epi != 2 or errs[1] <= 1.5e-2)
             bad += not ok
             print(f"check M{M} N{Nn} K{K} epi {epi}: err {errs[0]:.3e} {errs[1]:.3e} {'ok' if ok else 'FAIL'}", flush=True)

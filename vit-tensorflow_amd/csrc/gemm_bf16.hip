@@ -309,7 +309,7 @@ void launch_mode(const Bf16GemmArgs& g, const EpiParams& ep, hipStream_t s) {
     if (launch_gemm_bf16_pp(g, ep, MODE, s)) return;
     k = 14;
   }
-  if (k == 9 || k == 10 || k == 11 || k == 13 || k == 14 || k == 15) { launch_gemm_bf16_pipe(k, MODE, g, ep, s); return; }   // gemm_bf16_pipe.hip
+  if (k == 4 || k == 8 || k == 9 || k == 10 || k == 11 || k == 13 || k == 14 || k == 15) { launch_gemm_bf16_pipe(k, MODE, g, ep, s); return; }   // gemm_bf16_pipe.hip
   if (direct) {
     if (k == 1) launch_variant<128, 128, 2, 2, MODE, false>(g, ep, s);
     else if (k == 3) launch_variant<256, 128, 4, 2, MODE, false>(g, ep, s);
@@ -343,7 +343,7 @@ int gemm_bf16_pick(int M, int N) {
 int gemm_bf16_tile_m(int kernel, int M, int N) {
   kernel &= 15;
   if (kernel == 0) kernel = gemm_bf16_pick(M, N);
-  return kernel == 1 ? 128 : ((kernel == 5 || kernel == 7 || kernel == 10 || kernel == 11 || kernel == 15) ? 320 : 256);
+  return kernel == 1 ? 128 : ((kernel == 4 || kernel == 5 || kernel == 7 || kernel == 10 || kernel == 11 || kernel == 15) ? 320 : 256);
 }
 int gemm_bf16_tile_n(int kernel, int M, int N) {
   kernel &= 15;
@@ -405,7 +405,7 @@ void launch_gemm_bf16(const Bf16GemmArgs& g0, const EpiParams& ep, int mode, hip
   if (best < 0) {
     // (variant 12, the wave-group ping-pong kernel, is not a candidate: its 256 x 128 tile streams need 1.5x the operand bytes per FLOP and it measured
     //  slower than the 256 x 256 kernels on every shape -- gemm_bf16_pp.hip, profiles/r3/pingpong_*; it stays callable and tested)
-    static const int cand[] = {6, 9, 13, 14, 2, 7, 10, 11, 15, 5, 3, 1};   // 256x256 variants first, then 320x256 (only when allowed), then small tiles
+    static const int cand[] = {6, 8, 9, 13, 14, 2, 7, 4, 10, 11, 15, 5, 3, 1};   // 256x256 variants first, then 320x256 (only when allowed), then small tiles
     // 256x128 / 128x128 tiles only compete when 256x256 tiles cannot give every CU two of them (token subsets: MAE's encoder
     // sees 49 of 196 patches, M = 12544 -> 147 tiles for a 768-wide output)
     const bool small_m = ceil_div(g0.M, 256) * ceil_div(g0.N, 256) < 512;
@@ -417,7 +417,7 @@ void launch_gemm_bf16(const Bf16GemmArgs& g0, const EpiParams& ep, int mode, hip
     float best_ms = 1e30f;
     best = gemm_bf16_pick(g0.M, g0.N);
     for (int c : cand) {
-      const bool is320 = c == 5 || c == 7 || c == 10 || c == 11 || c == 15;
+      const bool is320 = c == 4 || c == 5 || c == 7 || c == 10 || c == 11 || c == 15;
       if (is320 && !g_allow_320) continue;
       if ((c == 1 || c == 3) && !small_m) continue;
       if (g_shared_gpu && c != 2 && c != 5 && c != 1 && c != 3) continue;   // no persistent variants beside collectives (see gemm_bf16_set_shared_gpu)

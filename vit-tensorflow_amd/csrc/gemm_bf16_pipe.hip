@@ -79,6 +79,13 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_pipe_kernel(Bf16Gem
     decode_tile(i_logical, tiles_m, tiles_n, gm, tm, tn);
     a_soff = (uint32_t)(((int64_t)tm * BM * g.lda + (int64_t)kt0 * BK) * 2);
     b_soff = (uint32_t)(((int64_t)tn * BN * g.ldb + (int64_t)kt0 * BK) * 2);
+    if constexpr (PAT == 5) {
+      // The uniformity analysis loses the cursor behind the wave-row-dependent barriers of this schedule and would hand the asm a VGPR.  Made
+      // scalar HERE, once per tile: a v_readfirstlane right in front of the piece is a VALU write of an SGPR that the buffer_load inside the
+      // asm reads as its scalar offset -- a 5-wait-state hazard the compiler cannot see (the pieces fetched from stale offsets).
+      a_soff = (uint32_t)__builtin_amdgcn_readfirstlane((int)a_soff);
+      b_soff = (uint32_t)__builtin_amdgcn_readfirstlane((int)b_soff);
+    }
   };
   i_set_tile();
   constexpr int P = A_INSTR + B_INSTR;   // DMA pieces (1 KiB each) per K-tile per wave
@@ -92,13 +99,14 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_pipe_kernel(Bf16Gem
   const int xp = g.stagger;   // timing experiments only (results are wrong): 1 = no DMA wait, 2 = no DMA issue in the K loop, 4 = no fragment reads in the K loop
   auto issue_piece = [&](uint32_t base, auto p_c) {   // base = LDS byte offset of the target stage
     constexpr int p = decltype(p_c)::value;
+    const uint32_t sa = a_soff + i_k * (BK * 2), sb = b_soff + i_k * (BK * 2), lb = base;
     if constexpr (p < A_INSTR) {
-      if constexpr ((p & 3) == 0) vitx_dma16(rsA, lds_wa + base + p * 1024, offA[p], a_soff + i_k * (BK * 2));
-      else vitx_dma16_cont<(p & 3) * 1024>(rsA, offA[p], a_soff + i_k * (BK * 2));
+      if constexpr ((p & 3) == 0) vitx_dma16(rsA, lds_wa + lb + p * 1024, offA[p], sa);
+      else vitx_dma16_cont<(p & 3) * 1024>(rsA, offA[p], sa);
     } else {
       constexpr int q = p - A_INSTR;
-      if constexpr ((q & 3) == 0) vitx_dma16(rsB, lds_wb + base + q * 1024, offB[q], b_soff + i_k * (BK * 2));
-      else vitx_dma16_cont<(q & 3) * 1024>(rsB, offB[q], b_soff + i_k * (BK * 2));
+      if constexpr ((q & 3) == 0) vitx_dma16(rsB, lds_wb + lb + q * 1024, offB[q], sb);
+      else vitx_dma16_cont<(q & 3) * 1024>(rsB, offB[q], sb);
     }
   };
   auto i_advance = [&]() {
@@ -194,8 +202,56 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_pipe_kernel(Bf16Gem
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    // PAT 5, the anti-phase schedule: every k-step is a MEMORY section (the next k-step's fragment reads + this section's share of the DMA
+    // pieces) and an MFMA section (the Q MFMAs of the k-step, nothing else), each closed by a workgroup barrier; the waves of the second wave
+    // row (4..7, the SIMD partners of 0..3) run ONE barrier behind, so that on every SIMD one wave is in its MFMA section while the other is in
+    // its memory section -- the matrix pipe never waits behind a wave's own memory instructions.  K-tile hand-over: vmcnt(0) lgkmcnt(0) at the end
+    // of the memory section of k-step 2 (the reads of k-step 3 were the last of the old buffer); the partner group passes that point one barrier
+    // later / earlier, and both the first reads of the new K-tile and the refill of the old buffer sit one full section behind it for either group.
+    if constexpr (PAT == 5) {
+      if (wm == 1) __builtin_amdgcn_s_barrier();
+    }
     for (int kt = 0; kt < nk; ++kt) {
       const char* base = smem + (it & 1) * STAGE;
+      if constexpr (PAT == 5) {
+        static_for<BK / 16>([&](auto ks_c) {
+          constexpr int ks = decltype(ks_c)::value, CUR = ks & 1;
+          constexpr int NP = ks == 3 ? N3 : (ks == 0 ? N0 : (ks == 1 ? N1 : 0));
+          constexpr int FP = ks == 3 ? 0 : (ks == 0 ? N3 : N3 + N0);
+          // ---- memory section
+          if constexpr (ks + 1 < BK / 16) {
+            if (!(xp & 4)) load_frags(fa[CUR ^ 1], fb[CUR ^ 1], base, ks + 1);
+          } else {
+            if (kt + 1 < nk && !(xp & 4)) load_frags(fa[0], fb[0], smem + ((it + 1) & 1) * STAGE, 0);
+            pending = i_more && kt + 1 < nk && !(xp & 2);
+          }
+          if constexpr (NP > 0) {
+            const uint32_t ibase = (issued & 1) * STAGE;
+            static_for<NP>([&](auto d_c) { if (pending) issue_piece(ibase, ic<FP + decltype(d_c)::value>{}); });
+            if constexpr (FP + NP == P) {
+              if (pending) i_advance();
+              pending = false;
+            }
+          }
+          if constexpr (ks == 2) {
+            if (xp & 1) __builtin_amdgcn_s_waitcnt(0xC07F);
+            else __builtin_amdgcn_s_waitcnt(0x0070);      // my pieces of K-tile it+1 have landed, my reads of buffer it&1 are in registers
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          __builtin_amdgcn_s_barrier();
+          asm volatile("" ::: "memory");
+          // ---- MFMA section
+          __builtin_amdgcn_s_waitcnt(0xC07F);             // lgkmcnt(0): the fragments read one section ago
+          __builtin_amdgcn_s_setprio(1);
+          mfma_range(ic<CUR>{}, ic<0>{}, ic<Q>{});
+          __builtin_amdgcn_s_setprio(0);
+          __builtin_amdgcn_sched_barrier(0);
+          __builtin_amdgcn_s_barrier();
+          asm volatile("" ::: "memory");
+        });
+        ++it;
+        continue;
+      }
       if constexpr (PAT >= 3) {
         static_for<BK / 16>([&](auto ks_c) {
           constexpr int ks = decltype(ks_c)::value, CUR = ks & 1;
@@ -278,6 +334,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_pipe_kernel(Bf16Gem
       ++it;
     }
 
+    if constexpr (PAT == 5) {
+      if (wm == 0) __builtin_amdgcn_s_barrier();   // the first wave row waits for the second one's last MFMA section
+    }
     // ---- epilogue: 32 output rows per round through the buffer of the last K-tile (its refill is deferred until after the epilogue)
     stamp(1);
     {
@@ -466,6 +525,8 @@ void pipe_mode(int variant, const Bf16GemmArgs& g, const EpiParams& ep, hipStrea
     case 14: launch_pipe<256, 256, 2, 4, MODE, 2>(g, ep, s); break;   // pieces behind MFMAs 2..4 of three k-steps, all waves at once
     case 15: launch_pipe<320, 256, 2, 4, MODE, 2>(g, ep, s); break;
     case 10: launch_pipe<320, 256, 2, 4, MODE, 3>(g, ep, s); break;   // uniform schedule for the pieces, fragment reads as a block
+    case 8: launch_pipe<256, 256, 2, 4, MODE, 5>(g, ep, s); break;    // anti-phase schedule (memory / MFMA sections, wave rows one barrier apart)
+    case 4: launch_pipe<320, 256, 2, 4, MODE, 5>(g, ep, s); break;
     default: launch_pipe<256, 256, 2, 4, MODE, 3>(g, ep, s); break;   // 9
   }
 }
