@@ -104,7 +104,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=256, help="images per GPU")
     ap.add_argument("--workload", default="vit_b16_224", choices=sorted(WORKLOADS))
-    ap.add_argument("--compute", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--compute", default="bf16", choices=["bf16", "fp32", "bf16x3"])
     ap.add_argument("--cpu-seconds", type=float, default=25.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
@@ -224,7 +224,7 @@ def main():
         "metric": "images/sec (fwd+bwd) ViT-B/16 224px bf16" if args.workload == "vit_b16_224" else f"images/sec (fwd+bwd) {args.workload}",
         "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * el / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "bf16" if args.compute == "bf16" else "f32", "data": "synthetic",
+        "dtype": {"bf16": "bf16", "fp32": "f32", "bf16x3": "bf16x3 (fp32 storage, split-operand bf16 MFMA GEMMs)"}[args.compute], "data": "synthetic",
         "config": {"workload": f"{args.workload} fwd+bwd, batch {b}/GPU, N(0,1) NHWC images resident in HBM, random-init weights, "
                                f"softmax-CE cotangent, dropout 0", "global_batch": b * world,
                    "parallelism": f"dp{world}", "compute": args.compute, **({"launch": "hip_graph"} if (args.graph and not dp) else {}), **({"grad_wire": args.grad_wire} if dp else {})},
@@ -274,6 +274,9 @@ def main():
             # dominant kernel family = the bf16 MFMA GEMM (NT form for forward/dgrad, TN form for the weight gradients)
             fam = [stats[i] for i in range(ns.value) if stats[i].name.decode().startswith("gemm_bf16_mfma")]
             peak = MFMA_BF16_PEAK
+            if not fam and args.compute == "bf16x3":   # split-operand mode: three bf16 MFMA products per fp32 product (achieved = fp32-equivalent FLOPs)
+                fam = [stats[i] for i in range(ns.value) if stats[i].name.decode() == "gemm_bf16x3_mfma"]
+                peak = MFMA_BF16_PEAK / 3.0
             if not fam:   # fp32 parity mode: the exact-fp32 matrix-pipe kernel (+ the scalar kernel for small / strided problems)
                 fam = [stats[i] for i in range(ns.value) if stats[i].name.decode() in ("gemm_f32_mfma", "gemm_generic_fma")]
                 peak = 157.3e12

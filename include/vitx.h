@@ -38,8 +38,10 @@ extern "C" {
 enum { VITX_VARIANT_VIT = 0, VITX_VARIANT_DEEPVIT = 1, VITX_VARIANT_CAIT = 2, VITX_VARIANT_PATCH_MERGER = 3 };
 enum { VITX_POOL_CLS = 0, VITX_POOL_MEAN = 1 };
 /* FP32_PARITY: fp32 storage and fp32 FMA everywhere (gates "logits within 1e-3 of the reference").
- * BF16: bf16 GEMM/attention operands on MFMA, fp32 accumulation, statistics and residual stream. */
-enum { VITX_COMPUTE_FP32_PARITY = 0, VITX_COMPUTE_BF16 = 1 };
+ * BF16: bf16 GEMM/attention operands on MFMA, fp32 accumulation, statistics and residual stream.
+ * BF16X3: the FP32_PARITY data path (fp32 storage, statistics, softmax, GELU, gradients) with every large GEMM evaluated as three bf16 MFMA
+ *   products of operands split into bf16 hi + lo parts (~2^-16 per product): the 1e-3 gate at matrix-pipe speed. */
+enum { VITX_COMPUTE_FP32_PARITY = 0, VITX_COMPUTE_BF16 = 1, VITX_COMPUTE_BF16X3 = 2 };
 
 /* Mirrors the constructor kwargs 1:1:
  *   ViT(image_size, patch_size, num_classes, dim, depth, heads, mlp_dim, pool, dim_head, dropout,

@@ -96,6 +96,37 @@ def test_fp32_engine_matches_reference_source_at_baseline_widths(case):
     print(f"[ref:{case}] fp32 max|dlogit| {err:.3e}, worst grad digest err {worst[1]:.3e} ({worst[0]})")
 
 
+@pytest.mark.parametrize("case", [c for c in G.CASES if not c.startswith("efficient")])
+def test_bf16x3_engine_matches_reference_source(case):
+    """BF16X3 compute mode (fp32 data path, every large GEMM as three bf16 MFMA products of hi / lo split operands, gemm_bf16x3.hip):
+    the SAME gates as the exact fp32 mode -- logits within 1e-3 (north_star), every gradient within 1e-3 of its tensor's max."""
+    z, cfg, P = _case(case)
+    m = _model(case, "bf16x3", 2, P)
+    logits = m(z["img"], training=True)
+    err = float(np.abs(logits - z["logits"]).max())
+    assert err <= FP32_LOGIT_TOL, err
+    grads, dimg = m.backward(z["dlogits"], want_dimg=True)
+    worst = ("", 0.0)
+    for n, _, _ in spec.param_spec(cfg):
+        e = rel_max_err(grads[n], z["grad/" + n])
+        worst = max(worst, (n, e), key=lambda t: t[1])
+        assert e <= FP32_GRAD_RTOL, f"{case}: grad {n} rel err {e:.3e}"
+    assert rel_max_err(dimg, z["dimg"]) <= FP32_GRAD_RTOL
+    print(f"[ref:{case}] bf16x3 max|dlogit| {err:.3e}, worst grad rel err {worst[1]:.3e} ({worst[0]})")
+
+
+@pytest.mark.parametrize("case", list(G.WIDE_CASES))
+def test_bf16x3_engine_matches_reference_source_at_baseline_widths(case):
+    z, cfg, P = _case(case)
+    m = _model(case, "bf16x3", 2, P)
+    logits = m(z["img"], training=True)
+    err = float(np.abs(logits - z["logits"]).max())
+    assert err <= FP32_LOGIT_TOL, err
+    grads, dimg = m.backward(z["dlogits"], want_dimg=True)
+    worst = _check_digest(case, cfg, z, grads, dimg, FP32_GRAD_RTOL)
+    print(f"[ref:{case}] bf16x3 max|dlogit| {err:.3e}, worst grad digest err {worst[1]:.3e} ({worst[0]})")
+
+
 @pytest.mark.parametrize("case", list(G.WIDE_CASES))
 def test_bf16_engine_matches_reference_source_at_baseline_widths(case):
     """The benchmarked mode on the benchmarked kernels (attn_bwd at N=197, 320x256 / 256x256 tiles, split-K weight gradients;

@@ -222,8 +222,15 @@ void engine_refresh_weights(vitx_engine* e) {
   e->params_dirty = false;
 }
 
+// profiler class of an all-generic GEMM launch = the kernel launch_gemm_generic will pick
+static const char* f32_gemm_class(const GenericGemmArgs& g, int ta, int tb, int to) {
+  if (g.x3 && gemm_bf16x3_supported(g, ta, tb, to)) return "gemm_bf16x3_mfma";
+  return gemm_f32_mfma_supported(g, ta, tb, to) ? "gemm_f32_mfma" : "gemm_generic_fma";
+}
+
 // ------------------------------------------------------------------------------------------------
 // Dense layer = x @ kernel[in,out] + bias (Keras nn.Dense; vit.py:39,42,59,63,143,156) and its VJPs
+
 // ------------------------------------------------------------------------------------------------
 static void dense_fwd(vitx_engine* e, const void* X, int64_t ldx, int rows, const Dense& w, int mode, EpiParams ep) {
   ep.M = rows;
@@ -248,10 +255,10 @@ static void dense_fwd(vitx_engine* e, const void* X, int64_t ldx, int rows, cons
     GenericGemmArgs g;
     g.A = X; g.B = dense_w(e, w);
     g.M = rows; g.N = w.out; g.K = w.in;
-    g.sam = ldx; g.sak = 1; g.sbk = w.out; g.sbn = 1;
+    g.sam = ldx; g.sak = 1; g.sbk = w.out; g.sbn = 1; g.x3 = e->x3;
     ep.zero_pad = 1;
     finalize_epi(ep);
-    Prof pr(e, gemm_f32_mfma_supported(g, e->bf16, 0, e->bf16) ? "gemm_f32_mfma" : "gemm_generic_fma", flops, bytes);   // the class of the kernel that runs
+    Prof pr(e, f32_gemm_class(g, e->bf16, 0, e->bf16), flops, bytes);   // the class of the kernel that runs
     launch_gemm_generic(g, ep, mode, e->bf16, 0, e->bf16, e->stream);
   }
 }
@@ -280,10 +287,10 @@ static void dense_dgrad(vitx_engine* e, const void* dY, int64_t ldy, int rows, c
     GenericGemmArgs g;
     g.A = dY; g.B = dense_w(e, w);
     g.M = rows; g.N = w.in; g.K = w.out;
-    g.sam = ldy; g.sak = 1; g.sbk = 1; g.sbn = w.out;
+    g.sam = ldy; g.sak = 1; g.sbk = 1; g.sbn = w.out; g.x3 = e->x3;
     ep.zero_pad = 1;
     finalize_epi(ep);
-    Prof pr(e, gemm_f32_mfma_supported(g, e->bf16, 0, e->bf16) ? "gemm_f32_mfma" : "gemm_generic_fma", flops, bytes);   // the class of the kernel that runs
+    Prof pr(e, f32_gemm_class(g, e->bf16, 0, e->bf16), flops, bytes);   // the class of the kernel that runs
     launch_gemm_generic(g, ep, mode, e->bf16, 0, e->bf16, e->stream);
   }
 }
@@ -340,12 +347,33 @@ static void dense_wgrad(vitx_engine* e, const void* X, int64_t ldx, const void* 
     GenericGemmArgs g;
     g.A = X; g.B = dY;
     g.M = w.in; g.N = w.out; g.K = rows;
-    g.sam = 1; g.sak = ldx; g.sbk = ldy; g.sbn = 1;
+    g.sam = 1; g.sak = ldx; g.sbk = ldy; g.sbn = 1; g.x3 = e->x3;
     EpiParams ep;
     ep.out = dW; ep.ldo = w.out; ep.M = w.in; ep.N = w.out;
+    // BF16X3 mode: a weight gradient is a handful of 128 x 128 tiles over tens of thousands of token rows -- split the rows into slices (the batch
+    // index of the kernel) so that tiles x slices fills the chip twice over, fp32 partials + the reduction pass of the bf16 mode
+    int slices = 1;
+    if (e->x3 && e->partial_ws && gemm_bf16x3_supported(g, 0, 0, 0)) {
+      const int64_t tiles = ceil_div(w.in, 128) * ceil_div(w.out, 128);
+      int64_t want = std::min<int64_t>({std::max<int64_t>(1, 1024 / tiles), std::max<int64_t>(1, rows / 256), e->partial_elems / ((int64_t)w.in * w.out)});
+      if (want > 1) {
+        const int ks = (int)round_up(ceil_div(rows, want), 32);
+        slices = (int)ceil_div(rows, ks);
+        if (slices > 1) {
+          g.K = ks; g.nb = slices; g.sAb = (int64_t)ks * ldx; g.sBb = (int64_t)ks * ldy; g.k_last = rows - (slices - 1) * ks;
+          ep.out = e->partial_ws; ep.out_batch_stride = (int64_t)w.in * w.out;
+        }
+      }
+    }
     finalize_epi(ep);
-    Prof pr(e, gemm_f32_mfma_supported(g, e->bf16, e->bf16, 0) ? "gemm_f32_mfma" : "gemm_generic_fma", flops, bytes);   // the class of the kernel that runs
-    launch_gemm_generic(g, ep, EPI_STORE_F32, e->bf16, e->bf16, 0, e->stream);
+    {
+      Prof pr(e, f32_gemm_class(g, e->bf16, e->bf16, 0), flops, bytes);   // the class of the kernel that runs
+      launch_gemm_generic(g, ep, EPI_STORE_F32, e->bf16, e->bf16, 0, e->stream);
+    }
+    if (slices > 1) {
+      Prof pr(e, "reduce_partials", 0, (double)(slices + 1) * w.in * w.out * 4);
+      launch_reduce_partials(e->partial_ws, slices, (int64_t)w.in * w.out, (int64_t)w.in * w.out, dW, 1.0f, e->stream);
+    }
   }
 }
 
@@ -444,6 +472,7 @@ static void bgemm(vitx_engine* e, const void* A, int ta, int64_t sam, int64_t sa
   g.A = A; g.B = B; g.M = M; g.N = N; g.K = K;
   g.sam = sam; g.sak = sak; g.sbk = sbk; g.sbn = sbn;
   g.nb = nb; g.nh = nh; g.sAb = sAb; g.sAh = sAh; g.sBb = sBb; g.sBh = sBh;
+  g.x3 = e->x3 && e->x3_attn;
   EpiParams ep;
   ep.out = out; ep.ldo = ldo; ep.out_batch_stride = ob; ep.out_head_stride = oh; ep.alpha = alpha;
   ep.M = M; ep.N = N;
@@ -887,7 +916,11 @@ static int engine_create_body(vitx_engine* e, const vitx_config& cfg, std::strin
   if (!perr.empty()) { err = perr; return VITX_ERR_INVALID; }
   e->n_params = e->table.back().offset + e->table.back().count;
   e->n_arena = e->table.back().aoff + round_up(e->table.back().count, 4);
+  if (c.compute != VITX_COMPUTE_FP32_PARITY && c.compute != VITX_COMPUTE_BF16 && c.compute != VITX_COMPUTE_BF16X3) { err = "unknown compute mode"; return VITX_ERR_INVALID; }
   e->bf16 = c.compute == VITX_COMPUTE_BF16;
+  e->x3 = c.compute == VITX_COMPUTE_BF16X3;
+  e->x3_attn = true;   // the materialised attention products too (8.3 vs 9.2 ms per ViT-B/16 step at batch 64); VITX_X3_ATTN=0 keeps them exact
+  if (const char* k = getenv("VITX_X3_ATTN")) e->x3_attn = atoi(k) != 0;
   e->esz = e->bf16 ? 2 : 4;
   e->inner = c.heads * c.dim_head;
   e->np_max = (c.image_h / c.patch_h) * (c.image_w / c.patch_w);
@@ -1136,6 +1169,10 @@ static int engine_create_body(vitx_engine* e, const vitx_config& cfg, std::strin
   DALLOC(e->zero_page, 256, false);
   DALLOC(e->tmp_f32, (size_t)rmax * std::max<int64_t>(d, e->pd) * 4, false);
   const int64_t maxfeat = std::max<int64_t>({(int64_t)d, 3LL * inner, (int64_t)m, (int64_t)e->pd_k, (int64_t)e->nc_k});
+  if (e->x3) {   // split-K partials of the weight gradients (dense_wgrad)
+    e->partial_elems = 64LL * 1024 * 1024;
+    DALLOC(e->partial_ws, (size_t)e->partial_elems * 4, false);
+  }
   if (e->bf16) {
     e->t_rows = round_up(maxfeat, 256);
     if (e->wgrad_via_transpose) {

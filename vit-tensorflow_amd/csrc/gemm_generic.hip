@@ -84,6 +84,7 @@ void launch_mode(const GenericGemmArgs& g, const EpiParams& ep, int mode, int m_
 // ta/tb/to: 0 = fp32, 1 = bf16.  Rows up to round_up(M, 64) are visited when ep.zero_pad is set
 // (the caller guarantees the output buffers are row-padded to a multiple of 256).
 void launch_gemm_generic(const GenericGemmArgs& g, const EpiParams& ep, int mode, int ta, int tb, int to, hipStream_t s) {
+  if (g.x3 && gemm_bf16x3_supported(g, ta, tb, to)) { launch_gemm_bf16x3(g, ep, mode, s); return; }   // BF16X3 mode: split operands, bf16 matrix pipe
   if (gemm_f32_mfma_supported(g, ta, tb, to)) { launch_gemm_f32_mfma(g, ep, mode, s); return; }   // fp32 matrix pipe, same bits
   const int rows = g.M;
   if (ta == 0 && tb == 0 && to == 0) launch_mode<float, float, float>(g, ep, mode, rows, s);

@@ -11,6 +11,8 @@ struct GenericGemmArgs {
   int64_t sam = 0, sak = 1, sbk = 0, sbn = 1;
   int nb = 1, nh = 1;
   int64_t sAb = 0, sAh = 0, sBb = 0, sBh = 0;
+  int k_last = 0;   // > 0: K extent of the LAST batch slice (split-K over the batch index: slices of K rows, the last one shorter); gemm_bf16x3.hip only
+  int x3 = 0;   // BF16X3 compute mode: all-fp32 problems run as three bf16 MFMA products of hi / lo split operands (gemm_bf16x3.hip)
 };
 void launch_gemm_generic(const GenericGemmArgs& g, const EpiParams& ep, int mode, int ta, int tb, int to, hipStream_t s);
 // ---------------------------------------------------------------- gemm_f32_mfma.hip
@@ -19,6 +21,11 @@ void launch_gemm_generic(const GenericGemmArgs& g, const EpiParams& ep, int mode
 bool gemm_f32_mfma_supported(const GenericGemmArgs& g, int ta, int tb, int to);
 void launch_gemm_f32_mfma(const GenericGemmArgs& g, const EpiParams& ep, int mode, hipStream_t s);
 void gemm_f32_mfma_read_env();   // VITX_F32_MFMA, read once per engine handle (not per launch)
+// ---------------------------------------------------------------- gemm_bf16x3.hip
+// the same contract with every fp32 operand split into bf16 hi + lo and three bf16 MFMA products per k-step (~2^-16 per product);
+// launch_gemm_generic routes to it when GenericGemmArgs::x3 is set
+bool gemm_bf16x3_supported(const GenericGemmArgs& g, int ta, int tb, int to);
+void launch_gemm_bf16x3(const GenericGemmArgs& g, const EpiParams& ep, int mode, hipStream_t s);
 
 // ---------------------------------------------------------------- attn_headchain.hip
 // fused head-axis chains (one wave per (image, query) row): CaiT talking heads, DeepViT re-attention, and their VJPs

@@ -175,8 +175,8 @@ class VitxModel:
         cfg.pool = N.POOL_MEAN if pool == 'mean' else N.POOL_CLS
         cfg.dropout, cfg.emb_dropout, cfg.layer_dropout = float(dropout), float(emb_dropout), float(layer_dropout)
         cfg.ln_eps = 1e-3  # Keras LayerNormalization default
-        assert compute in ("fp32", "bf16"), "compute must be 'fp32' (parity) or 'bf16' (throughput)"
-        cfg.compute = N.COMPUTE_BF16 if compute == "bf16" else N.COMPUTE_FP32
+        assert compute in ("fp32", "bf16", "bf16x3"), "compute must be 'fp32' (parity), 'bf16' (throughput) or 'bf16x3' (fp32 data path, split-operand bf16 GEMMs)"
+        cfg.compute = {"fp32": N.COMPUTE_FP32, "bf16": N.COMPUTE_BF16, "bf16x3": N.COMPUTE_BF16X3}[compute]
         cfg.num_parallel_branches = int(num_parallel_branches)
         cfg.patch_merge_layer = int(patch_merge_layer or 0)
         cfg.patch_merge_num_tokens = int(patch_merge_num_tokens)

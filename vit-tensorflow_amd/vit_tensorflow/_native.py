@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("VITX_LIB", os.path.join(_HERE, "..", "lib", "libvitx.
 
 VARIANT_VIT, VARIANT_DEEPVIT, VARIANT_CAIT, VARIANT_PATCH_MERGER = 0, 1, 2, 3
 POOL_CLS, POOL_MEAN = 0, 1
-COMPUTE_FP32, COMPUTE_BF16 = 0, 1
+COMPUTE_FP32, COMPUTE_BF16, COMPUTE_BF16X3 = 0, 1, 2
 OK, ERR_INVALID, ERR_HIP, ERR_UNSUPPORTED, ERR_STATE, ERR_COMM = 0, -1, -2, -3, -4, -5
 
 
