@@ -82,11 +82,15 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GenericGemmArgs g, 
   // zero word with step 0, and a load whose k lies beyond K (the last, partial K-tile; every load of the tiles behind the last one) is redirected
   // to the zero word by a select: the K loop has no predicated loads and no branches.  (Measured alternatives, both slower on MI355X: a uniform tile
   // pointer + 32-bit lane offsets with a separate edge path, 202 vs 237 TFLOP/s; buffer loads with hardware range checking.)
-  const char* pa[4];
-  const char* pb[4];
+  // (pointers in the GLOBAL address space: as generic pointers the loads became flat_load, which also counts on lgkmcnt -- every wait for a
+  //  fragment read then waited for the staging loads as well)
+  typedef const __attribute__((address_space(1))) char* gptr;
+  typedef const __attribute__((address_space(1))) f32x4* gptr4;
+  gptr pa[4];
+  gptr pb[4];
   int sta[4], stb[4], kka[4], kkb[4];
-  const char* const zero16 = (const char*)&x3_zero16;
-  auto lane_ptrs = [&](auto lay_c, const float* P, int64_t s_idx, int64_t s_k, int idx0, int lim, const char* (&ptr)[4], int (&st)[4], int (&kks)[4]) {
+  const gptr zero16 = (gptr)(const char*)&x3_zero16;
+  auto lane_ptrs = [&](auto lay_c, const float* P, int64_t s_idx, int64_t s_k, int idx0, int lim, gptr (&ptr)[4], int (&st)[4], int (&kks)[4]) {
     constexpr int LAY = decltype(lay_c)::value;
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
@@ -94,18 +98,18 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GenericGemmArgs g, 
       X3Operand<LAY>::coords(t, p, row, kk);
       const bool ok = idx0 + row < lim;
       const float* q = LAY == 1 ? P + (int64_t)(idx0 + row) * s_idx + kk : P + (int64_t)kk * s_k + (idx0 + row);
-      ptr[p] = ok ? (const char*)q : zero16;
+      ptr[p] = ok ? (gptr)(const char*)q : zero16;
       st[p] = ok ? (int)((LAY == 1 ? (int64_t)XK : (int64_t)XK * s_k) * 4) : 0;
       kks[p] = kk;
     }
   };
   lane_ptrs(std::integral_constant<int, LA>{}, A, g.sam, g.sak, m0, g.M, pa, sta, kka);
   lane_ptrs(std::integral_constant<int, LB>{}, B, g.sbn, g.sbk, n0, g.N, pb, stb, kkb);
-  float4 ra[4], rb[4];
-  auto load_tile = [&](int k0, const char* (&ptr)[4], const int (&st)[4], const int (&kks)[4], float4 (&r)[4]) {   // K-tile at k0; advances the pointers
+  f32x4 ra[4], rb[4];
+  auto load_tile = [&](int k0, gptr (&ptr)[4], const int (&st)[4], const int (&kks)[4], f32x4 (&r)[4]) {   // K-tile at k0; advances the pointers
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-      r[p] = *(const float4*)(k0 + kks[p] < Kz ? ptr[p] : zero16);
+      r[p] = *(gptr4)(k0 + kks[p] < Kz ? ptr[p] : zero16);
       ptr[p] += st[p];
     }
   };
@@ -117,16 +121,22 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GenericGemmArgs g, 
     X3Operand<LB>::coords(t, 0, row, kk);
     sb_off = X3Operand<LB>::lds_off(row, kk);
   }
-  auto store_tile = [&](char* hi, char* lo, int off0, const float4 (&r)[4]) {
+  auto store_tile = [&](char* hi, char* lo, int off0, const f32x4 (&r)[4]) {
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-      const float x[4] = {r[p].x, r[p].y, r[p].z, r[p].w};
+      // per PAIR of elements: one packed convert (hi), two bit operations (hi back to fp32), one packed subtract, one packed convert (lo)
+      typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+      typedef float f32x2 __attribute__((ext_vector_type(2)));
       bf16x4 h, l;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const bf16_t a = (bf16_t)x[e];
-        h[e] = a;
-        l[e] = (bf16_t)(x[e] - (float)a);
+      for (int e = 0; e < 4; e += 2) {
+        const f32x2 x = {r[p][e], r[p][e + 1]};
+        const bf16x2 hp = __builtin_convertvector(x, bf16x2);
+        const uint32_t hb = __builtin_bit_cast(uint32_t, hp);
+        const f32x2 hf = {__builtin_bit_cast(float, hb << 16), __builtin_bit_cast(float, hb & 0xffff0000u)};
+        const bf16x2 lp = __builtin_convertvector(x - hf, bf16x2);
+        h[e] = hp[0]; h[e + 1] = hp[1];
+        l[e] = lp[0]; l[e + 1] = lp[1];
       }
       *(bf16x4*)(hi + off0 + p * 2048) = h;
       *(bf16x4*)(lo + off0 + p * 2048) = l;
@@ -180,27 +190,43 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GenericGemmArgs g, 
         }
     }
   };
-  // Two register sets: the loads of K-tile t+2 are issued when tile t has been written to LDS, i.e. they have two multiply phases to arrive (with one
-  // set -- 32 KiB in flight per workgroup -- the loop ran at the memory latency: 8.6 B/clk/CU).  Tiles alternate between the sets and the LDS buffers.
-  float4 ra1[4], rb1[4];
+  // Software pipeline over K-tiles, two register sets and two LDS buffers:  iteration t multiplies tile t out of buffer t & 1 while it converts and
+  // writes tile t+1 (loaded two iterations ago) into the other buffer -- free since the barrier at the top of the iteration -- and then issues the loads
+  // of tile t+3 into the register set just emptied.  Split and multiply are in ONE basic block and the scheduler is asked to alternate them (one MFMA,
+  // a few VALU instructions): a wave issues in order, so a block of conversions in front of a block of MFMAs leaves the matrix pipe idle for the
+  // first and the vector ALU idle for the second (that form: 230 TFLOP/s, MFMA pipe ~33 % busy with two workgroups per CU taking turns).
+  f32x4 ra1[4], rb1[4];
   load_tile(0, pa, sta, kka, ra);
   load_tile(0, pb, stb, kkb, rb);
   load_tile(XK, pa, sta, kka, ra1);
   load_tile(XK, pb, stb, kkb, rb1);
+  store_tile(smem[0][0], smem[0][1], sa_off, ra);
+  store_tile(smem[0][2], smem[0][3], sb_off, rb);
+  load_tile(2 * XK, pa, sta, kka, ra);
+  load_tile(2 * XK, pb, stb, kkb, rb);
+  auto interleave = [&]() {
+#pragma unroll
+    for (int i = 0; i < 24; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
+      __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);   // then up to five VALU instructions
+    }
+  };
   for (int kt = 0; kt < nkt; kt += 2) {
-    store_tile(smem[0][0], smem[0][1], sa_off, ra);
-    store_tile(smem[0][2], smem[0][3], sb_off, rb);
-    __syncthreads();           // tile kt visible; every wave finished reading buffer 0 (tile kt-2) one barrier ago
-    load_tile((kt + 2) * XK, pa, sta, kka, ra);     // behind the last K-tile every load reads the zero word
-    load_tile((kt + 2) * XK, pb, stb, kkb, rb);
+    __syncthreads();           // tile kt visible in buffer 0; every wave finished reading buffer 1 (tile kt-1)
     compute(0);
+    store_tile(smem[1][0], smem[1][1], sa_off, ra1);            // tile kt+1 (zeros behind the last K-tile)
+    store_tile(smem[1][2], smem[1][3], sb_off, rb1);
+    interleave();
+    load_tile((kt + 3) * XK, pa, sta, kka, ra1);
+    load_tile((kt + 3) * XK, pb, stb, kkb, rb1);
     if (kt + 1 < nkt) {
-      store_tile(smem[1][0], smem[1][1], sa_off, ra1);
-      store_tile(smem[1][2], smem[1][3], sb_off, rb1);
       __syncthreads();
-      load_tile((kt + 3) * XK, pa, sta, kka, ra1);
-      load_tile((kt + 3) * XK, pb, stb, kkb, rb1);
       compute(1);
+      store_tile(smem[0][0], smem[0][1], sa_off, ra);           // tile kt+2
+      store_tile(smem[0][2], smem[0][3], sb_off, rb);
+      interleave();
+      load_tile((kt + 4) * XK, pa, sta, kka, ra);
+      load_tile((kt + 4) * XK, pb, stb, kkb, rb);
     }
   }
 
