@@ -106,10 +106,11 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GenericGemmArgs g, 
   lane_ptrs(std::integral_constant<int, LA>{}, A, g.sam, g.sak, m0, g.M, pa, sta, kka);
   lane_ptrs(std::integral_constant<int, LB>{}, B, g.sbn, g.sbk, n0, g.N, pb, stb, kkb);
   f32x4 ra[4], rb[4];
-  auto load_tile = [&](int k0, gptr (&ptr)[4], const int (&st)[4], const int (&kks)[4], f32x4 (&r)[4]) {   // K-tile at k0; advances the pointers
+  auto load_tile = [&](auto check_c, int k0, gptr (&ptr)[4], const int (&st)[4], const int (&kks)[4], f32x4 (&r)[4]) {   // K-tile at k0; advances the pointers
+    constexpr bool CHECK = decltype(check_c)::value;   // false: the caller knows that the whole K-tile lies inside K
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-      r[p] = *(gptr4)(k0 + kks[p] < Kz ? ptr[p] : zero16);
+      r[p] = *(gptr4)((!CHECK || k0 + kks[p] < Kz) ? ptr[p] : zero16);
       ptr[p] += st[p];
     }
   };
@@ -196,14 +197,16 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GenericGemmArgs g, 
   // a few VALU instructions): a wave issues in order, so a block of conversions in front of a block of MFMAs leaves the matrix pipe idle for the
   // first and the vector ALU idle for the second (that form: 230 TFLOP/s, MFMA pipe ~33 % busy with two workgroups per CU taking turns).
   f32x4 ra1[4], rb1[4];
-  load_tile(0, pa, sta, kka, ra);
-  load_tile(0, pb, stb, kkb, rb);
-  load_tile(XK, pa, sta, kka, ra1);
-  load_tile(XK, pb, stb, kkb, rb1);
+  using chk = std::true_type;
+  using nochk = std::false_type;
+  load_tile(chk{}, 0, pa, sta, kka, ra);
+  load_tile(chk{}, 0, pb, stb, kkb, rb);
+  load_tile(chk{}, XK, pa, sta, kka, ra1);
+  load_tile(chk{}, XK, pb, stb, kkb, rb1);
   store_tile(smem[0][0], smem[0][1], sa_off, ra);
   store_tile(smem[0][2], smem[0][3], sb_off, rb);
-  load_tile(2 * XK, pa, sta, kka, ra);
-  load_tile(2 * XK, pb, stb, kkb, rb);
+  load_tile(chk{}, 2 * XK, pa, sta, kka, ra);
+  load_tile(chk{}, 2 * XK, pb, stb, kkb, rb);
   auto interleave = [&]() {
 #pragma unroll
     for (int i = 0; i < 24; ++i) {
@@ -211,26 +214,57 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GenericGemmArgs g, 
       __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);   // then up to five VALU instructions
     }
   };
-  for (int kt = 0; kt < nkt; kt += 2) {
+  // one pair of K-tiles (kt from buffer 0 / set 1 -> buffer 1, kt + 1 from buffer 1 / set 0 -> buffer 0); CHECK = the prefetched tiles kt+3, kt+4 may
+  // reach beyond K (the main loop runs without the per-load select, the last two pairs with it)
+  auto pair = [&](auto check_c, int kt) {
     __syncthreads();           // tile kt visible in buffer 0; every wave finished reading buffer 1 (tile kt-1)
     compute(0);
     store_tile(smem[1][0], smem[1][1], sa_off, ra1);            // tile kt+1 (zeros behind the last K-tile)
     store_tile(smem[1][2], smem[1][3], sb_off, rb1);
     interleave();
-    load_tile((kt + 3) * XK, pa, sta, kka, ra1);
-    load_tile((kt + 3) * XK, pb, stb, kkb, rb1);
+    load_tile(check_c, (kt + 3) * XK, pa, sta, kka, ra1);
+    load_tile(check_c, (kt + 3) * XK, pb, stb, kkb, rb1);
     if (kt + 1 < nkt) {
       __syncthreads();
       compute(1);
       store_tile(smem[0][0], smem[0][1], sa_off, ra);           // tile kt+2
       store_tile(smem[0][2], smem[0][3], sb_off, rb);
       interleave();
-      load_tile((kt + 4) * XK, pa, sta, kka, ra);
-      load_tile((kt + 4) * XK, pb, stb, kkb, rb);
+      load_tile(check_c, (kt + 4) * XK, pa, sta, kka, ra);
+      load_tile(check_c, (kt + 4) * XK, pb, stb, kkb, rb);
     }
-  }
+  };
+  int kt = 0;
+  for (; (kt + 5) * XK <= Kz; kt += 2) pair(nochk{}, kt);   // tiles kt+3 and kt+4 lie fully inside K
+  for (; kt < nkt; kt += 2) pair(chk{}, kt);
 
   // lane: output row m = lane & 31 of each 32 x 32 block, columns 8q + 4 (lane >> 5) + {0..3}
+  if (epilogue_fast_ok(ep, MODE) && m0 + XM <= ep.M && n0 + XN <= ep.N) {   // interior tile: the branch-free form of the bf16 kernels' epilogues
+    auto run = [&](auto hb_c, auto hs_c) {
+      constexpr bool HB = decltype(hb_c)::value, HS = decltype(hs_c)::value;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int c = n0 + wn * 64 + j * 32 + 8 * q + 4 * kh;
+          const float4 b4 = HB ? *(const float4*)(ep.bias + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+          const float4 s4 = HS ? *(const float4*)(ep.scale + c) : make_float4(1.f, 1.f, 1.f, 1.f);
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            const int row = m0 + wm * 64 + i * 32 + col;
+            const float4 x = epilogue_fast_load<MODE, float>(ep, row, c);
+            epilogue_fast4<MODE, float, HB, HS>(ep, row, c, make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]),
+                                                b4, s4, x, out_off);
+          }
+        }
+    };
+    const bool has_bias = ep.bias != nullptr, has_scale = ep.scale != nullptr;
+    if (has_bias && has_scale) run(std::true_type{}, std::true_type{});
+    else if (has_bias) run(std::true_type{}, std::false_type{});
+    else if (has_scale) run(std::false_type{}, std::true_type{});
+    else run(std::false_type{}, std::false_type{});
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int row = m0 + wm * 64 + i * 32 + col;
