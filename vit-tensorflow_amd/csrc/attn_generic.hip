@@ -531,13 +531,22 @@ __global__ void add_T_kernel(T* __restrict__ a, const T* __restrict__ b2, int64_
 template <typename T>
 __global__ __launch_bounds__(256) void scale_grad_kernel(const T* __restrict__ fx, int64_t ldf_, const float* __restrict__ g, int64_t ldg,
                                                          int rows, int d, float* __restrict__ partial, const float* __restrict__ scale,
-                                                         T* __restrict__ out, int64_t ldo) {
+                                                         T* __restrict__ out, int64_t ldo, int want_colsum) {
+  // want_colsum (with out): the partial rows are [chunk][2 d] -- the second half holds the column sums of what was STORED in out (g * scale as T),
+  // i.e. the bias gradient of the Dense layer in front of the LayerScale (cait.py:47-48 after fc2 / to_out): no separate pass over out
   __shared__ float red[4][256];
+  __shared__ float redb[4][256];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int c = blockIdx.x * 256 + lane * 4;
   const int rows_per = (rows + gridDim.y - 1) / gridDim.y;
   const int r0 = blockIdx.y * rows_per, r1 = min(rows, r0 + rows_per);
-  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f), bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto put = [&](int r, float4 v) {   // store g * scale as T and add what T holds to the column sums
+    st4<T>(out + (int64_t)r * ldo + c, v);
+    if (want_colsum) {
+      bsum.x += (float)(T)v.x; bsum.y += (float)(T)v.y; bsum.z += (float)(T)v.z; bsum.w += (float)(T)v.w;
+    }
+  };
   // out != null (host: only when d % 4 == 0): the same pass also writes the gradient entering the branch, out = g * scale
   // (cait.py:47-48 VJP), instead of a second kernel reading g again
   if (c + 3 < d) {
@@ -549,15 +558,15 @@ __global__ __launch_bounds__(256) void scale_grad_kernel(const T* __restrict__ f
       const float4 f0 = ld4<T>(fx + (int64_t)r * ldf_ + c), f1 = ld4<T>(fx + (int64_t)(r + 4) * ldf_ + c);
       a.x += g0.x * f0.x + g1.x * f1.x; a.y += g0.y * f0.y + g1.y * f1.y; a.z += g0.z * f0.z + g1.z * f1.z; a.w += g0.w * f0.w + g1.w * f1.w;
       if (out) {
-        st4<T>(out + (int64_t)r * ldo + c, make_float4(g0.x * sc.x, g0.y * sc.y, g0.z * sc.z, g0.w * sc.w));
-        st4<T>(out + (int64_t)(r + 4) * ldo + c, make_float4(g1.x * sc.x, g1.y * sc.y, g1.z * sc.z, g1.w * sc.w));
+        put(r, make_float4(g0.x * sc.x, g0.y * sc.y, g0.z * sc.z, g0.w * sc.w));
+        put(r + 4, make_float4(g1.x * sc.x, g1.y * sc.y, g1.z * sc.z, g1.w * sc.w));
       }
     }
     for (; r < r1; r += 4) {
       const float4 g0 = *(const float4*)(g + (int64_t)r * ldg + c);
       const float4 f0 = ld4<T>(fx + (int64_t)r * ldf_ + c);
       a.x += g0.x * f0.x; a.y += g0.y * f0.y; a.z += g0.z * f0.z; a.w += g0.w * f0.w;
-      if (out) st4<T>(out + (int64_t)r * ldo + c, make_float4(g0.x * sc.x, g0.y * sc.y, g0.z * sc.z, g0.w * sc.w));
+      if (out) put(r, make_float4(g0.x * sc.x, g0.y * sc.y, g0.z * sc.z, g0.w * sc.w));
     }
   } else if (c < d) {
     float* ap = (float*)&a;
@@ -565,9 +574,14 @@ __global__ __launch_bounds__(256) void scale_grad_kernel(const T* __restrict__ f
       for (int i = 0; i < 4 && c + i < d; ++i) ap[i] += g[(int64_t)r * ldg + c + i] * ldf<T>(fx + (int64_t)r * ldf_ + c + i);
   }
   *(float4*)&red[w][lane * 4] = a;
+  if (want_colsum) *(float4*)&redb[w][lane * 4] = bsum;
   __syncthreads();
   const int cc = blockIdx.x * 256 + threadIdx.x;
-  if (cc < d) partial[(int64_t)blockIdx.y * d + cc] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+  const int64_t prow = want_colsum ? 2 * (int64_t)d : (int64_t)d;
+  if (cc < d) {
+    partial[(int64_t)blockIdx.y * prow + cc] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    if (want_colsum) partial[(int64_t)blockIdx.y * prow + d + cc] = (redb[0][threadIdx.x] + redb[1][threadIdx.x]) + (redb[2][threadIdx.x] + redb[3][threadIdx.x]);
+  }
 }
 template <typename TO>
 __global__ void mul_scale_kernel(const float* __restrict__ g, int64_t ldg, const float* __restrict__ scale, TO* __restrict__ out,
@@ -696,13 +710,16 @@ void launch_add_T(void* a, const void* b2, int is_bf16, int64_t n, hipStream_t s
   else hipLaunchKernelGGL(add_T_kernel<float>, dim3(grid_for(n)), dim3(256), 0, s, (float*)a, (const float*)b2, n);
 }
 void launch_scale_grad(const void* fx, int is_bf16, int64_t ldf_, const float* g, int64_t ldg, int rows, int d, float* partial_ws,
-                       float* dscale, hipStream_t s, const float* scale, void* out, int64_t ldo) {
+                       float* dscale, hipStream_t s, const float* scale, void* out, int64_t ldo, float* dbias) {
+  static const int blocks = [] { const char* v = getenv("VITX_SG_BLOCKS"); return v ? atoi(v) : 2048; }();   // (experiment: blocks per launch)
   const int cblocks = (int)ceil_div(d, 256);
-  const int chunks = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)SG_CHUNKS, ceil_div(rows, 16), ceil_div(2048, cblocks)}));
+  const int chunks = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)SG_CHUNKS, ceil_div(rows, 16), ceil_div(blocks, cblocks)}));
+  const int want = (dbias != nullptr && out != nullptr) ? 1 : 0;   // partial_ws holds SG_CHUNKS x 2 d sums + 64 d of second-level scratch
   dim3 grid((unsigned)cblocks, chunks), block(256);
-  if (is_bf16) hipLaunchKernelGGL(scale_grad_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)fx, ldf_, g, ldg, rows, d, partial_ws, scale, (bf16_t*)out, ldo);
-  else hipLaunchKernelGGL(scale_grad_kernel<float>, grid, block, 0, s, (const float*)fx, ldf_, g, ldg, rows, d, partial_ws, scale, (float*)out, ldo);
-  launch_reduce_partials3(partial_ws, chunks, d, d, 1, dscale, nullptr, nullptr, partial_ws + (int64_t)SG_CHUNKS * d, 1.0f, s);
+  if (is_bf16) hipLaunchKernelGGL(scale_grad_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)fx, ldf_, g, ldg, rows, d, partial_ws, scale, (bf16_t*)out, ldo, want);
+  else hipLaunchKernelGGL(scale_grad_kernel<float>, grid, block, 0, s, (const float*)fx, ldf_, g, ldg, rows, d, partial_ws, scale, (float*)out, ldo, want);
+  if (want) launch_reduce_partials3(partial_ws, chunks, 2 * (int64_t)d, d, 2, dscale, dbias, nullptr, partial_ws + (int64_t)SG_CHUNKS * 2 * d, 1.0f, s);
+  else launch_reduce_partials3(partial_ws, chunks, d, d, 1, dscale, nullptr, nullptr, partial_ws + (int64_t)SG_CHUNKS * d, 1.0f, s);
 }
 void launch_mul_scale(const float* g, int64_t ldg, const float* scale, void* out, int out_bf16, int64_t ldo, int rows, int d, hipStream_t s) {
   const int64_t total = (int64_t)rows * d;

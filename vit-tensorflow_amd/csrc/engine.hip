@@ -754,15 +754,17 @@ static int block_backward(vitx_engine* e, Stage& st, int si, int l, int b, int n
   void* ln_glp = (T && (!grouped || ba.par_last)) ? e->g_lp : nullptr;
 
   const void* dbranch = gT;
+  bool fc2_bias_done = false, out_bias_done = false;   // bias gradient already produced by the LayerScale VJP pass
   if (!ba.skip_mlp) {
   // ---- MLP branch: x_out = x_mid + scale * fc2(gelu(fc1(LN(x_mid))))
   if (bp.m_scale >= 0 || drop > 0.f) {   // LayerScale VJP (cait.py:47-48): dscale = sum g*f(x), d f = g*scale; Dropout VJP: same mask
     Prof pr(e, "branch_grad", 0, 0);
     // LayerScale without dropout: one pass over g gives dscale AND the branch gradient g * scale
     const bool one_pass = bp.m_scale >= 0 && drop == 0.f && d % 4 == 0;
+    fc2_bias_done = one_pass && dense_gb(e, bp.fc2) != nullptr;   // ... and the fc2 bias gradient = column sums of that branch gradient
     if (bp.m_scale >= 0)
       launch_scale_grad(ba.fm, T, d, e->g, d, rows, d, e->red_ws, e->grads + bp.m_scale, e->stream, one_pass ? e->params + bp.m_scale : nullptr,
-                        one_pass ? e->d_br : nullptr, d);
+                        one_pass ? e->d_br : nullptr, d, fc2_bias_done ? dense_gb(e, bp.fc2) : nullptr);
     if (!one_pass) launch_branch_grad(e->g, bp.m_scale >= 0 ? e->params + bp.m_scale : nullptr, e->d_br, T, rows, d, drop, seed, site0 + 3, e->stream);
     dbranch = e->d_br;
   }
@@ -792,7 +794,7 @@ static int block_backward(vitx_engine* e, Stage& st, int si, int l, int b, int n
   const bool fc2_bias_in_ln = dbranch != e->d_br && !grouped;   // db_fc2 = column sums of g: fused into the LayerNorm backward pass below
   auto fc2_param_grads = [&]() {
     dense_wgrad(e, ba.act, m, dbranch, d, rows, bp.fc2);
-    if (!fc2_bias_in_ln) bias_grad(e, dbranch == e->d_br ? (const void*)e->d_br : (const void*)e->g, dbranch == e->d_br ? T : 0, d, rows, bp.fc2);
+    if (!fc2_bias_in_ln && !fc2_bias_done) bias_grad(e, dbranch == e->d_br ? (const void*)e->d_br : (const void*)e->g, dbranch == e->d_br ? T : 0, d, rows, bp.fc2);
   };
   if (!e->mlp_bwd_consumers_first) fc2_param_grads();
   {
@@ -820,9 +822,10 @@ static int block_backward(vitx_engine* e, Stage& st, int si, int l, int b, int n
     Prof pr(e, "branch_grad", 0, 0);
     const float adrop = bp.has_out ? drop : 0.f;
     const bool one_pass = bp.a_scale >= 0 && adrop == 0.f && d % 4 == 0;
+    out_bias_done = one_pass && bp.has_out && dense_gb(e, bp.out) != nullptr;
     if (bp.a_scale >= 0)
       launch_scale_grad(ba.fa, T, d, e->g, d, rows, d, e->red_ws, e->grads + bp.a_scale, e->stream, one_pass ? e->params + bp.a_scale : nullptr,
-                        one_pass ? e->d_br : nullptr, d);
+                        one_pass ? e->d_br : nullptr, d, out_bias_done ? dense_gb(e, bp.out) : nullptr);
     if (!one_pass) launch_branch_grad(e->g, bp.a_scale >= 0 ? e->params + bp.a_scale : nullptr, e->d_br, T, rows, d, adrop, seed, site0 + 1, e->stream);
     dbranch = e->d_br;
   }
@@ -833,7 +836,7 @@ static int block_backward(vitx_engine* e, Stage& st, int si, int l, int b, int n
     dense_dgrad(e, dbranch, d, rows, bp.out, EPI_STORE, ep);
     dense_wgrad(e, ba.o, inner, dbranch, d, rows, bp.out);
     out_bias_in_ln = dbranch != e->d_br && !grouped;
-    if (!out_bias_in_ln) bias_grad(e, dbranch == e->d_br ? (const void*)e->d_br : (const void*)e->g, dbranch == e->d_br ? T : 0, d, rows, bp.out);
+    if (!out_bias_in_ln && !out_bias_done) bias_grad(e, dbranch == e->d_br ? (const void*)e->d_br : (const void*)e->g, dbranch == e->d_br ? T : 0, d, rows, bp.out);
     d_o = e->d_o;
   }
   AttnView av;
@@ -1185,7 +1188,7 @@ static int engine_create_body(vitx_engine* e, const vitx_config& cfg, std::strin
   }
   // (+ per-M-tile column sums of the fc2-dgrad epilogue: one row per 256 token rows, 32 second-level rows)
   e->red_elems = std::max<int64_t>({layernorm_bwd_ws_elems(d), colsum_ws_elems((int)maxfeat), headmix_ws_elems((int)B, c.heads, 1, 1),
-                                    (int64_t)256 * 2 * 32, (int64_t)(512 + 32) * d, (ceil_div(std::max<int64_t>(e->mp, e->mpp), 128) + 40) * (int64_t)m,
+                                    (int64_t)256 * 2 * 32, (int64_t)(1024 + 64) * d, (ceil_div(std::max<int64_t>(e->mp, e->mpp), 128) + 40) * (int64_t)m,
                                     headchain_ws_elems(c.heads), deepvit_point_ws_elems((int)B, c.heads, e->ntok_cap),
                                     deepvit_point_bwd_ws_elems(c.heads)});
   DALLOC(e->red_ws, (size_t)e->red_elems * 4, false);

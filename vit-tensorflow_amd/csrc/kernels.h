@@ -162,7 +162,8 @@ void launch_concat_ctx(const void* y, int y_bf16, const float* context, void* ct
 void launch_split_ctx_bwd(const void* dctx, int is_bf16, void* dy, float* dcontext, int b, int nq, int nc, int d, hipStream_t s);
 void launch_add_T(void* a_inout, const void* b_in, int is_bf16, int64_t n, hipStream_t s);
 void launch_scale_grad(const void* fx, int is_bf16, int64_t ldf, const float* g, int64_t ldg, int rows, int d, float* partial_ws,
-                       float* dscale, hipStream_t s, const float* scale_or_null = nullptr, void* out_or_null = nullptr, int64_t ldo = 0);  // dscale[c] = sum_r g[r][c]*fx[r][c]   (cait.py:47-48 VJP)
+                       float* dscale, hipStream_t s, const float* scale_or_null = nullptr, void* out_or_null = nullptr, int64_t ldo = 0,
+                       float* dbias_or_null = nullptr);   // dbias (with out): += nothing, = column sums of out (the bias gradient of the Dense in front of the LayerScale)  // dscale[c] = sum_r g[r][c]*fx[r][c]   (cait.py:47-48 VJP)
 void launch_mul_scale(const float* g, int64_t ldg, const float* scale, void* out, int out_bf16, int64_t ldo, int rows, int d,
                       hipStream_t s);          // out[T] = g * scale[col]
 void launch_broadcast_rows(const float* src, int d, float* dst, int rows, hipStream_t s);  // dst[r][:] = src[:]
