@@ -28,7 +28,20 @@ def _deps_mtime() -> float:
     return max(os.path.getmtime(h) for h in hdrs)
 
 
-def _compile(src: str, force: bool) -> str:
+ASAN_FLAGS = ["-fsanitize=address", "-shared-libsan", "-fno-gpu-sanitize", "-g"]   # host code only (the device side needs xnack+ targets)
+ASAN_RT = "/opt/rocm/lib/llvm/lib/clang/22/lib/linux/libclang_rt.asan-x86_64.so"
+
+
+def _compile(src: str, force: bool, asan: bool = False) -> str:
+    if asan:
+        obj = os.path.join(HERE, "build_asan", src.replace(".hip", ".o"))
+        s = os.path.join(CSRC, src)
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(s), _deps_mtime()):
+            return obj
+        r = subprocess.run([HIPCC, *FLAGS, *ASAN_FLAGS, "-c", s, "-o", obj], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc (asan) failed for {src}:\n{r.stderr}")
+        return obj
     obj = os.path.join(BUILD, src.replace(".hip", ".o"))
     s = os.path.join(CSRC, src)
     if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(s), _deps_mtime()):
@@ -53,5 +66,20 @@ def build(force: bool = False) -> str:
     return LIB
 
 
+def build_asan(force: bool = False) -> str:
+    """libvitx_asan.so: the same sources with the HOST side under AddressSanitizer (C-ABI argument handling, parameter tables, engine
+    bookkeeping).  Load it with LD_PRELOAD=ASAN_RT and VITX_LIB=<this file> (tests/test_asan.py)."""
+    os.makedirs(os.path.join(HERE, "build_asan"), exist_ok=True)
+    os.makedirs(LIBDIR, exist_ok=True)
+    lib = os.path.join(LIBDIR, "libvitx_asan.so")
+    with ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
+        objs = list(ex.map(lambda s: _compile(s, force, True), SOURCES))
+    if force or not os.path.exists(lib) or any(os.path.getmtime(o) > os.path.getmtime(lib) for o in objs):
+        r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *ASAN_FLAGS, "-o", lib, *objs, "-ldl"], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link (asan) failed:\n{r.stderr}")
+    return lib
+
+
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    print(build_asan(force="--force" in sys.argv) if "--asan" in sys.argv else build(force="--force" in sys.argv))
