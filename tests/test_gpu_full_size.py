@@ -110,3 +110,37 @@ def test_benchmark_configuration_vit_b16_batch_256_bf16_against_the_torch_oracle
     rd = x.grad.detach().double().cpu().numpy()
     gate(float(np.abs(dimg - rd).max()) / (float(np.abs(rd).max()) + 1e-30), 1.5e-2, "d(img)", "full_size_dimg")   # observed 7.3e-3
     print(f"[full-size] worst gradient: {worst[0]} {worst[1]:.3e}")
+
+
+def test_vit_b16_depth_12_batch_64_bf16x3_meets_the_fp32_gates_against_the_torch_oracle_on_the_gpu():
+    """The BF16X3 mode (fp32 data path, split-operand bf16 MFMA GEMMs) at the full ViT-B/16 depth and a batch that fills the split kernel's
+    tiles (12608 token rows, 99 row tiles; split-K weight gradients): north_star's 1e-3 on the logits, 1e-3 of each tensor's max on the gradients."""
+    import torch
+    name, b = "cfg2_vit_b16", 64
+    cfg = oracle_cfg(name)
+    P = spec.init_params(cfg, seed=3, randomize_all=True)
+    m = make_engine_model(name, "bf16x3", b, P)
+    img = rand_images(cfg, b, 11)
+    dl = (np.random.default_rng(12).standard_normal((b, cfg["num_classes"])) / b).astype(np.float32)
+    logits = m(img, training=True)
+    grads, dimg = m.backward(dl, want_dimg=True)
+
+    dev = torch.device("cuda:0")
+    Pt = {k: torch.tensor(np.asarray(v, np.float32), device=dev, requires_grad=True) for k, v in P.items()}
+    x = torch.tensor(img, device=dev, requires_grad=True)
+    ref = ref_torch.forward(cfg, Pt, x)
+    ref.backward(torch.tensor(dl, device=dev))
+    ref_logits = ref.detach().double().cpu().numpy()
+    e_logit = float(np.abs(logits - ref_logits).max())
+    print(f"[full-size bf16x3] logits: max|d| = {e_logit:.3e} (std {float(ref_logits.std()):.3f})")
+    gate(e_logit, 1e-3, "logits, 12 layers of split-operand GEMMs", "x3_full_size_logits")
+    worst = ("", 0.0)
+    for n, _, _ in spec.param_spec(cfg):
+        r = Pt[n].grad.detach().double().cpu().numpy()
+        g = np.asarray(grads[n], np.float64)
+        e_max = float(np.abs(g - r).max()) / (float(np.abs(r).max()) + 1e-30)
+        worst = max(worst, (n, e_max), key=lambda t: t[1])
+        gate(e_max, 1e-3, f"grad {n} (max error / max)", "x3_full_size_grad_max")
+    rd = x.grad.detach().double().cpu().numpy()
+    gate(float(np.abs(dimg - rd).max()) / (float(np.abs(rd).max()) + 1e-30), 1e-3, "d(img)", "x3_full_size_dimg")
+    print(f"[full-size bf16x3] worst gradient: {worst[0]} {worst[1]:.3e}")
