@@ -251,7 +251,8 @@ def main():
             classes, shapes = {}, []
             epi_names = {0: "bf16 store", 1: "fp32 store", 2: "bias+GELU (act, gelu')", 3: "bias+fp32 residual", 4: "patch embed",
                          5: "x gelu' + column sums", 6: "split-K partials"}
-            for i in range(ns.value):
+            nstat = min(ns.value, 160)   # (vitx_profile_end reports the number of classes even when it exceeds the capacity passed in)
+            for i in range(nstat):
                 s = stats[i]
                 name = s.name.decode()
                 if name.startswith("shape "):
@@ -272,13 +273,13 @@ def main():
             if shapes:
                 out["gemm_shapes"] = sorted(shapes, key=lambda r: -r["us"] * r["launches_per_step"])
             # dominant kernel family = the bf16 MFMA GEMM (NT form for forward/dgrad, TN form for the weight gradients)
-            fam = [stats[i] for i in range(ns.value) if stats[i].name.decode().startswith("gemm_bf16_mfma")]
+            fam = [stats[i] for i in range(nstat) if stats[i].name.decode().startswith("gemm_bf16_mfma")]
             peak = MFMA_BF16_PEAK
             if not fam and args.compute == "bf16x3":   # split-operand mode: three bf16 MFMA products per fp32 product (achieved = fp32-equivalent FLOPs)
-                fam = [stats[i] for i in range(ns.value) if stats[i].name.decode() == "gemm_bf16x3_mfma"]
+                fam = [stats[i] for i in range(nstat) if stats[i].name.decode() == "gemm_bf16x3_mfma"]
                 peak = MFMA_BF16_PEAK / 3.0
             if not fam:   # fp32 parity mode: the exact-fp32 matrix-pipe kernel (+ the scalar kernel for small / strided problems)
-                fam = [stats[i] for i in range(ns.value) if stats[i].name.decode() in ("gemm_f32_mfma", "gemm_generic_fma")]
+                fam = [stats[i] for i in range(nstat) if stats[i].name.decode() in ("gemm_f32_mfma", "gemm_generic_fma")]
                 peak = 157.3e12
             if fam:
                 fl = sum(s.flops for s in fam); ms = sum(s.total_ms for s in fam); ln = sum(s.launches for s in fam)

@@ -19,7 +19,7 @@ M_TOKENS = 256 * 197
 
 # (N, K, epilogues): 1 = bias + fp32 residual, 2 = bias + GELU (act and gelu' in bf16), 3 = bf16 store, 4 = x stored gelu' + fused column sums
 NT_LAUNCHES = [(3072, 768, (2, 4, 3)), (768, 3072, (1, 3)), (768, 768, (1, 3)), (2304, 768, (3,)), (768, 2304, (3,))]
-NT_VARIANTS = (4, 6, 7, 8, 9, 10, 11, 13, 14, 15)   # every persistent variant the per-shape measurement chooses from
+NT_VARIANTS = (6, 7, 9, 11, 12, 13, 14, 15)   # every persistent variant the per-shape measurement chooses from (12 / 13: wave-private epilogue)
 BF16_OUT_TOL = 1.1e-2    # ~2x observed (5.2e-3 = one bf16 ulp): the two kernels add in different orders, a value on a rounding boundary flips one ulp
 GELU_OUT2_TOL = 1.5e-2   # gelu'(h) / gelu(h) of a pre-activation that flipped (observed 7.2e-3)
 F32_OUT_TOL = 1e-3
@@ -46,19 +46,6 @@ def test_dense_launches_of_the_benchmarked_step_match_the_fp32_fma_kernel(N_, K,
                 gate(errs[1], GELU_OUT2_TOL, what + " (second output)", "gemm_full_size_epi2_out2")
             if epi == 4:
                 gate(errs[1], COLSUM_TOL, what + " (fused column sums)", "gemm_full_size_colsum")
-
-
-def test_ping_pong_variant_matches_the_fp32_fma_kernel():
-    """Variant 12 (gemm_bf16_pp.hip: two wave groups alternating K loop / epilogue + operand feed; a measured-slower experiment that stays
-    callable): single tile, one pair, odd tile counts, several tiles per workgroup, the ViT-B launch shapes."""
-    N, m = _handle()
-    errs = (C.c_float * 2)()
-    for (M, N_, K) in [(256, 128, 768), (256, 256, 768), (768, 128, 768), (768, 384, 1024), (256 * 33, 128 * 5, 640), (M_TOKENS, 3072, 768), (M_TOKENS, 768, 3072)]:
-        for epi in (3, 2):
-            N.check(N.lib().vitx_check_gemm(m._handle, 0, M, N_, K, 12, epi, errs))
-            gate(errs[0], BF16_OUT_TOL, f"ping-pong M {M} N {N_} K {K} epilogue {epi}", "gemm_pingpong")
-            if epi == 2:
-                gate(errs[1], GELU_OUT2_TOL, f"ping-pong M {M} N {N_} K {K} epilogue 2 (second output)", "gemm_pingpong_out2")
 
 
 @pytest.mark.parametrize("in_, out", [(768, 3072), (3072, 768), (768, 768), (768, 2304), (1024, 4096)])

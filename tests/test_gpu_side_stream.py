@@ -1,0 +1,78 @@
+"""GPU tier (-m gpu): weight gradients on the side stream (engine.hip, "side stream") give bit-identical results to the one-stream order.
+
+The side stream changes only the interleaving of kernels (the weight-gradient GEMMs + slice reductions run beside the input-gradient chain,
+ordered by events; buffers the chain rewrites live in rings), never their operands: every gradient must be EXACTLY what VITX_SIDE_STREAM=0
+produces, step after step (a missed dependency shows up as a difference that changes from run to run)."""
+import numpy as np
+import pytest
+
+from oracle import spec
+from util import CONFIGS, make_engine_model, oracle_cfg, rand_images
+
+pytestmark = pytest.mark.gpu
+
+CONFIGS.setdefault("vit_side_mid", ("vit", dict(image_size=224, patch_size=16, num_classes=100, dim=256, depth=6, heads=4, mlp_dim=1024)))
+CONFIGS.setdefault("cait_side_mid", ("cait", dict(image_size=128, patch_size=16, num_classes=100, dim=256, depth=4, cls_depth=2, heads=4, mlp_dim=512)))
+CONFIGS.setdefault("deepvit_side_mid", ("deepvit", dict(image_size=128, patch_size=16, num_classes=100, dim=256, depth=4, heads=4, mlp_dim=512)))
+
+
+def _run(name, b, steps, monkeypatch, side, dropout=0.0):
+    monkeypatch.setenv("VITX_SIDE_STREAM", side)
+    cfg = oracle_cfg(name)
+    P = spec.init_params(cfg, seed=5, randomize_all=True)
+    v, kw = CONFIGS[name]
+    if dropout:
+        CONFIGS[name + "_drop"] = (v, dict(kw, dropout=dropout))
+        name = name + "_drop"
+    m = make_engine_model(name, "bf16", b, P)
+    out = []
+    for s in range(steps):
+        img = rand_images(cfg, b, 20 + s)
+        dl = (np.random.default_rng(30 + s).standard_normal((b, cfg["num_classes"])) / b).astype(np.float32)
+        logits = m(img, training=True, seed=7 + s) if dropout else m(img, training=True)
+        grads, dimg = m.backward(dl, want_dimg=True)
+        out.append((logits.copy(), {k: np.array(g, copy=True) for k, g in grads.items()}, dimg.copy()))
+    return out
+
+
+@pytest.mark.parametrize("name,b,dropout", [("vit_side_mid", 48, 0.0), ("vit_side_mid", 16, 0.1), ("cait_side_mid", 32, 0.0), ("deepvit_side_mid", 32, 0.0),
+                                            ("cfg2_vit_b16", 64, 0.0)])
+def test_side_stream_gradients_are_bit_identical_to_the_one_stream_order(name, b, dropout, monkeypatch):
+    ref = _run(name, b, 3, monkeypatch, "0", dropout)
+    for mode in ("1", "2"):
+        got = _run(name, b, 3, monkeypatch, mode, dropout)
+        for s, ((l0, g0, d0), (l1, g1, d1)) in enumerate(zip(ref, got)):
+            assert np.array_equal(l0, l1), f"step {s}: logits differ (mode {mode})"
+            assert np.array_equal(d0, d1), f"step {s}: d(img) differs (mode {mode})"
+            for k in g0:
+                assert np.array_equal(g0[k], g1[k]), f"step {s}: gradient {k} differs (mode {mode})"
+
+
+def test_side_stream_composes_with_the_gradient_ready_callback(monkeypatch):
+    """Data parallel: a block's range is reported only behind a wait for the side stream's share of it, and every element of the arena is
+    reported exactly once per step."""
+    import ctypes as C
+    from vit_tensorflow import _native as N
+    monkeypatch.setenv("VITX_SIDE_STREAM", "1")
+    name, b = "vit_side_mid", 16
+    cfg = oracle_cfg(name)
+    m = make_engine_model(name, "bf16", b, spec.init_params(cfg, seed=5, randomize_all=True))
+    m.build((b,))
+    n = C.c_int64(); p = C.c_void_p()
+    N.check(N.lib().vitx_params_dev(m._handle, C.byref(p), C.byref(n)))
+    seen = []
+    cb = N.GRAD_READY_FN(lambda _u, off, cnt: seen.append((int(off), int(cnt))))
+    N.check(N.lib().vitx_set_grad_ready_callback(m._handle, cb, None))
+    try:
+        for s in range(2):
+            seen.clear()
+            img = rand_images(cfg, b, 40 + s)
+            dl = (np.random.default_rng(50 + s).standard_normal((b, cfg["num_classes"])) / b).astype(np.float32)
+            m(img, training=True)
+            m.backward(dl)
+            cover = np.zeros(n.value, np.int32)
+            for off, cnt in seen:
+                cover[off:off + cnt] += 1
+            assert cover.min() == 1 and cover.max() == 1, (cover.min(), cover.max())
+    finally:
+        N.check(N.lib().vitx_set_grad_ready_callback(m._handle, C.cast(None, N.GRAD_READY_FN), None))

@@ -75,6 +75,17 @@ struct ProfEvent {
   double flops, bytes;
 };
 
+// Weight-gradient side stream (engine.hip, "side stream" section): a buffer the dgrad chain rewrites every block while a weight-gradient
+// GEMM queued on the side stream may still be reading it.  The chain writes into the next slot of a small ring instead; a slot is reused
+// only after the side-stream reader recorded on it has finished (an event wait on the main stream, normally already satisfied).
+struct SideRing {
+  void* slot[3] = {nullptr, nullptr, nullptr};
+  hipEvent_t rd[3] = {nullptr, nullptr, nullptr};
+  bool pend[3] = {false, false, false};
+  int n = 0, cur = 0;
+};
+struct PendingReady { int64_t off, cnt; hipEvent_t ev; };
+
 struct vitx_engine {
   vitx_config cfg{};
   std::vector<ParamDesc> table;
@@ -93,6 +104,14 @@ struct vitx_engine {
   int64_t bp = 0;                    // max batch padded to 256
 
   hipStream_t own_stream = nullptr, stream = nullptr;
+  // weight gradients (no consumer until the optimizer / the gradient exchange) run on `side`, forked from / joined into `stream` by events
+  hipStream_t side = nullptr;
+  int side_mode = 1;                 // VITX_SIDE_STREAM=0: everything on one stream (A/B reference)
+  bool side_live = false;            // inside a backward pass that uses the side stream
+  bool side_dirty = false;           // work was queued on the side stream since the last join
+  SideRing rg_dh, rg_glp, rg_dqkv, rg_dbr;
+  std::vector<hipEvent_t> side_events; size_t side_ev_next = 0;
+  std::vector<PendingReady> side_ready;   // gradient-ready reports waiting for the side stream's share of their range
   float* params = nullptr;
   float* grads = nullptr;
   bool own_params = true, own_grads = true;

@@ -135,7 +135,9 @@ struct Prof {
   vitx_engine* e;
   ProfEvent pe;
   bool on;
-  Prof(vitx_engine* e_, const char* name, double flops, double bytes, const char* name2 = nullptr) : e(e_), on(e_->profiling) {
+  hipStream_t st;
+  Prof(vitx_engine* e_, const char* name, double flops, double bytes, const char* name2 = nullptr, hipStream_t st_ = nullptr)
+      : e(e_), on(e_->profiling), st(st_ ? st_ : e_->stream) {
     if (!on) return;
     pe.cls = prof_class(e, name);
     pe.cls2 = name2 ? prof_class(e, name2) : -1;
@@ -143,11 +145,11 @@ struct Prof {
     pe.bytes = bytes;
     (void)hipEventCreate(&pe.e0);
     (void)hipEventCreate(&pe.e1);
-    (void)hipEventRecord(pe.e0, e->stream);
+    (void)hipEventRecord(pe.e0, st);
   }
   ~Prof() {
     if (!on) return;
-    (void)hipEventRecord(pe.e1, e->stream);
+    (void)hipEventRecord(pe.e1, st);
     e->prof_events.push_back(pe);
   }
 };
@@ -228,6 +230,98 @@ static const char* f32_gemm_class(const GenericGemmArgs& g, int ta, int tb, int 
   return gemm_f32_mfma_supported(g, ta, tb, to) ? "gemm_f32_mfma" : "gemm_generic_fma";
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// side stream: weight gradients beside the input-gradient chain
+// ------------------------------------------------------------------------------------------------
+// A weight gradient dW = X^T dY has no consumer until the optimizer / the gradient exchange, while everything else in the backward pass is one
+// dependent chain (dgrad GEMM -> LayerNorm VJP -> dgrad GEMM ...).  On ONE stream the step is the SUM of its MFMA-bound kernels (GEMMs) and its
+// HBM-bound ones (LayerNorm VJP, attention VJP, reductions): the matrix pipes idle under the latter, the memory system under the former, and the
+// persistent GEMMs leave CUs idle in their last partial round of tiles.  The weight-gradient GEMMs and their slice reductions therefore go to a
+// second stream: forked from the main stream by an event at the point their operands exist, joined back at the end of the backward pass.
+//   * operands the chain rewrites every block (d hpre, d qkv, the bf16 residual gradient, the branch gradient) live in small rings (SideRing):
+//     the chain writes the NEXT slot, and waits (event) for the side-stream reader of that slot only when it comes round again;
+//   * saved activations (y1, y2, act, o, ctx) are not rewritten before the next forward, which is behind the join;
+//   * the split-K partial workspace is used by weight gradients only; launches on either stream are ordered by the fork / join events;
+//   * gradient-ready reports (data parallel) of a block are delivered one block late, behind a wait for the side stream's share of the range.
+// Results are bit-identical to the one-stream order: the same kernels on the same operands, only their interleaving changes.
+static hipEvent_t side_event(vitx_engine* e) {
+  if (e->side_events.empty()) {
+    e->side_events.resize(64);
+    for (auto& ev : e->side_events) (void)hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+  }
+  hipEvent_t ev = e->side_events[e->side_ev_next];
+  e->side_ev_next = (e->side_ev_next + 1) % e->side_events.size();
+  return ev;
+}
+// stream a weight gradient is launched on; forks the side stream behind everything queued on the main stream so far
+static hipStream_t side_fork(vitx_engine* e) {
+  if (!e->side_live) return e->stream;
+  hipEvent_t ev = side_event(e);
+  (void)hipEventRecord(ev, e->stream);
+  (void)hipStreamWaitEvent(e->side, ev, 0);
+  e->side_dirty = true;
+  return e->side;
+}
+// the current slot of `r` is being read by work just queued on the side stream
+static void side_note_read(vitx_engine* e, SideRing& r) {
+  if (!e->side_live || r.n == 0) return;
+  (void)hipEventRecord(r.rd[r.cur], e->side);
+  r.pend[r.cur] = true;
+}
+// next slot of `r` for a producer on the main stream (the pointer the engine uses for this buffer from here on)
+template <typename P>
+static void side_rotate(vitx_engine* e, SideRing& r, P*& ptr) {
+  if (!e->side_live || r.n == 0) return;
+  r.cur = (r.cur + 1) % r.n;
+  if (r.pend[r.cur]) { (void)hipStreamWaitEvent(e->stream, r.rd[r.cur], 0); r.pend[r.cur] = false; }
+  ptr = (P*)r.slot[r.cur];
+}
+static void side_flush_ready(vitx_engine* e, size_t keep) {
+  while (e->side_ready.size() > keep) {
+    PendingReady pr = e->side_ready.front();
+    e->side_ready.erase(e->side_ready.begin());
+    (void)hipStreamWaitEvent(e->stream, pr.ev, 0);
+    if (e->grad_cb) e->grad_cb(e->grad_cb_user, pr.off, pr.cnt);
+  }
+}
+// gradient-ready report of an arena range whose weight gradients may still be queued on the side stream
+static void report_ready(vitx_engine* e, int64_t off, int64_t cnt) {
+  if (!e->grad_cb) return;
+  if (!e->side_live) { e->grad_cb(e->grad_cb_user, off, cnt); return; }
+  hipEvent_t ev = side_event(e);
+  (void)hipEventRecord(ev, e->side);
+  e->side_ready.push_back({off, cnt, ev});
+  side_flush_ready(e, 1);   // everything but the newest: its side-stream work was queued a block ago
+}
+static void side_join(vitx_engine* e) {
+  if (e->side_dirty) {
+    hipEvent_t ev = side_event(e);
+    (void)hipEventRecord(ev, e->side);
+    (void)hipStreamWaitEvent(e->stream, ev, 0);
+    e->side_dirty = false;
+  }
+  for (SideRing* r : {&e->rg_dh, &e->rg_glp, &e->rg_dqkv, &e->rg_dbr})
+    for (int i = 0; i < 3; ++i) r->pend[i] = false;
+  side_flush_ready(e, 0);
+}
+// scope of a backward pass: decides whether this pass uses the side stream, joins on every way out
+struct SideScope {
+  vitx_engine* e;
+  SideScope(vitx_engine* e_, bool allowed) : e(e_) {
+    bool on = allowed && e->side_mode && e->side && e->bf16 && !e->force_generic_gemm && !e->wgrad_via_transpose && !e->profiling;
+    if (on) {
+      hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+      if (hipStreamIsCapturing(e->stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) on = false;
+    }
+    e->side_live = on;
+  }
+  ~SideScope() {
+    if (e->side_live) side_join(e);
+    e->side_live = false;
+  }
+};
+
 // ------------------------------------------------------------------------------------------------
 // Dense layer = x @ kernel[in,out] + bias (Keras nn.Dense; vit.py:39,42,59,63,143,156) and its VJPs
 
@@ -301,14 +395,15 @@ static void dense_wgrad(vitx_engine* e, const void* X, int64_t ldx, const void* 
   const double flops = 2.0 * rows * (double)w.out * w.in;
   const double bytes = (double)rows * w.in * e->esz + (double)rows * w.out * e->esz + (double)w.in * w.out * 4;
   if (e->bf16 && !e->force_generic_gemm) {
+    const hipStream_t ws = side_fork(e);        // the side stream inside a backward pass that uses it, else the main stream
     const int kext = (int)round_up(rows, 64);   // rows >= `rows` of both operands are zero (row-padding invariant)
     Bf16GemmArgs g;
     g.M = w.in; g.N = w.out; g.K = kext; g.kernel = e->gemm_kernel;
     int tm, tn;
     if (e->wgrad_via_transpose) {
       Prof pr(e, "transpose_bf16", 0, 2.0 * ((double)kext * w.in + (double)kext * w.out) * 2);
-      launch_transpose_bf16((const bf16_t*)X, ldx, kext, w.in, e->xt, kext, e->stream);
-      launch_transpose_bf16((const bf16_t*)dY, ldy, kext, w.out, e->dyt, kext, e->stream);
+      launch_transpose_bf16((const bf16_t*)X, ldx, kext, w.in, e->xt, kext, ws);
+      launch_transpose_bf16((const bf16_t*)dY, ldy, kext, w.out, e->dyt, kext, ws);
       g.A = e->xt; g.lda = kext;
       g.B = e->dyt; g.ldb = kext;
       tm = gemm_bf16_tile_m(g.kernel, g.M, g.N); tn = gemm_bf16_tile_n(g.kernel, g.M, g.N);
@@ -325,6 +420,12 @@ static void dense_wgrad(vitx_engine* e, const void* X, int64_t ldx, const void* 
     // one wave of workgroups (these kernels run 1 WG/CU): split-K so that tiles*split ~ 256, fewer slices = less partial traffic
     int split = (int)std::max<int64_t>(1, std::min<int64_t>(ceil_div(nk, 4), std::max<int64_t>(1, 256 / tiles)));
     while (split > 1 && (int64_t)split * w.in * w.out > e->partial_elems) --split;
+    if (!e->wgrad_via_transpose) {
+      // the weight-gradient kernel addresses a K slice of each operand through a buffer resource (31-bit byte offsets): a slice must stay below
+      // 2 GiB -- more slices if it would not (never at the shapes of the models here: 50k rows x 4096 features is 0.4 GB)
+      const int64_t max_rows = (((1LL << 31) - (1 << 20)) / (2 * std::max<int64_t>(ldx, ldy))) / 64 * 64;
+      split = (int)std::max<int64_t>(split, ceil_div(kext, std::max<int64_t>(64, max_rows)));
+    }
     g.split_k = split;
     const int slices = gemm_bf16_num_slices(kext, split);
     EpiParams ep;
@@ -335,13 +436,13 @@ static void dense_wgrad(vitx_engine* e, const void* X, int64_t ldx, const void* 
     {
       char shape[48];
       if (e->profiling) snprintf(shape, sizeof shape, "shape tn s%d %dx%dx%d", slices, g.M, g.N, g.K);   // dW[in, out] over K token rows
-      Prof pr(e, e->wgrad_via_transpose ? "gemm_bf16_mfma" : "gemm_bf16_mfma_tn", flops, bytes, e->profiling ? shape : nullptr);
-      if (e->wgrad_via_transpose) launch_gemm_bf16(g, ep, EPI_PARTIAL, e->stream);
-      else launch_gemm_bf16_tn(g, ep, e->stream);
+      Prof pr(e, e->wgrad_via_transpose ? "gemm_bf16_mfma" : "gemm_bf16_mfma_tn", flops, bytes, e->profiling ? shape : nullptr, ws);
+      if (e->wgrad_via_transpose) launch_gemm_bf16(g, ep, EPI_PARTIAL, ws);
+      else launch_gemm_bf16_tn(g, ep, ws);
     }
     if (slices > 1) {
-      Prof pr(e, "reduce_partials", 0, (double)(slices + 1) * w.in * w.out * 4);
-      launch_reduce_partials(e->partial_ws, slices, (int64_t)w.in * w.out, (int64_t)w.in * w.out, dW, 1.0f, e->stream);
+      Prof pr(e, "reduce_partials", 0, (double)(slices + 1) * w.in * w.out * 4, nullptr, ws);
+      launch_reduce_partials(e->partial_ws, slices, (int64_t)w.in * w.out, (int64_t)w.in * w.out, dW, 1.0f, ws);
     }
   } else {
     GenericGemmArgs g;
@@ -355,7 +456,7 @@ static void dense_wgrad(vitx_engine* e, const void* X, int64_t ldx, const void* 
     int slices = 1;
     if (e->x3 && e->partial_ws && gemm_bf16x3_supported(g, 0, 0, 0)) {
       const int64_t tiles = ceil_div(w.in, 128) * ceil_div(w.out, 128);
-      int64_t want = std::min<int64_t>({std::max<int64_t>(1, 1024 / tiles), std::max<int64_t>(1, rows / 256), e->partial_elems / ((int64_t)w.in * w.out)});
+      int64_t want = std::min<int64_t>({std::max<int64_t>(1, 1024 / tiles), std::max<int64_t>(1, rows / 256), e->partial_elems / ((int64_t)w.in * w.out), 32});   // (<= 32: the two-level reduction)
       if (want > 1) {
         const int ks = (int)round_up(ceil_div(rows, want), 32);
         slices = (int)ceil_div(rows, ks);
@@ -743,7 +844,7 @@ static int block_backward(vitx_engine* e, Stage& st, int si, int l, int b, int n
   const vitx_config& c = e->cfg;
   const int d = c.dim, inner = e->inner, m = c.mlp_dim, T = e->bf16, esz = e->esz;
   const int rows = b * nq, nk = nq + nc;
-  const void* gT = T ? e->g_lp : (const void*)e->g;   // T view of the residual gradient
+  const void* gT = T ? e->g_lp : (const void*)e->g;   // T view of the residual gradient (re-read after each LayerNorm VJP: side_rotate)
   const double lnb = (double)rows * d * (4 + 4 + 4 + esz + esz);
   // Parallel half-blocks (parallel_vit.py:36-42): every branch of a group sees the SAME output gradient g, and the gradient of the
   // group's common LayerNorm input is g + sum_i LN_i^T(...): it is accumulated in g2 while g / g_lp keep feeding the remaining
@@ -751,7 +852,13 @@ static int block_backward(vitx_engine* e, Stage& st, int si, int l, int b, int n
   const bool grouped = ba.par_first || ba.par_last || ba.ln1_src || ba.ln2_src;
   const float* ln_gin = (!grouped || ba.par_first) ? e->g : e->g2;
   float* ln_gout = (!grouped || ba.par_last) ? e->g : e->g2;
-  void* ln_glp = (T && (!grouped || ba.par_last)) ? e->g_lp : nullptr;
+  const bool ln_writes_glp = T && (!grouped || ba.par_last);
+  // the bf16 residual gradient a LayerNorm VJP writes: the next ring slot while weight gradients on the side stream may still read the current one
+  auto next_glp = [&]() -> void* {
+    if (!ln_writes_glp) return nullptr;
+    side_rotate(e, e->rg_glp, e->g_lp);
+    return e->g_lp;
+  };
 
   const void* dbranch = gT;
   bool fc2_bias_done = false, out_bias_done = false;   // bias gradient already produced by the LayerScale VJP pass
@@ -762,6 +869,7 @@ static int block_backward(vitx_engine* e, Stage& st, int si, int l, int b, int n
     // LayerScale without dropout: one pass over g gives dscale AND the branch gradient g * scale
     const bool one_pass = bp.m_scale >= 0 && drop == 0.f && d % 4 == 0;
     fc2_bias_done = one_pass && dense_gb(e, bp.fc2) != nullptr;   // ... and the fc2 bias gradient = column sums of that branch gradient
+    side_rotate(e, e->rg_dbr, e->d_br);
     if (bp.m_scale >= 0)
       launch_scale_grad(ba.fm, T, d, e->g, d, rows, d, e->red_ws, e->grads + bp.m_scale, e->stream, one_pass ? e->params + bp.m_scale : nullptr,
                         one_pass ? e->d_br : nullptr, d, fc2_bias_done ? dense_gb(e, bp.fc2) : nullptr);
@@ -773,6 +881,7 @@ static int block_backward(vitx_engine* e, Stage& st, int si, int l, int b, int n
   const bool fc1_bias_fused = e->bf16 && !e->force_generic_gemm && !(e->gemm_kernel & 256) && drop == 0.f && bp.fc1.b >= 0;
   const int cs_rows = (int)ceil_div(rows, 128);   // >= the M-tile count of every variant (128 / 256 / 320 rows per tile)
   {
+    side_rotate(e, e->rg_dh, e->d_h);
     EpiParams ep; ep.out = e->d_h; ep.ldo = m; ep.aux = ba.hpre; ep.ldaux = m;
     if (fc1_bias_fused) {
       HIPCHK(hipMemsetAsync(e->red_ws, 0, (size_t)cs_rows * m * 4, e->stream));   // rows the chosen tile shape does not reach stay 0
@@ -794,6 +903,7 @@ static int block_backward(vitx_engine* e, Stage& st, int si, int l, int b, int n
   const bool fc2_bias_in_ln = dbranch != e->d_br && !grouped;   // db_fc2 = column sums of g: fused into the LayerNorm backward pass below
   auto fc2_param_grads = [&]() {
     dense_wgrad(e, ba.act, m, dbranch, d, rows, bp.fc2);
+    side_note_read(e, dbranch == e->d_br ? e->rg_dbr : e->rg_glp);
     if (!fc2_bias_in_ln && !fc2_bias_done) bias_grad(e, dbranch == e->d_br ? (const void*)e->d_br : (const void*)e->g, dbranch == e->d_br ? T : 0, d, rows, bp.fc2);
   };
   if (!e->mlp_bwd_consumers_first) fc2_param_grads();
@@ -803,26 +913,30 @@ static int block_backward(vitx_engine* e, Stage& st, int si, int l, int b, int n
     dense_dgrad(e, e->d_h, m, rows, bp.fc1, EPI_STORE, ep);
   }
   dense_wgrad(e, ba.y2, d, e->d_h, m, rows, bp.fc1);
+  side_note_read(e, e->rg_dh);
   if (!fc1_bias_fused) bias_grad(e, e->d_h, T, m, rows, bp.fc1);
   if (e->mlp_bwd_consumers_first) fc2_param_grads();
   {
     Prof pr(e, "layernorm_bwd", 0, lnb);
+    void* ln_glp = next_glp();
     launch_layernorm_bwd(e->d_y, T, d, ba.ln2_src ? ba.ln2_src : ba.x_mid, d, ba.mean2, ba.rstd2, e->params + bp.ln2_g, ln_gin, d, ln_gout, d, ln_glp, d,
                          e->red_ws, e->grads + bp.ln2_g, e->grads + bp.ln2_b, fc2_bias_in_ln ? e->grads + bp.fc2.b : nullptr, rows, d, e->stream);
   }
   }   // !skip_mlp
   if (ba.skip_attn) {
-    if (e->grad_cb) e->grad_cb(e->grad_cb_user, bp.p_begin, bp.p_end - bp.p_begin);
+    report_ready(e, bp.p_begin, bp.p_end - bp.p_begin);
     return VITX_OK;
   }
 
   // ---- attention branch: x_mid = x_in + scale * to_out(attn(LN(x_in)))
+  gT = T ? e->g_lp : (const void*)e->g;
   dbranch = gT;
   if (bp.a_scale >= 0 || (drop > 0.f && bp.has_out)) {
     Prof pr(e, "branch_grad", 0, 0);
     const float adrop = bp.has_out ? drop : 0.f;
     const bool one_pass = bp.a_scale >= 0 && adrop == 0.f && d % 4 == 0;
     out_bias_done = one_pass && bp.has_out && dense_gb(e, bp.out) != nullptr;
+    side_rotate(e, e->rg_dbr, e->d_br);
     if (bp.a_scale >= 0)
       launch_scale_grad(ba.fa, T, d, e->g, d, rows, d, e->red_ws, e->grads + bp.a_scale, e->stream, one_pass ? e->params + bp.a_scale : nullptr,
                         one_pass ? e->d_br : nullptr, d, out_bias_done ? dense_gb(e, bp.out) : nullptr);
@@ -835,10 +949,12 @@ static int block_backward(vitx_engine* e, Stage& st, int si, int l, int b, int n
     EpiParams ep; ep.out = e->d_o; ep.ldo = inner;
     dense_dgrad(e, dbranch, d, rows, bp.out, EPI_STORE, ep);
     dense_wgrad(e, ba.o, inner, dbranch, d, rows, bp.out);
+    side_note_read(e, dbranch == e->d_br ? e->rg_dbr : e->rg_glp);
     out_bias_in_ln = dbranch != e->d_br && !grouped;
     if (!out_bias_in_ln && !out_bias_done) bias_grad(e, dbranch == e->d_br ? (const void*)e->d_br : (const void*)e->g, dbranch == e->d_br ? T : 0, d, rows, bp.out);
     d_o = e->d_o;
   }
+  side_rotate(e, e->rg_dqkv, e->d_qkv);   // d(q, k, v) of this block: the previous block's may still feed its weight gradient
   AttnView av;
   av.nq = nq; av.nk = nk; av.o = ba.o; av.ldo = inner; av.ob = (int64_t)nq * inner;
   AttnGrad ag;
@@ -864,8 +980,10 @@ static int block_backward(vitx_engine* e, Stage& st, int si, int l, int b, int n
     EpiParams ep2; ep2.out = e->d_ctx; ep2.ldo = d;
     dense_dgrad(e, dkv, 2 * inner, b * nk, bp.kv, EPI_STORE, ep2);              // d ctx (via k, v)
     dense_wgrad(e, ctx, d, dkv, 2 * inner, b * nk, bp.kv);
+    side_note_read(e, e->rg_dqkv);
     Prof pr(e, "ctx_bwd", 0, 0);
     if (nc > 0) {
+      side_rotate(e, e->rg_dbr, e->d_br);
       // d ctx = [d y1 part | d context part]  (cait.py:109-112 VJP); context is the un-normalised patch output
       launch_split_ctx_bwd(e->d_ctx, T, e->d_br, e->g_ctx, b, nq, nc, d, e->stream);
       launch_add_T(e->d_y, e->d_br, T, (int64_t)rows * d, e->stream);
@@ -892,13 +1010,15 @@ static int block_backward(vitx_engine* e, Stage& st, int si, int l, int b, int n
     ep.nt_out = (e->nt_mask >> 4) & 1;
     dense_dgrad(e, e->d_qkv, 3 * inner, rows, bp.qkv, EPI_STORE, ep);
     dense_wgrad(e, ba.y1, d, e->d_qkv, 3 * inner, rows, bp.qkv);
+    side_note_read(e, e->rg_dqkv);
   }
   {
     Prof pr(e, "layernorm_bwd", 0, lnb);
+    void* ln_glp = next_glp();
     launch_layernorm_bwd(e->d_y, T, d, ba.ln1_src ? ba.ln1_src : ba.x_in, d, ba.mean1, ba.rstd1, e->params + bp.ln1_g, ln_gin, d, ln_gout, d, ln_glp, d,
                          e->red_ws, e->grads + bp.ln1_g, e->grads + bp.ln1_b, out_bias_in_ln ? e->grads + bp.out.b : nullptr, rows, d, e->stream);
   }
-  if (e->grad_cb) e->grad_cb(e->grad_cb_user, bp.p_begin, bp.p_end - bp.p_begin);
+  report_ready(e, bp.p_begin, bp.p_end - bp.p_begin);
   return VITX_OK;
 }
 
@@ -953,6 +1073,7 @@ static int engine_create_body(vitx_engine* e, const vitx_config& cfg, std::strin
   if (const char* k = getenv("VITX_UNFUSED_HEADOPS")) e->unfused_headops = atoi(k) != 0;
   e->wgrad_via_transpose = env_flag("VITX_WGRAD_TRANSPOSE");
   e->keep_scores = !env_flag("VITX_RECOMPUTE_SCORES");
+  if (const char* k = getenv("VITX_SC_KEEP_MB")) e->sc_keep_budget = (int64_t)atoll(k) << 20;   // budget of the kept score tensors (blocks beyond it recompute)
   if (const char* k = getenv("VITX_GEMM_STAGGER")) {
     e->gemm_stagger = atoi(k);
     if (e->gemm_stagger & 3) fprintf(stderr, "[vitx] VITX_GEMM_STAGGER=%d: timing experiment bits set -- GEMM results are WRONG in this process\n", e->gemm_stagger);
@@ -961,6 +1082,13 @@ static int engine_create_body(vitx_engine* e, const vitx_config& cfg, std::strin
   HIPCHK(hipSetDevice(c.device_id));
   HIPCHK(hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking));
   e->stream = e->own_stream;
+  if (const char* k = getenv("VITX_SIDE_STREAM")) e->side_mode = atoi(k);
+  if (e->bf16 && e->side_mode) {
+    // lowest priority: the input-gradient chain is the critical path, the weight gradients fill what it leaves free (VITX_SIDE_STREAM=2: same priority)
+    int least = 0, greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+    HIPCHK(hipStreamCreateWithPriority(&e->side, hipStreamNonBlocking, e->side_mode == 2 ? greatest : least));
+  }
 
   const int d = c.dim, inner = e->inner, m = c.mlp_dim, esz = e->esz;
   const int64_t B = c.max_batch;
@@ -1168,12 +1296,26 @@ static int engine_create_body(vitx_engine* e, const vitx_config& cfg, std::strin
   DALLOC(e->d_qkv, (size_t)(rmax + 256) * 3 * inner * esz + (size_t)crow_max * 2 * inner * esz, true);
   DALLOC(e->d_ctx, (size_t)crow_max * d * esz, true);
   DALLOC(e->d_br, (size_t)rmax * d * esz, true);
+  if (e->side) {
+    // ring slots of the buffers the input-gradient chain rewrites while side-stream weight gradients read them (slot 0 = the buffer above)
+    auto ring = [&](SideRing& r, void* first, size_t bytes, int n) -> int {
+      r.n = n; r.cur = 0; r.slot[0] = first;
+      for (int i = 1; i < n; ++i) DALLOC(r.slot[i], bytes, true);
+      for (int i = 0; i < n; ++i) HIPCHK(hipEventCreateWithFlags(&r.rd[i], hipEventDisableTiming));
+      return VITX_OK;
+    };
+    if ((rc = ring(e->rg_dh, e->d_h, (size_t)rmax * m * esz, 2)) != VITX_OK) return rc;
+    if ((rc = ring(e->rg_glp, e->g_lp, (size_t)rmax * d * esz, 3)) != VITX_OK) return rc;
+    if ((rc = ring(e->rg_dqkv, e->d_qkv, (size_t)(rmax + 256) * 3 * inner * esz + (size_t)crow_max * 2 * inner * esz, 2)) != VITX_OK) return rc;
+    if ((rc = ring(e->rg_dbr, e->d_br, (size_t)rmax * d * esz, 3)) != VITX_OK) return rc;
+  }
   DALLOC(e->dsum, (size_t)B * c.heads * e->ntok_cap * 4 + 16, false);
   DALLOC(e->zero_page, 256, false);
   DALLOC(e->tmp_f32, (size_t)rmax * std::max<int64_t>(d, e->pd) * 4, false);
   const int64_t maxfeat = std::max<int64_t>({(int64_t)d, 3LL * inner, (int64_t)m, (int64_t)e->pd_k, (int64_t)e->nc_k});
-  if (e->x3) {   // split-K partials of the weight gradients (dense_wgrad)
-    e->partial_elems = 64LL * 1024 * 1024;
+  if (e->x3) {   // split-K partials of the weight gradients (dense_wgrad): at most 32 slices of the largest kernel, never more than 256 MB
+    const int64_t max_w = std::max<int64_t>({(int64_t)d * 3 * inner, (int64_t)d * m, (int64_t)e->pd * d, (int64_t)d * c.num_classes, (int64_t)inner * d});
+    e->partial_elems = std::min<int64_t>(64LL * 1024 * 1024, 32 * max_w);
     DALLOC(e->partial_ws, (size_t)e->partial_elems * 4, false);
   }
   if (e->bf16) {
@@ -1200,7 +1342,12 @@ static int engine_create_body(vitx_engine* e, const vitx_config& cfg, std::strin
 void engine_destroy(vitx_engine* e) {
   if (!e) return;
   (void)hipStreamSynchronize(e->stream);
+  if (e->side) (void)hipStreamSynchronize(e->side);
   for (void* p : e->allocs) (void)hipFree(p);
+  for (SideRing* r : {&e->rg_dh, &e->rg_glp, &e->rg_dqkv, &e->rg_dbr})
+    for (int i = 0; i < 3; ++i) if (r->rd[i]) (void)hipEventDestroy(r->rd[i]);
+  for (auto ev : e->side_events) (void)hipEventDestroy(ev);
+  if (e->side) (void)hipStreamDestroy(e->side);
   if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
   delete e;
 }
@@ -1630,6 +1777,7 @@ int engine_transformer_backward(vitx_engine* e, const float* dout_dev, float* dt
   HIPCHK(hipMemcpyAsync(e->g, dout_dev, bytes, hipMemcpyDeviceToDevice, e->stream));
   if (T) launch_convert(e->g, d, e->g_lp, 1, d, b * n, d, d, e->stream);
   int rc;
+  SideScope side_scope(e, true);
   for (int l = s0.depth - 1; l >= 0; --l)
     if ((rc = block_backward(e, s0, 0, l, b, n, 0, e->tf_drop, e->tf_seed, err)) != VITX_OK) return rc;
   if (dtokens_dev) HIPCHK(hipMemcpyAsync(dtokens_dev, e->g, bytes, hipMemcpyDeviceToDevice, e->stream));
@@ -1697,6 +1845,8 @@ int engine_backward(vitx_engine* e, const float* dlogits_dev, float* dimg_dev, s
   const int b = e->last_b, np = e->last_np, ntok = e->last_ntok, d = c.dim, T = e->bf16;
   const int nc = c.num_classes;
   const float drop = e->last_training ? c.dropout : 0.f;
+  // weight gradients of this pass on the side stream (not with the PatchMerger: its row-extent change re-zeroes K padding in place)
+  SideScope side_scope(e, !merging);
   {
     // every gradient tensor is overwritten by its producer; a full clear is only needed when part of the arena will not be
     // produced this step (pos_embedding rows beyond the image's tokens, blocks skipped by CaiT layer dropout)
@@ -1765,7 +1915,7 @@ int engine_backward(vitx_engine* e, const float* dlogits_dev, float* dimg_dev, s
       HIPCHK(hipMemcpy2DAsync(e->g + (int64_t)(ntok - 1) * d, (size_t)ntok * d * 4, d_distill_dev, (size_t)d * 4, (size_t)d * 4, b, hipMemcpyDeviceToDevice, e->stream));
     if (T) launch_convert(e->g, d, e->g_lp, 1, d, head_rows, d, d, e->stream);
   }
-  if (e->grad_cb) e->grad_cb(e->grad_cb_user, e->head_g, e->n_arena - e->head_g);
+  report_ready(e, e->head_g, e->n_arena - e->head_g);
 
   int rc;
   if (cait) {
@@ -1812,7 +1962,7 @@ int engine_backward(vitx_engine* e, const float* dlogits_dev, float* dimg_dev, s
       launch_fold_add(e->tmp_f32, e->pd, dimg_dev, b, e->last_H, e->last_W, c.channels, c.patch_h, c.patch_w, e->stream);
     }
   }
-  if (e->grad_cb) e->grad_cb(e->grad_cb_user, 0, e->stages[0].depth > 0 ? e->stages[0].bp[0].p_begin : e->head_g);
+  report_ready(e, 0, e->stages[0].depth > 0 ? e->stages[0].bp[0].p_begin : e->head_g);
   return VITX_OK;
 }
 
@@ -1837,7 +1987,7 @@ int engine_check_gemm(vitx_engine* e, int kind, int M, int N, int K, int kernel,
     const int64_t Mp = round_up(M, 1280), Np = round_up(N, 256);
     bf16_t *A, *B, *T1[2], *T2[2], *aux; float *F[2], *bias, *R, *cs[2];
     if (alloc((void**)&A, (size_t)Mp * K * 2) || alloc((void**)&B, (size_t)Np * K * 2) || alloc((void**)&bias, (size_t)Np * 4) || alloc((void**)&R, (size_t)Mp * Np * 4) ||
-        alloc((void**)&aux, (size_t)Mp * Np * 2) || alloc((void**)&cs[0], (size_t)(Mp / 256 + 8) * Np * 4) || alloc((void**)&cs[1], (size_t)Np * 4 * 64)) { cleanup(); err = "check_gemm: out of memory"; return VITX_ERR_HIP; }
+        alloc((void**)&aux, (size_t)Mp * Np * 2) || alloc((void**)&cs[0], (size_t)(Mp / 128 + 8) * Np * 4) || alloc((void**)&cs[1], (size_t)Np * 4 * 64)) { cleanup(); err = "check_gemm: out of memory"; return VITX_ERR_HIP; }
     for (int i = 0; i < 2; ++i)
       if (alloc((void**)&T1[i], (size_t)Mp * Np * 2) || alloc((void**)&T2[i], (size_t)Mp * Np * 2) || alloc((void**)&F[i], (size_t)Mp * Np * 4)) { cleanup(); err = "check_gemm: out of memory"; return VITX_ERR_HIP; }
     launch_fill_random_bf16(A, (int64_t)M * K, 11u, 1.0f, e->stream);          // rows >= M stay zero (row padding invariant)
@@ -1873,9 +2023,8 @@ int engine_check_gemm(vitx_engine* e, int kind, int M, int N, int K, int kernel,
     if (epilogue == 0 || epilogue == 1) launch_max_rel_diff(F[0], F[1], 0, M, N, Np, Np, dmax, e->stream);
     else launch_max_rel_diff(T1[0], T1[1], 1, M, N, Np, Np, dmax, e->stream);
     if (epilogue == 2) launch_max_rel_diff(T2[0], T2[1], 1, M, N, Np, Np, dmax + 1, e->stream);
-    if (epilogue == 4) {   // fused column sums (one partial row per M-tile of the launch) against the column sums of the reference output
-      const int tm = gemm_bf16_tile_m(g.kernel, M, N);
-      const int nt = (int)ceil_div(M, tm);
+    if (epilogue == 4) {   // fused column sums (one partial row per M-tile -- or per wave row of a tile -- of the launch; unwritten rows are zero)
+      const int nt = (int)ceil_div(M, 128);
       float* ws;
       if (alloc((void**)&ws, (size_t)std::max<int64_t>(colsum_ws_elems(N), (int64_t)nt * Np) * 4)) { cleanup(); err = "check_gemm: out of memory"; return VITX_ERR_HIP; }
       if (g.kernel == 0) { cleanup(); err = "check_gemm: epilogue 4 needs an explicit kernel variant (the column-sum rows follow its tile height)"; return VITX_ERR_INVALID; }
@@ -1927,7 +2076,7 @@ int engine_bench_gemm(vitx_engine* e, int M, int N, int K, int kernel, int epilo
   // bits 4..7 of `kernel` reach the kernels' `stagger` field, whose low bits double as timing-experiment switches (no DMA wait /
   // no DMA issue: WRONG results, faster launches).  A sweep that packs anything else into those bits measures the switch, not its
   // own parameter (profiles/r2/gemm_tile_band_README.txt), so they are refused unless the caller says it wants the experiment.
-  if (((kernel >> 4) & 7) && !getenv("VITX_GEMM_XP")) { err = "vitx_bench_gemm: kernel bits 4-5 are timing-experiment switches (results invalid); set VITX_GEMM_XP=1 to use them"; return VITX_ERR_INVALID; }
+  if (((kernel >> 4) & 7) && !getenv("VITX_GEMM_XP")) { err = "vitx_bench_gemm: kernel bits 4-6 are timing-experiment switches (results invalid); set VITX_GEMM_XP=1 to use them"; return VITX_ERR_INVALID; }
   const int64_t Mp = round_up(M, 1280), Np = round_up(N, 256);
   bf16_t *A, *B; float *C, *R, *bias; bf16_t* C2;
   HIPCHK(hipMalloc((void**)&A, (size_t)Mp * K * 2));

@@ -194,7 +194,13 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_kernel(Bf16GemmArgs
           float4 x[RPW];
 #pragma unroll
           for (int k = 0; k < RPW; ++k) x[k] = epilogue_fast_load<MODE, bf16_t>(ep, grow0 + (k * NW + wave) * RPIW, gcol);
-          if (has_bias) {
+          if (MODE == EPI_BIAS_RESID && has_scale) {   // LayerScale (cait.py:47-48): f(x) kept in out2, the branch scaled per column
+#pragma unroll
+            for (int k = 0; k < RPW; ++k) {
+              if (has_bias) epilogue_fast4<MODE, bf16_t, true, true>(ep, grow0 + (k * NW + wave) * RPIW, gcol, v[k], b4, s4, x[k], out_off);
+              else epilogue_fast4<MODE, bf16_t, false, true>(ep, grow0 + (k * NW + wave) * RPIW, gcol, v[k], b4, s4, x[k], out_off);
+            }
+          } else if (has_bias) {
 #pragma unroll
             for (int k = 0; k < RPW; ++k) cs_add(epilogue_fast4<MODE, bf16_t, true, false>(ep, grow0 + (k * NW + wave) * RPIW, gcol, v[k], b4, s4, x[k], out_off));
           } else {
@@ -305,11 +311,7 @@ void launch_mode(const Bf16GemmArgs& g, const EpiParams& ep, hipStream_t s) {
   const bool bf16_out = (MODE == EPI_STORE || MODE == EPI_BIAS_GELU || MODE == EPI_GELU_BWD);
   // (8-B per-lane pieces) are staged; with 32-row staging rounds (variants 5-8) staging wins for fp32 outputs too.
   const bool direct = (g.kernel & 256) ? true : ((g.kernel & 512) ? false : (!bf16_out && k < 5));
-  if (k == 12) {   // wave-group ping-pong kernel (gemm_bf16_pp.hip); problems it does not take go to the pipelined 256 x 256 kernel
-    if (launch_gemm_bf16_pp(g, ep, MODE, s)) return;
-    k = 14;
-  }
-  if (k == 4 || k == 8 || k == 9 || k == 10 || k == 11 || k == 13 || k == 14 || k == 15) { launch_gemm_bf16_pipe(k, MODE, g, ep, s); return; }   // gemm_bf16_pipe.hip
+  if (k == 9 || k == 11 || k == 12 || k == 13 || k == 14 || k == 15) { launch_gemm_bf16_pipe(k, MODE, g, ep, s); return; }   // gemm_bf16_pipe.hip
   if (direct) {
     if (k == 1) launch_variant<128, 128, 2, 2, MODE, false>(g, ep, s);
     else if (k == 3) launch_variant<256, 128, 4, 2, MODE, false>(g, ep, s);
@@ -343,12 +345,12 @@ int gemm_bf16_pick(int M, int N) {
 int gemm_bf16_tile_m(int kernel, int M, int N) {
   kernel &= 15;
   if (kernel == 0) kernel = gemm_bf16_pick(M, N);
-  return kernel == 1 ? 128 : ((kernel == 4 || kernel == 5 || kernel == 7 || kernel == 10 || kernel == 11 || kernel == 15) ? 320 : 256);
+  return kernel == 1 ? 128 : ((kernel == 5 || kernel == 7 || kernel == 11 || kernel == 15) ? 320 : 256);
 }
 int gemm_bf16_tile_n(int kernel, int M, int N) {
   kernel &= 15;
   if (kernel == 0) kernel = gemm_bf16_pick(M, N);
-  return (kernel == 1 || kernel == 3 || kernel == 12) ? 128 : 256;   // (12: the ping-pong kernel when it takes the problem; its fall-back is 256 wide)
+  return (kernel == 1 || kernel == 3) ? 128 : 256;
 }
 void gemm_bf16_allow_320(int on) { g_allow_320 = on; }
 void gemm_bf16_set_shared_gpu(int on) { g_shared_gpu = on; }
@@ -403,9 +405,7 @@ void launch_gemm_bf16(const Bf16GemmArgs& g0, const EpiParams& ep, int mode, hip
   }
   Bf16GemmArgs g = g0;
   if (best < 0) {
-    // (variant 12, the wave-group ping-pong kernel, is not a candidate: its 256 x 128 tile streams need 1.5x the operand bytes per FLOP and it measured
-    //  slower than the 256 x 256 kernels on every shape -- gemm_bf16_pp.hip, profiles/r3/pingpong_*; it stays callable and tested)
-    static const int cand[] = {6, 8, 9, 13, 14, 2, 7, 4, 10, 11, 15, 5, 3, 1};   // 256x256 variants first, then 320x256 (only when allowed), then small tiles
+    static const int cand[] = {12, 13, 9, 14, 6, 2, 11, 15, 7, 5, 3, 1};   // 256x256 variants first, then 320x256 (only when allowed), then small tiles
     // 256x128 / 128x128 tiles only compete when 256x256 tiles cannot give every CU two of them (token subsets: MAE's encoder
     // sees 49 of 196 patches, M = 12544 -> 147 tiles for a 768-wide output)
     const bool small_m = ceil_div(g0.M, 256) * ceil_div(g0.N, 256) < 512;
@@ -417,7 +417,7 @@ void launch_gemm_bf16(const Bf16GemmArgs& g0, const EpiParams& ep, int mode, hip
     float best_ms = 1e30f;
     best = gemm_bf16_pick(g0.M, g0.N);
     for (int c : cand) {
-      const bool is320 = c == 4 || c == 5 || c == 7 || c == 10 || c == 11 || c == 15;
+      const bool is320 = c == 5 || c == 7 || c == 11 || c == 15;
       if (is320 && !g_allow_320) continue;
       if ((c == 1 || c == 3) && !small_m) continue;
       if (g_shared_gpu && c != 2 && c != 5 && c != 1 && c != 3) continue;   // no persistent variants beside collectives (see gemm_bf16_set_shared_gpu)
@@ -440,6 +440,10 @@ void launch_gemm_bf16(const Bf16GemmArgs& g0, const EpiParams& ep, int mode, hip
     if (getenv("VITX_GEMM_AUTOTUNE_LOG"))
       fprintf(stderr, "[vitx] gemm autotune: mode %d M %d N %d K %d split %d -> variant %d (%.4f ms)\n", mode, g0.M, g0.N, g0.K, g0.split_k, best,
               best_ms);
+    // The candidates have different tile heights and each stores its per-tile column sums (EPI_GELU_BWD) with '=' into rows the caller
+    // zeroed ONCE: rows a taller-tiled winner does not write would keep what a shorter-tiled candidate left there, and the reduction behind
+    // the launch adds every row (the fc1 bias gradient of the first step of a process was wrong by that much).  Clear them again.
+    if (ep.colsum != nullptr) (void)hipMemsetAsync(ep.colsum, 0, (size_t)ceil_div(g0.M, 128) * ep.ldcs * sizeof(float), s);
     std::lock_guard<std::mutex> lk(g_tune_mu);
     g_tuned[key] = best;
   }

@@ -47,10 +47,7 @@ __device__ __forceinline__ void decode_tile_fwd(int L, int tiles_m, int tiles_n,
 
 }  // namespace
 
-// gemm_bf16_pipe.hip: the pipelined persistent NT kernel behind the variant numbers of launch_gemm_bf16 (4, 8, 9, 10, 11, 13, 14, 15)
+// gemm_bf16_pipe.hip: the pipelined persistent NT kernel behind the variant numbers of launch_gemm_bf16 (9, 12, 13, 14, 15)
 void launch_gemm_bf16_pipe(int variant, int mode, const Bf16GemmArgs& g, const EpiParams& ep, hipStream_t s);
 // gemm_bf16.hip: the persistent lockstep kernel (variants 6 / 7), the pipelined kernel's fall-back for operands beyond 2 GiB
 void launch_gemm_bf16_persistent_lockstep(int bm, int mode, const Bf16GemmArgs& g, const EpiParams& ep, hipStream_t s);
-// gemm_bf16_pp.hip: wave-group ping-pong kernel (variant 12); false = the problem is not eligible, nothing was launched
-bool gemm_bf16_pp_eligible(const Bf16GemmArgs& g, const EpiParams& ep, int mode);
-bool launch_gemm_bf16_pp(const Bf16GemmArgs& g, const EpiParams& ep, int mode, hipStream_t s);

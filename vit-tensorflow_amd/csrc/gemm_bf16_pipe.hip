@@ -13,7 +13,8 @@ namespace {
 //     front of the LAST k-step's MFMAs instead of between two tiles;
 //   * workgroups are persistent and their K-tile stream runs across output tiles (the next tile's first K-tile is in LDS before
 //     the epilogue of the current one starts).
-template <int BM, int BN, int WM, int WN, int MODE, int PAT>
+//   * WP (wave-private epilogue, 256-row tiles): see the epilogue section.
+template <int BM, int BN, int WM, int WN, int MODE, int PAT, bool WP>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_pipe_kernel(Bf16GemmArgs g, EpiParams ep, int tiles_m, int tiles_n,
                                                                          int kt_per_split) {
   constexpr int NW = WM * WN;
@@ -79,13 +80,6 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_pipe_kernel(Bf16Gem
     decode_tile(i_logical, tiles_m, tiles_n, gm, tm, tn);
     a_soff = (uint32_t)(((int64_t)tm * BM * g.lda + (int64_t)kt0 * BK) * 2);
     b_soff = (uint32_t)(((int64_t)tn * BN * g.ldb + (int64_t)kt0 * BK) * 2);
-    if constexpr (PAT == 5) {
-      // The uniformity analysis loses the cursor behind the wave-row-dependent barriers of this schedule and would hand the asm a VGPR.  Made
-      // scalar HERE, once per tile: a v_readfirstlane right in front of the piece is a VALU write of an SGPR that the buffer_load inside the
-      // asm reads as its scalar offset -- a 5-wait-state hazard the compiler cannot see (the pieces fetched from stale offsets).
-      a_soff = (uint32_t)__builtin_amdgcn_readfirstlane((int)a_soff);
-      b_soff = (uint32_t)__builtin_amdgcn_readfirstlane((int)b_soff);
-    }
   };
   i_set_tile();
   constexpr int P = A_INSTR + B_INSTR;   // DMA pieces (1 KiB each) per K-tile per wave
@@ -138,21 +132,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_pipe_kernel(Bf16Gem
 #pragma unroll
     for (int j = 0; j < NT; ++j) bfr[j] = *(const bf16x8*)(base + b_row_byte + j * 32 * 128 + cb);
   };
-  // one fragment of k-step `ks` (r-th in the order the next k-step's MFMAs first need them: b0, a0, b1, a1, a2, ...)
-  auto load_frag_one = [&](bf16x8(&af)[MT], bf16x8(&bfr)[NT], const char* base, int ks, auto r_c) {
-    constexpr int r = decltype(r_c)::value;
-    static_assert(NT == 2, "fragment order assumes two column fragments per wave");
-    const int cb = ((ks * 2 + khalf) ^ sw) << 4;
-    if constexpr (r == 0) bfr[0] = *(const bf16x8*)(base + b_row_byte + cb);
-    else if constexpr (r == 1) af[0] = *(const bf16x8*)(base + a_row_byte + cb);
-    else if constexpr (r == 2) bfr[1] = *(const bf16x8*)(base + b_row_byte + 32 * 128 + cb);
-    else af[r - 2] = *(const bf16x8*)(base + a_row_byte + (r - 2) * 32 * 128 + cb);
-  };
   constexpr int Q = MT * NT;             // MFMAs per k-step per wave
-  // PAT >= 3, the uniform schedule: every MFMA of the K loop is followed by AT MOST ONE memory instruction.  A wave's P pieces of the pending
-  // K-tile go behind every SP-th MFMA of the three k-steps after the hand-over, and the waves' slots are staggered (phase = wave % SP; the two
-  // waves of a SIMD, w and w + 4, always differ), so the CU's address unit sees ~one piece per 24 cycles instead of eight in the same cycle;
-  // PAT 4 also takes the next k-step's fragment reads one per MFMA (behind MFMAs 1 .. MT+NT) instead of as a block of six.
+  // PAT 3, the uniform schedule: a wave's P pieces of the pending K-tile go behind every SP-th MFMA of the three k-steps after the hand-over, and
+  // the waves' slots are staggered (phase = wave % SP; the two waves of a SIMD, w and w + 4, always differ), so the CU's address unit sees ~one
+  // piece per 24 cycles instead of eight in the same cycle.  (Measured and removed in round 4: fragment reads one per MFMA, and the two-barriers-
+  // per-k-step anti-phase schedule -- both within +-3 % of this one on every shape, profiles/r3/gemm_sweep_*.)
   // Measured on the previous schedule (8192^3, timing switches): 1284 TFLOP/s as built, 1570 without the pieces, 1452 without the fragment
   // reads, 1808 with neither -- the memory instructions cost by arriving in bursts from all eight waves at the same slots.
   constexpr int SP = (3 * Q) / P;
@@ -202,56 +186,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_pipe_kernel(Bf16Gem
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // PAT 5, the anti-phase schedule: every k-step is a MEMORY section (the next k-step's fragment reads + this section's share of the DMA
-    // pieces) and an MFMA section (the Q MFMAs of the k-step, nothing else), each closed by a workgroup barrier; the waves of the second wave
-    // row (4..7, the SIMD partners of 0..3) run ONE barrier behind, so that on every SIMD one wave is in its MFMA section while the other is in
-    // its memory section -- the matrix pipe never waits behind a wave's own memory instructions.  K-tile hand-over: vmcnt(0) lgkmcnt(0) at the end
-    // of the memory section of k-step 2 (the reads of k-step 3 were the last of the old buffer); the partner group passes that point one barrier
-    // later / earlier, and both the first reads of the new K-tile and the refill of the old buffer sit one full section behind it for either group.
-    if constexpr (PAT == 5) {
-      if (wm == 1) __builtin_amdgcn_s_barrier();
-    }
     for (int kt = 0; kt < nk; ++kt) {
       const char* base = smem + (it & 1) * STAGE;
-      if constexpr (PAT == 5) {
-        static_for<BK / 16>([&](auto ks_c) {
-          constexpr int ks = decltype(ks_c)::value, CUR = ks & 1;
-          constexpr int NP = ks == 3 ? N3 : (ks == 0 ? N0 : (ks == 1 ? N1 : 0));
-          constexpr int FP = ks == 3 ? 0 : (ks == 0 ? N3 : N3 + N0);
-          // ---- memory section
-          if constexpr (ks + 1 < BK / 16) {
-            if (!(xp & 4)) load_frags(fa[CUR ^ 1], fb[CUR ^ 1], base, ks + 1);
-          } else {
-            if (kt + 1 < nk && !(xp & 4)) load_frags(fa[0], fb[0], smem + ((it + 1) & 1) * STAGE, 0);
-            pending = i_more && kt + 1 < nk && !(xp & 2);
-          }
-          if constexpr (NP > 0) {
-            const uint32_t ibase = (issued & 1) * STAGE;
-            static_for<NP>([&](auto d_c) { if (pending) issue_piece(ibase, ic<FP + decltype(d_c)::value>{}); });
-            if constexpr (FP + NP == P) {
-              if (pending) i_advance();
-              pending = false;
-            }
-          }
-          if constexpr (ks == 2) {
-            if (xp & 1) __builtin_amdgcn_s_waitcnt(0xC07F);
-            else __builtin_amdgcn_s_waitcnt(0x0070);      // my pieces of K-tile it+1 have landed, my reads of buffer it&1 are in registers
-          }
-          __builtin_amdgcn_sched_barrier(0);
-          __builtin_amdgcn_s_barrier();
-          asm volatile("" ::: "memory");
-          // ---- MFMA section
-          __builtin_amdgcn_s_waitcnt(0xC07F);             // lgkmcnt(0): the fragments read one section ago
-          __builtin_amdgcn_s_setprio(1);
-          mfma_range(ic<CUR>{}, ic<0>{}, ic<Q>{});
-          __builtin_amdgcn_s_setprio(0);
-          __builtin_amdgcn_sched_barrier(0);
-          __builtin_amdgcn_s_barrier();
-          asm volatile("" ::: "memory");
-        });
-        ++it;
-        continue;
-      }
       if constexpr (PAT >= 3) {
         static_for<BK / 16>([&](auto ks_c) {
           constexpr int ks = decltype(ks_c)::value, CUR = ks & 1;
@@ -269,11 +205,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_pipe_kernel(Bf16Gem
           static_for<Q>([&](auto q_c) {
             constexpr int q = decltype(q_c)::value;
             mfma_range(ic<CUR>{}, ic<q>{}, ic<q + 1>{});
-            if constexpr (PAT == 3) {
-              if constexpr (q == 1) { if (reads && !(xp & 4)) load_frags(fa[CUR ^ 1], fb[CUR ^ 1], rbase, rks); }
-            } else if constexpr (q >= 1 && q - 1 < MT + NT) {
-              if (reads) load_frag_one(fa[CUR ^ 1], fb[CUR ^ 1], rbase, rks, ic<q - 1>{});
-            }
+            if constexpr (q == 1) { if (reads && !(xp & 4)) load_frags(fa[CUR ^ 1], fb[CUR ^ 1], rbase, rks); }
             if constexpr (ORD >= 0) {
               constexpr int u = ORD * Q + q;
               if constexpr (u / SP < P) { if (pending && phi == u % SP) issue_piece(ibase, ic<u / SP>{}); }
@@ -334,13 +266,215 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_pipe_kernel(Bf16Gem
       ++it;
     }
 
-    if constexpr (PAT == 5) {
-      if (wm == 0) __builtin_amdgcn_s_barrier();   // the first wave row waits for the second one's last MFMA section
-    }
     // ---- epilogue: 32 output rows per round through the buffer of the last K-tile (its refill is deferred until after the epilogue)
     stamp(1);
+    bool wp_done = false;   // this tile went out through the wave-private epilogue (no workgroup barrier before the refill)
     {
       const bool interior = epilogue_fast_ok(ep, MODE) && (tile_m + 1) * BM <= ep.M && (tile_n + 1) * BN <= ep.N;
+      // ---- WP, the wave-private epilogue (interior tiles of the four fused epilogues of the Dense layers).
+      // Each wave drains its OWN 128 x 64 accumulator tile through its OWN 8 KiB of the free pipeline buffer -- the two 4-KiB areas its own DMA
+      // pieces of the next refill land in (A rows 32 w .. 32 w + 31, B rows likewise) -- 32 rows at a time: accumulator layout in (a lane holds 4
+      // columns of one row), row-contiguous layout out (bf16 outputs: 8 lanes x 16 B = one full 128-B line per row, 8 rows per store instruction;
+      // fp32 outputs: 16 lanes x 16 B = 256 B per row, 4 rows per instruction).  LDS executes a wave's instructions in order, so the write-read
+      // round trip needs no wait and NO workgroup barrier: the eight waves drift apart, one wave's LDS round trip / GELU arithmetic runs under
+      // another wave's global loads and stores instead of all eight marching through eight write-barrier-read-store rounds in lock-step, and a
+      // wave that is done refills its slice and starts the next tile's first K-tile (already in LDS) without waiting for the others (the next
+      // workgroup barrier is that K-tile's hand-over).  Nobody else reads a wave's slice after the hand-over barrier of the last K-tile, and
+      // nobody else writes it before the refill the wave issues itself.
+      //   bf16 staging (plain store, GELU): a 32 x 64 block is 4 KiB -- area 0 / area 1 alternate (GELU: gelu' in area 0, gelu in area 1).
+      //   fp32 staging (residual, GELU VJP): columns 0..31 in area 0, 32..63 in area 1 with rows and chunk parity flipped (row ^ 1, chunk ^ 1) so that
+      //   the 16 lanes of a row-contiguous read hit 64 different banks; 16-B chunks are XOR-swizzled with (row >> 1) & 7 in both layouts.
+      if constexpr (WP && (MODE == EPI_STORE || MODE == EPI_BIAS_GELU || MODE == EPI_BIAS_RESID || MODE == EPI_GELU_BWD)) {
+        static_assert(!WP || ((BM == 256 || BM == 320) && A_INSTR >= 4 && B_INSTR == 4 && WTN == 64 && MT * 32 == WTM && NT == 2), "wave-private epilogue: 256 / 320 x 256 tiles, 2 x 4 waves");
+        const bool wp_ok = interior && (MODE == EPI_BIAS_RESID || ep.wide_ok) && !(MODE == EPI_STORE && has_bias);
+        if (wp_ok) {
+          wp_done = true;
+          char* const sa = smem + ((it + 1) & 1) * STAGE + wave * (A_INSTR * 1024);
+          char* const sb = smem + ((it + 1) & 1) * STAGE + A_BYTES + wave * (B_INSTR * 1024);
+          // every per-lane address below derives from `le`, a copy of the lane index the optimiser cannot see through: as loop invariants of
+          // the persistent tile loop they were hoisted in front of it and kept live across the K loop (78-107 registers spilled to scratch)
+          int le = lane;
+          asm volatile("" : "+v"(le));
+          const int m = le & 31, swm = (m >> 1) & 7, kh = le >> 5;
+          const int row_w = tile_m * BM + wm * WTM, col_w = tile_n * BN + wn * WTN;
+          auto to_bf16x4 = [](float a, float b, float c, float d) { bf16x4 o; o[0] = (bf16_t)a; o[1] = (bf16_t)b; o[2] = (bf16_t)c; o[3] = (bf16_t)d; return o; };
+          // fp32 staging of accumulator block i0 (32 rows x 64 columns)
+          auto stage_f32 = [&](auto i_c) {
+            constexpr int i0 = decltype(i_c)::value;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int ch = 2 * q + kh;
+              *(float4*)(sa + m * 128 + ((ch ^ swm) << 4)) = make_float4(acc[i0][0][4 * q], acc[i0][0][4 * q + 1], acc[i0][0][4 * q + 2], acc[i0][0][4 * q + 3]);
+              *(float4*)(sb + (m ^ 1) * 128 + ((ch ^ swm ^ 1) << 4)) = make_float4(acc[i0][1][4 * q], acc[i0][1][4 * q + 1], acc[i0][1][4 * q + 2], acc[i0][1][4 * q + 3]);
+            }
+          };
+          if constexpr (MODE == EPI_STORE) {
+            bf16_t* const outp = (bf16_t*)ep.out + out_off + (int64_t)row_w * ep.ldo + col_w;
+            const uint32_t ldo = (uint32_t)ep.ldo, ooff = (uint32_t)(le >> 3) * ldo + (uint32_t)(le & 7) * 8u;
+            auto run = [&](auto nt_c) {
+              constexpr bool NTS = decltype(nt_c)::value;
+              static_for<MT>([&](auto i_c) {
+                constexpr int i0 = decltype(i_c)::value;
+                char* const ar = (i0 & 1) ? sb : sa;
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+#pragma unroll
+                  for (int q = 0; q < 4; ++q)
+                    *(bf16x4*)(ar + m * 128 + (((j * 4 + q) ^ swm) << 4) + kh * 8) =
+                        to_bf16x4(acc[i0][j][4 * q], acc[i0][j][4 * q + 1], acc[i0][j][4 * q + 2], acc[i0][j][4 * q + 3]);
+                bf16x8 v[4];   // all four row groups are read before the first store: one LDS latency per block, not four in series
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                  const int r = k * 8 + (le >> 3);
+                  v[k] = *(const bf16x8*)(ar + r * 128 + (((le & 7) ^ ((r >> 1) & 7)) << 4));
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                  bf16x8* dst = (bf16x8*)(outp + (ooff + (uint32_t)(i0 * 32 + k * 8) * ldo));
+                  if constexpr (NTS) __builtin_nontemporal_store(v[k], dst);
+                  else *dst = v[k];
+                }
+              });
+            };
+            if (ep.nt_out) run(std::true_type{});
+            else run(std::false_type{});
+          } else if constexpr (MODE == EPI_BIAS_GELU) {
+            float4 bz[NT][4];
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+              for (int q = 0; q < 4; ++q)
+                bz[j][q] = has_bias ? *(const float4*)(ep.bias + col_w + j * 32 + 8 * q + 4 * kh) : make_float4(0.f, 0.f, 0.f, 0.f);
+            bf16_t* const o1 = (bf16_t*)ep.out + (int64_t)row_w * ep.ldo + col_w;
+            bf16_t* const o2 = (bf16_t*)ep.out2 + (int64_t)row_w * ep.ldo2 + col_w;
+            const uint32_t ldo = (uint32_t)ep.ldo, ldo2 = (uint32_t)ep.ldo2;
+            const uint32_t o1off = (uint32_t)(le >> 3) * ldo + (uint32_t)(le & 7) * 8u, o2off = (uint32_t)(le >> 3) * ldo2 + (uint32_t)(le & 7) * 8u;
+            auto run = [&](auto nt_c) {
+              constexpr bool NTS = decltype(nt_c)::value;
+              static_for<MT>([&](auto i_c) {
+                constexpr int i0 = decltype(i_c)::value;
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+#pragma unroll
+                  for (int q = 0; q < 4; ++q) {
+                    // GELU and its derivative of the pre-activation as bf16 would store it (same arithmetic as epilogue_wide8)
+                    const bf16x4 h = to_bf16x4(acc[i0][j][4 * q] + bz[j][q].x, acc[i0][j][4 * q + 1] + bz[j][q].y, acc[i0][j][4 * q + 2] + bz[j][q].z,
+                                               acc[i0][j][4 * q + 3] + bz[j][q].w);
+                    float4 g, gd;
+                    gelu_both4(make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]), g, gd);
+                    const int off = m * 128 + (((j * 4 + q) ^ swm) << 4) + kh * 8;
+                    *(bf16x4*)(sa + off) = to_bf16x4(gd.x, gd.y, gd.z, gd.w);
+                    *(bf16x4*)(sb + off) = to_bf16x4(g.x, g.y, g.z, g.w);
+                  }
+                bf16x8 vd[4], vg[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                  const int r = k * 8 + (le >> 3);
+                  const int off = r * 128 + (((le & 7) ^ ((r >> 1) & 7)) << 4);
+                  vd[k] = *(const bf16x8*)(sa + off);
+                  vg[k] = *(const bf16x8*)(sb + off);
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                  bf16x8* d1 = (bf16x8*)(o1 + (o1off + (uint32_t)(i0 * 32 + k * 8) * ldo));
+                  if constexpr (NTS) __builtin_nontemporal_store(vd[k], d1);
+                  else *d1 = vd[k];
+                  *(bf16x8*)(o2 + (o2off + (uint32_t)(i0 * 32 + k * 8) * ldo2)) = vg[k];
+                }
+              });
+            };
+            if (ep.nt_out) run(std::true_type{});
+            else run(std::false_type{});
+          } else if constexpr (MODE == EPI_BIAS_RESID) {
+            // out[f32] = resid + (acc + bias) [* scale]; LayerScale (cait.py:47-48) also keeps f = acc + bias in out2 (epilogue_fast4's arithmetic).
+            // Addresses: wave-uniform 64-bit bases + 32-bit lane offsets (a 64-bit multiply per row and lane cost the registers the rows need)
+            const int c16 = le & 15, ar1 = c16 >> 3;
+            const uint32_t lr = (uint32_t)(le >> 4), lc = (uint32_t)c16 * 4u;
+            const float4 bb = has_bias ? *(const float4*)(ep.bias + col_w + lc) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 ss = has_scale ? *(const float4*)(ep.scale + col_w + lc) : make_float4(1.f, 1.f, 1.f, 1.f);
+            const char* const rb = ar1 ? sb : sa;
+            const float* const rp = ep.resid + (int64_t)row_w * ep.ldr + col_w;
+            float* const op = (float*)ep.out + (int64_t)row_w * ep.ldo + col_w;
+            bf16_t* const o2 = (has_scale && ep.out2) ? (bf16_t*)ep.out2 + (int64_t)row_w * ep.ldo2 + col_w : nullptr;
+            const uint32_t ldr = (uint32_t)ep.ldr, ldo = (uint32_t)ep.ldo, ldo2 = (uint32_t)ep.ldo2;
+            const uint32_t roff = lr * ldr + lc, ooff = lr * ldo + lc, o2off = lr * ldo2 + lc;
+            static_for<MT>([&](auto i_c) {
+              constexpr int i0 = decltype(i_c)::value;
+              // two halves of 16 rows: the residual rows of the second half are in flight while the first half is added and stored
+              float4 x0[4], x1[4], v[4];
+#pragma unroll
+              for (int k = 0; k < 4; ++k) x0[k] = *(const float4*)(rp + (roff + (uint32_t)(i0 * 32 + k * 4) * ldr));
+              stage_f32(i_c);
+#pragma unroll
+              for (int k = 0; k < 4; ++k) x1[k] = *(const float4*)(rp + (roff + (uint32_t)(i0 * 32 + 16 + k * 4) * ldr));
+#pragma unroll
+              for (int hf = 0; hf < 2; ++hf) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                  const int r = hf * 16 + k * 4 + (int)lr;
+                  v[k] = *(const float4*)(rb + (r ^ ar1) * 128 + ((((c16 & 7) ^ ((r >> 1) & 7)) ^ ar1) << 4));
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                  const uint32_t rr = (uint32_t)(i0 * 32 + hf * 16 + k * 4);
+                  float4 f = make_float4(v[k].x + bb.x, v[k].y + bb.y, v[k].z + bb.z, v[k].w + bb.w);
+                  if (o2) st4<bf16_t>(o2 + (o2off + rr * ldo2), f);
+                  const float4 x = hf ? x1[k] : x0[k];
+                  *(float4*)(op + (ooff + rr * ldo)) = make_float4(x.x + f.x * ss.x, x.y + f.y * ss.y, x.z + f.z * ss.z, x.w + f.w * ss.w);
+                }
+              }
+            });
+          } else {   // EPI_GELU_BWD: out[bf16] = acc * stored gelu'(h), column sums of what was stored (epilogue_wide8's arithmetic)
+            const int c8 = le & 7, ar1 = c8 >> 2, ch0 = (c8 & 3) * 2;
+            const uint32_t lr = (uint32_t)(le >> 3), lc = (uint32_t)c8 * 8u;
+            const char* const rb = ar1 ? sb : sa;
+            const bf16_t* const xp = (const bf16_t*)ep.aux + (int64_t)row_w * ep.ldaux + col_w;
+            bf16_t* const op = (bf16_t*)ep.out + (int64_t)row_w * ep.ldo + col_w;
+            const uint32_t ldx = (uint32_t)ep.ldaux, ldo = (uint32_t)ep.ldo;
+            const uint32_t xoff = lr * ldx + lc, ooff = lr * ldo + lc;
+            const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 cs = z4, cs2 = z4;   // column sums of what this lane stores (columns col_w + lc .. + 7 over the wave's 128 rows)
+            static_for<MT>([&](auto i_c) {
+              constexpr int i0 = decltype(i_c)::value;
+              bf16x8 x[4];
+#pragma unroll
+              for (int k = 0; k < 4; ++k) x[k] = *(const bf16x8*)(xp + (xoff + (uint32_t)(i0 * 32 + k * 8) * ldx));
+              stage_f32(i_c);
+              float4 va[4], vb[4];
+#pragma unroll
+              for (int k = 0; k < 4; ++k) {
+                const int r = k * 8 + (int)lr;
+                const char* rowp = rb + (r ^ ar1) * 128;
+                const int swr = ((r >> 1) & 7) ^ ar1;
+                va[k] = *(const float4*)(rowp + ((ch0 ^ swr) << 4));
+                vb[k] = *(const float4*)(rowp + (((ch0 + 1) ^ swr) << 4));
+              }
+#pragma unroll
+              for (int k = 0; k < 4; ++k) {
+                const float4 a = va[k], b = vb[k];
+                const bf16x8 o = pack_bf16x8(make_float4(a.x * (float)x[k][0], a.y * (float)x[k][1], a.z * (float)x[k][2], a.w * (float)x[k][3]),
+                                             make_float4(b.x * (float)x[k][4], b.y * (float)x[k][5], b.z * (float)x[k][6], b.w * (float)x[k][7]));
+                *(bf16x8*)(op + (ooff + (uint32_t)(i0 * 32 + k * 8) * ldo)) = o;
+                cs.x += (float)o[0]; cs.y += (float)o[1]; cs.z += (float)o[2]; cs.w += (float)o[3];       // as stored (rounded to bf16)
+                cs2.x += (float)o[4]; cs2.y += (float)o[5]; cs2.z += (float)o[6]; cs2.w += (float)o[7];
+              }
+            });
+            if (ep.colsum != nullptr) {
+              // the 8 lanes with the same le & 7 hold the same columns for different rows: fixed-order butterfly over lane bits 3, 4, 5; the wave's
+              // partial row goes to colsum row 2 tile_m + wm (the reduction pass behind the launch adds the rows in order)
+              auto red = [&](float v) { v += __shfl_xor(v, 8); v += __shfl_xor(v, 16); v += __shfl_xor(v, 32); return v; };
+              cs.x = red(cs.x); cs.y = red(cs.y); cs.z = red(cs.z); cs.w = red(cs.w);
+              cs2.x = red(cs2.x); cs2.y = red(cs2.y); cs2.z = red(cs2.z); cs2.w = red(cs2.w);
+              if (le < 8) {
+                float* crow = ep.colsum + (int64_t)(tile_m * 2 + wm) * ep.ldcs + col_w + lc;
+                *(float4*)crow = cs;
+                *(float4*)(crow + 4) = cs2;
+              }
+            }
+          }
+        }
+      }
+      if (!wp_done) {
       float* st = (float*)(smem + ((it + 1) & 1) * STAGE);
       const int gcol = tile_n * BN + lane * 4;
       float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f), s4 = make_float4(1.f, 1.f, 1.f, 1.f);
@@ -438,7 +572,13 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_pipe_kernel(Bf16Gem
           float4 x[RPW];
 #pragma unroll
           for (int k = 0; k < RPW; ++k) x[k] = epilogue_fast_load<MODE, bf16_t>(ep, grow0 + k * NW + wave, gcol);
-          if (has_bias) {
+          if (MODE == EPI_BIAS_RESID && has_scale) {   // LayerScale (cait.py:47-48): f(x) kept in out2, the branch scaled per column
+#pragma unroll
+            for (int k = 0; k < RPW; ++k) {
+              if (has_bias) epilogue_fast4<MODE, bf16_t, true, true>(ep, grow0 + k * NW + wave, gcol, v[k], b4, s4, x[k], out_off);
+              else epilogue_fast4<MODE, bf16_t, false, true>(ep, grow0 + k * NW + wave, gcol, v[k], b4, s4, x[k], out_off);
+            }
+          } else if (has_bias) {
 #pragma unroll
             for (int k = 0; k < RPW; ++k) cs_add(epilogue_fast4<MODE, bf16_t, true, false>(ep, grow0 + k * NW + wave, gcol, v[k], b4, s4, x[k], out_off));
           } else {
@@ -471,9 +611,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_pipe_kernel(Bf16Gem
           float a = 0.f;
           for (int w = 0; w < nrows; ++w) a += st[w * BN + tid];
           const int c = tile_n * BN + tid;
-          if (c < ep.N) ep.colsum[(int64_t)tile_m * ep.ldcs + c] = a;
+          if (c < ep.N) ep.colsum[(int64_t)(WP ? 2 * tile_m : tile_m) * ep.ldcs + c] = a;   // (WP: one colsum row per WAVE row, see above)
         }
       }
+      }   // !wp_done
     }
     stamp(2);
     // (every path out of the epilogue has waited for its loads -- see S_WIDE / S_NARROW above; the structurizer routes the `break` through the
@@ -481,7 +622,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_pipe_kernel(Bf16Gem
     if (!has_next) break;
     // staging reads done everywhere (no DMA piece is in flight here: the refill is issued below, the prefetched K-tile landed before the epilogue)
     __builtin_amdgcn_s_waitcnt(0xC07F);           // lgkmcnt(0)
-    __builtin_amdgcn_s_barrier();
+    if (!wp_done) __builtin_amdgcn_s_barrier();   // (wave-private epilogue: a wave's staging slice is the target of its OWN refill pieces only)
     asm volatile("" ::: "memory");
     issue();                                      // deferred refill of the staging buffer: stream item it+1
     load_frags(fa[0], fb[0], smem + (it & 1) * STAGE, 0);
@@ -489,7 +630,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_pipe_kernel(Bf16Gem
   }
 }
 
-template <int BM, int BN, int WM, int WN, int MODE, int PAT = 0>
+template <int BM, int BN, int WM, int WN, int MODE, int PAT = 0, bool WP = false>
 void launch_pipe(const Bf16GemmArgs& g, const EpiParams& ep, hipStream_t s) {
   constexpr int SMEM = 2 * (BM + BN) * BK * 2;
   // buffer-addressed DMA: 31-bit byte offsets inside each operand; larger operands take the flat-addressed persistent kernel
@@ -497,7 +638,7 @@ void launch_pipe(const Bf16GemmArgs& g, const EpiParams& ep, hipStream_t s) {
     launch_gemm_bf16_persistent_lockstep(BM, MODE, g, ep, s);
     return;
   }
-  auto kern = gemm_bf16_nt_pipe_kernel<BM, BN, WM, WN, MODE, PAT>;
+  auto kern = gemm_bf16_nt_pipe_kernel<BM, BN, WM, WN, MODE, PAT, WP>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
@@ -520,14 +661,12 @@ void launch_pipe(const Bf16GemmArgs& g, const EpiParams& ep, hipStream_t s) {
 template <int MODE>
 void pipe_mode(int variant, const Bf16GemmArgs& g, const EpiParams& ep, hipStream_t s) {
   switch (variant) {
-    case 13: launch_pipe<256, 256, 2, 4, MODE, 4>(g, ep, s); break;   // uniform schedule, fragment reads one per MFMA
-    case 11: launch_pipe<320, 256, 2, 4, MODE, 4>(g, ep, s); break;
+    case 12: launch_pipe<256, 256, 2, 4, MODE, 3, true>(g, ep, s); break;   // variant 9's K loop + the wave-private epilogue
+    case 13: launch_pipe<256, 256, 2, 4, MODE, 2, true>(g, ep, s); break;   // variant 14's K loop + the wave-private epilogue
+    case 11: launch_pipe<320, 256, 2, 4, MODE, 2, true>(g, ep, s); break;   // variant 15's K loop + the wave-private epilogue
     case 14: launch_pipe<256, 256, 2, 4, MODE, 2>(g, ep, s); break;   // pieces behind MFMAs 2..4 of three k-steps, all waves at once
     case 15: launch_pipe<320, 256, 2, 4, MODE, 2>(g, ep, s); break;
-    case 10: launch_pipe<320, 256, 2, 4, MODE, 3>(g, ep, s); break;   // uniform schedule for the pieces, fragment reads as a block
-    case 8: launch_pipe<256, 256, 2, 4, MODE, 5>(g, ep, s); break;    // anti-phase schedule (memory / MFMA sections, wave rows one barrier apart)
-    case 4: launch_pipe<320, 256, 2, 4, MODE, 5>(g, ep, s); break;
-    default: launch_pipe<256, 256, 2, 4, MODE, 3>(g, ep, s); break;   // 9
+    default: launch_pipe<256, 256, 2, 4, MODE, 3>(g, ep, s); break;   // 9: uniform schedule for the pieces, fragment reads as a block
   }
 }
 

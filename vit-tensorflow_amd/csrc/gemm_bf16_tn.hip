@@ -274,6 +274,15 @@ void launch_gemm_bf16_tn(const Bf16GemmArgs& g0, const EpiParams& ep, hipStream_
   }();
   Bf16GemmArgs g = g0;
   g.stagger = xp;
+  {   // K slices are addressed through a buffer resource with 31-bit offsets (dense_wgrad picks the slice count accordingly): never launch beyond it
+    const int nk = g.K / BK, split = g.split_k > 1 ? g.split_k : 1;
+    const int64_t slice_rows = ceil_div(nk, split) * BK;
+    if ((slice_rows * std::max(g.lda, g.ldb) + 256) * 2 >= (1LL << 31)) {
+      fprintf(stderr, "[vitx] launch_gemm_bf16_tn: a K slice of %lld rows x %lld features exceeds the 2 GiB buffer range -- more slices needed\n",
+              (long long)slice_rows, (long long)std::max(g.lda, g.ldb));
+      abort();
+    }
+  }
   static const int sched = [] { const char* v = getenv("VITX_TN_SCHED"); return v ? atoi(v) : 0; }();   // 1 = anti-phase sections (A/B switch)
   if (gemm_bf16_tn_tile(g.kernel, g.M, g.N) == 128) launch_tn_variant<128, 2, 2>(g, ep, s);
   else if (sched == 1) launch_tn_variant<256, 2, 4, 1>(g, ep, s);

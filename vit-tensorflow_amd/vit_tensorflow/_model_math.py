@@ -38,7 +38,7 @@ def kernel_source_id() -> str:
     profile taken on other GEMM sources.  Changes to other kernels (attention, LayerNorm, the DeepViT / CaiT paths) do not move it."""
     h = hashlib.sha1()
     root = os.path.join(_HERE, "..", "csrc")
-    files = [os.path.join(root, f) for f in ("common.h", "epilogue.h", "gemm_bf16_common.h", "gemm_bf16.hip", "gemm_bf16_pipe.hip", "gemm_bf16_tn.hip")]
+    files = [os.path.join(root, f) for f in ("common.h", "epilogue.h", "gemm_bf16_common.h", "gemm_bf16.hip", "gemm_bf16_pipe.hip", "gemm_bf16_tn.hip", "gemm_bf16x3.hip")]
     for f in files:
         with open(f, "rb") as fh:
             h.update(os.path.basename(f).encode() + b"\0" + fh.read())
