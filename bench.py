@@ -51,10 +51,11 @@ def flops_per_image(kw) -> float:
     return f(kw.pop("variant", "vit"), **kw)
 
 
-def cpu_baseline(kw, seconds: float, batch: int = 32):
+def cpu_baseline(kw, seconds: float, batch: int = 16):
     """Reference-restatement CPU baseline (torch-CPU fp32, NOT TensorFlow: TF is absent from the image): the oracle's op-for-op
-    restatement of vit.py, forward + autograd backward, batch 32, on the thread count that measures fastest on this host
-    (torch-CPU with hundreds of threads on a shared host oversubscribes badly; 16 / 32 / 64 are tried for one step each)."""
+    restatement of vit.py, forward + autograd backward, batch 16, on the thread count that measures fastest on this host
+    (torch-CPU with hundreds of threads on a shared host oversubscribes badly; 16 / 32 / 64 are tried for one step each), then
+    AT LEAST FIVE timed steps (more until the time budget is used)."""
     from oracle import ref_torch, spec
     cfg = spec.make_config("vit", **kw)
     try:
@@ -89,7 +90,7 @@ def cpu_baseline(kw, seconds: float, batch: int = 32):
         step()
         n += 1
         el = time.perf_counter() - t0
-        if el >= budget or n >= 50:
+        if (el >= budget and n >= 5) or n >= 50:
             break
     return {"value": round(batch * n / el, 3), "unit": "images/sec", "cores": ncores, "host_cpus": avail, "kind": "port",
             "threads_tried_s_per_step": {str(k): round(v, 2) for k, v in tried.items()},

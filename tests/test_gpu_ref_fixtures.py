@@ -360,3 +360,32 @@ def test_bf16_engine_matches_reference_source_small(case):
     for n, _, _ in spec.param_spec(cfg):
         gate(rel_max_err(grads[n], z["grad/" + n]), gtol, n, f"{module} gradients")
     gate(rel_max_err(dimg, z["dimg"]), gtol, "dimg", f"{module} gradients")
+
+
+def test_bf16x3_fused_attention_agrees_with_the_materialised_split_operand_path(monkeypatch):
+    """BF16X3 mode, ViT attention (vit.py:73-82): the fused split-operand kernel (attn_x3.hip: scores never leave the chip) against the same
+    mode with materialised scores (VITX_X3_ATTN=2: batched split-operand GEMMs + a softmax pass), token counts on both sides of every key-tile
+    boundary the kernel is instantiated for (65, 197, 257) and a ragged one (50).  Both are fp32-accurate to ~1e-5; gate 2e-4 of each tensor's max."""
+    from util import CONFIGS
+    for tag, kw, b in [("n65", dict(image_size=64, patch_size=8, num_classes=10, dim=128, depth=2, heads=2, mlp_dim=256), 3),
+                       ("n197", dict(image_size=224, patch_size=16, num_classes=10, dim=128, depth=2, heads=2, mlp_dim=256), 2),
+                       ("n257", dict(image_size=256, patch_size=16, num_classes=10, dim=192, depth=1, heads=3, mlp_dim=256), 2),
+                       ("n50", dict(image_size=(56, 56), patch_size=8, num_classes=10, dim=64, depth=2, heads=1, mlp_dim=128), 3)]:
+        name = "x3_attn_" + tag
+        CONFIGS[name] = ("vit", kw)
+        cfg = oracle_cfg(name)
+        P = spec.init_params(cfg, seed=9, randomize_all=True)
+        img = rand_images(cfg, b, 3)
+        dl = (np.random.default_rng(4).standard_normal((b, cfg["num_classes"])) / b).astype(np.float32)
+        res = {}
+        for mode in ("2", "1"):
+            monkeypatch.setenv("VITX_X3_ATTN", mode)
+            m = make_engine_model(name, "bf16x3", b, P)
+            logits = m(img, training=True)
+            grads, dimg = m.backward(dl, want_dimg=True)
+            res[mode] = (logits, grads, dimg)
+        (l2, g2, d2), (l1, g1, d1) = res["2"], res["1"]
+        gate(float(np.abs(l1 - l2).max()), 2e-4, f"{tag} logits fused vs materialised", "x3_fused_attn")
+        for k in g2:
+            gate(float(np.abs(g1[k] - g2[k]).max()) / (float(np.abs(g2[k]).max()) + 1e-30), 2e-4, f"{tag} grad {k}", "x3_fused_attn")
+        gate(float(np.abs(d1 - d2).max()) / (float(np.abs(d2).max()) + 1e-30), 2e-4, f"{tag} d(img)", "x3_fused_attn")

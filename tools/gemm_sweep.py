@@ -29,7 +29,7 @@ def main():
     which = sys.argv[1] if len(sys.argv) > 1 else "vitb"
     iters = int(sys.argv[2]) if len(sys.argv) > 2 else 10
     xp = len(sys.argv) > 3 and sys.argv[3] == "xp"
-    variants = [int(v) for v in os.environ.get("VITX_SWEEP_VARIANTS", "13,14,15,6,7").split(",")]
+    variants = [int(v) for v in os.environ.get("VITX_SWEEP_VARIANTS", "13,11,6,7").split(",")]
     m = make_engine_model("vit_bf16_small", "bf16", 1)
     m.build((1,))
     avg, err = C.c_float(), C.c_float()

@@ -1,0 +1,309 @@
+// Fused multi-head self-attention for the BF16X3 mode (vit.py:73-82: split -> QK^T*scale -> softmax -> AV -> merge heads) and its VJP:
+// fp32 storage, every matrix product as THREE bf16 MFMA products of split operands (x = hi + lo, x y ~ hi hi + hi lo + lo hi; the dropped
+// lo lo term is 2^-16 of the product), fp32 accumulation and fp32 softmax.  The [b,h,n,n] score matrix is never written to HBM -- before this
+// kernel the two 1e-3 modes materialised it (477 MB of fp32 scores per layer at ViT-B/16 batch 256, written and re-read; 31 % of the step).
+//
+// Same mapping as attn_bf16.hip (one workgroup per (image, head); K, V -- then Q, dO in the second backward phase -- as swizzled row-major LDS
+// images read as row fragments or through the hardware transpose; scores computed transposed so a lane owns a query column; P recomputed from
+// the saved row LSE in the backward), with two differences: every LDS image exists as a hi PLANE and a lo PLANE (the split is done once, when
+// the head is staged: global fp32 -> registers -> split -> LDS; no direct-to-LDS DMA because the data is converted on the way), and the
+// probabilities / score gradients are split in registers before they become MFMA operands.
+//   layout: packed qkv [b, n, 3, h, 64] fp32 exactly as the to_qkv Dense emits it, output o [b, n, h*64] fp32 (vit.py:82).
+#include "kernels.h"
+#include "attn_lds.h"
+
+namespace {
+
+using namespace attn_lds;
+
+constexpr int X3_THREADS = 512;   // 8 waves share one head's LDS images
+
+struct P2 { bf16x8 hi, lo; };     // a split MFMA operand
+
+__device__ __forceinline__ P2 split8(const f32x4& a, const f32x4& b) {
+  P2 r;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const bf16_t h0 = (bf16_t)a[e], h1 = (bf16_t)b[e];
+    r.hi[e] = h0; r.hi[4 + e] = h1;
+    r.lo[e] = (bf16_t)(a[e] - (float)h0); r.lo[4 + e] = (bf16_t)(b[e] - (float)h1);
+  }
+  return r;
+}
+__device__ __forceinline__ P2 load_split8(const float* p) {   // 8 consecutive floats (32-B aligned)
+  const f32x4 a = *(const f32x4*)p, b = *(const f32x4*)(p + 4);
+  return split8(a, b);
+}
+// c += a b with the small cross terms first
+__device__ __forceinline__ f32x4 mfma3(const P2& a, const P2& b, f32x4 c) {
+  c = mfma16(a.lo, b.hi, c);
+  c = mfma16(a.hi, b.lo, c);
+  return mfma16(a.hi, b.hi, c);
+}
+// rows [0, npad) of a [*, 64] fp32 matrix (row stride `stride` elements) -> hi / lo swizzled row-major LDS images; rows >= nvalid are zero
+__device__ __forceinline__ void stage_head_x3(const float* src, int64_t stride, int nvalid, int npad, char* hi, char* lo, int tid, int nthreads) {
+  for (int idx = tid; idx < npad * 8; idx += nthreads) {
+    const int row = idx >> 3, c = idx & 7;
+    P2 v;
+    if (row < nvalid) v = load_split8(src + (int64_t)row * stride + c * 8);
+    else { v.hi = zero8(); v.lo = zero8(); }
+    const int off = row * ROWB + swz_chunk(row, c);
+    *(bf16x8*)(hi + off) = v.hi;
+    *(bf16x8*)(lo + off) = v.lo;
+  }
+}
+__device__ __forceinline__ P2 frag_rm2(const char* hi, const char* lo, int row, int chunk) {
+  P2 r;
+  r.hi = frag_rm(hi, row, chunk);
+  r.lo = frag_rm(lo, row, chunk);
+  return r;
+}
+__device__ __forceinline__ P2 frag_trr2(const char* hi, const char* lo, int c, int u, int lane) {
+  P2 r;
+  r.hi = frag_trr(hi, c, u, lane);
+  r.lo = frag_trr(lo, c, u, lane);
+  return r;
+}
+
+// ------------------------------------------------------------------------------------------ forward
+template <int NTP>
+__global__ __launch_bounds__(X3_THREADS) void attn_x3_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ o, float* __restrict__ lse, int n, int h,
+                                                                 float scale) {
+  constexpr int NKP = 16 * NTP, PL = NKP * ROWB;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* k_hi = smem; char* k_lo = smem + PL; char* v_hi = smem + 2 * PL; char* v_lo = smem + 3 * PL;
+  const int bh = blockIdx.x, bi = bh / h, hi_ = bh - bi * h;
+  const int inner = h * DH;
+  const int64_t tok_stride = 3 * (int64_t)inner;
+  const float* qbase = qkv + (int64_t)bi * n * tok_stride + hi_ * DH;
+  const int tid = threadIdx.x, lane = tid & 63, nwaves = blockDim.x >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  stage_head_x3(qbase + inner, tok_stride, n, NKP, k_hi, k_lo, tid, blockDim.x);
+  stage_head_x3(qbase + 2 * inner, tok_stride, n, NKP, v_hi, v_lo, tid, blockDim.x);
+  __syncthreads();
+
+  const int qi = lane & 15, g = lane >> 4;
+  const int nqb = (n + 15) / 16;
+  const float sl2 = scale * 1.44269504088896340736f;
+  for (int qb = wave; qb < nqb; qb += nwaves) {
+    const int q = qb * 16 + qi, qc = min(q, n - 1);
+    P2 qf[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) qf[ks] = load_split8(qbase + (int64_t)qc * tok_stride + (g + 4 * ks) * 8);
+    // pass 1: row maximum of the scores.  S^T tile t: lane holds S[query qi][key 16t + 4g + r].
+    float m = -INFINITY;
+    for (int t = 0; t < NTP && t * 16 < n; ++t) {
+      f32x4 a = {0.f, 0.f, 0.f, 0.f};
+      a = mfma3(frag_rm2(k_hi, k_lo, t * 16 + qi, g), qf[0], a);
+      a = mfma3(frag_rm2(k_hi, k_lo, t * 16 + qi, g + 4), qf[1], a);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) m = fmaxf(m, (t * 16 + 4 * g + r) < n ? a[r] : -INFINITY);
+    }
+    m = fmaxf(m, __shfl_xor(m, 16, 64));
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    m *= sl2;
+    // pass 2: recompute the tile pair, p = 2^(s - m), accumulate the row sum and O^T += V^T P^T (unnormalised)
+    float l = 0.f;
+    f32x4 oacc[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) oacc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int u_end = min(NTP / 2, (n + 31) >> 5);
+#pragma unroll 1
+    for (int u = 0; u < u_end; ++u) {
+      f32x4 p[2];
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) {
+        const int t = 2 * u + tt;
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+        a = mfma3(frag_rm2(k_hi, k_lo, t * 16 + qi, g), qf[0], a);
+        a = mfma3(frag_rm2(k_hi, k_lo, t * 16 + qi, g + 4), qf[1], a);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) p[tt][r] = (t * 16 + 4 * g + r) < n ? fast_exp2(fmaf(a[r], sl2, -m)) : 0.f;
+        l += (p[tt][0] + p[tt][1]) + (p[tt][2] + p[tt][3]);
+      }
+      const P2 pf = split8(p[0], p[1]);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) oacc[c] = mfma3(frag_trr2(v_hi, v_lo, c, u, lane), pf, oacc[c]);
+    }
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    const float inv_l = 1.0f / l;
+    if (g == 0 && q < n) lse[(int64_t)bh * n + q] = (m + log2f(l)) * 0.69314718055994530942f;   // natural-log LSE
+    if (q < n) {
+      float* op = o + ((int64_t)bi * n + q) * inner + hi_ * DH;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) *(f32x4*)(op + 16 * c + 4 * g) = oacc[c] * inv_l;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------ backward, both phases in one launch
+// Phase 1: dQ and the row sums D = sum_d dO O (kept in LDS) with the K, V images; phase 2: dK, dV with the Q, dO images in the same planes.
+template <int NTP>
+__global__ __launch_bounds__(X3_THREADS) void attn_x3_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ o, const float* __restrict__ d_o,
+                                                                 const float* __restrict__ lse, float* __restrict__ dqkv, int n, int h, float scale) {
+  constexpr int NP = 16 * NTP, PL = NP * ROWB;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* a_hi = smem; char* a_lo = smem + PL; char* b_hi = smem + 2 * PL; char* b_lo = smem + 3 * PL;   // phase 1: K, V     phase 2: Q, dO
+  float* lse_s = (float*)(smem + 4 * PL);   // [NP] (log2 domain), rows >= n: 0
+  float* d_s = lse_s + NP;                  // [NP] D[q], rows >= n: 0
+  const int bh = blockIdx.x, bi = bh / h, hi_ = bh - bi * h;
+  const int inner = h * DH;
+  const int64_t tok_stride = 3 * (int64_t)inner;
+  const float* qbase = qkv + (int64_t)bi * n * tok_stride + hi_ * DH;
+  const float* dobase = d_o + (int64_t)bi * n * inner + hi_ * DH;
+  const float* obase = o + (int64_t)bi * n * inner + hi_ * DH;
+  const int tid = threadIdx.x, lane = tid & 63, nwaves = blockDim.x >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  stage_head_x3(qbase + inner, tok_stride, n, NP, a_hi, a_lo, tid, blockDim.x);
+  stage_head_x3(qbase + 2 * inner, tok_stride, n, NP, b_hi, b_lo, tid, blockDim.x);
+  for (int i = tid; i < NP; i += blockDim.x) {
+    lse_s[i] = i < n ? lse[(int64_t)bh * n + i] * 1.44269504088896340736f : 0.f;
+    d_s[i] = 0.f;
+  }
+  __syncthreads();
+  const float sl2 = scale * 1.44269504088896340736f;
+  const int u_end = min(NTP / 2, (n + 31) >> 5);
+  {   // ---------------------------------------------------------------- phase 1: dQ, D
+    const int qi = lane & 15, g = lane >> 4;
+    const int nqb = (n + 15) / 16;
+    for (int qb = wave; qb < nqb; qb += nwaves) {
+      const int q = qb * 16 + qi, qc = min(q, n - 1);
+      P2 qf[2], dof[2];
+      float dp_ = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        qf[ks] = load_split8(qbase + (int64_t)qc * tok_stride + (g + 4 * ks) * 8);
+        const float* dop = dobase + (int64_t)qc * inner + (g + 4 * ks) * 8;
+        const float* op = obase + (int64_t)qc * inner + (g + 4 * ks) * 8;
+        const f32x4 d0 = *(const f32x4*)dop, d1 = *(const f32x4*)(dop + 4), o0 = *(const f32x4*)op, o1 = *(const f32x4*)(op + 4);
+        dof[ks] = split8(d0, d1);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dp_ += d0[e] * o0[e] + d1[e] * o1[e];
+      }
+      dp_ += __shfl_xor(dp_, 16, 64);
+      dp_ += __shfl_xor(dp_, 32, 64);   // D[q] = sum_d dO*O
+      if (g == 0 && q < n) d_s[q] = dp_;
+      const float l2 = lse_s[qc], nds = -dp_ * scale;
+      f32x4 dq[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) dq[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+      for (int u = 0; u < u_end; ++u) {
+        f32x4 ds[2];
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+          const int t = 2 * u + tt;
+          f32x4 sa = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+          sa = mfma3(frag_rm2(a_hi, a_lo, t * 16 + qi, g), qf[0], sa);
+          sa = mfma3(frag_rm2(a_hi, a_lo, t * 16 + qi, g + 4), qf[1], sa);
+          dp = mfma3(frag_rm2(b_hi, b_lo, t * 16 + qi, g), dof[0], dp);
+          dp = mfma3(frag_rm2(b_hi, b_lo, t * 16 + qi, g + 4), dof[1], dp);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float p = (t * 16 + 4 * g + r) < n ? fast_exp2(fmaf(sa[r], sl2, -l2)) : 0.f;
+            ds[tt][r] = p * fmaf(dp[r], scale, nds);
+          }
+        }
+        const P2 dsf = split8(ds[0], ds[1]);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) dq[c] = mfma3(frag_trr2(a_hi, a_lo, c, u, lane), dsf, dq[c]);
+      }
+      if (q < n) {
+        float* dp_out = dqkv + ((int64_t)bi * n + q) * tok_stride + hi_ * DH;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) *(f32x4*)(dp_out + 16 * c + 4 * g) = dq[c];
+      }
+    }
+  }
+  __syncthreads();               // every wave is done with the K / V images; D is complete
+  stage_head_x3(qbase, tok_stride, n, NP, a_hi, a_lo, tid, blockDim.x);
+  stage_head_x3(dobase, inner, n, NP, b_hi, b_lo, tid, blockDim.x);
+  __syncthreads();
+  {   // ---------------------------------------------------------------- phase 2: dK, dV
+    // No masks: query rows >= n are zero rows of q / dO with lse = D = 0, so their P = 1 meets dO = 0 and their dS = 1 * (0 - 0); key lanes >= n
+    // compute on the clamped key n-1 and are never stored.  Tile pairs past n are skipped.
+    const int ki = lane & 15, g = lane >> 4;
+    const int nkb = (n + 15) / 16;
+    for (int kb = wave; kb < nkb; kb += nwaves) {
+      const int key = kb * 16 + ki, kc = min(key, n - 1);
+      P2 kf[2], vf[2];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        kf[ks] = load_split8(qbase + inner + (int64_t)kc * tok_stride + (g + 4 * ks) * 8);
+        vf[ks] = load_split8(qbase + 2 * inner + (int64_t)kc * tok_stride + (g + 4 * ks) * 8);
+      }
+      f32x4 dk[4], dv[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) { dk[c] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[c] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll 1
+      for (int u = 0; u < u_end; ++u) {
+        f32x4 pp[2], ds[2];
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+          const int t = 2 * u + tt;
+          f32x4 sa = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+          sa = mfma3(frag_rm2(a_hi, a_lo, t * 16 + ki, g), kf[0], sa);       // S[query 16t+4g+r][key ki]
+          sa = mfma3(frag_rm2(a_hi, a_lo, t * 16 + ki, g + 4), kf[1], sa);
+          dp = mfma3(frag_rm2(b_hi, b_lo, t * 16 + ki, g), vf[0], dp);       // dP, same layout
+          dp = mfma3(frag_rm2(b_hi, b_lo, t * 16 + ki, g + 4), vf[1], dp);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float p = fast_exp2(fmaf(sa[r], sl2, -lse_s[t * 16 + 4 * g + r]));
+            pp[tt][r] = p;
+            ds[tt][r] = p * ((dp[r] - d_s[t * 16 + 4 * g + r]) * scale);
+          }
+        }
+        const P2 pf = split8(pp[0], pp[1]), dsf = split8(ds[0], ds[1]);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          dv[c] = mfma3(frag_trr2(b_hi, b_lo, c, u, lane), pf, dv[c]);
+          dk[c] = mfma3(frag_trr2(a_hi, a_lo, c, u, lane), dsf, dk[c]);
+        }
+      }
+      if (key < n) {
+        float* dkp = dqkv + ((int64_t)bi * n + key) * tok_stride + inner + hi_ * DH;
+        float* dvp = dkp + inner;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          *(f32x4*)(dkp + 16 * c + 4 * g) = dk[c];
+          *(f32x4*)(dvp + 16 * c + 4 * g) = dv[c];
+        }
+      }
+    }
+  }
+}
+
+template <typename K>
+void set_smem(K kern, int bytes) {   // one attribute call per distinct kernel (function-pointer keyed)
+  static const void* done[16];
+  static int ndone = 0;
+  for (int i = 0; i < ndone; ++i) if (done[i] == (const void*)kern) return;
+  (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (ndone < 16) done[ndone++] = (const void*)kern;
+}
+inline int pick_ntp(int n) { return n <= 64 ? 4 : n <= 96 ? 6 : n <= 224 ? 14 : 18; }
+
+}  // namespace
+
+// four (forward) planes of 16 NTP x 128 B + the two row vectors of the backward must fit the 160 KiB of LDS: n <= 288
+bool attn_x3_supported(int n, int dim_head) { return dim_head == DH && n >= 1 && n <= 288; }
+
+#define VITX_NTP_DISPATCH(ntp, CALL) \
+  do { if ((ntp) == 4) { CALL(4); } else if ((ntp) == 6) { CALL(6); } else if ((ntp) == 14) { CALL(14); } else { CALL(18); } } while (0)
+
+void launch_attn_x3_fwd(const float* qkv, float* o, float* lse, int b, int n, int h, float scale, hipStream_t s) {
+  const int ntp = pick_ntp(n);
+  const int smem = 4 * 16 * ntp * ROWB;
+#define CALL(NTP) { set_smem(attn_x3_fwd_kernel<NTP>, smem); hipLaunchKernelGGL(attn_x3_fwd_kernel<NTP>, dim3(b * h), dim3(X3_THREADS), smem, s, qkv, o, lse, n, h, scale); }
+  VITX_NTP_DISPATCH(ntp, CALL);
+#undef CALL
+}
+
+void launch_attn_x3_bwd(const float* qkv, const float* o, const float* d_o, const float* lse, float* dqkv, int b, int n, int h, float scale, hipStream_t s) {
+  const int ntp = pick_ntp(n);
+  const int smem = 4 * 16 * ntp * ROWB + 2 * 16 * ntp * 4;
+#define CALL(NTP) { set_smem(attn_x3_bwd_kernel<NTP>, smem); hipLaunchKernelGGL(attn_x3_bwd_kernel<NTP>, dim3(b * h), dim3(X3_THREADS), smem, s, qkv, o, d_o, lse, dqkv, n, h, scale); }
+  VITX_NTP_DISPATCH(ntp, CALL);
+#undef CALL
+}

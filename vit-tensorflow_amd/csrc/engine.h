@@ -93,6 +93,7 @@ struct vitx_engine {
   int64_t n_arena = 0;               // device arena element count (>= n_params, zero padding between tensors)
   bool bf16 = false;
   bool x3_attn = false;
+  bool x3_fused_attn = true;         // BF16X3: ViT attention through the fused split-operand kernel (attn_x3.hip) instead of materialised scores
   bool x3 = false;                   // BF16X3: the fp32 mode's data path with the GEMMs on split bf16 operands (gemm_bf16x3.hip)
   int esz = 4;                       // bytes per "T" element
 

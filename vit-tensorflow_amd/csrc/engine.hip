@@ -719,6 +719,10 @@ static void attn_generic_bwd(vitx_engine* e, const BlockParams& bp, const AttnVi
 static bool use_fused_attn(const vitx_engine* e, int n) {
   return e->bf16 && e->cfg.variant == VITX_VARIANT_VIT && !e->force_generic_attn && attn_bf16_supported(n, e->cfg.dim_head);
 }
+// BF16X3 mode: the fused split-operand attention (attn_x3.hip); VITX_X3_ATTN=2 keeps the materialised path with split-operand products, 0 exact ones
+static bool use_fused_attn_x3(const vitx_engine* e, int n) {
+  return e->x3 && e->x3_attn && e->x3_fused_attn && e->cfg.variant == VITX_VARIANT_VIT && !e->force_generic_attn && attn_x3_supported(n, e->cfg.dim_head);
+}
 
 // ------------------------------------------------------------------------------------------------
 // one transformer block: x = attn(LN(x)) [*scale] + x ; x = mlp(LN(x)) [*scale] + x
@@ -763,7 +767,10 @@ static int block_forward(vitx_engine* e, Stage& st, int si, int l, int b, int nq
     av.ldq = av.ldk = av.ldv = 3 * inner;
     av.qb = av.kb = av.vb = (int64_t)nq * 3 * inner;
   }
-  if (use_fused_attn(e, nq)) {
+  if (use_fused_attn_x3(e, nq)) {
+    Prof pr(e, "attn_x3_fwd", 4.0 * b * c.heads * (double)nq * nq * c.dim_head, (double)rows * inner * 4 * esz);
+    launch_attn_x3_fwd((const float*)ba.qkv, (float*)ba.o, ba.lse, b, nq, c.heads, 1.0f / std::sqrt((float)c.dim_head), e->stream);
+  } else if (use_fused_attn(e, nq)) {
     Prof pr(e, "attn_bf16_fwd", 4.0 * b * c.heads * (double)nq * nq * c.dim_head, (double)rows * inner * 4 * esz);
     launch_attn_bf16_fwd((const bf16_t*)ba.qkv, (bf16_t*)ba.o, ba.lse, b, nq, c.heads, 1.0f / std::sqrt((float)c.dim_head), (const bf16_t*)e->zero_page, (e->reverse_mask >> 2) & 1, e->stream);
   } else {
@@ -997,7 +1004,11 @@ static int block_backward(vitx_engine* e, Stage& st, int si, int l, int b, int n
     ag.dq = e->d_qkv; ag.dk = boff(e->d_qkv, inner, esz); ag.dv = boff(e->d_qkv, 2 * inner, esz);
     ag.lddq = ag.lddk = ag.lddv = 3 * inner;
     ag.dqb = ag.dkb = ag.dvb = (int64_t)nq * 3 * inner;
-    if (use_fused_attn(e, nq)) {
+    if (use_fused_attn_x3(e, nq)) {
+      Prof pr(e, "attn_x3_bwd", 14.0 * b * c.heads * (double)nq * nq * c.dim_head, (double)rows * inner * 8 * esz);
+      launch_attn_x3_bwd((const float*)ba.qkv, (const float*)ba.o, (const float*)d_o, ba.lse, (float*)e->d_qkv, b, nq, c.heads,
+                         1.0f / std::sqrt((float)c.dim_head), e->stream);
+    } else if (use_fused_attn(e, nq)) {
       Prof pr(e, "attn_bf16_bwd", 14.0 * b * c.heads * (double)nq * nq * c.dim_head, (double)rows * inner * 8 * esz);
       launch_attn_bf16_bwd((const bf16_t*)ba.qkv, (const bf16_t*)ba.o, (const bf16_t*)d_o, ba.lse, e->dsum, (bf16_t*)e->d_qkv, b, nq,
                            c.heads, 1.0f / std::sqrt((float)c.dim_head), (const bf16_t*)e->zero_page, e->stream);
@@ -1043,7 +1054,7 @@ static int engine_create_body(vitx_engine* e, const vitx_config& cfg, std::strin
   e->bf16 = c.compute == VITX_COMPUTE_BF16;
   e->x3 = c.compute == VITX_COMPUTE_BF16X3;
   e->x3_attn = true;   // the materialised attention products too (8.3 vs 9.2 ms per ViT-B/16 step at batch 64); VITX_X3_ATTN=0 keeps them exact
-  if (const char* k = getenv("VITX_X3_ATTN")) e->x3_attn = atoi(k) != 0;
+  if (const char* k = getenv("VITX_X3_ATTN")) { e->x3_attn = atoi(k) != 0; e->x3_fused_attn = atoi(k) == 1; }
   e->esz = e->bf16 ? 2 : 4;
   e->inner = c.heads * c.dim_head;
   e->np_max = (c.image_h / c.patch_h) * (c.image_w / c.patch_w);

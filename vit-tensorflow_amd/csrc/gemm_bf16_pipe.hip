@@ -3,6 +3,13 @@
 
 namespace {
 
+// lane index from the hardware, opaque to the optimiser (no live range across the K loop, nothing derived from it is loop-invariant)
+__device__ __forceinline__ int wp_lane() {
+  int l;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+  return l;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Software-pipelined persistent NT kernel (the default for N >= 256).  Same tile / wave decomposition, LDS image and swizzle as
 // gemm_bf16_nt_kernel, but
@@ -13,8 +20,8 @@ namespace {
 //     front of the LAST k-step's MFMAs instead of between two tiles;
 //   * workgroups are persistent and their K-tile stream runs across output tiles (the next tile's first K-tile is in LDS before
 //     the epilogue of the current one starts).
-//   * WP (wave-private epilogue, 256-row tiles): see the epilogue section.
-template <int BM, int BN, int WM, int WN, int MODE, int PAT, bool WP>
+//   * the epilogue is wave-private (no workgroup barrier): see the epilogue section.
+template <int BM, int BN, int WM, int WN, int MODE>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_pipe_kernel(Bf16GemmArgs g, EpiParams ep, int tiles_m, int tiles_n,
                                                                          int kt_per_split) {
   constexpr int NW = WM * WN;
@@ -22,9 +29,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_pipe_kernel(Bf16Gem
   constexpr int MT = WTM / 32, NT = WTN / 32;
   constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
   constexpr int A_INSTR = BM / 8 / NW, B_INSTR = BN / 8 / NW;
-  constexpr int SROW = BN + 4;                     // epilogue staging row (floats); +16 B keeps ds_write_b128 groups conflict-free
   static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile rows must split evenly over the waves");
-  static_assert(BN == 256 && 2 * 32 * BN * 4 <= STAGE, "two 32-row epilogue staging areas must fit one pipeline buffer");
+  static_assert(BN == 256, "256-column tiles");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int nwg = gridDim.x, bid = blockIdx.x;
@@ -80,14 +86,21 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_pipe_kernel(Bf16Gem
     decode_tile(i_logical, tiles_m, tiles_n, gm, tm, tn);
     a_soff = (uint32_t)(((int64_t)tm * BM * g.lda + (int64_t)kt0 * BK) * 2);
     b_soff = (uint32_t)(((int64_t)tn * BN * g.ldb + (int64_t)kt0 * BK) * 2);
+    {
+      // The uniformity analysis loses the cursor behind the lane-dependent branches of the wave-private epilogue and would hand the asm a VGPR
+      // for the scalar offset.  Made scalar HERE, once per tile: a v_readfirstlane right in front of a piece is a VALU write of an SGPR that the
+      // buffer_load inside the asm reads as its scalar offset -- a 5-wait-state hazard the compiler cannot see (pieces fetched from stale offsets).
+      a_soff = (uint32_t)__builtin_amdgcn_readfirstlane((int)a_soff);
+      b_soff = (uint32_t)__builtin_amdgcn_readfirstlane((int)b_soff);
+    }
   };
   i_set_tile();
   constexpr int P = A_INSTR + B_INSTR;   // DMA pieces (1 KiB each) per K-tile per wave
   // where the P pieces of K-tile it+2 are issued: k-step 3 of tile it (after the hand-over), k-steps 0 and 1 of tile it+1.
   // 64 pieces issued by 8 waves at the same moment queue up behind one address unit (~50 cycles each, all waves blocked);
   // spread over the tile each one costs ~18 cycles and hides under an MFMA.
-  constexpr int N3 = PAT == 0 ? P : (PAT == 1 ? (P + 1) / 2 : (P + 2) / 3);
-  constexpr int N0 = PAT == 0 ? 0 : (PAT == 1 ? P / 2 : (P + 1) / 3);
+  constexpr int N3 = (P + 2) / 3;
+  constexpr int N0 = (P + 1) / 3;
   constexpr int N1 = P - N3 - N0;
   bool pending = false;                  // pieces of the cursor's K-tile still to be issued
   const int xp = g.stagger;   // timing experiments only (results are wrong): 1 = no DMA wait, 2 = no DMA issue in the K loop, 4 = no fragment reads in the K loop
@@ -133,14 +146,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_pipe_kernel(Bf16Gem
     for (int j = 0; j < NT; ++j) bfr[j] = *(const bf16x8*)(base + b_row_byte + j * 32 * 128 + cb);
   };
   constexpr int Q = MT * NT;             // MFMAs per k-step per wave
-  // PAT 3, the uniform schedule: a wave's P pieces of the pending K-tile go behind every SP-th MFMA of the three k-steps after the hand-over, and
-  // the waves' slots are staggered (phase = wave % SP; the two waves of a SIMD, w and w + 4, always differ), so the CU's address unit sees ~one
-  // piece per 24 cycles instead of eight in the same cycle.  (Measured and removed in round 4: fragment reads one per MFMA, and the two-barriers-
-  // per-k-step anti-phase schedule -- both within +-3 % of this one on every shape, profiles/r3/gemm_sweep_*.)
-  // Measured on the previous schedule (8192^3, timing switches): 1284 TFLOP/s as built, 1570 without the pieces, 1452 without the fragment
-  // reads, 1808 with neither -- the memory instructions cost by arriving in bursts from all eight waves at the same slots.
-  constexpr int SP = (3 * Q) / P;
-  const int phi = wave % (SP > 0 ? SP : 1);
+  // (Measured and removed in round 4: pieces one behind every SP-th MFMA with per-wave phases, fragment reads one per MFMA, the two-barriers-per-
+  //  k-step anti-phase schedule, the wave-group ping-pong kernel -- all within +-3 % of this schedule on every shape, profiles/r3/gemm_sweep_*.)
   f32x16 acc[MT][NT];
   auto mfma_range = [&](auto cur_c, auto first_c, auto last_c) {   // MFMAs [first, last) of a k-step, fragments set `cur`
     constexpr int CUR = decltype(cur_c)::value, FIRST = decltype(first_c)::value, LAST = decltype(last_c)::value;
@@ -188,38 +195,6 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_pipe_kernel(Bf16Gem
 
     for (int kt = 0; kt < nk; ++kt) {
       const char* base = smem + (it & 1) * STAGE;
-      if constexpr (PAT >= 3) {
-        static_for<BK / 16>([&](auto ks_c) {
-          constexpr int ks = decltype(ks_c)::value, CUR = ks & 1;
-          constexpr int ORD = ks == 3 ? 0 : (ks == 0 ? 1 : (ks == 1 ? 2 : -1));   // place of this k-step in the issue window of the pending K-tile
-          const char* rbase = base;
-          bool reads = true;
-          if constexpr (ks == 3) {
-            handover();                                   // K-tile it+1 landed; buffer it&1 fully read by every wave
-            rbase = smem + ((it + 1) & 1) * STAGE;
-            reads = kt + 1 < nk;                          // at the last K-tile of an output tile the first fragments are loaded after the epilogue
-            pending = i_more && kt + 1 < nk && !(xp & 2);
-          }
-          constexpr int rks = (ks + 1) % (BK / 16);
-          const uint32_t ibase = (issued & 1) * STAGE;
-          static_for<Q>([&](auto q_c) {
-            constexpr int q = decltype(q_c)::value;
-            mfma_range(ic<CUR>{}, ic<q>{}, ic<q + 1>{});
-            if constexpr (q == 1) { if (reads && !(xp & 4)) load_frags(fa[CUR ^ 1], fb[CUR ^ 1], rbase, rks); }
-            if constexpr (ORD >= 0) {
-              constexpr int u = ORD * Q + q;
-              if constexpr (u / SP < P) { if (pending && phi == u % SP) issue_piece(ibase, ic<u / SP>{}); }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-          });
-          if constexpr (ks == 1) {
-            if (pending) i_advance();
-            pending = false;
-          }
-        });
-        ++it;
-        continue;
-      }
       static_for<BK / 16>([&](auto ks_c) {
         constexpr int ks = decltype(ks_c)::value, CUR = ks & 1;
         // Order is pinned with sched_barrier(0): two MFMAs, then the ds_reads of the NEXT k-step, then the remaining MFMAs with
@@ -268,7 +243,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_pipe_kernel(Bf16Gem
 
     // ---- epilogue: 32 output rows per round through the buffer of the last K-tile (its refill is deferred until after the epilogue)
     stamp(1);
-    bool wp_done = false;   // this tile went out through the wave-private epilogue (no workgroup barrier before the refill)
+    bool wp_done = false;   // this tile went out through one of the fast forms
     {
       const bool interior = epilogue_fast_ok(ep, MODE) && (tile_m + 1) * BM <= ep.M && (tile_n + 1) * BN <= ep.N;
       // ---- WP, the wave-private epilogue (interior tiles of the four fused epilogues of the Dense layers).
@@ -284,17 +259,17 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_pipe_kernel(Bf16Gem
       //   bf16 staging (plain store, GELU): a 32 x 64 block is 4 KiB -- area 0 / area 1 alternate (GELU: gelu' in area 0, gelu in area 1).
       //   fp32 staging (residual, GELU VJP): columns 0..31 in area 0, 32..63 in area 1 with rows and chunk parity flipped (row ^ 1, chunk ^ 1) so that
       //   the 16 lanes of a row-contiguous read hit 64 different banks; 16-B chunks are XOR-swizzled with (row >> 1) & 7 in both layouts.
-      if constexpr (WP && (MODE == EPI_STORE || MODE == EPI_BIAS_GELU || MODE == EPI_BIAS_RESID || MODE == EPI_GELU_BWD)) {
-        static_assert(!WP || ((BM == 256 || BM == 320) && A_INSTR >= 4 && B_INSTR == 4 && WTN == 64 && MT * 32 == WTM && NT == 2), "wave-private epilogue: 256 / 320 x 256 tiles, 2 x 4 waves");
+      static_assert((BM == 256 || BM == 320) && A_INSTR >= 4 && B_INSTR == 4 && WTN == 64 && MT * 32 == WTM && NT == 2, "wave-private epilogue: 256 / 320 x 256 tiles, 2 x 4 waves");
+      if constexpr (MODE == EPI_STORE || MODE == EPI_BIAS_GELU || MODE == EPI_BIAS_RESID || MODE == EPI_GELU_BWD) {
         const bool wp_ok = interior && (MODE == EPI_BIAS_RESID || ep.wide_ok) && !(MODE == EPI_STORE && has_bias);
         if (wp_ok) {
           wp_done = true;
           char* const sa = smem + ((it + 1) & 1) * STAGE + wave * (A_INSTR * 1024);
           char* const sb = smem + ((it + 1) & 1) * STAGE + A_BYTES + wave * (B_INSTR * 1024);
-          // every per-lane address below derives from `le`, a copy of the lane index the optimiser cannot see through: as loop invariants of
-          // the persistent tile loop they were hoisted in front of it and kept live across the K loop (78-107 registers spilled to scratch)
-          int le = lane;
-          asm volatile("" : "+v"(le));
+          // every per-lane address below derives from `le`, the lane index RECOMPUTED here behind an asm the optimiser cannot see through: as loop
+          // invariants of the persistent tile loop the addresses were hoisted in front of it and kept live across the K loop (78-107 registers
+          // spilled to scratch -- and a scratch reload is a VMEM load the compiler then waits for INSIDE the K loop, where vmcnt also counts the DMA)
+          const int le = wp_lane();
           const int m = le & 31, swm = (m >> 1) & 7, kh = le >> 5;
           const int row_w = tile_m * BM + wm * WTM, col_w = tile_n * BN + wn * WTN;
           auto to_bf16x4 = [](float a, float b, float c, float d) { bf16x4 o; o[0] = (bf16_t)a; o[1] = (bf16_t)b; o[2] = (bf16_t)c; o[3] = (bf16_t)d; return o; };
@@ -400,27 +375,29 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_pipe_kernel(Bf16Gem
             const uint32_t roff = lr * ldr + lc, ooff = lr * ldo + lc, o2off = lr * ldo2 + lc;
             static_for<MT>([&](auto i_c) {
               constexpr int i0 = decltype(i_c)::value;
-              // two halves of 16 rows: the residual rows of the second half are in flight while the first half is added and stored
-              float4 x0[4], x1[4], v[4];
+              // the 32 rows in steps of 16 (320-row tiles: 8 -- 160 accumulator registers leave room for less); the residual rows of a step are
+              // requested before the LDS round trip / under the stores of the step before (a missing bias / scale is the exact identity: + 0, x 1 --
+              // one instruction stream for the four combinations)
+              constexpr int RS = BM == 256 ? 16 : 8, NR = RS / 4, NS = 32 / RS;
+              float4 x[NR], v[NR];
 #pragma unroll
-              for (int k = 0; k < 4; ++k) x0[k] = *(const float4*)(rp + (roff + (uint32_t)(i0 * 32 + k * 4) * ldr));
+              for (int k = 0; k < NR; ++k) x[k] = *(const float4*)(rp + (roff + (uint32_t)(i0 * 32 + k * 4) * ldr));
               stage_f32(i_c);
 #pragma unroll
-              for (int k = 0; k < 4; ++k) x1[k] = *(const float4*)(rp + (roff + (uint32_t)(i0 * 32 + 16 + k * 4) * ldr));
+              for (int hf = 0; hf < NS; ++hf) {
 #pragma unroll
-              for (int hf = 0; hf < 2; ++hf) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                  const int r = hf * 16 + k * 4 + (int)lr;
+                for (int k = 0; k < NR; ++k) {
+                  const int r = hf * RS + k * 4 + (int)lr;
                   v[k] = *(const float4*)(rb + (r ^ ar1) * 128 + ((((c16 & 7) ^ ((r >> 1) & 7)) ^ ar1) << 4));
                 }
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                  const uint32_t rr = (uint32_t)(i0 * 32 + hf * 16 + k * 4);
-                  float4 f = make_float4(v[k].x + bb.x, v[k].y + bb.y, v[k].z + bb.z, v[k].w + bb.w);
+                for (int k = 0; k < NR; ++k) {
+                  const uint32_t rr = (uint32_t)(i0 * 32 + hf * RS + k * 4);
+                  const float4 f = make_float4(v[k].x + bb.x, v[k].y + bb.y, v[k].z + bb.z, v[k].w + bb.w);
                   if (o2) st4<bf16_t>(o2 + (o2off + rr * ldo2), f);
-                  const float4 x = hf ? x1[k] : x0[k];
-                  *(float4*)(op + (ooff + rr * ldo)) = make_float4(x.x + f.x * ss.x, x.y + f.y * ss.y, x.z + f.z * ss.z, x.w + f.w * ss.w);
+                  const float4 o = make_float4(x[k].x + f.x * ss.x, x[k].y + f.y * ss.y, x[k].z + f.z * ss.z, x[k].w + f.w * ss.w);
+                  if (hf + 1 < NS) x[k] = *(const float4*)(rp + (roff + (rr + (uint32_t)RS) * ldr));   // the next step's residual row, in flight under the stores
+                  *(float4*)(op + (ooff + rr * ldo)) = o;
                 }
               }
             });
@@ -474,155 +451,55 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_pipe_kernel(Bf16Gem
           }
         }
       }
-      if (!wp_done) {
-      float* st = (float*)(smem + ((it + 1) & 1) * STAGE);
-      const int gcol = tile_n * BN + lane * 4;
-      float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f), s4 = make_float4(1.f, 1.f, 1.f, 1.f);
-      if (interior && has_bias) b4 = *(const float4*)(ep.bias + gcol);
-      if (interior && has_scale) s4 = *(const float4*)(ep.scale + gcol);
-      constexpr int RPW = 32 / NW;   // rows per wave per round (one 1-KiB row per wave instruction)
-      float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);   // EPI_GELU_BWD: column sums of what this lane stores (fused bias gradient)
-      auto cs_add = [&](float4 r) { if (MODE == EPI_GELU_BWD) { cs.x += r.x; cs.y += r.y; cs.z += r.z; cs.w += r.w; } };
-      // Two 32-row staging areas ([32][BN] fp32 = 32 KiB each, 16-B chunks swizzled chunk ^= row & 7 instead of padded rows) used
-      // alternately: ONE barrier per round -- the accumulator rows of round R+1 are written while round R is still being read and
-      // stored (the round trip  barrier - LDS write - barrier - LDS read - global store  was the epilogue's critical path, not HBM).
-      // Reuse of an area two rounds later is ordered by the barrier in between (every wave waits for its own reads first).
-      // bf16 outputs (WIDE): a lane takes EIGHT consecutive columns of a row (two staged 16-B chunks -> one 16-B global access per
-      // output, two rows per wave instruction): half the store instructions for the same bytes.  Even chunks of a staged row live
-      // in its first 512 B, odd chunks in the second, so both reads of a 16-lane group stay conflict-free.
-      // (256-row tiles only: in the 320-row variants the second code path costs the registers the accumulators need -- 44-116 B of scratch;
-      //  same-box A/B on fc1-shaped launches, profiles/r2/epilogue_wide_ab_r2d.log: +1.0..2.5 % plain store, +1 % GELU, +2.5 % GELU VJP)
-      constexpr bool WIDE = BM == 256 && (MODE == EPI_STORE || MODE == EPI_BIAS_GELU || MODE == EPI_GELU_BWD);
-      const bool wide = WIDE && interior && ep.wide_ok;
-      // Global stores the LAST staging round of each path issues behind its last global load: only the epilogue's LOADS have to be back before
-      // the next tile (bias / residual / stored gelu' -- their registers are reused); the last stores may drain under the next tile's K loop.
-      // Memory operations of a wave retire in order, so "all but the S youngest" = every load.  The wait sits INSIDE each path, behind its last
-      // store, where the compiler's scoreboard knows which operations are the youngest (one merged wait after the paths made it keep loads
-      // "pending" and re-insert waits at the tile loop's header).  With vmcnt(0) every tile waited 1.5-3k cycles for its stores to reach L2.
-      constexpr int S_WIDE = (16 / NW) * (MODE == EPI_BIAS_GELU ? 2 : 1);    // rows per wave per round x outputs
-      constexpr int S_NARROW = (32 / NW) * (MODE == EPI_BIAS_GELU ? 2 : 1);
-      constexpr int vm_wide = (S_WIDE & 15) | 0x0F70, vm_narrow = (S_NARROW & 15) | 0x0F70;
-      float4 cs2 = make_float4(0.f, 0.f, 0.f, 0.f);   // WIDE column sums: columns 4..7 of the lane's eight
-      const int cc = lane & 31, gcol8 = tile_n * BN + cc * 8;
-      float4 b8lo = make_float4(0.f, 0.f, 0.f, 0.f), b8hi = b8lo;
-      if (wide && has_bias && MODE != EPI_GELU_BWD) { b8lo = *(const float4*)(ep.bias + gcol8); b8hi = *(const float4*)(ep.bias + gcol8 + 4); }
-#pragma clang loop unroll(full)
-      for (int R = 0; R < BM / 32; ++R) {
-        const int wm_r = (R * 32) / WTM, i0 = ((R * 32) % WTM) / 32;
-        float* sr = st + (R & 1) * (32 * BN);
-        if (wm == wm_r) {
-          const int m = lane & 31;
-#pragma unroll
-          for (int j = 0; j < NT; ++j)
+      {
+        if (!wp_done) {
+          // Everything the fast forms above do not take (ragged edge tiles, unaligned leading dimensions, a plain store with a bias, the fp32 /
+          // patch-embedding / split-K epilogues): the same wave-private fp32 staging, then the GENERIC epilogue functor on row-contiguous float4
+          // pieces (16 lanes x 16 B per row) with every bounds test per element.
+          const int le = wp_lane();
+          char* const sa = smem + ((it + 1) & 1) * STAGE + wave * (A_INSTR * 1024);
+          char* const sb = smem + ((it + 1) & 1) * STAGE + A_BYTES + wave * (B_INSTR * 1024);
+          const int m = le & 31, swm = (m >> 1) & 7, kh = le >> 5;
+          const int row_w = tile_m * BM + wm * WTM, col_w = tile_n * BN + wn * WTN;
+          const int c16 = le & 15, ar1 = c16 >> 3, lr = le >> 4, gcolr = col_w + c16 * 4;
+          const char* const rb = ar1 ? sb : sa;
+          float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
+          static_for<MT>([&](auto i_c) {
+            constexpr int i0 = decltype(i_c)::value;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-              const int chunk = (wn * WTN + j * 32 + 8 * q + 4 * khalf) >> 2;
-              const int pc = WIDE ? ((chunk >> 1) | ((chunk & 1) << 5)) : chunk;
-              *(float4*)(sr + m * BN + ((pc ^ (m & 7)) << 2)) =
-                  make_float4(acc[i0][j][4 * q], acc[i0][j][4 * q + 1], acc[i0][j][4 * q + 2], acc[i0][j][4 * q + 3]);
+              const int ch = 2 * q + kh;
+              *(float4*)(sa + m * 128 + ((ch ^ swm) << 4)) = make_float4(acc[i0][0][4 * q], acc[i0][0][4 * q + 1], acc[i0][0][4 * q + 2], acc[i0][0][4 * q + 3]);
+              *(float4*)(sb + (m ^ 1) * 128 + ((ch ^ swm ^ 1) << 4)) = make_float4(acc[i0][1][4 * q], acc[i0][1][4 * q + 1], acc[i0][1][4 * q + 2], acc[i0][1][4 * q + 3]);
             }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (R == 0) {
-          // the bias values are loaded for both epilogue forms but each path uses one set: a dummy use retires the other set's loads in the
-          // compiler's scoreboard (left "pending" they were protected with vmcnt waits at the tile loop's header, which at run time wait for the
-          // refill DMA and the last stores)
-          asm volatile("" ::"v"(b4.x), "v"(b4.y), "v"(b4.z), "v"(b4.w));
-          if constexpr (MODE == EPI_BIAS_RESID) asm volatile("" ::"v"(s4.x), "v"(s4.y), "v"(s4.z), "v"(s4.w));
-          if constexpr (WIDE) asm volatile("" ::"v"(b8lo.x), "v"(b8lo.y), "v"(b8lo.z), "v"(b8lo.w), "v"(b8hi.x), "v"(b8hi.y), "v"(b8hi.z), "v"(b8hi.w));
-        }
-        const int grow0 = tile_m * BM + R * 32;
-        if constexpr (WIDE) {
-          if (wide) {
-            constexpr int RPW2 = 16 / NW;    // two rows per wave instruction, 16 instructions per 32-row round
-            float4 lo[RPW2], hi[RPW2];
-            bf16x8 x[RPW2];
-#pragma unroll
-            for (int k = 0; k < RPW2; ++k) {
-              const int r = (k * NW + wave) * 2 + (lane >> 5);
-              const int pc = cc ^ (r & 7);
-              lo[k] = *(const float4*)(sr + r * BN + (pc << 2));
-              hi[k] = *(const float4*)(sr + r * BN + ((pc + 32) << 2));
-              x[k] = epilogue_wide_load<MODE>(ep, grow0 + r, gcol8);
+#pragma unroll 2
+            for (int k = 0; k < 8; ++k) {
+              const int r = k * 4 + lr;
+              const float4 v = *(const float4*)(rb + (r ^ ar1) * 128 + ((((c16 & 7) ^ ((r >> 1) & 7)) ^ ar1) << 4));
+              const float4 res = epilogue_apply4<MODE, bf16_t>(ep, row_w + i0 * 32 + r, gcolr, v, out_off);
+              if (MODE == EPI_GELU_BWD) { cs.x += res.x; cs.y += res.y; cs.z += res.z; cs.w += res.w; }
             }
-#pragma unroll
-            for (int k = 0; k < RPW2; ++k) {
-              const int r = (k * NW + wave) * 2 + (lane >> 5);
-              if (has_bias) epilogue_wide8<MODE, true>(ep, grow0 + r, gcol8, lo[k], hi[k], b8lo, b8hi, x[k], out_off);
-              else epilogue_wide8<MODE, false>(ep, grow0 + r, gcol8, lo[k], hi[k], b8lo, b8hi, x[k], out_off);
-              if (MODE == EPI_GELU_BWD) {
-                cs.x += lo[k].x; cs.y += lo[k].y; cs.z += lo[k].z; cs.w += lo[k].w;
-                cs2.x += hi[k].x; cs2.y += hi[k].y; cs2.z += hi[k].z; cs2.w += hi[k].w;
-              }
+          });
+          if (MODE == EPI_GELU_BWD && ep.colsum != nullptr) {   // lanes 16 apart hold the same columns for different rows
+            auto red = [&](float v) { v += __shfl_xor(v, 16); v += __shfl_xor(v, 32); return v; };
+            cs.x = red(cs.x); cs.y = red(cs.y); cs.z = red(cs.z); cs.w = red(cs.w);
+            if (le < 16 && gcolr < ep.N) {
+              float* crow = ep.colsum + (int64_t)(tile_m * 2 + wm) * ep.ldcs + gcolr;
+              if (gcolr + 3 < ep.N) *(float4*)crow = cs;
+              else { crow[0] = cs.x; if (gcolr + 1 < ep.N) crow[1] = cs.y; if (gcolr + 2 < ep.N) crow[2] = cs.z; }
             }
-            if (R == BM / 32 - 1) __builtin_amdgcn_s_waitcnt(vm_wide);
-            continue;
           }
         }
-        float4 v[RPW];
-#pragma unroll
-        for (int k = 0; k < RPW; ++k) {
-          const int r = k * NW + wave;
-          const int pc = WIDE ? (((lane >> 1) | ((lane & 1) << 5)) ^ (r & 7)) : (lane ^ (r & 7));
-          v[k] = *(const float4*)(sr + r * BN + (pc << 2));
-        }
-        if (interior) {
-          float4 x[RPW];
-#pragma unroll
-          for (int k = 0; k < RPW; ++k) x[k] = epilogue_fast_load<MODE, bf16_t>(ep, grow0 + k * NW + wave, gcol);
-          if (MODE == EPI_BIAS_RESID && has_scale) {   // LayerScale (cait.py:47-48): f(x) kept in out2, the branch scaled per column
-#pragma unroll
-            for (int k = 0; k < RPW; ++k) {
-              if (has_bias) epilogue_fast4<MODE, bf16_t, true, true>(ep, grow0 + k * NW + wave, gcol, v[k], b4, s4, x[k], out_off);
-              else epilogue_fast4<MODE, bf16_t, false, true>(ep, grow0 + k * NW + wave, gcol, v[k], b4, s4, x[k], out_off);
-            }
-          } else if (has_bias) {
-#pragma unroll
-            for (int k = 0; k < RPW; ++k) cs_add(epilogue_fast4<MODE, bf16_t, true, false>(ep, grow0 + k * NW + wave, gcol, v[k], b4, s4, x[k], out_off));
-          } else {
-#pragma unroll
-            for (int k = 0; k < RPW; ++k) cs_add(epilogue_fast4<MODE, bf16_t, false, false>(ep, grow0 + k * NW + wave, gcol, v[k], b4, s4, x[k], out_off));
-          }
-          if (R == BM / 32 - 1) __builtin_amdgcn_s_waitcnt(vm_narrow);
-        } else {
-#pragma unroll
-          for (int k = 0; k < RPW; ++k) cs_add(epilogue_apply4<MODE, bf16_t>(ep, grow0 + k * NW + wave, gcol, v[k], out_off));
-          if (R == BM / 32 - 1) __builtin_amdgcn_s_waitcnt(0x0F70);
-        }
       }
-      if (MODE == EPI_GELU_BWD && ep.colsum != nullptr) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        // per-tile column sums: partial rows through the staging buffer (one per wave; two per wave in the eight-column form)
-        const int nrows = wide ? 2 * NW : NW;
-        if (wide) {
-          *(float4*)(st + (wave * 2 + (lane >> 5)) * BN + cc * 8) = cs;
-          *(float4*)(st + (wave * 2 + (lane >> 5)) * BN + cc * 8 + 4) = cs2;
-        } else {
-          *(float4*)(st + wave * BN + lane * 4) = cs;
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (tid < BN) {
-          float a = 0.f;
-          for (int w = 0; w < nrows; ++w) a += st[w * BN + tid];
-          const int c = tile_n * BN + tid;
-          if (c < ep.N) ep.colsum[(int64_t)(WP ? 2 * tile_m : tile_m) * ep.ldcs + c] = a;   // (WP: one colsum row per WAVE row, see above)
-        }
-      }
-      }   // !wp_done
+
     }
     stamp(2);
     // (every path out of the epilogue has waited for its loads -- see S_WIDE / S_NARROW above; the structurizer routes the `break` through the
     //  block that is also the loop latch, so a path that left loads pending would show up as waits at the loop header)
     if (!has_next) break;
-    // staging reads done everywhere (no DMA piece is in flight here: the refill is issued below, the prefetched K-tile landed before the epilogue)
+    // this wave's staging reads are done; NO workgroup barrier: its staging slice is the target of its OWN refill pieces only (no DMA piece is in
+    // flight here: the refill is issued below, the prefetched K-tile landed before the epilogue)
     __builtin_amdgcn_s_waitcnt(0xC07F);           // lgkmcnt(0)
-    if (!wp_done) __builtin_amdgcn_s_barrier();   // (wave-private epilogue: a wave's staging slice is the target of its OWN refill pieces only)
     asm volatile("" ::: "memory");
     issue();                                      // deferred refill of the staging buffer: stream item it+1
     load_frags(fa[0], fb[0], smem + (it & 1) * STAGE, 0);
@@ -630,7 +507,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_pipe_kernel(Bf16Gem
   }
 }
 
-template <int BM, int BN, int WM, int WN, int MODE, int PAT = 0, bool WP = false>
+template <int BM, int BN, int WM, int WN, int MODE>
 void launch_pipe(const Bf16GemmArgs& g, const EpiParams& ep, hipStream_t s) {
   constexpr int SMEM = 2 * (BM + BN) * BK * 2;
   // buffer-addressed DMA: 31-bit byte offsets inside each operand; larger operands take the flat-addressed persistent kernel
@@ -638,7 +515,7 @@ void launch_pipe(const Bf16GemmArgs& g, const EpiParams& ep, hipStream_t s) {
     launch_gemm_bf16_persistent_lockstep(BM, MODE, g, ep, s);
     return;
   }
-  auto kern = gemm_bf16_nt_pipe_kernel<BM, BN, WM, WN, MODE, PAT, WP>;
+  auto kern = gemm_bf16_nt_pipe_kernel<BM, BN, WM, WN, MODE>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
@@ -661,12 +538,8 @@ void launch_pipe(const Bf16GemmArgs& g, const EpiParams& ep, hipStream_t s) {
 template <int MODE>
 void pipe_mode(int variant, const Bf16GemmArgs& g, const EpiParams& ep, hipStream_t s) {
   switch (variant) {
-    case 12: launch_pipe<256, 256, 2, 4, MODE, 3, true>(g, ep, s); break;   // variant 9's K loop + the wave-private epilogue
-    case 13: launch_pipe<256, 256, 2, 4, MODE, 2, true>(g, ep, s); break;   // variant 14's K loop + the wave-private epilogue
-    case 11: launch_pipe<320, 256, 2, 4, MODE, 2, true>(g, ep, s); break;   // variant 15's K loop + the wave-private epilogue
-    case 14: launch_pipe<256, 256, 2, 4, MODE, 2>(g, ep, s); break;   // pieces behind MFMAs 2..4 of three k-steps, all waves at once
-    case 15: launch_pipe<320, 256, 2, 4, MODE, 2>(g, ep, s); break;
-    default: launch_pipe<256, 256, 2, 4, MODE, 3>(g, ep, s); break;   // 9: uniform schedule for the pieces, fragment reads as a block
+    case 11: launch_pipe<320, 256, 2, 4, MODE>(g, ep, s); break;   // fewer, taller tiles: 768-wide outputs (474 instead of 591 tiles at 50k rows: 1.85 rounds of 256 CUs)
+    default: launch_pipe<256, 256, 2, 4, MODE>(g, ep, s); break;   // 13
   }
 }
 

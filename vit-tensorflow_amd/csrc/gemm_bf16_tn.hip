@@ -21,7 +21,7 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* p0, const char* p1) {
   return u.v;
 }
 
-template <int BT, int WM, int WN, int MODE, int SCHED = 0>   // BT = tile extent in both feature dimensions; SCHED 1 = anti-phase sections (see the K loop)
+template <int BT, int WM, int WN, int MODE>   // BT = tile extent in both feature dimensions
 __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_tn_kernel(Bf16GemmArgs g, EpiParams ep, int tiles_m, int tiles_n,
                                                                     int kt_per_split) {
   constexpr int NW = WM * WN;
@@ -144,47 +144,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_tn_kernel(Bf16GemmArgs
   load_frags(fa[0], fb[0], smem, 0);
   bool pending = false;
   constexpr int QH = Q < 2 ? Q : 2;      // MFMAs issued ahead of the prefetch reads
-  // SCHED 1, the anti-phase schedule of the NT kernel (gemm_bf16_pipe.hip, PAT 5): every k-step is a memory section (next fragments + DMA pieces)
-  // and an MFMA section, each closed by a barrier; the second wave row runs one barrier behind, so each SIMD has one wave in each kind of section.
-  if constexpr (SCHED == 1) {
-    if (wm == 1) __builtin_amdgcn_s_barrier();
-  }
   for (int kt = 0; kt < nk; ++kt) {
     const char* base = smem + (kt & 1) * STAGE;
-    if constexpr (SCHED == 1) {
-      static_for<BK / 16>([&](auto ks_c) {
-        constexpr int ks = decltype(ks_c)::value, CUR = ks & 1;
-        constexpr int NP = ks == 3 ? N3 : (ks == 0 ? N0 : (ks == 1 ? N1 : 0));
-        constexpr int FP = ks == 3 ? 0 : (ks == 0 ? N3 : N3 + N0);
-        if constexpr (ks + 1 < BK / 16) {
-          if (!(xp & 4)) load_frags(fa[CUR ^ 1], fb[CUR ^ 1], base, ks + 1);
-        } else {
-          if (!(xp & 4)) load_frags(fa[0], fb[0], smem + ((kt + 1) & 1) * STAGE, 0);
-          pending = kt + 2 < nk && !(xp & 2);
-        }
-        if constexpr (NP > 0) {
-          const int ikt = ks == 3 ? kt + 2 : kt + 1;
-          const int ibuf = ikt & 1;
-          static_for<NP>([&](auto d_c) { if (pending) issue_piece(ibuf, ikt, ic<FP + decltype(d_c)::value>{}); });
-          if constexpr (FP + NP == P) pending = false;
-        }
-        if constexpr (ks == 2) {
-          if (xp & 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // my pieces of K-tile kt+1 landed, my reads of buffer kt&1 are in registers
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_setprio(1);
-        mfma_range(ic<CUR>{}, ic<0>{}, ic<Q>{});
-        __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-      });
-      continue;
-    }
     static_for<BK / 16>([&](auto ks_c) {
       constexpr int ks = decltype(ks_c)::value, CUR = ks & 1;
       constexpr int NP = ks == 3 ? N3 : (ks == 0 ? N0 : (ks == 1 ? N1 : 0));
@@ -221,9 +182,6 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_tn_kernel(Bf16GemmArgs
     });
   }
 
-  if constexpr (SCHED == 1) {
-    if (wm == 0) __builtin_amdgcn_s_barrier();   // balance the barrier counts of the two wave rows
-  }
   const int64_t out_off = (int64_t)z * ep.partial_stride;
   const bool interior = epilogue_fast_ok(ep, MODE) && (tile_m + 1) * BT <= ep.M && (tile_n + 1) * BT <= ep.N;
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -243,10 +201,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_tn_kernel(Bf16GemmArgs
   }
 }
 
-template <int BT, int WM, int WN, int SCHED = 0>
+template <int BT, int WM, int WN>
 void launch_tn_variant(const Bf16GemmArgs& g, const EpiParams& ep, hipStream_t s) {
   constexpr int SMEM = 2 * 2 * BK * BT * 2;
-  auto kern = gemm_bf16_tn_kernel<BT, WM, WN, EPI_PARTIAL, SCHED>;
+  auto kern = gemm_bf16_tn_kernel<BT, WM, WN, EPI_PARTIAL>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
@@ -283,8 +241,6 @@ void launch_gemm_bf16_tn(const Bf16GemmArgs& g0, const EpiParams& ep, hipStream_
       abort();
     }
   }
-  static const int sched = [] { const char* v = getenv("VITX_TN_SCHED"); return v ? atoi(v) : 0; }();   // 1 = anti-phase sections (A/B switch)
   if (gemm_bf16_tn_tile(g.kernel, g.M, g.N) == 128) launch_tn_variant<128, 2, 2>(g, ep, s);
-  else if (sched == 1) launch_tn_variant<256, 2, 4, 1>(g, ep, s);
   else launch_tn_variant<256, 2, 4>(g, ep, s);
 }

@@ -49,12 +49,10 @@ struct X3Operand {
   }
 };
 
-#ifndef X3_SINGLE
-#define X3_SINGLE 0   // experiment: one LDS buffer + one register set, three workgroups per CU (148-158 VGPRs): 26.45 vs 25.67 ms per ViT-B/16 step at batch 64, not the default
-#endif
+// (measured and removed: one LDS buffer + one register set, three workgroups per CU -- 26.45 vs 25.67 ms per ViT-B/16 step at batch 64)
 template <int MODE, int LA, int LB>
-__global__ __launch_bounds__(256, X3_SINGLE ? 3 : 2) void gemm_bf16x3_kernel(GenericGemmArgs g, EpiParams ep) {
-  __shared__ __attribute__((aligned(16))) char smem[X3_SINGLE ? 1 : 2][4][PLANE];
+__global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GenericGemmArgs g, EpiParams ep) {
+  __shared__ __attribute__((aligned(16))) char smem[2][4][PLANE];
   const int z = blockIdx.z, zb = z / g.nh, zh = z - zb * g.nh;
   const float* A = (const float*)g.A + (int64_t)zb * g.sAb + (int64_t)zh * g.sAh;
   const float* B = (const float*)g.B + (int64_t)zb * g.sBb + (int64_t)zh * g.sBh;
@@ -201,19 +199,6 @@ __global__ __launch_bounds__(256, X3_SINGLE ? 3 : 2) void gemm_bf16x3_kernel(Gen
   // first and the vector ALU idle for the second (that form: 230 TFLOP/s, MFMA pipe ~33 % busy with two workgroups per CU taking turns).
   using chk = std::true_type;
   using nochk = std::false_type;
-#if X3_SINGLE
-  load_tile(chk{}, 0, pa, sta, kka, ra);
-  load_tile(chk{}, 0, pb, stb, kkb, rb);
-  for (int kt = 0; kt < nkt; ++kt) {
-    store_tile(smem[0][0], smem[0][1], sa_off, ra);
-    store_tile(smem[0][2], smem[0][3], sb_off, rb);
-    __syncthreads();
-    load_tile(chk{}, (kt + 1) * XK, pa, sta, kka, ra);
-    load_tile(chk{}, (kt + 1) * XK, pb, stb, kkb, rb);
-    compute(0);
-    __syncthreads();
-  }
-#else
   f32x4 ra1[4], rb1[4];
   load_tile(chk{}, 0, pa, sta, kka, ra);
   load_tile(chk{}, 0, pb, stb, kkb, rb);
@@ -253,7 +238,6 @@ __global__ __launch_bounds__(256, X3_SINGLE ? 3 : 2) void gemm_bf16x3_kernel(Gen
   int kt = 0;
   for (; (kt + 5) * XK <= Kz; kt += 2) pair(nochk{}, kt);   // tiles kt+3 and kt+4 lie fully inside K
   for (; kt < nkt; kt += 2) pair(chk{}, kt);
-#endif
 
   // lane: output row m = lane & 31 of each 32 x 32 block, columns 8q + 4 (lane >> 5) + {0..3}
   if (epilogue_fast_ok(ep, MODE) && m0 + XM <= ep.M && n0 + XN <= ep.N) {   // interior tile: the branch-free form of the bf16 kernels' epilogues

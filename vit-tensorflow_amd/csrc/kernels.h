@@ -76,6 +76,10 @@ int gemm_bf16_tn_tile(int kernel, int M, int N);
 bool attn_bf16_supported(int n, int dim_head);
 void launch_attn_bf16_fwd(const bf16_t* qkv, bf16_t* o, float* lse, int b, int n, int h, float scale, const bf16_t* zero_page, int reverse,
                           hipStream_t s);   // zero_page: >= 128 B of zeros; reverse: 1 = (image, head) tasks from the last to the first
+// attn_x3.hip: the same fused attention on fp32 storage with split-operand (hi + lo) bf16 MFMA products (BF16X3 mode)
+bool attn_x3_supported(int n, int dim_head);
+void launch_attn_x3_fwd(const float* qkv, float* o, float* lse, int b, int n, int h, float scale, hipStream_t s);
+void launch_attn_x3_bwd(const float* qkv, const float* o, const float* d_o, const float* lse, float* dqkv, int b, int n, int h, float scale, hipStream_t s);
 void launch_attn_bf16_bwd(const bf16_t* qkv, const bf16_t* o, const bf16_t* d_o, const float* lse, float* dsum_ws,
                           bf16_t* dqkv, int b, int n, int h, float scale, const bf16_t* zero_page, hipStream_t s);
 
