@@ -260,7 +260,18 @@ int32_t vitx_check_gemm(vitx_handle h, int32_t kind, int32_t M, int32_t N, int32
  * The random masking indices are an input (the reference draws them with tf.random.uniform + argsort / top_k, mae.py:58,
  * simmim.py:108): MAE int32 [b, num_patches] = rand_indices, whose first num_masked columns are the masked patches;
  * SimMIM int32 [b, num_masked] = masked_indices.  num_masked = int(masking_ratio * num_patches). */
-enum { VITX_MIM_MAE = 0, VITX_MIM_SIMMIM = 1 };
+/* MPP(image_size, transformer, patch_size, output_channel_bits, channels, max_pixel_val, mask_prob, replace_prob, random_patch_prob,
+ *     mean, std)                                                                                              mpp.py:133-218
+ * Masked patch prediction: the encoder's own embedding (patch Dense + cls + pos + dropout, mpp.py:200-209), its transformer on all
+ * tokens (:212), a Dense to 2^(bits * channels) classes (`to_bits`, :149,213) and a loss over the masked positions (MPPLoss, :90-131).
+ * Parameters {to_bits.kernel/.bias, mask_token}.  indices: int32 [b, num_masked] = the top_k draw of get_mask_subset_with_prob (:79-88),
+ * num_masked = ceil(mask_prob * num_patches).  Two places where the reference's code does not do what it evidently means are reproduced
+ * literally by default (literal_loss = 1) and documented in DESIGN.md: the in-place replacements of mpp.py:185,190 are written into
+ * `.numpy()` COPIES and never reach the tensor (the transformer sees the unmasked patches; mask_token receives no gradient), and
+ * MPPLoss passes (predictions, labels) to tf.nn.softmax_cross_entropy_with_logits(labels, logits) in swapped order with
+ * clip_by_value(target, max_pixel_val, max_pixel_val), so the loss as written is log(2^(bits c)) * mean_i sum_j logits_ij.
+ * literal_loss = 0: softmax cross-entropy of the masked positions' logits against the discretised mean colour of their patches. */
+enum { VITX_MIM_MAE = 0, VITX_MIM_SIMMIM = 1, VITX_MIM_MPP = 2 };
 typedef struct vitx_mim_config {
   int32_t kind;
   int32_t decoder_dim, decoder_depth, decoder_heads, decoder_dim_head; /* MAE only (mae.py:21-25) */
@@ -268,8 +279,12 @@ typedef struct vitx_mim_config {
    * second positional argument of tf.square is `name`, i.e. mean(pred^2); 0 = the evidently intended mean((pred - masked_patches)^2).
    * SimMIM ignores it (simmim.py:128 is a plain L1). */
   int32_t literal_loss;
-  double masking_ratio;
-  int32_t reserved[8];
+  double masking_ratio;            /* MPP: mask_prob */
+  int32_t output_channel_bits;     /* MPP (mpp.py:137), default 3 */
+  float max_pixel_val;             /* MPP (mpp.py:139), default 1.0 */
+  int32_t has_norm;                /* MPP: 1 = un-normalise the target with norm_mean / norm_std (mpp.py:108-109), channels <= 4 */
+  float norm_mean[4], norm_std[4];
+  int32_t reserved[5];
 } vitx_mim_config;
 typedef struct vitx_mim* vitx_mim_handle;
 

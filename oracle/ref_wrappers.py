@@ -144,3 +144,59 @@ def simmim_forward_backward(enc_cfg, enc_params, wrap_params, img, masked_indice
                                    detach_like_reference, q)
     loss.backward()
     return float(loss.detach()), pred.detach().numpy(), _grads(E), _grads(Wp)
+
+
+# ------------------------------------------------------------------------------------------------ MPP (mpp.py:90-218)
+def mpp_num_masked(mask_prob: float, num_patches: int) -> int:
+    import math
+    return min(num_patches, math.ceil(mask_prob * num_patches))        # mpp.py:80
+
+
+def mpp_param_spec(enc_cfg: dict, output_channel_bits: int = 3):
+    """(name, shape) of MPP's own parameters in the attribute order of MPP.__init__ (mpp.py:149,159)."""
+    ph, pw = enc_cfg["patch_size"]
+    c = enc_cfg.get("channels", 3)
+    return [("to_bits.kernel", (enc_cfg["dim"], 2 ** (output_channel_bits * c))), ("to_bits.bias", (2 ** (output_channel_bits * c),)),
+            ("mask_token", (c * ph * pw,))]
+
+
+def mpp_labels(img: torch.Tensor, patch: int, bits: int, max_pixel_val: float, mean=None, std=None) -> torch.Tensor:
+    """MPPLoss target labels [b, num_patches] as the code evidently means them (mpp.py:104-123 with the clamp to [0, max_pixel_val])."""
+    t = img
+    if mean and std:
+        t = t * torch.tensor(std, dtype=t.dtype) + torch.tensor(mean, dtype=t.dtype)     # mpp.py:108-109 (per channel, NHWC)
+    t = t.clamp(0.0, max_pixel_val)
+    b, H, W, c = t.shape
+    avg = t.reshape(b, H // patch, patch, W // patch, patch, c).mean(dim=(2, 4)).reshape(b, -1, c)         # mpp.py:113
+    bin_size = max_pixel_val / (2 ** bits)
+    bounds = torch.tensor(np.arange(bin_size, max_pixel_val, bin_size), dtype=torch.float64)               # mpp.py:115
+    disc = torch.bucketize(avg.detach().to(torch.float64), bounds, right=True)                             # Bucketize: boundaries <= value
+    weights = torch.tensor([(2 ** bits) ** i for i in range(c)])                                           # mpp.py:118
+    return (disc * weights).sum(-1)                                                                        # mpp.py:121
+
+
+def mpp_forward(enc_cfg: dict, E: Dict[str, torch.Tensor], Wp: Dict[str, torch.Tensor], img: torch.Tensor, masked_indices: np.ndarray,
+                output_channel_bits: int = 3, max_pixel_val: float = 1.0, mean=None, std=None, literal: bool = True, q=None):
+    """MPP.call (mpp.py:166-218) -> (loss, logits of the masked positions [b, nm, 2^(bits c)]).  `masked_indices` int [b, nm] is the top_k draw
+    of get_mask_subset_with_prob (:79-88).  literal=True restates the code AS IT RUNS under TensorFlow:
+      * the replacements of :177-190 are written into `.numpy()` copies and never reach masked_input -- the transformer sees the patches;
+      * the loss is tf.nn.softmax_cross_entropy_with_logits(labels=predictions, logits=label ids [n, 1]) (argument order of :125): the
+        broadcast logits are all equal, log_softmax = -log(nb), loss = log(nb) * mean_i sum_j predictions_ij.
+    literal=False: cross-entropy of the masked positions' logits against mpp_labels()."""
+    q = q or R._ident
+    ph, pw = enc_cfg["patch_size"]
+    patches = R.patch_unfold(img, ph, pw)                                                   # mpp.py:175
+    x = R._dense(q(patches), E, "patch_embedding", q)                                       # mpp.py:200
+    b, n, _ = x.shape
+    x = torch.cat([E["cls_token"].expand(b, -1, -1), x], dim=1) + E["pos_embedding"][:, :n + 1]   # mpp.py:203-208 (dropout rate 0 here)
+    enc = R._transformer(x, E, enc_cfg, "transformer", enc_cfg["depth"], q)                 # mpp.py:212
+    idx = torch.as_tensor(np.ascontiguousarray(masked_indices), dtype=torch.long)
+    rows = enc[:, 1:][torch.arange(b)[:, None], idx]                                        # logits[:, 1:][mask]  (mpp.py:214, :125), row order irrelevant to the mean
+    logits = R._dense(rows, Wp, "to_bits", q)                                               # mpp.py:213
+    nb = logits.shape[-1]
+    if literal:
+        loss = float(np.log(nb)) * logits.sum(-1).mean()
+    else:
+        lab = mpp_labels(img, ph, output_channel_bits, max_pixel_val, mean, std)[torch.arange(b)[:, None], idx]
+        loss = torch.nn.functional.cross_entropy(logits.reshape(-1, nb), lab.reshape(-1))
+    return loss, logits

@@ -55,7 +55,9 @@ class _T(torch.Tensor):
     """float64 torch tensor whose .numpy() leaves the autograd graph the way EagerTensor.numpy() leaves the tape."""
 
     def numpy(self):  # noqa: D401
-        return torch.Tensor.numpy(self.detach().as_subclass(torch.Tensor))
+        # EagerTensor.numpy() returns a COPY ("Copy of the contents of this Tensor into a NumPy array"): writing into the result never reaches
+        # the tensor -- mpp.py:185,190 assign into `masked_input.numpy()[...]`, which therefore leaves masked_input as it was
+        return torch.Tensor.numpy(self.detach().as_subclass(torch.Tensor)).copy()
 
     @property
     def ndim_(self):
@@ -117,7 +119,45 @@ def _random_normal(shape, mean=0.0, stddev=1.0, dtype=None, seed=None, name=None
 
 
 def _random_uniform(shape, minval=0.0, maxval=1.0, dtype=None, seed=None, name=None):
+    if dtype in (torch.int32, torch.int64):      # integers in [minval, maxval)  (mpp.py:182)
+        return _t(torch.randint(int(minval), int(maxval), _shape_list(shape), generator=_GEN))
     return _t(torch.rand(_shape_list(shape), generator=_GEN, dtype=DTYPE) * (maxval - minval) + minval)
+
+
+def zeros(shape, dtype=None, name=None):
+    return _t(torch.zeros(_shape_list(shape), dtype=DTYPE))
+
+
+def expand_dims(input, axis, name=None):
+    return _t(input).unsqueeze(axis)
+
+
+def reshape(tensor, shape, name=None):
+    return _t(tensor).reshape(_shape_list(shape))
+
+
+def clip_by_value(t, clip_value_min, clip_value_max, name=None):
+    """tf.clip_by_value: min(max(t, lo), hi) -- with lo > hi every element becomes hi (mpp.py:112 passes lo = reduce_min(max_pixel_val))."""
+    return torch.minimum(torch.maximum(_t(t), _t(clip_value_min)), _t(clip_value_max))
+
+
+def reduce_min(input_tensor, axis=None, keepdims=False, name=None):
+    x = _t(input_tensor)
+    return x.min() if axis is None else x.amin(dim=axis, keepdim=keepdims)
+
+
+def bucketize(input, boundaries, name=None):
+    """tf.raw_ops.Bucketize: output = number of boundaries <= input (boundaries sorted ascending), int32."""
+    b = torch.as_tensor(np.asarray(boundaries, dtype=np.float64))
+    return _t(torch.bucketize(_t(input).detach().to(torch.float64), b, right=True))
+
+
+def softmax_cross_entropy_with_logits(labels, logits, axis=-1, name=None):
+    """tf.nn.softmax_cross_entropy_with_logits(labels, logits): -sum(labels * log_softmax(logits), axis); the kernel broadcasts the two
+    operands against each other (xent_op.cc: "logits and labels must be broadcastable") and backpropagates into both.  mpp.py:125 passes
+    (predictions, target labels) in THAT order, i.e. labels = the predicted logits [n, 2^bits], logits = the label ids [n, 1]."""
+    lab, lg = torch.broadcast_tensors(_t(labels), _t(logits))
+    return -(lab * torch.log_softmax(lg, dim=axis)).sum(dim=axis)
 
 
 def cast(x, dtype):
@@ -224,6 +264,9 @@ def log_softmax(logits, axis=-1, name=None):
 class _TopK:
     def __init__(self, values, indices):
         self.values, self.indices = values, indices
+
+    def __iter__(self):          # `_, sampled_indices = tf.math.top_k(...)` (mpp.py:83)
+        return iter((self.values, self.indices))
 
 
 def top_k(input, k=1, sorted=True, name=None):
@@ -463,19 +506,23 @@ def install() -> types.ModuleType:
                      KLDivergence=KLDivergence, Reduction=_Reduction)
     backend = _module("tensorflow.keras.backend", is_keras_tensor=lambda x: False)   # einops probes it while choosing a backend
     keras = _module("tensorflow.keras", Model=Model, Sequential=Sequential, layers=layers, losses=losses, backend=backend)
-    nn_ = _module("tensorflow.nn", softmax=softmax, log_softmax=log_softmax)
+    nn_ = _module("tensorflow.nn", softmax=softmax, log_softmax=log_softmax, softmax_cross_entropy_with_logits=softmax_cross_entropy_with_logits)
+    raw_ops = _module("tensorflow.compat.v1.raw_ops", Bucketize=bucketize)
+    compat_v1 = _module("tensorflow.compat.v1", raw_ops=raw_ops)
+    compat = _module("tensorflow.compat", v1=compat_v1)
     math_ = _module("tensorflow.math", erf=lambda x: torch.erf(_t(x)), top_k=top_k, tanh=lambda x: torch.tanh(_t(x)))
     random_ = _module("tensorflow.random", normal=_random_normal, uniform=_random_uniform)
     image_ = _module("tensorflow.image", extract_patches=extract_patches)
     tf = _module("tensorflow", __vitx_shim__=True, __version__="0.0-vitx-shim", Tensor=Tensor, Variable=Variable,
-                 keras=keras, nn=nn_, math=math_, random=random_, image=image_,
+                 keras=keras, nn=nn_, math=math_, random=random_, image=image_, compat=compat, zeros=zeros, expand_dims=expand_dims, reshape=reshape,
+                 clip_by_value=clip_by_value, reduce_min=reduce_min,
                  float32=torch.float32, float64=torch.float64, int32=torch.int32, int64=torch.int64, bool=torch.bool,
                  cast=cast, split=split, concat=concat, einsum=einsum, matmul=matmul, transpose=transpose,
                  reduce_mean=reduce_mean, reduce_sum=reduce_sum, fill=fill, identity=identity, stop_gradient=stop_gradient,
                  argmax=argmax, argsort=argsort, range=range_, where=where, square=square, abs=lambda x: torch.abs(_t(x)),
                  tanh=lambda x: torch.tanh(_t(x)), pow=lambda x, y: torch.pow(_t(x), y), sqrt=lambda x: torch.sqrt(_t(x)),
                  convert_to_tensor=_t, constant=_t, executing_eagerly=lambda: True, is_tensor=lambda x: False)
-    for m in (tf, keras, layers, losses, backend, nn_, math_, random_, image_):
+    for m in (tf, keras, layers, losses, backend, nn_, math_, random_, image_, compat, compat_v1, raw_ops):
         sys.modules[m.__name__] = m
     return tf
 

@@ -190,6 +190,13 @@ def test_optimizer_state_survives_a_handle_regrow(tmp_path):
         m2 = make_engine_model("vit_small", "fp32", 2)
         m2.load_weights(str(tmp_path / name))
         assert all(np.array_equal(v, m2.state_dict()[k]) for k, v in m.state_dict().items())
+    # the Keras get_weights()-order list form (what np.savez(path, *keras_model.get_weights()) writes on the TensorFlow side)
+    m.save_weights(str(tmp_path / "klist"), format="keras_list")
+    with np.load(str(tmp_path / "klist.npz")) as z:
+        assert z.files == [f"arr_{i}" for i in range(len(m.get_weights()))] and z["arr_0"].shape == m.weights[0].shape
+    m3 = make_engine_model("vit_small", "fp32", 2)
+    m3.load_weights(str(tmp_path / "klist"))
+    assert all(np.array_equal(v, m3.state_dict()[k]) for k, v in m.state_dict().items())
 
 
 @pytest.mark.parametrize("name", ["vit_small", "deepvit_small", "cait_small", "cfg2_vit_b16"])

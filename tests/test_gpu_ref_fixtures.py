@@ -366,7 +366,7 @@ def test_bf16x3_fused_attention_agrees_with_the_materialised_split_operand_path(
     """BF16X3 mode, ViT attention (vit.py:73-82): the fused split-operand kernel (attn_x3.hip: scores never leave the chip) against the same
     mode with materialised scores (VITX_X3_ATTN=2: batched split-operand GEMMs + a softmax pass), token counts on both sides of every key-tile
     boundary the kernel is instantiated for (65, 197, 257) and a ragged one (50).  Both are fp32-accurate to ~1e-5; gate 2e-4 of each tensor's max."""
-    from util import CONFIGS
+    from util import CONFIGS, gate, make_engine_model, oracle_cfg, rand_images
     for tag, kw, b in [("n65", dict(image_size=64, patch_size=8, num_classes=10, dim=128, depth=2, heads=2, mlp_dim=256), 3),
                        ("n197", dict(image_size=224, patch_size=16, num_classes=10, dim=128, depth=2, heads=2, mlp_dim=256), 2),
                        ("n257", dict(image_size=256, patch_size=16, num_classes=10, dim=192, depth=1, heads=3, mlp_dim=256), 2),

@@ -186,3 +186,86 @@ def test_wrapper_errors_and_regrowth():
     big = np.concatenate([img, img, img], axis=0)
     l_big = mae(big, indices=np.concatenate([perm, perm, perm], axis=0))
     assert enc._cfg.max_batch >= 6 and abs(l_big - l_small) <= 1e-5 * abs(l_small)
+
+
+# ------------------------------------------------------------------------------------------------ MPP (mpp.py:90-218)
+def test_mpp_matches_the_reference_fixture():
+    """vit_tensorflow.mpp.MPP in fp32 mode on the weights, image and mask of tests/golden/ref_mpp_vit.npz -- produced by the reference's OWN
+    mpp.py under oracle/tf_shim: the loss as written and every gradient, including WHICH variables receive none (mask_token: the
+    replacements of mpp.py:185,190 go into `.numpy()` copies; the encoder's mlp_head: unused)."""
+    import os
+    from oracle import gen_ref_fixtures as G
+    from vit_tensorflow import ViT
+    from vit_tensorflow.mpp import MPP
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_mpp_vit.npz"))
+    ekw, wkw = G.MPP_CASES["mpp_vit"]
+    ecfg = spec.make_config("vit", **ekw)
+    E = spec.init_params(ecfg, int(z["enc_seed"]), randomize_all=True)
+    rng = np.random.Generator(np.random.PCG64(int(z["wrap_seed"])))
+    Wp = {n: (0.3 * rng.standard_normal(shape)).astype(np.float32) for n, shape in RW.mpp_param_spec(ecfg, wkw["output_channel_bits"])}
+    b = z["img"].shape[0]
+    enc = ViT(**ekw, compute="fp32", max_batch=b, seed=0)
+    enc.load_state_dict({k: np.asarray(a, np.float32) for k, a in E.items()})
+    mpp = MPP(image_size=ekw["image_size"], transformer=enc, seed=3, **wkw)
+    mpp.load_state_dict(Wp)
+    assert mpp.num_masked() == (16, z["indices"].shape[1])
+    loss = mpp(z["img"], indices=z["indices"])
+    assert abs(loss - float(z["loss"])) <= 1e-4 * abs(float(z["loss"])), (loss, float(z["loss"]))
+    grads = mpp.backward()
+    for k in [f[5:] for f in z.files if f.startswith("grad/")]:
+        ref = z["grad/" + k]
+        if not bool(z["has_grad/" + k]):
+            assert not np.asarray(grads[k]).any(), k
+            continue
+        _close(grads[k], ref, 1e-4, k)
+
+
+@pytest.mark.parametrize("key,literal,drop", [("fp32", False, 0.0), ("fp32", True, 0.0), ("bf16", False, 0.0), ("bf16", True, 0.0), ("fp32", False, 0.1)])
+def test_mpp_matches_the_oracle(key, literal, drop):
+    """Both loss forms against oracle/ref_wrappers.py:mpp_forward (pinned to the reference's mpp.py by tests/test_ref_fixtures.py): the literal
+    form, and the cross-entropy against the discretised mean patch colour the code evidently means (normalised images, 3 bits per channel).
+    With dropout the loss is only checked to be deterministic in the seed (the masks are the engine's counter-based ones)."""
+    import torch
+    from vit_tensorflow import ViT
+    from vit_tensorflow.mpp import MPP
+    b = 3
+    kw = dict(ENC[key], dropout=drop, emb_dropout=drop)
+    ecfg = spec.make_config("vit", **ENC[key])
+    E = spec.init_params(ecfg, 1, randomize_all=True)
+    enc = ViT(**kw, compute=key, max_batch=b, seed=0)
+    enc.load_state_dict({k: np.asarray(a, np.float32) for k, a in E.items()})
+    mean, std = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
+    mpp = MPP(image_size=ecfg["image_size"], transformer=enc, patch_size=8, output_channel_bits=3, mask_prob=0.4, mean=mean, std=std, literal_loss=literal, seed=3)
+    Ws = _randomize(mpp, 12)
+    img = ((np.random.default_rng(8).uniform(0, 1, (b, *ecfg["image_size"], 3)) - mean) / std).astype(np.float32)
+    npat, nm = mpp.num_masked()
+    midx = np.argsort(-np.random.default_rng(10).uniform(size=(b, npat)), axis=-1)[:, :nm].astype(np.int32)
+    if drop > 0:
+        l1 = mpp(img, indices=midx, seed=5)
+        g1 = mpp.backward()
+        l2 = mpp(img, indices=midx, seed=5)
+        g2 = mpp.backward()
+        assert l1 == l2 and all(np.array_equal(g1[k], g2[k]) for k in g1) and np.isfinite(l1)
+        assert mpp(img, indices=midx, seed=6) != l1
+        return
+    loss = mpp(img, indices=midx)
+    grads = mpp.backward()
+    q = ref_torch.bf16_round if key == "bf16" else None
+    Et = {k: torch.tensor(np.asarray(v, np.float64), requires_grad=True) for k, v in E.items()}
+    Wt = {k: torch.tensor(np.asarray(v, np.float64), requires_grad=True) for k, v in Ws.items()}
+    rl, rlogits = RW.mpp_forward(ecfg, Et, Wt, torch.tensor(np.asarray(img, np.float64)), midx, 3, 1.0, mean, std, literal=literal, q=q)
+    rl.backward()
+    tol = 1e-4 if key == "fp32" else 1.5e-2
+    assert abs(loss - float(rl)) <= tol * max(1.0, abs(float(rl))), (loss, float(rl))
+    _close(mpp.read("pred"), rlogits.detach().numpy(), tol if key == "fp32" else 3e-2, "pred_pixel_values")
+    gtol, nrm = (tol, False) if key == "fp32" else (8e-2, True)
+    for k, t in Wt.items():
+        if t.grad is None:
+            assert not np.asarray(grads[k]).any(), k        # mask_token
+        else:
+            _close(grads[k], t.grad.numpy(), gtol, k, nrm)
+    for k, t in Et.items():
+        if t.grad is None:
+            assert not np.asarray(grads["encoder." + k]).any(), k
+        else:
+            _close(grads["encoder." + k], t.grad.numpy(), gtol, "encoder." + k, nrm)

@@ -83,6 +83,59 @@ def test_committed_fixture_is_what_the_reference_source_produces(case):
     assert r.returncode == 0 and "OK" in r.stdout, r.stderr[-2000:]
 
 
+@pytest.mark.skipif(not os.path.isdir(G.REF), reason="/root/reference is not present on this machine (GPU box)")
+def test_committed_mpp_fixture_is_what_the_reference_source_produces():
+    """tests/golden/ref_mpp_vit.npz = the reference's own mpp.py (MPP.call mpp.py:166-218, MPPLoss :90-131) re-run under the shim in a fresh
+    interpreter, bit for bit."""
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "from oracle import gen_ref_fixtures as G\n"
+        "d = G.make_mpp('mpp_vit'); z = np.load(%r)\n"
+        "assert sorted(d) == sorted(z.files), (sorted(d), sorted(z.files))\n"
+        "bad = [k for k in d if not np.array_equal(np.asarray(d[k]), z[k])]\n"
+        "assert not bad, bad\n"
+        "import mpp, inspect; assert inspect.getsourcefile(mpp).startswith(%r)\n"
+        "print('OK')\n" % (ROOT, os.path.join(ROOT, "tests"), os.path.join(GOLDEN_DIR, "ref_mpp_vit.npz"), os.path.dirname(G.REF))
+    )
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stderr[-2000:]
+
+
+def test_mpp_oracle_reproduces_reference_fixture():
+    """oracle/ref_wrappers.py:mpp_forward (literal form) against what the reference's own mpp.py produced under the shim on the mask it drew:
+    the loss AS WRITTEN (mpp.py:125 passes (predictions, labels) to softmax_cross_entropy_with_logits(labels, logits); :185,190 write the
+    replacements into `.numpy()` copies), every variable's gradient, and which variables have none (mask_token, the encoder's mlp_head)."""
+    import torch
+    from oracle import ref_wrappers as RW
+    z = _load("mpp_vit")
+    ekw, wkw = G.MPP_CASES["mpp_vit"]
+    ecfg = spec.make_config("vit", **ekw)
+    E = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in spec.init_params(ecfg, int(z["enc_seed"]), randomize_all=True).items()}
+    rng = np.random.Generator(np.random.PCG64(int(z["wrap_seed"])))
+    Wp = {n: torch.tensor(0.3 * rng.standard_normal(shape), dtype=torch.float64, requires_grad=True) for n, shape in RW.mpp_param_spec(ecfg, wkw["output_channel_bits"])}
+    img = torch.tensor(np.asarray(z["img"], np.float64))
+    assert z["indices"].shape[1] == RW.mpp_num_masked(wkw["mask_prob"], (ekw["image_size"] // ekw["patch_size"]) ** 2)
+    loss, _ = RW.mpp_forward(ecfg, E, Wp, img, z["indices"], wkw["output_channel_bits"], literal=True)
+    assert abs(float(loss) - float(z["loss"])) <= F64_TOL * abs(float(z["loss"]))
+    loss.backward()
+    got = {**{"encoder." + k: v for k, v in E.items()}, **Wp}
+    names = [k[5:] for k in z.files if k.startswith("grad/")]
+    assert sorted(names) == sorted(got), sorted(set(names) ^ set(got))
+    with_grad = 0
+    for n in names:
+        g = got[n].grad
+        if not bool(z["has_grad/" + n]):
+            assert g is None or not g.numpy().any(), n
+            continue
+        with_grad += 1
+        ref = z["grad/" + n]
+        assert np.abs(g.numpy().reshape(ref.shape) - ref).max() <= F64_TOL * max(1.0, np.abs(ref).max()), n
+    assert with_grad == 28
+    # the intended form (literal=False) is a different loss: a proper cross-entropy, finite and positive
+    l2, _ = RW.mpp_forward(ecfg, {k: v.detach() for k, v in E.items()}, {k: v.detach() for k, v in Wp.items()}, img, z["indices"], wkw["output_channel_bits"], literal=False)
+    assert np.isfinite(float(l2)) and float(l2) > 0
+
+
 def test_shim_does_not_leak_into_this_process():
     assert "tensorflow" not in sys.modules or not getattr(sys.modules["tensorflow"], "__vitx_shim__", False)
 

@@ -82,57 +82,91 @@ __global__ __launch_bounds__(X3_THREADS) void attn_x3_fwd_kernel(const float* __
   stage_head_x3(qbase + 2 * inner, tok_stride, n, NKP, v_hi, v_lo, tid, blockDim.x);
   __syncthreads();
 
+  // a wave owns QB = 2 blocks of 16 queries at a time: every K / V fragment pair read from LDS feeds six MFMAs instead of three
+  constexpr int QB = 2;
   const int qi = lane & 15, g = lane >> 4;
-  const int nqb = (n + 15) / 16;
+  const int nqb = (n + 16 * QB - 1) / (16 * QB);
   const float sl2 = scale * 1.44269504088896340736f;
   for (int qb = wave; qb < nqb; qb += nwaves) {
-    const int q = qb * 16 + qi, qc = min(q, n - 1);
-    P2 qf[2];
+    int q[QB];
+    P2 qf[QB][2];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) qf[ks] = load_split8(qbase + (int64_t)qc * tok_stride + (g + 4 * ks) * 8);
-    // pass 1: row maximum of the scores.  S^T tile t: lane holds S[query qi][key 16t + 4g + r].
-    float m = -INFINITY;
-    for (int t = 0; t < NTP && t * 16 < n; ++t) {
-      f32x4 a = {0.f, 0.f, 0.f, 0.f};
-      a = mfma3(frag_rm2(k_hi, k_lo, t * 16 + qi, g), qf[0], a);
-      a = mfma3(frag_rm2(k_hi, k_lo, t * 16 + qi, g + 4), qf[1], a);
+    for (int s = 0; s < QB; ++s) {
+      q[s] = (qb * QB + s) * 16 + qi;
+      const int qc = min(q[s], n - 1);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) m = fmaxf(m, (t * 16 + 4 * g + r) < n ? a[r] : -INFINITY);
+      for (int ks = 0; ks < 2; ++ks) qf[s][ks] = load_split8(qbase + (int64_t)qc * tok_stride + (g + 4 * ks) * 8);
     }
-    m = fmaxf(m, __shfl_xor(m, 16, 64));
-    m = fmaxf(m, __shfl_xor(m, 32, 64));
-    m *= sl2;
-    // pass 2: recompute the tile pair, p = 2^(s - m), accumulate the row sum and O^T += V^T P^T (unnormalised)
-    float l = 0.f;
-    f32x4 oacc[4];
+    // pass 1: row maxima of the scores.  S^T tile t: lane holds S[query qi][key 16t + 4g + r].
+    float m[QB];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) oacc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < QB; ++s) m[s] = -INFINITY;
+    for (int t = 0; t < NTP && t * 16 < n; ++t) {
+      const P2 kf0 = frag_rm2(k_hi, k_lo, t * 16 + qi, g), kf1 = frag_rm2(k_hi, k_lo, t * 16 + qi, g + 4);
+#pragma unroll
+      for (int s = 0; s < QB; ++s) {
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+        a = mfma3(kf0, qf[s][0], a);
+        a = mfma3(kf1, qf[s][1], a);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) m[s] = fmaxf(m[s], (t * 16 + 4 * g + r) < n ? a[r] : -INFINITY);
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < QB; ++s) {
+      m[s] = fmaxf(m[s], __shfl_xor(m[s], 16, 64));
+      m[s] = fmaxf(m[s], __shfl_xor(m[s], 32, 64));
+      m[s] *= sl2;
+    }
+    // pass 2: recompute the tile pair, p = 2^(s - m), accumulate the row sum and O^T += V^T P^T (unnormalised)
+    float l[QB];
+    f32x4 oacc[QB][4];
+#pragma unroll
+    for (int s = 0; s < QB; ++s) {
+      l[s] = 0.f;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) oacc[s][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     const int u_end = min(NTP / 2, (n + 31) >> 5);
 #pragma unroll 1
     for (int u = 0; u < u_end; ++u) {
-      f32x4 p[2];
+      f32x4 p[QB][2];
 #pragma unroll
       for (int tt = 0; tt < 2; ++tt) {
         const int t = 2 * u + tt;
-        f32x4 a = {0.f, 0.f, 0.f, 0.f};
-        a = mfma3(frag_rm2(k_hi, k_lo, t * 16 + qi, g), qf[0], a);
-        a = mfma3(frag_rm2(k_hi, k_lo, t * 16 + qi, g + 4), qf[1], a);
+        const P2 kf0 = frag_rm2(k_hi, k_lo, t * 16 + qi, g), kf1 = frag_rm2(k_hi, k_lo, t * 16 + qi, g + 4);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) p[tt][r] = (t * 16 + 4 * g + r) < n ? fast_exp2(fmaf(a[r], sl2, -m)) : 0.f;
-        l += (p[tt][0] + p[tt][1]) + (p[tt][2] + p[tt][3]);
+        for (int s = 0; s < QB; ++s) {
+          f32x4 a = {0.f, 0.f, 0.f, 0.f};
+          a = mfma3(kf0, qf[s][0], a);
+          a = mfma3(kf1, qf[s][1], a);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) p[s][tt][r] = (t * 16 + 4 * g + r) < n ? fast_exp2(fmaf(a[r], sl2, -m[s])) : 0.f;
+          l[s] += (p[s][tt][0] + p[s][tt][1]) + (p[s][tt][2] + p[s][tt][3]);
+        }
       }
-      const P2 pf = split8(p[0], p[1]);
+      P2 pf[QB];
 #pragma unroll
-      for (int c = 0; c < 4; ++c) oacc[c] = mfma3(frag_trr2(v_hi, v_lo, c, u, lane), pf, oacc[c]);
+      for (int s = 0; s < QB; ++s) pf[s] = split8(p[s][0], p[s][1]);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const P2 vf = frag_trr2(v_hi, v_lo, c, u, lane);
+#pragma unroll
+        for (int s = 0; s < QB; ++s) oacc[s][c] = mfma3(vf, pf[s], oacc[s][c]);
+      }
     }
-    l += __shfl_xor(l, 16, 64);
-    l += __shfl_xor(l, 32, 64);
-    const float inv_l = 1.0f / l;
-    if (g == 0 && q < n) lse[(int64_t)bh * n + q] = (m + log2f(l)) * 0.69314718055994530942f;   // natural-log LSE
-    if (q < n) {
-      float* op = o + ((int64_t)bi * n + q) * inner + hi_ * DH;
 #pragma unroll
-      for (int c = 0; c < 4; ++c) *(f32x4*)(op + 16 * c + 4 * g) = oacc[c] * inv_l;
+    for (int s = 0; s < QB; ++s) {
+      float ls = l[s];
+      ls += __shfl_xor(ls, 16, 64);
+      ls += __shfl_xor(ls, 32, 64);
+      const float inv_l = 1.0f / ls;
+      if (g == 0 && q[s] < n) lse[(int64_t)bh * n + q[s]] = (m[s] + log2f(ls)) * 0.69314718055994530942f;   // natural-log LSE
+      if (q[s] < n) {
+        float* op = o + ((int64_t)bi * n + q[s]) * inner + hi_ * DH;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) *(f32x4*)(op + 16 * c + 4 * g) = oacc[s][c] * inv_l;
+      }
     }
   }
 }

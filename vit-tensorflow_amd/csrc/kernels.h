@@ -189,6 +189,9 @@ void launch_select_rowsum(const float* x, const int32_t* inv_or_null, int j0, in
                           hipStream_t s);   // partial_ws: b * d floats
 void launch_simmim_select(float* x, const int32_t* inv, const float* mask_token, const float* pos, int b, int n, int d, hipStream_t s);
 void launch_zero_selected_rows(float* x, const int32_t* inv, int64_t rows, int d, hipStream_t s);
+void launch_scatter_by_index(const float* src, const int32_t* idx, int b, int k, int d, float* dst, int64_t dst_batch_stride, int row0, hipStream_t s);
+void launch_mpp_labels(const float* img, int b, int H, int W, int C, int p, int bits, float mpv, int has_norm, const float* mean, const float* std_,
+                       const int32_t* idx, int k, int32_t* labels, hipStream_t s);
 int64_t recon_loss_ws_elems(int64_t count);
 // kind 0: squared, 1: absolute; loss_out = scale * sum f(pred - target), dpred = scale * f'(pred - target); target may be null (= 0)
 void launch_recon_loss(const float* pred, const float* target_or_null, int64_t count, int kind, float scale, float* dpred, float* partial_ws,

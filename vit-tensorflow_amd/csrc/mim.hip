@@ -31,6 +31,10 @@ struct vitx_mim {
   int64_t w_ed = -1, b_ed = -1, mask_tok = -1, dpos = -1, w_px = -1, b_px = -1;   // arena offsets
   int np_max = 0, d = 0, dd = 0, pd = 0, B = 0;
   bool mae = false, project = false;  // project: enc_to_dec is a Dense (encoder_dim != decoder_dim), else Identity (mae.py:41)
+  bool mpp = false;                   // MPP (mpp.py:133): px = to_bits, Dense(dim -> 2^(bits * channels))
+  int po = 0;                         // output width of the wrapper's last Dense: patch_dim (to_pixels) or 2^(bits * channels) (to_bits)
+  float *tok1 = nullptr, *enc1 = nullptr;   // MPP: [B, np + 1, d] embedded tokens / transformer output (cls row included)
+  int32_t* labels = nullptr;          // MPP, literal_loss = 0: class of each masked patch
   std::vector<void*> allocs;
   float *img = nullptr, *patches = nullptr, *tok = nullptr, *sel = nullptr, *enc_out = nullptr, *proj = nullptr, *dec_in = nullptr,
         *dec_out = nullptr, *rows_m = nullptr, *pred = nullptr, *target = nullptr, *dpred = nullptr;
@@ -44,9 +48,16 @@ struct vitx_mim {
   int64_t t_rows = 0, glue_geom = -1;
   bool have_fwd = false;
   int b = 0, np = 0, nm = 0;
+  float mpp_edrop = 0.f; uint64_t mpp_seed = 0;   // embedding-dropout mask of the last MPP forward
 };
 
 namespace {
+
+// patches the wrapper masks at an image of np patches: int(masking_ratio * np) (mae.py:57, simmim.py:106); MPP: ceil(mask_prob * np) (mpp.py:80)
+int mim_num_masked(const vitx_mim* m, int np) {
+  if (m->mpp) return std::min(np, (int)std::ceil(m->cfg.masking_ratio * (double)np));
+  return (int)(m->cfg.masking_ratio * (double)np);
+}
 
 int64_t add_param(vitx_mim* m, const std::string& name, std::vector<int64_t> shape) {
   ParamDesc p;
@@ -62,7 +73,11 @@ int64_t add_param(vitx_mim* m, const std::string& name, std::vector<int64_t> sha
 // the wrappers' parameter order follows the attribute order of the reference constructors (mae.py:41-45, simmim.py:83-84)
 void build_mim_table(vitx_mim* m) {
   m->table.clear(); m->n_params = m->n_arena = 0;
-  if (m->mae) {
+  if (m->mpp) {   // attribute order of MPP.__init__ (mpp.py:149,159)
+    m->w_px = add_param(m, "to_bits.kernel", {m->d, m->po});
+    m->b_px = add_param(m, "to_bits.bias", {m->po});
+    m->mask_tok = add_param(m, "mask_token", {m->pd});
+  } else if (m->mae) {
     if (m->project) { m->w_ed = add_param(m, "enc_to_dec.kernel", {m->d, m->dd}); m->b_ed = add_param(m, "enc_to_dec.bias", {m->dd}); }
     m->mask_tok = add_param(m, "mask_token", {m->dd});
     // num_patches is read off pos_embedding.shape[-2] (mae.py:37), i.e. it counts the cls row: the table has np + 1 rows
@@ -133,7 +148,7 @@ int glue_prepare(vitx_mim* m, int b, int np, std::string& err) {
     const int64_t dm = std::max(m->d, m->dd);
     HIPCHK(hipMemsetAsync(m->x_px_T, 0, (size_t)m->t_rows * dm * 2, s));
     HIPCHK(hipMemsetAsync(m->x_ed_T, 0, (size_t)m->t_rows * dm * 2, s));
-    HIPCHK(hipMemsetAsync(m->dy_px_T, 0, (size_t)m->t_rows * m->pd * 2, s));
+    HIPCHK(hipMemsetAsync(m->dy_px_T, 0, (size_t)m->t_rows * m->po * 2, s));
     HIPCHK(hipMemsetAsync(m->dy_ed_T, 0, (size_t)m->t_rows * dm * 2, s));
   }
   m->glue_geom = geom;
@@ -168,12 +183,25 @@ void glue_bwd(vitx_mim* m, const Dense& w, const void* xT, void* dyT, const floa
 
 int mim_create(vitx_engine* enc, const vitx_mim_config& cfg, vitx_mim** out, std::string& err) {
   if (!(cfg.masking_ratio > 0.0 && cfg.masking_ratio < 1.0)) { err = "masking ratio must be kept between 0 and 1"; return VITX_ERR_INVALID; }   // mae.py:28, simmim.py:71
-  if (cfg.kind != VITX_MIM_MAE && cfg.kind != VITX_MIM_SIMMIM) { err = "unknown wrapper kind"; return VITX_ERR_INVALID; }
-  if (enc->cfg.variant == VITX_VARIANT_CAIT || enc->cfg.variant == VITX_VARIANT_PATCH_MERGER) { err = "MAE / SimMIM need an encoder with pos_embedding[:, 1:] and .transformer (ViT / DeepViT)"; return VITX_ERR_UNSUPPORTED; }
+  if (cfg.kind != VITX_MIM_MAE && cfg.kind != VITX_MIM_SIMMIM && cfg.kind != VITX_MIM_MPP) { err = "unknown wrapper kind"; return VITX_ERR_INVALID; }
+  if (enc->cfg.variant == VITX_VARIANT_CAIT || enc->cfg.variant == VITX_VARIANT_PATCH_MERGER) { err = "MAE / SimMIM / MPP need an encoder with pos_embedding[:, 1:] and .transformer (ViT / DeepViT)"; return VITX_ERR_UNSUPPORTED; }
+  if (cfg.kind == VITX_MIM_MPP) {
+    const int bits = cfg.output_channel_bits > 0 ? cfg.output_channel_bits : 3;
+    if (bits * enc->cfg.channels > 14) { err = "output_channel_bits * channels must be <= 14 (2^14 classes)"; return VITX_ERR_UNSUPPORTED; }
+    if (enc->cfg.patch_h != enc->cfg.patch_w) { err = "MPP needs square patches (mpp.py:113: p1 = p2 = patch_size)"; return VITX_ERR_UNSUPPORTED; }
+    if (cfg.has_norm && enc->cfg.channels > 4) { err = "mean / std: at most 4 channels"; return VITX_ERR_UNSUPPORTED; }
+    if (enc->cfg.num_parallel_branches > 1) { err = "MPP: not for parallel_vit encoders"; return VITX_ERR_UNSUPPORTED; }
+  }
   vitx_mim* m = new vitx_mim();
   m->cfg = cfg; m->enc = enc;
   m->mae = cfg.kind == VITX_MIM_MAE;
+  m->mpp = cfg.kind == VITX_MIM_MPP;
+  if (m->mpp) {
+    if (m->cfg.output_channel_bits <= 0) m->cfg.output_channel_bits = 3;       // mpp.py:137
+    if (!(m->cfg.max_pixel_val > 0.f)) m->cfg.max_pixel_val = 1.0f;            // mpp.py:139
+  }
   m->np_max = enc->np_max; m->d = enc->cfg.dim; m->pd = enc->pd; m->B = enc->cfg.max_batch;
+  m->po = m->mpp ? (1 << (m->cfg.output_channel_bits * enc->cfg.channels)) : m->pd;
   m->dd = m->mae ? cfg.decoder_dim : m->d;
   if (m->mae && (cfg.decoder_dim <= 0 || cfg.decoder_depth < 0 || cfg.decoder_heads <= 0 || cfg.decoder_dim_head <= 0)) {
     delete m; err = "decoder_dim, decoder_heads, decoder_dim_head must be positive"; return VITX_ERR_INVALID;
@@ -198,9 +226,14 @@ int mim_create(vitx_engine* enc, const vitx_mim_config& cfg, vitx_mim** out, std
   MALLOC(m->tok, (size_t)R * m->d * 4);
   MALLOC(m->enc_out, (size_t)R * m->d * 4);
   MALLOC(m->rows_m, (size_t)R * dm * 4);
-  MALLOC(m->pred, (size_t)R * m->pd * 4);
+  MALLOC(m->pred, (size_t)R * m->po * 4);
   MALLOC(m->target, (size_t)R * m->pd * 4);
-  MALLOC(m->dpred, (size_t)R * m->pd * 4);
+  MALLOC(m->dpred, (size_t)R * m->po * 4);
+  if (m->mpp) {
+    MALLOC(m->tok1, (size_t)m->B * (m->np_max + 1) * m->d * 4);
+    MALLOC(m->enc1, (size_t)m->B * (m->np_max + 1) * m->d * 4);
+    MALLOC(m->labels, (size_t)R * 4);
+  }
   if (m->mae) {
     MALLOC(m->sel, (size_t)R * m->d * 4);
     MALLOC(m->proj, (size_t)R * m->dd * 4);
@@ -211,22 +244,22 @@ int mim_create(vitx_engine* enc, const vitx_mim_config& cfg, vitx_mim** out, std
   MALLOC(m->g_a, (size_t)R * dm * 4);
   MALLOC(m->g_b, (size_t)R * dm * 4);
   MALLOC(m->g_c, (size_t)R * dm * 4);
-  const int64_t ws_elems = std::max<int64_t>({colsum_ws_elems((int)std::max<int64_t>(m->pd, dm)), recon_loss_ws_elems(R * m->pd), (int64_t)m->B * dm}) + 64;
+  const int64_t ws_elems = std::max<int64_t>({colsum_ws_elems((int)std::max<int64_t>({(int64_t)m->pd, (int64_t)m->po, dm})), recon_loss_ws_elems(R * std::max(m->pd, m->po)), (int64_t)m->B * dm}) + 64;
   MALLOC(m->ws, (size_t)ws_elems * 4);
   MALLOC(m->loss, 256);
   MALLOC(m->idx, (size_t)R * 4);
   MALLOC(m->inv, (size_t)R * 4);
-  m->mfma = enc->bf16 && !enc->force_generic_gemm && m->d % 64 == 0 && m->dd % 64 == 0 && m->pd % 64 == 0;
+  m->mfma = enc->bf16 && !enc->force_generic_gemm && m->d % 64 == 0 && m->dd % 64 == 0 && m->po % 64 == 0;
   if (m->mfma) {
     int rc;
     const int in_px = m->mae ? m->dd : m->d;
-    if ((rc = engine_ext_dense_init(enc, m->px, in_px, m->pd, m->params + m->w_px, m->params + m->b_px, m->grads + m->w_px, m->grads + m->b_px, err)) != VITX_OK) return rc;
+    if ((rc = engine_ext_dense_init(enc, m->px, in_px, m->po, m->params + m->w_px, m->params + m->b_px, m->grads + m->w_px, m->grads + m->b_px, err)) != VITX_OK) return rc;
     if (m->project &&
         (rc = engine_ext_dense_init(enc, m->ed, m->d, m->dd, m->params + m->w_ed, m->params + m->b_ed, m->grads + m->w_ed, m->grads + m->b_ed, err)) != VITX_OK) return rc;
     m->t_rows = round_up(R, 256) + 384;   // GEMM tiles may read up to 319 rows past M
     MALLOC(m->x_px_T, (size_t)m->t_rows * dm * 2);
     MALLOC(m->x_ed_T, (size_t)m->t_rows * dm * 2);
-    MALLOC(m->dy_px_T, (size_t)m->t_rows * m->pd * 2);
+    MALLOC(m->dy_px_T, (size_t)m->t_rows * m->po * 2);
     MALLOC(m->dy_ed_T, (size_t)m->t_rows * dm * 2);
   }
   HIPCHK(hipStreamSynchronize(enc->stream));
@@ -254,12 +287,38 @@ int mim_forward(vitx_mim* m, const float* img_dev, int b, int H, int W, const in
     err = "Image dimensions must be divisible by the patch size."; return VITX_ERR_INVALID;
   }
   const int np = (H / c.patch_h) * (W / c.patch_w), d = m->d, dd = m->dd, pd = m->pd;
-  const int nm = (int)(m->cfg.masking_ratio * (double)np);   // int(self.masking_ratio * num_patches)  mae.py:57, simmim.py:106
+  const int nm = mim_num_masked(m, np);
   const int nu = np - nm;
-  if (nm <= 0 || nu <= 0) { err = "masking ratio leaves no masked (or no visible) patch at this image size"; return VITX_ERR_UNSUPPORTED; }
+  if (nm <= 0 || (nu <= 0 && !m->mpp)) { err = "masking ratio leaves no masked (or no visible) patch at this image size"; return VITX_ERR_UNSUPPORTED; }
   m->have_fwd = false;
   int rc;
   if ((rc = glue_prepare(m, b, np, err)) != VITX_OK) return rc;
+  if (m->mpp) {
+    // MPP.call (mpp.py:166-218).  The replacements of mpp.py:177-190 are assignments into `.numpy()` copies: masked_input stays the patches.
+    const float* Pm = m->params;
+    const int nb = m->po, ntok = np + 1;
+    if ((rc = engine_embed_forward(e, img_dev, b, H, W, m->tok1, err)) != VITX_OK) return rc;                 // mpp.py:200-206: patch Dense, cls, pos
+    const float edrop = training ? c.emb_dropout : 0.f;
+    if (edrop > 0.f) launch_dropout(m->tok1, 0, (int64_t)b * ntok * d, edrop, seed, 0u, s);                     // transformer.dropout (mpp.py:209) = nn.Dropout(emb_dropout), vit.py:148
+    if ((rc = engine_transformer_forward(e, m->tok1, b, ntok, training, seed, m->enc1, err)) != VITX_OK) return rc;          // mpp.py:212
+    // to_bits is applied row by row and the loss reads the masked positions only (mpp.py:213-216, :125): those rows are gathered first
+    launch_gather_rows(m->enc1 + d, (int64_t)ntok * d, idx_dev, nm, 0, b, nm, d, m->rows_m, s);
+    glue_fwd(m, m->px, m->x_px_T, m->rows_m, b * nm, d, Pm + m->w_px, Pm + m->b_px, nb, m->pred);
+    if (m->cfg.literal_loss) {
+      // tf.nn.softmax_cross_entropy_with_logits(labels = predictions, logits = label ids [n, 1] broadcast): log_softmax of nb equal logits is
+      // -log(nb), so the loss is log(nb) * mean_i sum_j pred_ij whatever the labels are (mpp.py:125-126)
+      launch_recon_loss(m->pred, nullptr, (int64_t)b * nm * nb, 2, (float)(std::log((double)nb) / ((double)b * nm)), m->dpred, m->ws, m->loss, s);
+    } else {
+      launch_mpp_labels(img_dev, b, H, W, c.channels, c.patch_h, m->cfg.output_channel_bits, m->cfg.max_pixel_val, m->cfg.has_norm, m->cfg.norm_mean,
+                        m->cfg.norm_std, idx_dev, nm, m->labels, s);
+      launch_ce_grad(m->pred, nb, m->labels, b * nm, nb, (float)(1.0 / ((double)b * nm)), m->dpred, m->target, s);   // per-row losses (already x 1/rows) ...
+      launch_sum_rows(m->target, b * nm, 1, m->loss, s);                                                                // ... summed in row order
+    }
+    if (idx_dev != m->idx) HIPCHK(hipMemcpyAsync(m->idx, idx_dev, (size_t)b * nm * 4, hipMemcpyDeviceToDevice, s));
+    m->have_fwd = true; m->b = b; m->np = np; m->nm = nm;
+    m->mpp_edrop = edrop; m->mpp_seed = seed;
+    return VITX_OK;
+  }
   if ((rc = engine_patch_tokens_forward(e, img_dev, b, H, W, m->tok, m->patches, err)) != VITX_OK) return rc;   // mae.py:49-55 / simmim.py:88-100
   const float* P = m->params;
   float scale;
@@ -310,6 +369,16 @@ int mim_backward(vitx_mim* m, std::string& err) {
   float* G = m->grads;
   int rc;
   launch_fill_zero(G, m->n_arena * 4, s);
+  if (m->mpp) {
+    const int nb = m->po, ntok = np + 1;
+    glue_bwd(m, m->px, m->x_px_T, m->dy_px_T, m->rows_m, P + m->w_px, m->dpred, b * nm, d, nb, m->g_rows_m, G + m->w_px, G + m->b_px);
+    launch_fill_zero(m->tok1, (int64_t)round_up((int64_t)b * ntok * d, 4) * 4, s);                           // tok1 is free: d(transformer output), zero but for the masked rows
+    launch_scatter_by_index(m->g_rows_m, m->idx, b, nm, d, m->tok1, (int64_t)ntok * d, 1, s);
+    if ((rc = engine_transformer_backward(e, m->tok1, m->enc1, err)) != VITX_OK) return rc;                   // enc1 = d(tokens) [b, np + 1, d]
+    if (m->mpp_edrop > 0.f) launch_dropout(m->enc1, 0, (int64_t)b * ntok * d, m->mpp_edrop, m->mpp_seed, 0u, s);
+    if ((rc = engine_embed_backward(e, m->enc1, nullptr, err)) != VITX_OK) return rc;                         // patch_embedding, cls_token, pos_embedding
+    return VITX_OK;                                                                                          // (mask_token: no path to the loss, see the header)
+  }
   if (m->mae) {
     glue_bwd(m, m->px, m->x_px_T, m->dy_px_T, m->rows_m, P + m->w_px, m->dpred, b * nm, dd, pd, m->g_rows_m, G + m->w_px, G + m->b_px);
     launch_fill_zero(m->g_a, (int64_t)round_up((int64_t)b * np * dd, 4) * 4, s);
@@ -455,7 +524,7 @@ int32_t vitx_mim_num_masked(vitx_mim_handle m, int32_t H, int32_t W, int32_t* nu
   if (H <= 0 || W <= 0 || H % c.patch_h || W % c.patch_w) return capi_fail(VITX_ERR_INVALID, "Image dimensions must be divisible by the patch size.");
   const int np = (H / c.patch_h) * (W / c.patch_w);
   if (num_patches) *num_patches = np;
-  if (num_masked) *num_masked = (int)(m->cfg.masking_ratio * (double)np);
+  if (num_masked) *num_masked = mim_num_masked(m, np);
   return VITX_OK;
 }
 
@@ -476,7 +545,7 @@ int32_t vitx_mim_forward(vitx_mim_handle m, const float* img_host, int32_t b, in
   if (b <= 0 || b > c.max_batch) return capi_fail(VITX_ERR_INVALID, "batch must be in [1, max_batch]");
   if (H <= 0 || W <= 0 || H > c.image_h || W > c.image_w || H % c.patch_h || W % c.patch_w)
     return capi_fail(VITX_ERR_INVALID, "Image dimensions must be divisible by the patch size.");
-  const int np = (H / c.patch_h) * (W / c.patch_w), nm = (int)(m->cfg.masking_ratio * (double)np);
+  const int np = (H / c.patch_h) * (W / c.patch_w), nm = mim_num_masked(m, np);
   std::string err;
   int rc = check_indices(m, idx_host, b, np, nm, err);
   if (rc != VITX_OK) return capi_fail(rc, err);
@@ -508,9 +577,10 @@ int32_t vitx_mim_read(vitx_mim_handle m, const char* which, float* out_host, int
   const float* src = nullptr;
   int64_t n = 0;
   const int64_t b = m->b, np = m->np, nm = m->nm;
-  if (w == "pred") { src = m->pred; n = b * nm * m->pd; }
+  if (w == "pred") { src = m->pred; n = b * nm * m->po; }
   else if (w == "target") { src = m->target; n = b * nm * m->pd; }
   else if (w == "patches") { src = m->patches; n = b * np * m->pd; }
+  else if (w == "encoded" && m->mpp) { src = m->enc1; n = b * (np + 1) * m->d; }
   else if (w == "encoded") { src = m->enc_out; n = b * (m->mae ? np - nm : np) * m->d; }
   else if (w == "decoded" && m->mae) { src = m->dec_out; n = b * np * m->dd; }
   else return capi_fail(VITX_ERR_INVALID, "unknown tensor name");

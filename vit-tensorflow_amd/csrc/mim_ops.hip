@@ -138,6 +138,7 @@ __global__ __launch_bounds__(LOSS_THREADS) void recon_loss_kernel(const float* _
     if (e < count) {
       const float diff = pred[e] - (target ? target[e] : 0.f);
       if (kind == 0) { a += diff * diff; dpred[e] = 2.f * diff * scale; }
+      else if (kind == 2) { a += diff; dpred[e] = scale; }   // the MPP loss as written (mpp.py:125): a linear functional of the logits
       else { a += fabsf(diff); dpred[e] = (float)((diff > 0.f) - (diff < 0.f)) * scale; }
     }
   }
@@ -155,6 +156,44 @@ __global__ __launch_bounds__(64) void final_sum_kernel(const float* __restrict__
   for (int i = threadIdx.x; i < n; i += 64) a += partial[i];   // fixed assignment of partials to lanes, fixed DPP tree
   a = wave_sum(a);
   if (threadIdx.x == 0) *out = a;
+}
+
+// dst[b][row0 + idx[b][j]][:] = src[b][j][:] (rows not named by idx are left as they are: the caller zero-fills)
+__global__ void scatter_by_index_kernel(const float* __restrict__ src, const int32_t* __restrict__ idx, int b, int k, int d, float* __restrict__ dst,
+                                        int64_t dst_batch_stride, int row0) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (int64_t)b * k * d) return;
+  const int c = (int)(e % d);
+  const int64_t r = e / d;
+  const int bi = (int)(r / k);
+  dst[(int64_t)bi * dst_batch_stride + (int64_t)(row0 + idx[r]) * d + c] = src[e];
+}
+// MPPLoss target labels of the masked patches (mpp.py:104-123): mean colour of the patch per channel (after the optional un-normalisation
+// and the clamp to [0, max_pixel_val]), Bucketize against arange(bin, mpv, bin) (= number of boundaries <= value), label = sum_c (2^bits)^c bucket_c
+__global__ void mpp_labels_kernel(const float* __restrict__ img, int H, int W, int C, int p, int bits, float mpv, int has_norm, float4 mean4, float4 std4,
+                                  const int32_t* __restrict__ idx, int b, int k, int32_t* __restrict__ labels) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= b * k) return;
+  const int bi = r / k, wp = W / p, t = idx[r], py = t / wp, px = t - py * wp;
+  const float mean[4] = {mean4.x, mean4.y, mean4.z, mean4.w}, sd[4] = {std4.x, std4.y, std4.z, std4.w};
+  const float bin = mpv / (float)(1 << bits);
+  const int nbound = (int)ceilf((mpv - bin) / bin - 1e-6f);   // len(np.arange(bin, mpv, bin))
+  int label = 0, mul = 1;
+  for (int c = 0; c < C; ++c) {
+    float acc = 0.f;
+    for (int y = 0; y < p; ++y)
+      for (int x = 0; x < p; ++x) {
+        float v = img[(((int64_t)bi * H + py * p + y) * W + px * p + x) * C + c];
+        if (has_norm) v = v * sd[c] + mean[c];
+        acc += fminf(fmaxf(v, 0.f), mpv);
+      }
+    const float avg = acc / (float)(p * p);
+    int bucket = 0;
+    for (int j = 1; j <= nbound; ++j) bucket += (bin * (float)j <= avg) ? 1 : 0;
+    label += mul * bucket;
+    mul <<= bits;
+  }
+  labels[r] = label;
 }
 
 inline unsigned blocks_for(int64_t total) { return (unsigned)ceil_div(total, 256); }   // one element per thread, no grid-stride loop
@@ -246,6 +285,18 @@ void launch_zero_selected_rows(float* x, const int32_t* inv, int64_t rows, int d
     hipLaunchKernelGGL(zero_selected_rows_kernel<4>, dim3(blocks_for(rows * (d / 4))), dim3(256), 0, s, F4M(x), inv, rows, d / 4);
   else
     hipLaunchKernelGGL(zero_selected_rows_kernel<1>, dim3(blocks_for(rows * d)), dim3(256), 0, s, x, inv, rows, d);
+}
+
+void launch_scatter_by_index(const float* src, const int32_t* idx, int b, int k, int d, float* dst, int64_t dst_batch_stride, int row0, hipStream_t s) {
+  const int64_t total = (int64_t)b * k * d;
+  if (total == 0) return;
+  hipLaunchKernelGGL(scatter_by_index_kernel, dim3(blocks_for(total)), dim3(256), 0, s, src, idx, b, k, d, dst, dst_batch_stride, row0);
+}
+void launch_mpp_labels(const float* img, int b, int H, int W, int C, int p, int bits, float mpv, int has_norm, const float* mean, const float* std_,
+                       const int32_t* idx, int k, int32_t* labels, hipStream_t s) {
+  if (b * k == 0) return;
+  const float4 m4 = make_float4(mean[0], mean[1], mean[2], mean[3]), s4 = make_float4(std_[0], std_[1], std_[2], std_[3]);
+  hipLaunchKernelGGL(mpp_labels_kernel, dim3(blocks_for((int64_t)b * k)), dim3(256), 0, s, img, H, W, C, p, bits, mpv, has_norm, m4, s4, idx, b, k, labels);
 }
 
 int64_t recon_loss_ws_elems(int64_t count) { return ceil_div(count, LOSS_THREADS * LOSS_PER_THREAD) + 1; }

@@ -16,7 +16,7 @@ class MimWrapper:
     _kind = N.MIM_MAE
 
     def _init_mim(self, image_size, encoder: VitxModel, masking_ratio: float, *, decoder_dim=0, decoder_depth=0, decoder_heads=0,
-                  decoder_dim_head=0, literal_loss=True, seed=None):
+                  decoder_dim_head=0, literal_loss=True, seed=None, mpp=None):
         assert masking_ratio > 0 and masking_ratio < 1, 'masking ratio must be kept between 0 and 1'   # mae.py:28, simmim.py:71
         assert isinstance(encoder, VitxModel), "encoder must be a vit_tensorflow ViT / DeepViT"
         self.masking_ratio = masking_ratio
@@ -28,6 +28,15 @@ class MimWrapper:
         cfg.decoder_dim, cfg.decoder_depth, cfg.decoder_heads, cfg.decoder_dim_head = decoder_dim, decoder_depth, decoder_heads, decoder_dim_head
         cfg.literal_loss = 1 if literal_loss else 0
         cfg.masking_ratio = float(masking_ratio)
+        if mpp is not None:                      # MPP(...) arguments (mpp.py:133-146)
+            cfg.output_channel_bits = int(mpp["output_channel_bits"])
+            cfg.max_pixel_val = float(mpp["max_pixel_val"])
+            mean, std = mpp.get("mean"), mpp.get("std")
+            if mean and std:                     # `if exists(self.mean) and exists(self.std)` (mpp.py:108), mean / std truthy (:102-103)
+                assert len(mean) <= 4 and len(mean) == len(std), "mean / std: one value per channel, at most 4"
+                cfg.has_norm = 1
+                for i, (a, s_) in enumerate(zip(mean, std)):
+                    cfg.norm_mean[i], cfg.norm_std[i] = float(a), float(s_)
         self._mcfg = cfg
         self._mim: Optional[C.c_void_p] = None
         self._enc_gen = -1

@@ -313,15 +313,27 @@ class VitxModel:
         path = str(path)
         return path if path.endswith(".npz") else path + ".npz"    # np.savez appends the suffix: both directions agree on the name
 
-    def save_weights(self, path: str) -> None:
-        """Weights by engine parameter name in one .npz (NOT the Keras TF-checkpoint / H5 the reference's inherited
-        Model.save_weights writes -- those formats need TensorFlow / h5py; `set_weights(list)` takes Keras' get_weights() order
-        for tensors exported elsewhere)."""
-        np.savez(self._npz_path(path), **self.state_dict())
+    def save_weights(self, path: str, format: str = "named") -> None:
+        """format="named" (default): weights by engine parameter name in one .npz.  format="keras_list": the arrays of `get_weights()` in
+        order as arr_0, arr_1, ... -- exactly what `np.savez(path, *keras_model.get_weights())` writes on the TensorFlow side, so a list
+        exported there loads here and the other way round (order: model variables first -- pos_embedding, cls_token -- then the layers in
+        attribute order, kernel before bias, gamma before beta).  NOT the TF-checkpoint / H5 files the reference's
+        inherited Model.save_weights writes: those formats need TensorFlow / h5py, neither of which exists in this environment."""
+        if format == "keras_list":
+            np.savez(self._npz_path(path), *self.get_weights())
+        elif format == "named":
+            np.savez(self._npz_path(path), **self.state_dict())
+        else:
+            raise ValueError("format must be 'named' or 'keras_list'")
 
     def load_weights(self, path: str) -> None:
+        """Either .npz form of save_weights (recognised by its keys)."""
         with np.load(self._npz_path(path)) as z:
-            self.load_state_dict({k: z[k] for k in z.files})
+            files = list(z.files)
+            if files and all(f.startswith("arr_") and f[4:].isdigit() for f in files):
+                self.set_weights([z[f"arr_{i}"] for i in range(len(files))])     # Keras get_weights() order
+            else:
+                self.load_state_dict({k: z[k] for k in files})
 
     @property
     def pos_embedding(self):

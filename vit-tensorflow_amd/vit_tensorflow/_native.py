@@ -48,7 +48,7 @@ class KernelStat(C.Structure):
                 ("bytes", C.c_double)]
 
 
-MIM_MAE, MIM_SIMMIM = 0, 1
+MIM_MAE, MIM_SIMMIM, MIM_MPP = 0, 1, 2
 
 
 class MimConfig(C.Structure):
@@ -57,7 +57,9 @@ class MimConfig(C.Structure):
         ("decoder_dim", C.c_int32), ("decoder_depth", C.c_int32), ("decoder_heads", C.c_int32), ("decoder_dim_head", C.c_int32),
         ("literal_loss", C.c_int32),
         ("masking_ratio", C.c_double),
-        ("reserved", C.c_int32 * 8),
+        ("output_channel_bits", C.c_int32), ("max_pixel_val", C.c_float), ("has_norm", C.c_int32),
+        ("norm_mean", C.c_float * 4), ("norm_std", C.c_float * 4),
+        ("reserved", C.c_int32 * 5),
     ]
 
 
