@@ -56,7 +56,7 @@ def _against_torch(name, b, g_logit, g_max, g_l2, tag):
 def test_cfg3_vit_large_16_depth_24_batch_64_bf16_against_the_torch_oracle_on_the_gpu():
     from util import CONFIGS
     CONFIGS.setdefault("cfg3_vit_l16", ("vit", dict(image_size=224, patch_size=16, num_classes=1000, dim=1024, depth=24, heads=16, mlp_dim=4096)))
-    _against_torch("cfg3_vit_l16", 64, 4.1e-2, 2.0e-2, 1.7e-2, "full_size_vit_l16")   # observed 2.05e-2 / 9.5e-3 / 8.1e-3 (profiles/r4)
+    _against_torch("cfg3_vit_l16", 64, 4.5e-2, 2.6e-2, 1.7e-2, "full_size_vit_l16")   # observed 2.2e-2 / 1.3e-2 / 8.1e-3 (profiles/r4)
 
 
 def test_cfg4_deepvit_depth_12_batch_256_bf16_against_the_torch_oracle_on_the_gpu():

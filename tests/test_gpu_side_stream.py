@@ -76,3 +76,25 @@ def test_side_stream_composes_with_the_gradient_ready_callback(monkeypatch):
             assert cover.min() == 1 and cover.max() == 1, (cover.min(), cover.max())
     finally:
         N.check(N.lib().vitx_set_grad_ready_callback(m._handle, C.cast(None, N.GRAD_READY_FN), None))
+
+
+def test_first_step_of_a_process_gives_the_same_gradients_as_the_second():
+    """The first launch of each GEMM shape measures the tile variants on the caller's operands (launch_gemm_bf16).  Every fused output is
+    rewritten by the winner, but the per-tile column sums of the fc2 input-gradient epilogue (= the fc1 bias gradient) are stored row by row
+    into a buffer the caller zeroed once: a shorter-tiled candidate used to leave rows behind that a taller-tiled winner never overwrote
+    (step 0's fc1.bias gradient of the first block processed was wrong).  Same input twice: bit-identical gradients."""
+    name, b = "cfg2_vit_b16", 64
+    cfg = oracle_cfg(name)
+    # widths no other test of this process has used, so that this model's first step IS a measuring step: 640 / 2560 instead of 768 / 3072
+    CONFIGS["vit_first_step"] = ("vit", dict(image_size=224, patch_size=16, num_classes=100, dim=640, depth=2, heads=10, mlp_dim=2560))
+    cfg = oracle_cfg("vit_first_step")
+    m = make_engine_model("vit_first_step", "bf16", b, spec.init_params(cfg, seed=5, randomize_all=True))
+    img = rand_images(cfg, b, 1)
+    dl = (np.random.default_rng(2).standard_normal((b, cfg["num_classes"])) / b).astype(np.float32)
+    m(img, training=True)
+    g0, _ = m.backward(dl)
+    g0 = {k: np.array(v, copy=True) for k, v in g0.items()}
+    m(img, training=True)
+    g1, _ = m.backward(dl)
+    for k in g0:
+        assert np.array_equal(g0[k], g1[k]), k

@@ -198,56 +198,77 @@ __global__ __launch_bounds__(X3_THREADS) void attn_x3_bwd_kernel(const float* __
   __syncthreads();
   const float sl2 = scale * 1.44269504088896340736f;
   const int u_end = min(NTP / 2, (n + 31) >> 5);
+  constexpr int QB = 2;   // two 16-row blocks per wave in both phases: every LDS fragment pair feeds six MFMAs
   {   // ---------------------------------------------------------------- phase 1: dQ, D
     const int qi = lane & 15, g = lane >> 4;
-    const int nqb = (n + 15) / 16;
+    const int nqb = (n + 16 * QB - 1) / (16 * QB);
     for (int qb = wave; qb < nqb; qb += nwaves) {
-      const int q = qb * 16 + qi, qc = min(q, n - 1);
-      P2 qf[2], dof[2];
-      float dp_ = 0.f;
+      int q[QB];
+      P2 qf[QB][2], dof[QB][2];
+      float l2[QB], nds[QB];
+      f32x4 dq[QB][4];
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        qf[ks] = load_split8(qbase + (int64_t)qc * tok_stride + (g + 4 * ks) * 8);
-        const float* dop = dobase + (int64_t)qc * inner + (g + 4 * ks) * 8;
-        const float* op = obase + (int64_t)qc * inner + (g + 4 * ks) * 8;
-        const f32x4 d0 = *(const f32x4*)dop, d1 = *(const f32x4*)(dop + 4), o0 = *(const f32x4*)op, o1 = *(const f32x4*)(op + 4);
-        dof[ks] = split8(d0, d1);
+      for (int s = 0; s < QB; ++s) {
+        q[s] = (qb * QB + s) * 16 + qi;
+        const int qc = min(q[s], n - 1);
+        float dp_ = 0.f;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) dp_ += d0[e] * o0[e] + d1[e] * o1[e];
+        for (int ks = 0; ks < 2; ++ks) {
+          qf[s][ks] = load_split8(qbase + (int64_t)qc * tok_stride + (g + 4 * ks) * 8);
+          const float* dop = dobase + (int64_t)qc * inner + (g + 4 * ks) * 8;
+          const float* op = obase + (int64_t)qc * inner + (g + 4 * ks) * 8;
+          const f32x4 d0 = *(const f32x4*)dop, d1 = *(const f32x4*)(dop + 4), o0 = *(const f32x4*)op, o1 = *(const f32x4*)(op + 4);
+          dof[s][ks] = split8(d0, d1);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) dp_ += d0[e] * o0[e] + d1[e] * o1[e];
+        }
+        dp_ += __shfl_xor(dp_, 16, 64);
+        dp_ += __shfl_xor(dp_, 32, 64);   // D[q] = sum_d dO*O
+        if (g == 0 && q[s] < n) d_s[q[s]] = dp_;
+        l2[s] = lse_s[qc];
+        nds[s] = -dp_ * scale;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) dq[s][c] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
-      dp_ += __shfl_xor(dp_, 16, 64);
-      dp_ += __shfl_xor(dp_, 32, 64);   // D[q] = sum_d dO*O
-      if (g == 0 && q < n) d_s[q] = dp_;
-      const float l2 = lse_s[qc], nds = -dp_ * scale;
-      f32x4 dq[4];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) dq[c] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
       for (int u = 0; u < u_end; ++u) {
-        f32x4 ds[2];
+        f32x4 ds[QB][2];
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
           const int t = 2 * u + tt;
-          f32x4 sa = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-          sa = mfma3(frag_rm2(a_hi, a_lo, t * 16 + qi, g), qf[0], sa);
-          sa = mfma3(frag_rm2(a_hi, a_lo, t * 16 + qi, g + 4), qf[1], sa);
-          dp = mfma3(frag_rm2(b_hi, b_lo, t * 16 + qi, g), dof[0], dp);
-          dp = mfma3(frag_rm2(b_hi, b_lo, t * 16 + qi, g + 4), dof[1], dp);
+          const P2 kf0 = frag_rm2(a_hi, a_lo, t * 16 + qi, g), kf1 = frag_rm2(a_hi, a_lo, t * 16 + qi, g + 4);
+          const P2 vf0 = frag_rm2(b_hi, b_lo, t * 16 + qi, g), vf1 = frag_rm2(b_hi, b_lo, t * 16 + qi, g + 4);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float p = (t * 16 + 4 * g + r) < n ? fast_exp2(fmaf(sa[r], sl2, -l2)) : 0.f;
-            ds[tt][r] = p * fmaf(dp[r], scale, nds);
+          for (int s = 0; s < QB; ++s) {
+            f32x4 sa = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+            sa = mfma3(kf0, qf[s][0], sa);
+            sa = mfma3(kf1, qf[s][1], sa);
+            dp = mfma3(vf0, dof[s][0], dp);
+            dp = mfma3(vf1, dof[s][1], dp);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float p = (t * 16 + 4 * g + r) < n ? fast_exp2(fmaf(sa[r], sl2, -l2[s])) : 0.f;
+              ds[s][tt][r] = p * fmaf(dp[r], scale, nds[s]);
+            }
           }
         }
-        const P2 dsf = split8(ds[0], ds[1]);
+        P2 dsf[QB];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) dq[c] = mfma3(frag_trr2(a_hi, a_lo, c, u, lane), dsf, dq[c]);
-      }
-      if (q < n) {
-        float* dp_out = dqkv + ((int64_t)bi * n + q) * tok_stride + hi_ * DH;
+        for (int s = 0; s < QB; ++s) dsf[s] = split8(ds[s][0], ds[s][1]);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) *(f32x4*)(dp_out + 16 * c + 4 * g) = dq[c];
+        for (int c = 0; c < 4; ++c) {
+          const P2 kt = frag_trr2(a_hi, a_lo, c, u, lane);
+#pragma unroll
+          for (int s = 0; s < QB; ++s) dq[s][c] = mfma3(kt, dsf[s], dq[s][c]);
+        }
       }
+#pragma unroll
+      for (int s = 0; s < QB; ++s)
+        if (q[s] < n) {
+          float* dp_out = dqkv + ((int64_t)bi * n + q[s]) * tok_stride + hi_ * DH;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) *(f32x4*)(dp_out + 16 * c + 4 * g) = dq[s][c];
+        }
     }
   }
   __syncthreads();               // every wave is done with the K / V images; D is complete
@@ -258,52 +279,73 @@ __global__ __launch_bounds__(X3_THREADS) void attn_x3_bwd_kernel(const float* __
     // No masks: query rows >= n are zero rows of q / dO with lse = D = 0, so their P = 1 meets dO = 0 and their dS = 1 * (0 - 0); key lanes >= n
     // compute on the clamped key n-1 and are never stored.  Tile pairs past n are skipped.
     const int ki = lane & 15, g = lane >> 4;
-    const int nkb = (n + 15) / 16;
+    const int nkb = (n + 16 * QB - 1) / (16 * QB);
     for (int kb = wave; kb < nkb; kb += nwaves) {
-      const int key = kb * 16 + ki, kc = min(key, n - 1);
-      P2 kf[2], vf[2];
+      int key[QB];
+      P2 kf[QB][2], vf[QB][2];
+      f32x4 dk[QB][4], dv[QB][4];
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        kf[ks] = load_split8(qbase + inner + (int64_t)kc * tok_stride + (g + 4 * ks) * 8);
-        vf[ks] = load_split8(qbase + 2 * inner + (int64_t)kc * tok_stride + (g + 4 * ks) * 8);
+      for (int s = 0; s < QB; ++s) {
+        key[s] = (kb * QB + s) * 16 + ki;
+        const int kc = min(key[s], n - 1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          kf[s][ks] = load_split8(qbase + inner + (int64_t)kc * tok_stride + (g + 4 * ks) * 8);
+          vf[s][ks] = load_split8(qbase + 2 * inner + (int64_t)kc * tok_stride + (g + 4 * ks) * 8);
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { dk[s][c] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[s][c] = f32x4{0.f, 0.f, 0.f, 0.f}; }
       }
-      f32x4 dk[4], dv[4];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) { dk[c] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[c] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll 1
       for (int u = 0; u < u_end; ++u) {
-        f32x4 pp[2], ds[2];
+        f32x4 pp[QB][2], ds[QB][2];
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
           const int t = 2 * u + tt;
-          f32x4 sa = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-          sa = mfma3(frag_rm2(a_hi, a_lo, t * 16 + ki, g), kf[0], sa);       // S[query 16t+4g+r][key ki]
-          sa = mfma3(frag_rm2(a_hi, a_lo, t * 16 + ki, g + 4), kf[1], sa);
-          dp = mfma3(frag_rm2(b_hi, b_lo, t * 16 + ki, g), vf[0], dp);       // dP, same layout
-          dp = mfma3(frag_rm2(b_hi, b_lo, t * 16 + ki, g + 4), vf[1], dp);
+          const P2 qa0 = frag_rm2(a_hi, a_lo, t * 16 + ki, g), qa1 = frag_rm2(a_hi, a_lo, t * 16 + ki, g + 4);
+          const P2 da0 = frag_rm2(b_hi, b_lo, t * 16 + ki, g), da1 = frag_rm2(b_hi, b_lo, t * 16 + ki, g + 4);
+          float lq[4], dd[4];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float p = fast_exp2(fmaf(sa[r], sl2, -lse_s[t * 16 + 4 * g + r]));
-            pp[tt][r] = p;
-            ds[tt][r] = p * ((dp[r] - d_s[t * 16 + 4 * g + r]) * scale);
+          for (int r = 0; r < 4; ++r) { lq[r] = lse_s[t * 16 + 4 * g + r]; dd[r] = d_s[t * 16 + 4 * g + r]; }
+#pragma unroll
+          for (int s = 0; s < QB; ++s) {
+            f32x4 sa = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+            sa = mfma3(qa0, kf[s][0], sa);       // S[query 16t+4g+r][key ki]
+            sa = mfma3(qa1, kf[s][1], sa);
+            dp = mfma3(da0, vf[s][0], dp);       // dP, same layout
+            dp = mfma3(da1, vf[s][1], dp);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float p = fast_exp2(fmaf(sa[r], sl2, -lq[r]));
+              pp[s][tt][r] = p;
+              ds[s][tt][r] = p * ((dp[r] - dd[r]) * scale);
+            }
           }
         }
-        const P2 pf = split8(pp[0], pp[1]), dsf = split8(ds[0], ds[1]);
+        P2 pf[QB], dsf[QB];
+#pragma unroll
+        for (int s = 0; s < QB; ++s) { pf[s] = split8(pp[s][0], pp[s][1]); dsf[s] = split8(ds[s][0], ds[s][1]); }
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-          dv[c] = mfma3(frag_trr2(b_hi, b_lo, c, u, lane), pf, dv[c]);
-          dk[c] = mfma3(frag_trr2(a_hi, a_lo, c, u, lane), dsf, dk[c]);
-        }
-      }
-      if (key < n) {
-        float* dkp = dqkv + ((int64_t)bi * n + key) * tok_stride + inner + hi_ * DH;
-        float* dvp = dkp + inner;
+          const P2 a1 = frag_trr2(b_hi, b_lo, c, u, lane), a2 = frag_trr2(a_hi, a_lo, c, u, lane);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          *(f32x4*)(dkp + 16 * c + 4 * g) = dk[c];
-          *(f32x4*)(dvp + 16 * c + 4 * g) = dv[c];
+          for (int s = 0; s < QB; ++s) {
+            dv[s][c] = mfma3(a1, pf[s], dv[s][c]);
+            dk[s][c] = mfma3(a2, dsf[s], dk[s][c]);
+          }
         }
       }
+#pragma unroll
+      for (int s = 0; s < QB; ++s)
+        if (key[s] < n) {
+          float* dkp = dqkv + ((int64_t)bi * n + key[s]) * tok_stride + inner + hi_ * DH;
+          float* dvp = dkp + inner;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            *(f32x4*)(dkp + 16 * c + 4 * g) = dk[s][c];
+            *(f32x4*)(dvp + 16 * c + 4 * g) = dv[s][c];
+          }
+        }
     }
   }
 }

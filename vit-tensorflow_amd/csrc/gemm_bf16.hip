@@ -339,7 +339,7 @@ int gemm_bf16_pick(int M, int N) {
   const int64_t t256 = ceil_div(M, 256) * tn, t320 = ceil_div(M, 320) * tn;
   const double e256 = (double)M * N / ((double)ceil_div(t256, 256) * 256 * 256 * 256);
   const double e320 = (double)M * N / ((double)ceil_div(t320, 256) * 256 * 320 * 256);
-  if (g_shared_gpu) return (g_allow_320 && e320 > e256 * 1.08) ? 5 : 2;   // the hardware dispatcher balances one-tile workgroups
+  if (g_shared_gpu) return (g_allow_320 && e320 > e256 * 1.08) ? 11 : 13;   // (one tile per workgroup beside collectives: launch_pipe)
   return (g_allow_320 && e320 > e256 * 1.08) ? 11 : 13;                    // pipelined persistent kernel (gemm_bf16_pipe.hip), 320 / 256-row tiles
 }
 int gemm_bf16_tile_m(int kernel, int M, int N) {
@@ -354,6 +354,7 @@ int gemm_bf16_tile_n(int kernel, int M, int N) {
 }
 void gemm_bf16_allow_320(int on) { g_allow_320 = on; }
 void gemm_bf16_set_shared_gpu(int on) { g_shared_gpu = on; }
+int gemm_bf16_shared_gpu() { return g_shared_gpu; }
 
 // Number of K slices a split-K launch actually produces (matches launch_variant)
 int gemm_bf16_num_slices(int K, int split_k) {
@@ -423,7 +424,7 @@ void launch_gemm_bf16(const Bf16GemmArgs& g0, const EpiParams& ep, int mode, hip
       const bool is320 = c == 5 || c == 11;
       if (is320 && !g_allow_320) continue;
       if ((c == 1 || c == 3) && !small_m) continue;
-      if (g_shared_gpu ? (c == 13 || c == 11) : (c == 2 || c == 5)) continue;   // no persistent variants beside collectives (see gemm_bf16_set_shared_gpu)
+      if (!g_shared_gpu && (c == 2 || c == 5)) continue;   // beside collectives the pipelined kernel runs one tile per workgroup too (launch_pipe) and competes with 2 / 5
       g.kernel = c;
       dispatch_gemm_bf16(g, ep, mode, s);   // warm-up (first-use attribute setup, instruction cache)
       (void)hipEventRecord(ev[0], s);

@@ -49,5 +49,7 @@ __device__ __forceinline__ void decode_tile_fwd(int L, int tiles_m, int tiles_n,
 
 // gemm_bf16_pipe.hip: the pipelined persistent NT kernel behind the variant numbers of launch_gemm_bf16 (9, 12, 13, 14, 15)
 void launch_gemm_bf16_pipe(int variant, int mode, const Bf16GemmArgs& g, const EpiParams& ep, hipStream_t s);
+// gemm_bf16.hip: 1 = collectives share the CUs (a gradient-ready callback is registered): no persistent grids
+int gemm_bf16_shared_gpu();
 // gemm_bf16.hip: the persistent lockstep kernel (variants 6 / 7), the pipelined kernel's fall-back for operands beyond 2 GiB
 void launch_gemm_bf16_persistent_lockstep(int bm, int mode, const Bf16GemmArgs& g, const EpiParams& ep, hipStream_t s);

@@ -1,6 +1,10 @@
 // Software-pipelined persistent NT kernel of the bf16 MFMA GEMM family (see gemm_bf16.hip for the family's design notes).
 #include "gemm_bf16_common.h"
 
+#include <cmath>
+#include <cstring>
+#include <vector>
+
 namespace {
 
 // lane index from the hardware, opaque to the optimiser (no live range across the K loop, nothing derived from it is loop-invariant)
@@ -8,6 +12,34 @@ __device__ __forceinline__ int wp_lane() {
   int l;
   asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
   return l;
+}
+
+// ---- GELU by table (the fc1 epilogue, 256-row tiles).  The pre-activation is rounded to bf16 BEFORE the activation is applied (what a bf16
+// tensor of it would hold), so gelu / gelu' are functions of a 16-bit pattern: for 2^-12 <= |x| < 8 (15 binades x 128 mantissas x 2 signs = 3840
+// patterns) they are read from a 15-KiB LDS table; smaller |x| take the first entry of their sign (Phi = 1/2, gelu' = 1/2 to bf16 precision), larger
+// ones the last (Phi = 1 or 0, gelu' = 1 or 0).  Entry = Phi(x) as fp16 (high half) | gelu'(x) as bf16 (low half); gelu(x) = x * Phi(x), so both
+// ends are exact without a fix-up.  Built on the host from erf in double precision (closer to the exact-erf GELU of vit.py:34 than the degree-7
+// polynomial of the other epilogues: |Phi error| <= 2.4e-4 relative, below a quarter of a bf16 ulp).  Why: the polynomial form costs 17.5 VALU issue
+// slots per element (two v_exp_f32 per pair at quarter rate), the epilogue of a 256 x 256 tile 18k cycles per SIMD next to a 33k-cycle K loop; the
+// table form ~11 slots and one LDS gather per element (the LDS is idle in the epilogue).
+constexpr int GT_LO = (127 - 12) << 7, GT_NE = ((127 + 3) << 7) - GT_LO, GT_BYTES = 2 * GT_NE * 4;   // 14720, 1920 entries per sign, 15360 B
+const uint32_t* gelu_table_dev() {
+  static const uint32_t* tab = [] {
+    std::vector<uint32_t> h((size_t)2 * GT_NE);
+    auto f32_to_bf16 = [](float f) { uint32_t u; memcpy(&u, &f, 4); u += 0x7fffu + ((u >> 16) & 1u); return (uint16_t)(u >> 16); };
+    auto f32_to_f16 = [](float f) { _Float16 hh = (_Float16)f; uint16_t u; memcpy(&u, &hh, 2); return u; };
+    for (int sgn = 0; sgn < 2; ++sgn)
+      for (int t = 0; t < GT_NE; ++t) {
+        const uint32_t bits = ((uint32_t)sgn << 31) | ((uint32_t)(t + GT_LO) << 16);
+        float xf; memcpy(&xf, &bits, 4);
+        const double x = xf, phi = 0.5 * (1.0 + erf(x * 0.70710678118654752440)), gd = phi + x * 0.39894228040143267794 * exp(-0.5 * x * x);
+        h[(size_t)sgn * GT_NE + t] = ((uint32_t)f32_to_f16((float)phi) << 16) | f32_to_bf16((float)gd);
+      }
+    uint32_t* d = nullptr;
+    if (hipMalloc((void**)&d, GT_BYTES) != hipSuccess || hipMemcpy(d, h.data(), GT_BYTES, hipMemcpyHostToDevice) != hipSuccess) return (const uint32_t*)nullptr;
+    return (const uint32_t*)d;
+  }();
+  return tab;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -23,7 +55,7 @@ __device__ __forceinline__ int wp_lane() {
 //   * the epilogue is wave-private (no workgroup barrier): see the epilogue section.
 template <int BM, int BN, int WM, int WN, int MODE>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_pipe_kernel(Bf16GemmArgs g, EpiParams ep, int tiles_m, int tiles_n,
-                                                                         int kt_per_split) {
+                                                                         int kt_per_split, const uint32_t* __restrict__ gelu_tab) {
   constexpr int NW = WM * WN;
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int MT = WTM / 32, NT = WTN / 32;
@@ -170,6 +202,13 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_pipe_kernel(Bf16Gem
 
   issue();      // stream items 0 and 1
   issue();
+  constexpr bool GTAB = MODE == EPI_BIAS_GELU && BM == 256;   // GELU by table: 15 KiB behind the two pipeline buffers (the 320-row tile has no room)
+  if constexpr (GTAB) {
+    if (gelu_tab != nullptr) {
+      uint32_t* t = (uint32_t*)(smem + 2 * STAGE);
+      for (int i = tid; i < 2 * GT_NE; i += NW * 64) t[i] = gelu_tab[i];   // visible to every wave behind the hand-over barrier below
+    }
+  }
   handover();
   load_frags(fa[0], fb[0], smem, 0);
   int it = 0;   // consumed K-tile counter of the stream
@@ -314,33 +353,55 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_pipe_kernel(Bf16Gem
             if (ep.nt_out) run(std::true_type{});
             else run(std::false_type{});
           } else if constexpr (MODE == EPI_BIAS_GELU) {
-            float4 bz[NT][4];
-#pragma unroll
-            for (int j = 0; j < NT; ++j)
-#pragma unroll
-              for (int q = 0; q < 4; ++q)
-                bz[j][q] = has_bias ? *(const float4*)(ep.bias + col_w + j * 32 + 8 * q + 4 * kh) : make_float4(0.f, 0.f, 0.f, 0.f);
+            // (the bias values of a 32-column block are re-read for every 32 x 32 accumulator block -- L1 hits -- instead of living in 32 registers
+            //  through the epilogue: with them the table form spilled, and a scratch reload is a VMEM load the compiler waits for inside the K loop)
+            const float* const bias_w = has_bias ? ep.bias + col_w + 4 * kh : nullptr;
             bf16_t* const o1 = (bf16_t*)ep.out + (int64_t)row_w * ep.ldo + col_w;
             bf16_t* const o2 = (bf16_t*)ep.out2 + (int64_t)row_w * ep.ldo2 + col_w;
             const uint32_t ldo = (uint32_t)ep.ldo, ldo2 = (uint32_t)ep.ldo2;
             const uint32_t o1off = (uint32_t)(le >> 3) * ldo + (uint32_t)(le & 7) * 8u, o2off = (uint32_t)(le >> 3) * ldo2 + (uint32_t)(le & 7) * 8u;
-            auto run = [&](auto nt_c) {
-              constexpr bool NTS = decltype(nt_c)::value;
+            const bool use_tab = GTAB && gelu_tab != nullptr;
+            const char* const gt = smem + 2 * STAGE;
+            auto run = [&](auto nt_c, auto tab_c) {
+              constexpr bool NTS = decltype(nt_c)::value, TAB = decltype(tab_c)::value;
               static_for<MT>([&](auto i_c) {
                 constexpr int i0 = decltype(i_c)::value;
 #pragma unroll
-                for (int j = 0; j < NT; ++j)
+                for (int j = 0; j < NT; ++j) {
+                  float4 bzj[4];
+#pragma unroll
+                  for (int q = 0; q < 4; ++q) bzj[q] = bias_w ? *(const float4*)(bias_w + j * 32 + 8 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
                   for (int q = 0; q < 4; ++q) {
-                    // GELU and its derivative of the pre-activation as bf16 would store it (same arithmetic as epilogue_wide8)
-                    const bf16x4 h = to_bf16x4(acc[i0][j][4 * q] + bz[j][q].x, acc[i0][j][4 * q + 1] + bz[j][q].y, acc[i0][j][4 * q + 2] + bz[j][q].z,
-                                               acc[i0][j][4 * q + 3] + bz[j][q].w);
-                    float4 g, gd;
-                    gelu_both4(make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]), g, gd);
+                    // GELU and its derivative of the pre-activation as bf16 would store it
+                    const bf16x4 h = to_bf16x4(acc[i0][j][4 * q] + bzj[q].x, acc[i0][j][4 * q + 1] + bzj[q].y, acc[i0][j][4 * q + 2] + bzj[q].z,
+                                               acc[i0][j][4 * q + 3] + bzj[q].w);
                     const int off = m * 128 + (((j * 4 + q) ^ swm) << 4) + kh * 8;
-                    *(bf16x4*)(sa + off) = to_bf16x4(gd.x, gd.y, gd.z, gd.w);
-                    *(bf16x4*)(sb + off) = to_bf16x4(g.x, g.y, g.z, g.w);
+                    if constexpr (TAB) {
+                      // (Phi as fp16 | gelu' as bf16) of each 16-bit pattern from the LDS table; gelu = x Phi
+                      const uint32_t p0 = __builtin_bit_cast(uint2, h).x, p1 = __builtin_bit_cast(uint2, h).y;
+                      auto look = [&](uint32_t bits15, uint32_t sign) {
+                        const int t = min(max((int)bits15 - GT_LO, 0), GT_NE - 1);             // clamp to the table's binades (both ends are exact: see above)
+                        return *(const uint32_t*)(gt + ((uint32_t)t + sign * GT_NE) * 4u);
+                      };
+                      const uint32_t e0 = look(p0 & 0x7fffu, (p0 >> 15) & 1u), e1 = look((p0 >> 16) & 0x7fffu, p0 >> 31);
+                      const uint32_t e2 = look(p1 & 0x7fffu, (p1 >> 15) & 1u), e3 = look((p1 >> 16) & 0x7fffu, p1 >> 31);
+                      auto phi = [](uint32_t e) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(e >> 16)); };
+                      const float x0 = __builtin_bit_cast(float, p0 << 16), x1 = __builtin_bit_cast(float, p0 & 0xffff0000u);
+                      const float x2 = __builtin_bit_cast(float, p1 << 16), x3 = __builtin_bit_cast(float, p1 & 0xffff0000u);
+                      uint2 gdw;   // gelu' of the four columns: the low halves of the entries, packed
+                      gdw.x = __builtin_amdgcn_perm(e1, e0, 0x05040100u);
+                      gdw.y = __builtin_amdgcn_perm(e3, e2, 0x05040100u);
+                      *(uint2*)(sa + off) = gdw;
+                      *(bf16x4*)(sb + off) = to_bf16x4(x0 * phi(e0), x1 * phi(e1), x2 * phi(e2), x3 * phi(e3));
+                    } else {
+                      float4 g, gd;
+                      gelu_both4(make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]), g, gd);
+                      *(bf16x4*)(sa + off) = to_bf16x4(gd.x, gd.y, gd.z, gd.w);
+                      *(bf16x4*)(sb + off) = to_bf16x4(g.x, g.y, g.z, g.w);
+                    }
                   }
+                }
                 bf16x8 vd[4], vg[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
@@ -358,8 +419,14 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_pipe_kernel(Bf16Gem
                 }
               });
             };
-            if (ep.nt_out) run(std::true_type{});
-            else run(std::false_type{});
+            if constexpr (GTAB) {
+              if (use_tab) { if (ep.nt_out) run(std::true_type{}, std::true_type{}); else run(std::false_type{}, std::true_type{}); }
+              else if (ep.nt_out) run(std::true_type{}, std::false_type{});
+              else run(std::false_type{}, std::false_type{});
+            } else {
+              if (ep.nt_out) run(std::true_type{}, std::false_type{});
+              else run(std::false_type{}, std::false_type{});
+            }
           } else if constexpr (MODE == EPI_BIAS_RESID) {
             // out[f32] = resid + (acc + bias) [* scale]; LayerScale (cait.py:47-48) also keeps f = acc + bias in out2 (epilogue_fast4's arithmetic).
             // Addresses: wave-uniform 64-bit bases + 32-bit lane offsets (a 64-bit multiply per row and lane cost the registers the rows need)
@@ -509,7 +576,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_pipe_kernel(Bf16Gem
 
 template <int BM, int BN, int WM, int WN, int MODE>
 void launch_pipe(const Bf16GemmArgs& g, const EpiParams& ep, hipStream_t s) {
-  constexpr int SMEM = 2 * (BM + BN) * BK * 2;
+  constexpr int SMEM = 2 * (BM + BN) * BK * 2 + ((MODE == EPI_BIAS_GELU && BM == 256) ? GT_BYTES : 0);
   // buffer-addressed DMA: 31-bit byte offsets inside each operand; larger operands take the flat-addressed persistent kernel
   if (((int64_t)ceil_div(g.M, BM) * BM * g.lda + g.K) * 2 >= (1LL << 31) || ((int64_t)ceil_div(g.N, BN) * BN * g.ldb + g.K) * 2 >= (1LL << 31)) {
     launch_gemm_bf16_persistent_lockstep(BM, MODE, g, ep, s);
@@ -530,9 +597,14 @@ void launch_pipe(const Bf16GemmArgs& g, const EpiParams& ep, hipStream_t s) {
   Bf16GemmArgs gp = g;
   if (gp.phase == 0) gp.phase = phase_env;
   static const int grid_cap = [] { const char* v = getenv("VITX_GEMM_GRID"); return v ? atoi(v) : 256; }();   // experiment: fewer persistent workgroups
-  const unsigned gx = zs == 1 ? (unsigned)std::min(tiles_m * tiles_n, grid_cap) : (unsigned)(tiles_m * tiles_n);
+  // Beside collectives (data parallel: RCCL's workgroups hold CUs for as long as a collective runs) a persistent grid with static tile lists waits
+  // for the workgroups that could not be placed; one tile per workgroup lets the hardware dispatcher balance.  Same kernel: a workgroup whose tile
+  // list has one entry simply never takes the cross-tile path.
+  const unsigned gx = (zs == 1 && !gemm_bf16_shared_gpu()) ? (unsigned)std::min(tiles_m * tiles_n, grid_cap) : (unsigned)(tiles_m * tiles_n);
   dim3 grid(gx, (unsigned)zs), block(WM * WN * 64);
-  hipLaunchKernelGGL(kern, grid, block, SMEM, s, gp, ep, tiles_m, tiles_n, per);
+  static const int gelu_table_on = [] { const char* v = getenv("VITX_GELU_TABLE"); return v ? atoi(v) : 1; }();   // 0: the polynomial form everywhere (A/B)
+  const uint32_t* gtab = (MODE == EPI_BIAS_GELU && BM == 256 && gelu_table_on) ? gelu_table_dev() : nullptr;
+  hipLaunchKernelGGL(kern, grid, block, SMEM, s, gp, ep, tiles_m, tiles_n, per, gtab);
 }
 
 template <int MODE>
