@@ -25,7 +25,6 @@ struct Dense {
   int64_t w = -1, b = -1;           // arena offsets (Keras kernel [in,out], bias [out])
   bf16_t* wt = nullptr;             // [round_up(out,256)][in_k]   forward operand  (W^T)
   bf16_t* wn = nullptr;             // [round_up(in,256)][out_k]   dgrad operand    (W)
-  bf16_t *xh = nullptr, *xl = nullptr;   // BF16X3 mode: hi / lo bf16 planes of the kernel [in][out], split once per weight refresh (gemm_bf16x3.hip, Bh / Bl)
   // a layer whose fp32 parameters / gradients live outside the engine's arenas (the MAE / SimMIM wrappers' own Dense layers)
   const float *ext_w = nullptr, *ext_b = nullptr;
   float *ext_gw = nullptr, *ext_gb = nullptr;
@@ -94,7 +93,6 @@ struct vitx_engine {
   int64_t n_arena = 0;               // device arena element count (>= n_params, zero padding between tensors)
   bool bf16 = false;
   bool x3_attn = false;
-  bool x3_presplit = true;           // BF16X3: Dense kernels pre-split into hi / lo bf16 planes at every weight refresh
   bool x3_fused_attn = true;         // BF16X3: ViT attention through the fused split-operand kernel (attn_x3.hip) instead of materialised scores
   bool x3 = false;                   // BF16X3: the fp32 mode's data path with the GEMMs on split bf16 operands (gemm_bf16x3.hip)
   int esz = 4;                       // bytes per "T" element

@@ -203,10 +203,6 @@ static int init_dense(vitx_engine* e, Dense& w, const std::string& kname, const 
     DALLOC(w.wt, (size_t)round_up(out, 256) * w.in_k * 2, false);
     DALLOC(w.wn, (size_t)round_up(in, 256) * w.out_k * 2, false);
   }
-  if (e->x3 && e->x3_presplit && w.w >= 0 && ((int64_t)in * out) % 4 == 0) {
-    DALLOC(w.xh, (size_t)in * out * 2, false);
-    DALLOC(w.xl, (size_t)in * out * 2, false);
-  }
   return VITX_OK;
 }
 
@@ -216,16 +212,6 @@ static inline float* dense_gw(const vitx_engine* e, const Dense& w) { return w.e
 static inline float* dense_gb(const vitx_engine* e, const Dense& w) { return w.ext_gb ? w.ext_gb : (w.b >= 0 ? e->grads + w.b : nullptr); }
 
 void engine_refresh_weights(vitx_engine* e) {
-  if (e->x3) {   // hi / lo planes of every Dense kernel, once per refresh instead of once per consuming workgroup of every GEMM
-    Prof pr(e, "convert_weights", 0, (double)e->n_params * 8);
-    auto sp = [&](const Dense& w) { if (w.xh) launch_split_bf16x3(e->params + w.w, (int64_t)w.in * w.out, w.xh, w.xl, e->stream); };
-    sp(e->patch);
-    sp(e->head);
-    for (auto& st : e->stages)
-      for (auto& b : st.bp) { sp(b.qkv); sp(b.q); sp(b.kv); sp(b.out); sp(b.fc1); sp(b.fc2); }
-    e->params_dirty = false;
-    return;
-  }
   if (!e->bf16) { e->params_dirty = false; return; }
   Prof pr(e, "convert_weights", 0, (double)e->n_params * 8);
   auto conv = [&](const Dense& w) {
@@ -364,7 +350,6 @@ static void dense_fwd(vitx_engine* e, const void* X, int64_t ldx, int rows, cons
     g.A = X; g.B = dense_w(e, w);
     g.M = rows; g.N = w.out; g.K = w.in;
     g.sam = ldx; g.sak = 1; g.sbk = w.out; g.sbn = 1; g.x3 = e->x3;
-    if (e->x3 && !w.ext_w) { g.Bh = w.xh; g.Bl = w.xl; }
     ep.zero_pad = 1;
     finalize_epi(ep);
     Prof pr(e, f32_gemm_class(g, e->bf16, 0, e->bf16), flops, bytes);   // the class of the kernel that runs
@@ -397,7 +382,6 @@ static void dense_dgrad(vitx_engine* e, const void* dY, int64_t ldy, int rows, c
     g.A = dY; g.B = dense_w(e, w);
     g.M = rows; g.N = w.in; g.K = w.out;
     g.sam = ldy; g.sak = 1; g.sbk = 1; g.sbn = w.out; g.x3 = e->x3;
-    if (e->x3 && !w.ext_w) { g.Bh = w.xh; g.Bl = w.xl; }
     ep.zero_pad = 1;
     finalize_epi(ep);
     Prof pr(e, f32_gemm_class(g, e->bf16, 0, e->bf16), flops, bytes);   // the class of the kernel that runs
@@ -1071,7 +1055,6 @@ static int engine_create_body(vitx_engine* e, const vitx_config& cfg, std::strin
   e->x3 = c.compute == VITX_COMPUTE_BF16X3;
   e->x3_attn = true;   // the materialised attention products too (8.3 vs 9.2 ms per ViT-B/16 step at batch 64); VITX_X3_ATTN=0 keeps them exact
   if (const char* k = getenv("VITX_X3_ATTN")) { e->x3_attn = atoi(k) != 0; e->x3_fused_attn = atoi(k) == 1; }
-  if (const char* k = getenv("VITX_X3_PRESPLIT")) e->x3_presplit = atoi(k) != 0;   // 0: the Dense kernels are split on the fly by every workgroup (round 3; A/B)
   e->esz = e->bf16 ? 2 : 4;
   e->inner = c.heads * c.dim_head;
   e->np_max = (c.image_h / c.patch_h) * (c.image_w / c.patch_w);

@@ -3,6 +3,8 @@
 
 #include <cmath>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <vector>
 
 namespace {
@@ -23,23 +25,28 @@ __device__ __forceinline__ int wp_lane() {
 // slots per element (two v_exp_f32 per pair at quarter rate), the epilogue of a 256 x 256 tile 18k cycles per SIMD next to a 33k-cycle K loop; the
 // table form ~11 slots and one LDS gather per element (the LDS is idle in the epilogue).
 constexpr int GT_LO = (127 - 12) << 7, GT_NE = ((127 + 3) << 7) - GT_LO, GT_BYTES = 2 * GT_NE * 4;   // 14720, 1920 entries per sign, 15360 B
-const uint32_t* gelu_table_dev() {
-  static const uint32_t* tab = [] {
-    std::vector<uint32_t> h((size_t)2 * GT_NE);
-    auto f32_to_bf16 = [](float f) { uint32_t u; memcpy(&u, &f, 4); u += 0x7fffu + ((u >> 16) & 1u); return (uint16_t)(u >> 16); };
-    auto f32_to_f16 = [](float f) { _Float16 hh = (_Float16)f; uint16_t u; memcpy(&u, &hh, 2); return u; };
-    for (int sgn = 0; sgn < 2; ++sgn)
-      for (int t = 0; t < GT_NE; ++t) {
-        const uint32_t bits = ((uint32_t)sgn << 31) | ((uint32_t)(t + GT_LO) << 16);
-        float xf; memcpy(&xf, &bits, 4);
-        const double x = xf, phi = 0.5 * (1.0 + erf(x * 0.70710678118654752440)), gd = phi + x * 0.39894228040143267794 * exp(-0.5 * x * x);
-        h[(size_t)sgn * GT_NE + t] = ((uint32_t)f32_to_f16((float)phi) << 16) | f32_to_bf16((float)gd);
-      }
-    uint32_t* d = nullptr;
-    if (hipMalloc((void**)&d, GT_BYTES) != hipSuccess || hipMemcpy(d, h.data(), GT_BYTES, hipMemcpyHostToDevice) != hipSuccess) return (const uint32_t*)nullptr;
-    return (const uint32_t*)d;
-  }();
-  return tab;
+const uint32_t* gelu_table_dev() {   // one copy per device (one process may drive several handles on different GPUs)
+  static std::mutex mu;
+  static std::map<int, const uint32_t*> per_dev;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = per_dev.find(dev);
+  if (it != per_dev.end()) return it->second;
+  std::vector<uint32_t> h((size_t)2 * GT_NE);
+  auto f32_to_bf16 = [](float f) { uint32_t u; memcpy(&u, &f, 4); u += 0x7fffu + ((u >> 16) & 1u); return (uint16_t)(u >> 16); };
+  auto f32_to_f16 = [](float f) { _Float16 hh = (_Float16)f; uint16_t u; memcpy(&u, &hh, 2); return u; };
+  for (int sgn = 0; sgn < 2; ++sgn)
+    for (int t = 0; t < GT_NE; ++t) {
+      const uint32_t bits = ((uint32_t)sgn << 31) | ((uint32_t)(t + GT_LO) << 16);
+      float xf; memcpy(&xf, &bits, 4);
+      const double x = xf, phi = 0.5 * (1.0 + erf(x * 0.70710678118654752440)), gd = phi + x * 0.39894228040143267794 * exp(-0.5 * x * x);
+      h[(size_t)sgn * GT_NE + t] = ((uint32_t)f32_to_f16((float)phi) << 16) | f32_to_bf16((float)gd);
+    }
+  uint32_t* d = nullptr;
+  if (hipMalloc((void**)&d, GT_BYTES) != hipSuccess || hipMemcpy(d, h.data(), GT_BYTES, hipMemcpyHostToDevice) != hipSuccess) d = nullptr;   // null: the polynomial form
+  per_dev[dev] = d;
+  return d;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -50,8 +50,7 @@ struct X3Operand {
 };
 
 // (measured and removed: one LDS buffer + one register set, three workgroups per CU -- 26.45 vs 25.67 ms per ViT-B/16 step at batch 64)
-// BS: the B operand comes as two bf16 planes split ahead of time (GenericGemmArgs::Bh / Bl): 8-B loads straight into the LDS words, no VALU work for B
-template <int MODE, int LA, int LB, bool BS>
+template <int MODE, int LA, int LB>
 __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GenericGemmArgs g, EpiParams ep) {
   __shared__ __attribute__((aligned(16))) char smem[2][4][PLANE];
   const int z = blockIdx.z, zb = z / g.nh, zh = z - zb * g.nh;
@@ -107,43 +106,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GenericGemmArgs g, 
   };
   lane_ptrs(std::integral_constant<int, LA>{}, A, g.sam, g.sak, m0, g.M, pa, sta, kka);
   lane_ptrs(std::integral_constant<int, LB>{}, B, g.sbn, g.sbk, n0, g.N, pb, stb, kkb);
-  // pre-split B: the same lane -> (row, k) assignment on the two bf16 planes (half the byte offsets and steps of the fp32 operand)
-  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-  typedef const __attribute__((address_space(1))) u32x2* gptr2;
-  gptr pbh[4], pbl[4];
-  if constexpr (BS) {
-    const char* b32 = (const char*)B;
-    const char* bh0 = (const char*)(g.Bh + (int64_t)zb * g.sBb + (int64_t)zh * g.sBh);
-    const char* bl0 = (const char*)(g.Bl + (int64_t)zb * g.sBb + (int64_t)zh * g.sBh);
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      const bool ok = stb[p] != 0 || pb[p] != zero16;   // (a load parked on the zero word has step 0 AND the zero pointer)
-      const int64_t off = ok ? ((const char*)pb[p] - b32) / 2 : 0;
-      pbh[p] = ok ? (gptr)(bh0 + off) : zero16;
-      pbl[p] = ok ? (gptr)(bl0 + off) : zero16;
-      stb[p] /= 2;
-    }
-  }
   f32x4 ra[4], rb[4];
-  u32x2 rbh[4], rbl[4], rbh1[4], rbl1[4];
-  auto load_tile_bs = [&](auto check_c, int k0, u32x2 (&rh)[4], u32x2 (&rl)[4]) {
-    constexpr bool CHECK = decltype(check_c)::value;
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      const bool in = !CHECK || k0 + kkb[p] < Kz;
-      rh[p] = *(gptr2)(in ? pbh[p] : zero16);
-      rl[p] = *(gptr2)(in ? pbl[p] : zero16);
-      pbh[p] += stb[p];
-      pbl[p] += stb[p];
-    }
-  };
-  auto store_tile_bs = [&](char* hi, char* lo, int off0, const u32x2 (&rh)[4], const u32x2 (&rl)[4]) {
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      *(u32x2*)(hi + off0 + p * 2048) = rh[p];
-      *(u32x2*)(lo + off0 + p * 2048) = rl[p];
-    }
-  };
   auto load_tile = [&](auto check_c, int k0, gptr (&ptr)[4], const int (&st)[4], const int (&kks)[4], f32x4 (&r)[4]) {   // K-tile at k0; advances the pointers
     constexpr bool CHECK = decltype(check_c)::value;   // false: the caller knows that the whole K-tile lies inside K
 #pragma unroll
@@ -237,26 +200,14 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GenericGemmArgs g, 
   using chk = std::true_type;
   using nochk = std::false_type;
   f32x4 ra1[4], rb1[4];
-  auto load_b = [&](auto check_c, int k0, auto set_c) {     // B K-tile at k0 into register set 0 / 1
-    constexpr int SET = decltype(set_c)::value;
-    if constexpr (BS) { if constexpr (SET == 0) load_tile_bs(check_c, k0, rbh, rbl); else load_tile_bs(check_c, k0, rbh1, rbl1); }
-    else { if constexpr (SET == 0) load_tile(check_c, k0, pb, stb, kkb, rb); else load_tile(check_c, k0, pb, stb, kkb, rb1); }
-  };
-  auto store_b = [&](int buf, auto set_c) {
-    constexpr int SET = decltype(set_c)::value;
-    if constexpr (BS) { if constexpr (SET == 0) store_tile_bs(smem[buf][2], smem[buf][3], sb_off, rbh, rbl); else store_tile_bs(smem[buf][2], smem[buf][3], sb_off, rbh1, rbl1); }
-    else { if constexpr (SET == 0) store_tile(smem[buf][2], smem[buf][3], sb_off, rb); else store_tile(smem[buf][2], smem[buf][3], sb_off, rb1); }
-  };
-  using set0 = std::integral_constant<int, 0>;
-  using set1 = std::integral_constant<int, 1>;
   load_tile(chk{}, 0, pa, sta, kka, ra);
-  load_b(chk{}, 0, set0{});
+  load_tile(chk{}, 0, pb, stb, kkb, rb);
   load_tile(chk{}, XK, pa, sta, kka, ra1);
-  load_b(chk{}, XK, set1{});
+  load_tile(chk{}, XK, pb, stb, kkb, rb1);
   store_tile(smem[0][0], smem[0][1], sa_off, ra);
-  store_b(0, set0{});
+  store_tile(smem[0][2], smem[0][3], sb_off, rb);
   load_tile(chk{}, 2 * XK, pa, sta, kka, ra);
-  load_b(chk{}, 2 * XK, set0{});
+  load_tile(chk{}, 2 * XK, pb, stb, kkb, rb);
   auto interleave = [&]() {
 #pragma unroll
     for (int i = 0; i < 24; ++i) {
@@ -270,18 +221,18 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GenericGemmArgs g, 
     __syncthreads();           // tile kt visible in buffer 0; every wave finished reading buffer 1 (tile kt-1)
     compute(0);
     store_tile(smem[1][0], smem[1][1], sa_off, ra1);            // tile kt+1 (zeros behind the last K-tile)
-    store_b(1, set1{});
+    store_tile(smem[1][2], smem[1][3], sb_off, rb1);
     interleave();
     load_tile(check_c, (kt + 3) * XK, pa, sta, kka, ra1);
-    load_b(check_c, (kt + 3) * XK, set1{});
+    load_tile(check_c, (kt + 3) * XK, pb, stb, kkb, rb1);
     if (kt + 1 < nkt) {
       __syncthreads();
       compute(1);
       store_tile(smem[0][0], smem[0][1], sa_off, ra);           // tile kt+2
-      store_b(0, set0{});
+      store_tile(smem[0][2], smem[0][3], sb_off, rb);
       interleave();
       load_tile(check_c, (kt + 4) * XK, pa, sta, kka, ra);
-      load_b(check_c, (kt + 4) * XK, set0{});
+      load_tile(check_c, (kt + 4) * XK, pb, stb, kkb, rb);
     }
   };
   int kt = 0;
@@ -340,13 +291,7 @@ int x3_layout(const GenericGemmArgs& g, const void* P, int64_t s_idx, int64_t s_
 template <int LA, int LB>
 void x3_launch(const GenericGemmArgs& g, const EpiParams& ep, int mode, hipStream_t s) {
   dim3 grid((unsigned)(ceil_div(g.N, XN) * ceil_div(g.M, XM)), 1, (unsigned)(g.nb * g.nh)), block(256);
-  // pre-split B planes: 8-B loads need the same element offsets to be multiples of 4 (guaranteed by x3_layout) and 8-B aligned bases
-  const bool bs = g.Bh != nullptr && g.Bl != nullptr && (((uintptr_t)g.Bh | (uintptr_t)g.Bl) & 7) == 0;
-#define VITX_CASE(MODE)                                                                                    \
-  case MODE:                                                                                               \
-    if (bs) hipLaunchKernelGGL((gemm_bf16x3_kernel<MODE, LA, LB, true>), grid, block, 0, s, g, ep);        \
-    else hipLaunchKernelGGL((gemm_bf16x3_kernel<MODE, LA, LB, false>), grid, block, 0, s, g, ep);          \
-    break;
+#define VITX_CASE(MODE) case MODE: hipLaunchKernelGGL((gemm_bf16x3_kernel<MODE, LA, LB>), grid, block, 0, s, g, ep); break;
   switch (mode) {
     VITX_CASE(EPI_STORE) VITX_CASE(EPI_STORE_F32) VITX_CASE(EPI_BIAS_GELU) VITX_CASE(EPI_BIAS_RESID)
     VITX_CASE(EPI_PATCH) VITX_CASE(EPI_GELU_BWD) VITX_CASE(EPI_PARTIAL)
@@ -355,25 +300,7 @@ void x3_launch(const GenericGemmArgs& g, const EpiParams& ep, int mode, hipStrea
 #undef VITX_CASE
 }
 
-__global__ void split_bf16x3_kernel(const float4* __restrict__ x, int64_t n4, bf16x4* __restrict__ hi, bf16x4* __restrict__ lo) {
-  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (int64_t)gridDim.x * blockDim.x) {
-    const float4 v = x[e];
-    const float f[4] = {v.x, v.y, v.z, v.w};
-    bf16x4 h, l;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { h[i] = (bf16_t)f[i]; l[i] = (bf16_t)(f[i] - (float)h[i]); }
-    hi[e] = h;
-    lo[e] = l;
-  }
-}
-
 }  // namespace
-
-void launch_split_bf16x3(const float* x, int64_t n, bf16_t* hi, bf16_t* lo, hipStream_t s) {
-  if (n <= 0) return;
-  const int64_t n4 = n / 4;
-  hipLaunchKernelGGL(split_bf16x3_kernel, dim3((unsigned)std::min<int64_t>(4096, ceil_div(n4, 256))), dim3(256), 0, s, (const float4*)x, n4, (bf16x4*)hi, (bf16x4*)lo);
-}
 
 // fp32 operands and outputs only, both operands readable with 16-B loads; anything else (small, oddly strided) stays on the exact kernels
 bool gemm_bf16x3_supported(const GenericGemmArgs& g, int ta, int tb, int to) {

@@ -13,12 +13,7 @@ struct GenericGemmArgs {
   int64_t sAb = 0, sAh = 0, sBb = 0, sBh = 0;
   int k_last = 0;   // > 0: K extent of the LAST batch slice (split-K over the batch index: slices of K rows, the last one shorter); gemm_bf16x3.hip only
   int x3 = 0;   // BF16X3 compute mode: all-fp32 problems run as three bf16 MFMA products of hi / lo split operands (gemm_bf16x3.hip)
-  // gemm_bf16x3.hip only: B already split into hi = bf16(B), lo = bf16(B - hi) planes with B's element strides (the Dense kernels: split once per
-  // step by engine_refresh_weights instead of once per consuming workgroup); null = split on the fly like A
-  const bf16_t* Bh = nullptr;
-  const bf16_t* Bl = nullptr;
 };
-void launch_split_bf16x3(const float* x, int64_t n, bf16_t* hi, bf16_t* lo, hipStream_t s);   // n multiple of 4, 16-B aligned pointers
 void launch_gemm_generic(const GenericGemmArgs& g, const EpiParams& ep, int mode, int ta, int tb, int to, hipStream_t s);
 // ---------------------------------------------------------------- gemm_f32_mfma.hip
 // the same contract on v_mfma_f32_32x32x2_f32 for all-fp32 problems (bit-identical to the scalar kernel: a k-ordered fmaf chain);
