@@ -1,0 +1,15 @@
+#!/bin/bash
+# round 4, call P: evidence for the final tree -- driver-style bench line, rocprofv3 kernel stats (one stream: stand-alone kernel durations), PMC traffic,
+# the other BASELINE workloads, the BF16X3 and fp32 modes
+cd $GRAFT_REPO_ROOT 2>/dev/null || cd /root/repo
+bash tools/gpu_round.sh r4p bench
+VITX_SIDE_STREAM=0 bash tools/gpu_round.sh r4p rocprof pmc_bench
+OUT=gpurun_out/r4p
+for w in vit_l16_224 deepvit_256 cait_256 vit_b16_256 vit_readme_256; do timeout 600 python bench.py --workload $w --steps 10 --warmup 3 --no-cpu-baseline > $OUT/bench_$w.json 2> $OUT/bench_$w.err; python -c "
+import json; d=json.load(open('$OUT/bench_$w.json')); print('$w', d['value'], d['ms_per_step'], d.get('roofline',{}).get('frac'), d.get('path_mfma_frac'))"; done
+for b in 64 256; do timeout 600 python bench.py --compute bf16x3 --batch $b --steps 8 --warmup 2 --no-cpu-baseline > $OUT/bench_bf16x3_b$b.json 2> $OUT/bench_bf16x3_b$b.err; python -c "
+import json; d=json.load(open('$OUT/bench_bf16x3_b$b.json')); print('bf16x3 b$b', d['value'], d['ms_per_step'], d.get('roofline',{}).get('frac'))"; done
+timeout 600 python bench.py --compute fp32 --batch 64 --steps 4 --warmup 1 --no-cpu-baseline > $OUT/bench_fp32_b64.json 2> $OUT/bench_fp32_b64.err; python -c "
+import json; d=json.load(open('$OUT/bench_fp32_b64.json')); print('fp32 b64', d['value'], d['ms_per_step'])"
+find $OUT -name "*kernel_trace.csv" -size +5M -delete 2>/dev/null
+du -sh $OUT
