@@ -22,7 +22,9 @@ LLVM = "/opt/rocm/lib/llvm/bin"
 def disassemble(obj: str) -> str:
     with tempfile.TemporaryDirectory() as td:
         co, fb = f"{td}/dev.co", f"{td}/fat.bin"
-        subprocess.run([f"{LLVM}/llvm-objcopy", f"--dump-section=.hip_fatbin={fb}", obj], capture_output=True, text=True, check=True)   # the fat binary of a HIP object
+        # the fat binary of a HIP object; the explicit output file keeps llvm-objcopy from rewriting `obj` in place (which would bump its
+        # mtime and make build.py skip the next recompile of an edited source)
+        subprocess.run([f"{LLVM}/llvm-objcopy", f"--dump-section=.hip_fatbin={fb}", obj, f"{td}/copy.o"], capture_output=True, text=True, check=True)
         r = subprocess.run([f"{LLVM}/clang-offload-bundler", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--input={fb}", f"--output={co}", "--unbundle"],
                            capture_output=True, text=True)
         if r.returncode != 0:

@@ -20,6 +20,10 @@ LIB = os.path.join(LIBDIR, "libvitx.so")
 SOURCES = ["elementwise.hip", "gemm_generic.hip", "gemm_f32_mfma.hip", "gemm_bf16x3.hip", "gemm_bf16.hip", "gemm_bf16_pipe.hip", "gemm_bf16_tn.hip", "attn_bf16.hip", "attn_x3.hip", "attn_generic.hip", "attn_bgemm_mfma.hip", "attn_headchain.hip", "attn_deepvit_fused.hip", "mim_ops.hip", "mim.hip", "distill.hip", "engine.hip", "capi.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
+# per-source additions.  attn_bf16.hip: its running row maxima come straight out of MFMA accumulators; with NaNs honoured every fmaxf first
+# canonicalises its operands (v_max_f32 x, x, x: 8 extra VALU instructions per key tile in a VALU-bound loop).  No NaN is produced or
+# consumed on that path (masked keys are -inf selects, never arithmetic on NaN).
+EXTRA_FLAGS = {"attn_bf16.hip": ["-fno-honor-nans"]}
 
 
 def _deps_mtime() -> float:
@@ -38,7 +42,7 @@ def _compile(src: str, force: bool, asan: bool = False) -> str:
         s = os.path.join(CSRC, src)
         if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(s), _deps_mtime()):
             return obj
-        r = subprocess.run([HIPCC, *FLAGS, *ASAN_FLAGS, "-c", s, "-o", obj], capture_output=True, text=True)
+        r = subprocess.run([HIPCC, *FLAGS, *EXTRA_FLAGS.get(src, []), *ASAN_FLAGS, "-c", s, "-o", obj], capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc (asan) failed for {src}:\n{r.stderr}")
         return obj
@@ -46,7 +50,7 @@ def _compile(src: str, force: bool, asan: bool = False) -> str:
     s = os.path.join(CSRC, src)
     if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(s), _deps_mtime()):
         return obj
-    cmd = [HIPCC, *FLAGS, "-c", s, "-o", obj]
+    cmd = [HIPCC, *FLAGS, *EXTRA_FLAGS.get(src, []), "-c", s, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr}")

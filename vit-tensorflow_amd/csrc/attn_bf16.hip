@@ -17,6 +17,16 @@
 #include "kernels.h"
 #include "attn_lds.h"
 
+// tools/probe_attn.hip compiles this file with -DVITX_ATTN_PROBE: wave 0 of every workgroup then records 100-MHz timestamps at its
+// phase boundaries (staging done / first pass / second pass / stores) -- the per-workgroup timeline behind DESIGN.md's attention notes.
+#ifdef VITX_ATTN_PROBE
+__device__ unsigned long long* vitx_attn_probe_buf;
+#define ATTN_STAMP(i) do { if (threadIdx.x == 0 && vitx_attn_probe_buf) { vitx_attn_probe_buf[(size_t)blockIdx.x * 8 + (i)] = wall_clock64(); \
+    if ((i) == 0) vitx_attn_probe_buf[(size_t)blockIdx.x * 8 + 6] = (unsigned long long)__builtin_amdgcn_s_getreg(63492) | ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32); } } while (0)   /* HW_ID | XCC_ID << 32 */
+#else
+#define ATTN_STAMP(i) do { } while (0)
+#endif
+
 namespace {
 
 using namespace attn_lds;
@@ -53,10 +63,86 @@ __device__ __forceinline__ bf16x8 frag_tr(const bf16_t* tr, int vs, int dh, int 
 // NTP = number of 16-key tiles (even); keys padded to 16*NTP.  A wave owns QB = 2 blocks of 16 queries at a time, so every
 // K / V^T fragment read from LDS feeds two MFMAs (LDS bandwidth, not the matrix pipe, bounds these kernels).
 constexpr int QB_FWD = 2;   // forward: 114 VGPRs, still two workgroups per CU
-constexpr int QB_BWD = 1;   // backward: QB = 2 costs a workgroup of occupancy (146 / 212 VGPRs) and measured slower
+// (backward: one 16-row block per wave at a time -- two cost a workgroup of occupancy (146 / 212 VGPRs) and measured slower)
+
+// One pair of 16-key tiles of the forward's second pass for QB query blocks.  These kernels are VALU-bound (rocprofv3 SQ counters:
+// VALU ~53 % busy, the matrix pipe 23 %), so the body is written for instruction count: the four S^T chains (2 tiles x QB blocks) are
+// issued chain-interleaved (no MFMA -> VALU wait states), the scale / shift and the row sums run as packed fp32 operations on register
+// pairs, and the key mask exists only in the MASKED instantiation that the one pair reaching past n runs.
+template <bool MASKED, int QB>
+__device__ __forceinline__ void fwd_pair(const char* k_rm, const char* v_rm, int u, int qi, int g, int lane, int n, const bf16x8 (&qf)[QB][2],
+                                         float sl2, const float (&m)[QB], f32x2 (&lv)[QB], f32x4 (&oacc)[QB][4]) {
+  bf16x8 kf[2][2], vf[4];
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh) kf[tt][kh] = frag_rm(k_rm, (2 * u + tt) * 16 + qi, g + 4 * kh);
+#pragma unroll
+  for (int c = 0; c < 4; ++c) vf[c] = frag_trr(v_rm, c, u, lane);
+  f32x4 a[2][QB];
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+    for (int s = 0; s < QB; ++s) a[tt][s] = mfma16(kf[tt][0], qf[s][0], f32x4{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+    for (int s = 0; s < QB; ++s) a[tt][s] = mfma16(kf[tt][1], qf[s][1], a[tt][s]);
+  bf16x8 pf[QB];
+#pragma unroll
+  for (int s = 0; s < QB; ++s) {
+    f32x4 p[2];
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+      const f32x4 e = a[tt][s] * sl2 - m[s];          // two packed fmas
+#pragma unroll
+      for (int r = 0; r < 4; ++r) p[tt][r] = fast_exp2(e[r]);
+      if (MASKED) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) p[tt][r] = ((2 * u + tt) * 16 + 4 * g + r) < n ? p[tt][r] : 0.f;
+      }
+      lv[s] += f32x2{p[tt][0], p[tt][1]} + f32x2{p[tt][2], p[tt][3]};
+    }
+    pf[s] = pack8(p[0], p[1]);
+  }
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int s = 0; s < QB; ++s) oacc[s][c] = mfma16(vf[c], pf[s], oacc[s][c]);
+}
+
+// first pass: row maxima over one pair of tiles (MASKED: keys >= n count as -inf)
+template <bool MASKED, int QB>
+__device__ __forceinline__ void fwd_max_pair(const char* k_rm, int u, int qi, int g, int n, const bf16x8 (&qf)[QB][2], float (&m)[QB]) {
+  bf16x8 kf[2][2];
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh) kf[tt][kh] = frag_rm(k_rm, (2 * u + tt) * 16 + qi, g + 4 * kh);
+  f32x4 a[2][QB];
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+    for (int s = 0; s < QB; ++s) a[tt][s] = mfma16(kf[tt][0], qf[s][0], f32x4{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+    for (int s = 0; s < QB; ++s) a[tt][s] = mfma16(kf[tt][1], qf[s][1], a[tt][s]);
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+    for (int s = 0; s < QB; ++s) {
+      f32x4 v = a[tt][s];
+      if (MASKED) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = ((2 * u + tt) * 16 + 4 * g + r) < n ? v[r] : -INFINITY;
+      }
+      m[s] = fmaxf(fmaxf(m[s], fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
+    }
+}
 
 template <int NTP>
-__global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o, float* __restrict__ lse,
+__global__ __launch_bounds__(ATT_THREADS, 4) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o, float* __restrict__ lse,
                                                        int n, int h, float scale, const bf16_t* __restrict__ zero_page, int reverse) {
   constexpr int NKP = 16 * NTP, QB = QB_FWD;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -68,112 +154,68 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(const bf16_t* __r
   const bf16_t* qbase = qkv + (int64_t)bi * n * tok_stride + hi * DH;
   const int tid = threadIdx.x, lane = tid & 63, nwaves = blockDim.x >> 6;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  ATTN_STAMP(0);
   stage_head_dma(qbase + inner, tok_stride, n, NKP, k_rm, zero_page, wave, lane, nwaves);
   stage_head_dma(qbase + 2 * inner, tok_stride, n, NKP, v_rm, zero_page, wave, lane, nwaves);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
 
   const int qi = lane & 15, g = lane >> 4;
   const int nqb = (n + 16 * QB - 1) / (16 * QB);
   const float sl2 = scale * 1.44269504088896340736f;
-  for (int qb = wave; qb < nqb; qb += nwaves) {
-    int q[QB];
-    bf16x8 qf[QB][2];
+  bf16x8 qf[QB][2];
+  auto load_q = [&](int qb) {                        // rows >= n of the last block compute on the clamped row n-1 and are never stored
 #pragma unroll
     for (int s = 0; s < QB; ++s) {
-      q[s] = (qb * QB + s) * 16 + qi;
-      const int qc = min(q[s], n - 1);
+      const int qc = min((qb * QB + s) * 16 + qi, n - 1);
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) qf[s][ks] = *(const bf16x8*)(qbase + (int64_t)qc * tok_stride + (g + 4 * ks) * 8);
     }
+  };
+  if (wave < nqb) load_q(wave);                      // in flight together with the K / V images
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  ATTN_STAMP(1);
+  __syncthreads();
+  ATTN_STAMP(2);
+
+  const int u_full = n >> 5;                        // tile pairs [0, u_full) hold valid keys only
+  const int u_end = min(NTP / 2, (n + 31) >> 5);    // at most one more pair holds any valid key
+  for (int qb = wave; qb < nqb; qb += nwaves) {
     // pass 1: row maxima of the scores.  S^T tile t: lane holds S[query qi][key 16t + 4g + r].
     float m[QB];
 #pragma unroll
     for (int s = 0; s < QB; ++s) m[s] = -INFINITY;
-    // only the last key tiles reach past n: the key mask (a compare + select per score, in kernels whose softmax arithmetic keeps
-    // the VALU as busy as the matrix pipe) is applied there alone
-    const int t_full = n >> 4;                      // tiles [0, t_full) hold valid keys only
-#pragma unroll 2
-    for (int t = 0; t < t_full; ++t) {
-      const bf16x8 kf0 = frag_rm(k_rm, t * 16 + qi, g), kf1 = frag_rm(k_rm, t * 16 + qi, g + 4);
-#pragma unroll
-      for (int s = 0; s < QB; ++s) {
-        f32x4 a = {0.f, 0.f, 0.f, 0.f};
-        a = mfma16(kf0, qf[s][0], a);
-        a = mfma16(kf1, qf[s][1], a);
-        m[s] = fmaxf(fmaxf(m[s], fmaxf(a[0], a[1])), fmaxf(a[2], a[3]));
-      }
-    }
-    for (int t = t_full; t < NTP && t * 16 < n; ++t) {
-      const bf16x8 kf0 = frag_rm(k_rm, t * 16 + qi, g), kf1 = frag_rm(k_rm, t * 16 + qi, g + 4);
-#pragma unroll
-      for (int s = 0; s < QB; ++s) {
-        f32x4 a = {0.f, 0.f, 0.f, 0.f};
-        a = mfma16(kf0, qf[s][0], a);
-        a = mfma16(kf1, qf[s][1], a);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) m[s] = fmaxf(m[s], (t * 16 + 4 * g + r) < n ? a[r] : -INFINITY);
-      }
-    }
+#pragma unroll 1
+    for (int u = 0; u < u_full; ++u) fwd_max_pair<false, QB>(k_rm, u, qi, g, n, qf, m);
+    if (u_full < u_end) fwd_max_pair<true, QB>(k_rm, u_full, qi, g, n, qf, m);
 #pragma unroll
     for (int s = 0; s < QB; ++s) {
       m[s] = fmaxf(m[s], __shfl_xor(m[s], 16, 64));
       m[s] = fmaxf(m[s], __shfl_xor(m[s], 32, 64));
       m[s] *= sl2;
     }
+    ATTN_STAMP(3);
     // pass 2: recompute the tile pair, p = 2^(s - m), accumulate the row sum and O^T += V^T P^T (unnormalised)
-    float l[QB];
+    f32x2 lv[QB];
     f32x4 oacc[QB][4];
 #pragma unroll
     for (int s = 0; s < QB; ++s) {
-      l[s] = 0.f;
+      lv[s] = f32x2{0.f, 0.f};
 #pragma unroll
       for (int c = 0; c < 4; ++c) oacc[s][c] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    const int u_full = n >> 5;                      // tile pairs [0, u_full) hold valid keys only
-    const int u_end = min(NTP / 2, (n + 31) >> 5);  // pairs beyond hold no valid key at all (P = 0: nothing to accumulate)
 #pragma unroll 1
-    for (int u = 0; u < u_end; ++u) {
-      f32x4 p[QB][2];
-      const bool masked = u >= u_full;              // wave-uniform
-#pragma unroll
-      for (int tt = 0; tt < 2; ++tt) {
-        const int t = 2 * u + tt;
-        const bf16x8 kf0 = frag_rm(k_rm, t * 16 + qi, g), kf1 = frag_rm(k_rm, t * 16 + qi, g + 4);
-#pragma unroll
-        for (int s = 0; s < QB; ++s) {
-          f32x4 a = {0.f, 0.f, 0.f, 0.f};
-          a = mfma16(kf0, qf[s][0], a);
-          a = mfma16(kf1, qf[s][1], a);
-          if (!masked) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) p[s][tt][r] = fast_exp2(fmaf(a[r], sl2, -m[s]));
-          } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) p[s][tt][r] = (t * 16 + 4 * g + r) < n ? fast_exp2(fmaf(a[r], sl2, -m[s])) : 0.f;
-          }
-          l[s] += (p[s][tt][0] + p[s][tt][1]) + (p[s][tt][2] + p[s][tt][3]);
-        }
-      }
-      bf16x8 pf[QB];
-#pragma unroll
-      for (int s = 0; s < QB; ++s) pf[s] = pack8(p[s][0], p[s][1]);
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const bf16x8 vf = frag_trr(v_rm, c, u, lane);
-#pragma unroll
-        for (int s = 0; s < QB; ++s) oacc[s][c] = mfma16(vf, pf[s], oacc[s][c]);
-      }
-    }
+    for (int u = 0; u < u_full; ++u) fwd_pair<false, QB>(k_rm, v_rm, u, qi, g, lane, n, qf, sl2, m, lv, oacc);
+    if (u_full < u_end) fwd_pair<true, QB>(k_rm, v_rm, u_full, qi, g, lane, n, qf, sl2, m, lv, oacc);
+    ATTN_STAMP(4);
 #pragma unroll
     for (int s = 0; s < QB; ++s) {
-      float ls = l[s];
+      const int q = (qb * QB + s) * 16 + qi;
+      float ls = lv[s][0] + lv[s][1];
       ls += __shfl_xor(ls, 16, 64);
       ls += __shfl_xor(ls, 32, 64);
       const float inv_l = 1.0f / ls;
-      if (g == 0 && q[s] < n) lse[(int64_t)bh * n + q[s]] = (m[s] + log2f(ls)) * 0.69314718055994530942f;  // natural-log LSE
-      if (q[s] < n) {
-        bf16_t* op = o + ((int64_t)bi * n + q[s]) * inner + hi * DH;
+      if (g == 0 && q < n) lse[(int64_t)bh * n + q] = (m[s] + log2f(ls)) * 0.69314718055994530942f;  // natural-log LSE
+      if (q < n) {
+        bf16_t* op = o + ((int64_t)bi * n + q) * inner + hi * DH;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
           bf16x4 ov;
@@ -183,16 +225,183 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(const bf16_t* __r
         }
       }
     }
+    if (qb + nwaves < nqb) load_q(qb + nwaves);
+  }
+  ATTN_STAMP(5);
+}
+
+// ------------------------------------------------------------------------------------------ backward
+// One 16-query block of the dQ pass (K, V images in LDS): D[q] = sum_d dO*O, then per pair of key tiles P = 2^(S*sl2 - lse),
+// dS = P * (dP - D) * scale, dQ^T += K^T dS^T.  `lse2` = this lane's query's LSE in the log2 domain; returns D for the caller to keep.
+// The key mask is a template flag: only the one tile pair reaching past n pays for the compares and selects (these loops are VALU-bound).
+template <bool MASKED>
+__device__ __forceinline__ void dq_pair(const char* k_rm, const char* v_rm, int u, int qi, int g, int lane, int n, const bf16x8 (&qf)[2],
+                                        const bf16x8 (&dof)[2], float sl2, float lse2, float scale, float nds, f32x4 (&dq)[4]) {
+  bf16x8 kf[2][2], vf[2][2], kt[4];
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh) {
+      kf[tt][kh] = frag_rm(k_rm, (2 * u + tt) * 16 + qi, g + 4 * kh);
+      vf[tt][kh] = frag_rm(v_rm, (2 * u + tt) * 16 + qi, g + 4 * kh);
+    }
+#pragma unroll
+  for (int c = 0; c < 4; ++c) kt[c] = frag_trr(k_rm, c, u, lane);
+  f32x4 sa[2], dp[2];
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt) {
+    sa[tt] = mfma16(kf[tt][0], qf[0], f32x4{0.f, 0.f, 0.f, 0.f});
+    dp[tt] = mfma16(vf[tt][0], dof[0], f32x4{0.f, 0.f, 0.f, 0.f});
+  }
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt) {
+    sa[tt] = mfma16(kf[tt][1], qf[1], sa[tt]);
+    dp[tt] = mfma16(vf[tt][1], dof[1], dp[tt]);
+  }
+  f32x4 ds[2];
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt) {
+    const f32x4 e = sa[tt] * sl2 - lse2;
+    const f32x4 w = dp[tt] * scale + nds;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float p = fast_exp2(e[r]);
+      if (MASKED) p = ((2 * u + tt) * 16 + 4 * g + r) < n ? p : 0.f;
+      ds[tt][r] = p * w[r];
+    }
+  }
+  const bf16x8 dsf = pack8(ds[0], ds[1]);
+#pragma unroll
+  for (int c = 0; c < 4; ++c) dq[c] = mfma16(kt[c], dsf, dq[c]);
+}
+
+// per-lane global operands of one 16-query block (its q, dO and O rows): loaded one block AHEAD of their use, so that the round trip
+// (1.5-2 us under load, tools/probe_attn) runs under the previous block's tile loop instead of in front of this one's
+struct DqOperands { bf16x8 qf[2], dof[2], of[2]; };
+__device__ __forceinline__ void dq_load(DqOperands& x, const bf16_t* qbase, int64_t tok_stride, const bf16_t* o_rows, const bf16_t* do_rows, int inner,
+                                        int qb, int lane, int n) {
+  const int qc = min(qb * 16 + (lane & 15), n - 1), g = lane >> 4;   // rows >= n compute on the clamped row n-1 (finite) and are never stored
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    x.qf[ks] = *(const bf16x8*)(qbase + (int64_t)qc * tok_stride + (g + 4 * ks) * 8);
+    x.dof[ks] = *(const bf16x8*)(do_rows + (int64_t)qc * inner + (g + 4 * ks) * 8);
+    x.of[ks] = *(const bf16x8*)(o_rows + (int64_t)qc * inner + (g + 4 * ks) * 8);
   }
 }
 
-// ------------------------------------------------------------------------------------------ backward: dQ (+ row sums D)
+template <int NTP>
+__device__ __forceinline__ float dq_block(const char* k_rm, const char* v_rm, const DqOperands& x, int64_t tok_stride, bf16_t* dq_rows, int qb, int lane,
+                                          int n, float scale, float lse2) {
+  const int qi = lane & 15, g = lane >> 4;
+  const int q = qb * 16 + qi;
+  const float sl2 = scale * 1.44269504088896340736f;
+  const bf16x8 (&qf)[2] = x.qf;
+  const bf16x8 (&dof)[2] = x.dof;
+  float dsum = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dsum += (float)x.dof[ks][e] * (float)x.of[ks][e];
+  dsum += __shfl_xor(dsum, 16, 64);
+  dsum += __shfl_xor(dsum, 32, 64);   // D[q] = sum_d dO*O
+  const float nds = -dsum * scale;
+  f32x4 dq[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) dq[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int u_full = n >> 5, u_end = min(NTP / 2, (n + 31) >> 5);
+#pragma unroll 1
+  for (int u = 0; u < u_full; ++u) dq_pair<false>(k_rm, v_rm, u, qi, g, lane, n, qf, dof, sl2, lse2, scale, nds, dq);
+  if (u_full < u_end) dq_pair<true>(k_rm, v_rm, u_full, qi, g, lane, n, qf, dof, sl2, lse2, scale, nds, dq);
+  if (q < n) {
+    bf16_t* out = dq_rows + (int64_t)q * tok_stride;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      bf16x4 ov;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ov[r] = (bf16_t)dq[c][r];
+      *(bf16x4*)(out + 16 * c + 4 * g) = ov;
+    }
+  }
+  return dsum;
+}
+
+// One 16-key block of the dK / dV pass (Q, dO images in LDS; lse_s (log2 domain) and d_s per query in LDS, rows >= n: 0).
+// No masks: query rows >= n are zero rows of q / dO with lse = D = 0, so their P = 1 meets dO = 0 and their dS = 1 * (0 - 0); key lanes >= n
+// compute on the clamped key n-1 and are never stored.  Tile pairs past n are skipped.
+struct DkvOperands { bf16x8 kf[2], vf[2]; };   // one 16-key block's k and v rows (the B operands of S and dP), loaded one block ahead as well
+__device__ __forceinline__ void dkv_load(DkvOperands& x, const bf16_t* kbase, int64_t tok_stride, int inner, int kb, int lane, int n) {
+  const int kc = min(kb * 16 + (lane & 15), n - 1), g = lane >> 4;
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    x.kf[ks] = *(const bf16x8*)(kbase + (int64_t)kc * tok_stride + (g + 4 * ks) * 8);
+    x.vf[ks] = *(const bf16x8*)(kbase + inner + (int64_t)kc * tok_stride + (g + 4 * ks) * 8);
+  }
+}
+
+template <int NTP>
+__device__ __forceinline__ void dkv_block(const char* q_rm, const char* do_rm, const float* lse_s, const float* d_s, const DkvOperands& x,
+                                          int64_t tok_stride, int inner, bf16_t* dk_rows, int kb, int lane, int n, float scale) {
+  const int ki = lane & 15, g = lane >> 4;
+  const int key = kb * 16 + ki;
+  const float sl2 = scale * 1.44269504088896340736f;
+  const bf16x8 (&kf)[2] = x.kf;
+  const bf16x8 (&vf)[2] = x.vf;
+  f32x4 dk[4], dv[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) { dk[c] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[c] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  const int u_end = min(NTP / 2, (n + 31) >> 5);
+#pragma unroll 1
+  for (int u = 0; u < u_end; ++u) {
+    f32x4 pp[2], ds[2];
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+      const int t = 2 * u + tt;
+      const bf16x8 qa0 = frag_rm(q_rm, t * 16 + ki, g), qa1 = frag_rm(q_rm, t * 16 + ki, g + 4);
+      const bf16x8 da0 = frag_rm(do_rm, t * 16 + ki, g), da1 = frag_rm(do_rm, t * 16 + ki, g + 4);
+      float lq[4], dd[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { lq[r] = lse_s[t * 16 + 4 * g + r]; dd[r] = d_s[t * 16 + 4 * g + r]; }
+      f32x4 sa = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+      sa = mfma16(qa0, kf[0], sa);     // S[query 16t+4g+r][key ki]
+      sa = mfma16(qa1, kf[1], sa);
+      dp = mfma16(da0, vf[0], dp);     // dP same layout
+      dp = mfma16(da1, vf[1], dp);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p = fast_exp2(fmaf(sa[r], sl2, -lq[r]));
+        pp[tt][r] = p;
+        ds[tt][r] = p * ((dp[r] - dd[r]) * scale);
+      }
+    }
+    const bf16x8 pf = pack8(pp[0], pp[1]), dsf = pack8(ds[0], ds[1]);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const bf16x8 a1 = frag_trr(do_rm, c, u, lane), a2 = frag_trr(q_rm, c, u, lane);
+      dv[c] = mfma16(a1, pf, dv[c]);
+      dk[c] = mfma16(a2, dsf, dk[c]);
+    }
+  }
+  if (key < n) {
+    bf16_t* dkp = dk_rows + (int64_t)key * tok_stride;
+    bf16_t* dvp = dkp + inner;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      bf16x4 a, b2;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { a[r] = (bf16_t)dk[c][r]; b2[r] = (bf16_t)dv[c][r]; }
+      *(bf16x4*)(dkp + 16 * c + 4 * g) = a;
+      *(bf16x4*)(dvp + 16 * c + 4 * g) = b2;
+    }
+  }
+}
+
+// backward as two launches (VITX_ATTN_BWD_SPLIT=1: the A/B and bit-identity form): dQ (+ row sums D to HBM) ...
 template <int NTP>
 __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
                                                           const bf16_t* __restrict__ d_o, const float* __restrict__ lse,
                                                           float* __restrict__ dsum, bf16_t* __restrict__ dqkv, int n, int h, float scale,
                                                           const bf16_t* __restrict__ zero_page) {
-  constexpr int NKP = 16 * NTP, QB = QB_BWD;
+  constexpr int NKP = 16 * NTP;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* k_rm = smem;
   char* v_rm = smem + NKP * ROWB;
@@ -206,97 +415,23 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dq_kernel(const bf16_t* 
   stage_head_dma(qbase + 2 * inner, tok_stride, n, NKP, v_rm, zero_page, wave, lane, nwaves);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-
-  const int qi = lane & 15, g = lane >> 4;
-  const int nqb = (n + 16 * QB - 1) / (16 * QB);
-  const float sl2 = scale * 1.44269504088896340736f;
-  for (int qb = wave; qb < nqb; qb += nwaves) {
-    int q[QB];
-    bf16x8 qf[QB][2], dof[QB][2];
-    float dpart[QB], l2[QB];
-    f32x4 dq[QB][4];
-#pragma unroll
-    for (int s = 0; s < QB; ++s) {
-      q[s] = (qb * QB + s) * 16 + qi;
-      const int qc = min(q[s], n - 1);
-      const int64_t orow = ((int64_t)bi * n + qc) * inner + hi * DH;
-      float dp_ = 0.f;
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        qf[s][ks] = *(const bf16x8*)(qbase + (int64_t)qc * tok_stride + (g + 4 * ks) * 8);
-        dof[s][ks] = *(const bf16x8*)(d_o + orow + (g + 4 * ks) * 8);
-        const bf16x8 of = *(const bf16x8*)(o + orow + (g + 4 * ks) * 8);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) dp_ += (float)dof[s][ks][e] * (float)of[e];
-      }
-      dp_ += __shfl_xor(dp_, 16, 64);
-      dp_ += __shfl_xor(dp_, 32, 64);   // D[q] = sum_d dO*O
-      if (g == 0 && q[s] < n) dsum[(int64_t)bh * n + q[s]] = dp_;
-      dpart[s] = dp_;
-      l2[s] = lse[(int64_t)bh * n + qc] * 1.44269504088896340736f;
-#pragma unroll
-      for (int c = 0; c < 4; ++c) dq[s][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    // key masks only where a tile pair reaches past n (wave-uniform branch); query rows >= n of the last block compute on the
-    // clamped row n-1 (finite) and are never stored, so they need no mask here
-    const int u_full = n >> 5, u_end = min(NTP / 2, (n + 31) >> 5);
-#pragma unroll 1
-    for (int u = 0; u < u_end; ++u) {
-      f32x4 ds[QB][2];
-      const bool masked = u >= u_full;
-#pragma unroll
-      for (int tt = 0; tt < 2; ++tt) {
-        const int t = 2 * u + tt;
-        const bf16x8 kf0 = frag_rm(k_rm, t * 16 + qi, g), kf1 = frag_rm(k_rm, t * 16 + qi, g + 4);
-        const bf16x8 vf0 = frag_rm(v_rm, t * 16 + qi, g), vf1 = frag_rm(v_rm, t * 16 + qi, g + 4);
-#pragma unroll
-        for (int s = 0; s < QB; ++s) {
-          f32x4 sa = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-          sa = mfma16(kf0, qf[s][0], sa);
-          sa = mfma16(kf1, qf[s][1], sa);
-          dp = mfma16(vf0, dof[s][0], dp);
-          dp = mfma16(vf1, dof[s][1], dp);
-          const float nds = -dpart[s] * scale;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            float p = fast_exp2(fmaf(sa[r], sl2, -l2[s]));
-            if (masked) p = (t * 16 + 4 * g + r) < n ? p : 0.f;
-            ds[s][tt][r] = p * fmaf(dp[r], scale, nds);
-          }
-        }
-      }
-      bf16x8 dsf[QB];
-#pragma unroll
-      for (int s = 0; s < QB; ++s) dsf[s] = pack8(ds[s][0], ds[s][1]);
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const bf16x8 kt = frag_trr(k_rm, c, u, lane);
-#pragma unroll
-        for (int s = 0; s < QB; ++s) dq[s][c] = mfma16(kt, dsf[s], dq[s][c]);
-      }
-    }
-#pragma unroll
-    for (int s = 0; s < QB; ++s) {
-      if (q[s] < n) {
-        bf16_t* dp_out = dqkv + ((int64_t)bi * n + q[s]) * tok_stride + hi * DH;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          bf16x4 ov;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) ov[r] = (bf16_t)dq[s][c][r];
-          *(bf16x4*)(dp_out + 16 * c + 4 * g) = ov;
-        }
-      }
-    }
+  const int64_t orow0 = (int64_t)bi * n * inner + hi * DH;
+  for (int qb = wave; qb < (n + 15) / 16; qb += nwaves) {
+    const int qi = lane & 15, q = qb * 16 + qi, qc = min(q, n - 1);
+    DqOperands x;
+    dq_load(x, qbase, tok_stride, o + orow0, d_o + orow0, inner, qb, lane, n);
+    const float d = dq_block<NTP>(k_rm, v_rm, x, tok_stride, dqkv + (int64_t)bi * n * tok_stride + hi * DH, qb, lane, n, scale,
+                                  lse[(int64_t)bh * n + qc] * 1.44269504088896340736f);
+    if ((lane >> 4) == 0 && q < n) dsum[(int64_t)bh * n + q] = d;
   }
 }
 
-// ------------------------------------------------------------------------------------------ backward: dK, dV
+// ... and dK, dV
 template <int NTP>
 __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ d_o,
                                                            const float* __restrict__ lse, const float* __restrict__ dsum,
                                                            bf16_t* __restrict__ dqkv, int n, int h, float scale, const bf16_t* __restrict__ zero_page) {
-  constexpr int NQP = 16 * NTP, QB = QB_BWD;
+  constexpr int NQP = 16 * NTP;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* q_rm = smem;
   char* do_rm = smem + NQP * ROWB;
@@ -316,97 +451,24 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dkv_kernel(const bf16_t*
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-
-  const int ki = lane & 15, g = lane >> 4;
-  const int nkb = (n + 16 * QB - 1) / (16 * QB);
-  const float sl2 = scale * 1.44269504088896340736f;
-  for (int kb = wave; kb < nkb; kb += nwaves) {
-    int key[QB];
-    bf16x8 kf[QB][2], vf[QB][2];
-    f32x4 dk[QB][4], dv[QB][4];
-#pragma unroll
-    for (int s = 0; s < QB; ++s) {
-      key[s] = (kb * QB + s) * 16 + ki;
-      const int kc = min(key[s], n - 1);
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        kf[s][ks] = *(const bf16x8*)(qbase + inner + (int64_t)kc * tok_stride + (g + 4 * ks) * 8);
-        vf[s][ks] = *(const bf16x8*)(qbase + 2 * inner + (int64_t)kc * tok_stride + (g + 4 * ks) * 8);
-      }
-#pragma unroll
-      for (int c = 0; c < 4; ++c) { dk[s][c] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[s][c] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-    }
-    // No masks: query rows >= n are zero rows of q / dO with lse = D = 0 staged above, so their P = 1 meets dO = 0 and their
-    // dS = 1 * (0 - 0); key lanes >= n compute on the clamped key n-1 and are never stored.  Tile pairs past n are skipped.
-    const int u_end = min(NTP / 2, (n + 31) >> 5);
-#pragma unroll 1
-    for (int u = 0; u < u_end; ++u) {
-      f32x4 pp[QB][2], ds[QB][2];
-#pragma unroll
-      for (int tt = 0; tt < 2; ++tt) {
-        const int t = 2 * u + tt;
-        const bf16x8 qa0 = frag_rm(q_rm, t * 16 + ki, g), qa1 = frag_rm(q_rm, t * 16 + ki, g + 4);
-        const bf16x8 da0 = frag_rm(do_rm, t * 16 + ki, g), da1 = frag_rm(do_rm, t * 16 + ki, g + 4);
-        float lq[4], dd[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { lq[r] = lse_s[t * 16 + 4 * g + r]; dd[r] = d_s[t * 16 + 4 * g + r]; }
-#pragma unroll
-        for (int s = 0; s < QB; ++s) {
-          f32x4 sa = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-          sa = mfma16(qa0, kf[s][0], sa);     // S[query 16t+4g+r][key ki]
-          sa = mfma16(qa1, kf[s][1], sa);
-          dp = mfma16(da0, vf[s][0], dp);     // dP same layout
-          dp = mfma16(da1, vf[s][1], dp);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float p = fast_exp2(fmaf(sa[r], sl2, -lq[r]));
-            pp[s][tt][r] = p;
-            ds[s][tt][r] = p * ((dp[r] - dd[r]) * scale);
-          }
-        }
-      }
-      bf16x8 pf[QB], dsf[QB];
-#pragma unroll
-      for (int s = 0; s < QB; ++s) { pf[s] = pack8(pp[s][0], pp[s][1]); dsf[s] = pack8(ds[s][0], ds[s][1]); }
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const bf16x8 a1 = frag_trr(do_rm, c, u, lane), a2 = frag_trr(q_rm, c, u, lane);
-#pragma unroll
-        for (int s = 0; s < QB; ++s) {
-          dv[s][c] = mfma16(a1, pf[s], dv[s][c]);
-          dk[s][c] = mfma16(a2, dsf[s], dk[s][c]);
-        }
-      }
-    }
-#pragma unroll
-    for (int s = 0; s < QB; ++s) {
-      if (key[s] < n) {
-        bf16_t* dkp = dqkv + ((int64_t)bi * n + key[s]) * tok_stride + inner + hi * DH;
-        bf16_t* dvp = dkp + inner;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          bf16x4 a, b2;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) { a[r] = (bf16_t)dk[s][c][r]; b2[r] = (bf16_t)dv[s][c][r]; }
-          *(bf16x4*)(dkp + 16 * c + 4 * g) = a;
-          *(bf16x4*)(dvp + 16 * c + 4 * g) = b2;
-        }
-      }
-    }
+  for (int kb = wave; kb < (n + 15) / 16; kb += nwaves) {
+    DkvOperands x;
+    dkv_load(x, qbase + inner, tok_stride, inner, kb, lane, n);
+    dkv_block<NTP>(q_rm, do_rm, lse_s, d_s, x, tok_stride, inner, dqkv + (int64_t)bi * n * tok_stride + inner + hi * DH, kb, lane, n, scale);
   }
 }
 
 // ------------------------------------------------------------------------------------------ backward, both phases in one launch
-// Phase 1 is the dQ kernel above, phase 2 the dK / dV kernel below, run back to back by the SAME workgroup on the same two LDS
-// buffers (K, V images, then Q, dO images).  The arithmetic is unchanged (same bits); what changes is the traffic: as two launches
+// Phase 1 is the dQ pass, phase 2 the dK / dV pass, run back to back by the SAME workgroup on the same two LDS buffers (K, V images,
+// then Q, dO images).  The arithmetic is that of the two-launch form (same bits); what changes is the traffic: as two launches
 // each pass fetched its head's q, k, v, dO from HBM (310 MB per pass at ViT-B/16, more than the 256-MB MALL holds between them),
 // here phase 2 finds them in the L2 its own phase 1 pulled them through 10-20 us earlier, and the row sums D never leave LDS.
 template <int NTP>
-__global__ __launch_bounds__(ATT_THREADS) void attn_bwd_fused_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
+__global__ __launch_bounds__(ATT_THREADS, 4) void attn_bwd_fused_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
                                                              const bf16_t* __restrict__ d_o, const float* __restrict__ lse,
                                                              bf16_t* __restrict__ dqkv, int n, int h, float scale,
                                                              const bf16_t* __restrict__ zero_page) {
-  constexpr int NKP = 16 * NTP, NQP = 16 * NTP, QB = QB_BWD;
+  constexpr int NKP = 16 * NTP, NQP = 16 * NTP;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* k_rm = smem;                                 // phase 1: K, V      phase 2: Q, dO
   char* v_rm = smem + NKP * ROWB;
@@ -426,176 +488,39 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_fused_kernel(const bf16_
     lse_s[i] = i < n ? lse[(int64_t)bh * n + i] * 1.44269504088896340736f : 0.f;
     d_s[i] = 0.f;
   }
+  const int64_t orow0 = (int64_t)bi * n * inner + hi * DH;
+  const int nblk = (n + 15) / 16;
+  DqOperands xq;
+  if (wave < nblk) dq_load(xq, qbase, tok_stride, o + orow0, d_o + orow0, inner, wave, lane, n);   // in flight together with the K / V images
+  ATTN_STAMP(0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  {   // ---------------------------------------------------------------- phase 1: dQ, D
-    const int qi = lane & 15, g = lane >> 4;
-    const int nqb = (n + 16 * QB - 1) / (16 * QB);
-    const float sl2 = scale * 1.44269504088896340736f;
-    for (int qb = wave; qb < nqb; qb += nwaves) {
-      int q[QB];
-      bf16x8 qf[QB][2], dof[QB][2];
-      float dpart[QB], l2[QB];
-      f32x4 dq[QB][4];
-  #pragma unroll
-      for (int s = 0; s < QB; ++s) {
-        q[s] = (qb * QB + s) * 16 + qi;
-        const int qc = min(q[s], n - 1);
-        const int64_t orow = ((int64_t)bi * n + qc) * inner + hi * DH;
-        float dp_ = 0.f;
-  #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          qf[s][ks] = *(const bf16x8*)(qbase + (int64_t)qc * tok_stride + (g + 4 * ks) * 8);
-          dof[s][ks] = *(const bf16x8*)(d_o + orow + (g + 4 * ks) * 8);
-          const bf16x8 of = *(const bf16x8*)(o + orow + (g + 4 * ks) * 8);
-  #pragma unroll
-          for (int e = 0; e < 8; ++e) dp_ += (float)dof[s][ks][e] * (float)of[e];
-        }
-        dp_ += __shfl_xor(dp_, 16, 64);
-        dp_ += __shfl_xor(dp_, 32, 64);   // D[q] = sum_d dO*O
-        if (g == 0 && q[s] < n) d_s[q[s]] = dp_;        // stays in LDS for phase 2
-        dpart[s] = dp_;
-        l2[s] = lse_s[qc];
-  #pragma unroll
-        for (int c = 0; c < 4; ++c) dq[s][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-      }
-      // key masks only where a tile pair reaches past n (wave-uniform branch); query rows >= n of the last block compute on the
-      // clamped row n-1 (finite) and are never stored, so they need no mask here
-      const int u_full = n >> 5, u_end = min(NTP / 2, (n + 31) >> 5);
-  #pragma unroll 1
-      for (int u = 0; u < u_end; ++u) {
-        f32x4 ds[QB][2];
-        const bool masked = u >= u_full;
-  #pragma unroll
-        for (int tt = 0; tt < 2; ++tt) {
-          const int t = 2 * u + tt;
-          const bf16x8 kf0 = frag_rm(k_rm, t * 16 + qi, g), kf1 = frag_rm(k_rm, t * 16 + qi, g + 4);
-          const bf16x8 vf0 = frag_rm(v_rm, t * 16 + qi, g), vf1 = frag_rm(v_rm, t * 16 + qi, g + 4);
-  #pragma unroll
-          for (int s = 0; s < QB; ++s) {
-            f32x4 sa = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-            sa = mfma16(kf0, qf[s][0], sa);
-            sa = mfma16(kf1, qf[s][1], sa);
-            dp = mfma16(vf0, dof[s][0], dp);
-            dp = mfma16(vf1, dof[s][1], dp);
-            const float nds = -dpart[s] * scale;
-  #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              float p = fast_exp2(fmaf(sa[r], sl2, -l2[s]));
-              if (masked) p = (t * 16 + 4 * g + r) < n ? p : 0.f;
-              ds[s][tt][r] = p * fmaf(dp[r], scale, nds);
-            }
-          }
-        }
-        bf16x8 dsf[QB];
-  #pragma unroll
-        for (int s = 0; s < QB; ++s) dsf[s] = pack8(ds[s][0], ds[s][1]);
-  #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const bf16x8 kt = frag_trr(k_rm, c, u, lane);
-  #pragma unroll
-          for (int s = 0; s < QB; ++s) dq[s][c] = mfma16(kt, dsf[s], dq[s][c]);
-        }
-      }
-  #pragma unroll
-      for (int s = 0; s < QB; ++s) {
-        if (q[s] < n) {
-          bf16_t* dp_out = dqkv + ((int64_t)bi * n + q[s]) * tok_stride + hi * DH;
-  #pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            bf16x4 ov;
-  #pragma unroll
-            for (int r = 0; r < 4; ++r) ov[r] = (bf16_t)dq[s][c][r];
-            *(bf16x4*)(dp_out + 16 * c + 4 * g) = ov;
-          }
-        }
-      }
-    }
+  ATTN_STAMP(1);
+  for (int qb = wave; qb < nblk; qb += nwaves) {   // ------------------------------------ phase 1: dQ, D
+    const int q = qb * 16 + (lane & 15);
+    DqOperands nx;
+    if (qb + nwaves < nblk) dq_load(nx, qbase, tok_stride, o + orow0, d_o + orow0, inner, qb + nwaves, lane, n);
+    const float d = dq_block<NTP>(k_rm, v_rm, xq, tok_stride, dqkv + (int64_t)bi * n * tok_stride + hi * DH, qb, lane, n, scale, lse_s[min(q, n - 1)]);
+    if ((lane >> 4) == 0 && q < n) d_s[q] = d;      // stays in LDS for phase 2
+    xq = nx;
   }
+  DkvOperands xk;
+  if (wave < nblk) dkv_load(xk, qbase + inner, tok_stride, inner, wave, lane, n);   // L2 hits, in flight across the barrier and the restaging
+  ATTN_STAMP(2);
   __syncthreads();               // every wave is done with the K / V images; D is complete
+  ATTN_STAMP(3);
   stage_head_dma(qbase, tok_stride, n, NQP, q_rm, zero_page, wave, lane, nwaves);
-  stage_head_dma(d_o + (int64_t)bi * n * inner + hi * DH, inner, n, NQP, do_rm, zero_page, wave, lane, nwaves);
+  stage_head_dma(d_o + orow0, inner, n, NQP, do_rm, zero_page, wave, lane, nwaves);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  {   // ---------------------------------------------------------------- phase 2: dK, dV
-    const int ki = lane & 15, g = lane >> 4;
-    const int nkb = (n + 16 * QB - 1) / (16 * QB);
-    const float sl2 = scale * 1.44269504088896340736f;
-    for (int kb = wave; kb < nkb; kb += nwaves) {
-      int key[QB];
-      bf16x8 kf[QB][2], vf[QB][2];
-      f32x4 dk[QB][4], dv[QB][4];
-  #pragma unroll
-      for (int s = 0; s < QB; ++s) {
-        key[s] = (kb * QB + s) * 16 + ki;
-        const int kc = min(key[s], n - 1);
-  #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          kf[s][ks] = *(const bf16x8*)(qbase + inner + (int64_t)kc * tok_stride + (g + 4 * ks) * 8);
-          vf[s][ks] = *(const bf16x8*)(qbase + 2 * inner + (int64_t)kc * tok_stride + (g + 4 * ks) * 8);
-        }
-  #pragma unroll
-        for (int c = 0; c < 4; ++c) { dk[s][c] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[s][c] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-      }
-      // No masks: query rows >= n are zero rows of q / dO with lse = D = 0 staged above, so their P = 1 meets dO = 0 and their
-      // dS = 1 * (0 - 0); key lanes >= n compute on the clamped key n-1 and are never stored.  Tile pairs past n are skipped.
-      const int u_end = min(NTP / 2, (n + 31) >> 5);
-  #pragma unroll 1
-      for (int u = 0; u < u_end; ++u) {
-        f32x4 pp[QB][2], ds[QB][2];
-  #pragma unroll
-        for (int tt = 0; tt < 2; ++tt) {
-          const int t = 2 * u + tt;
-          const bf16x8 qa0 = frag_rm(q_rm, t * 16 + ki, g), qa1 = frag_rm(q_rm, t * 16 + ki, g + 4);
-          const bf16x8 da0 = frag_rm(do_rm, t * 16 + ki, g), da1 = frag_rm(do_rm, t * 16 + ki, g + 4);
-          float lq[4], dd[4];
-  #pragma unroll
-          for (int r = 0; r < 4; ++r) { lq[r] = lse_s[t * 16 + 4 * g + r]; dd[r] = d_s[t * 16 + 4 * g + r]; }
-  #pragma unroll
-          for (int s = 0; s < QB; ++s) {
-            f32x4 sa = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-            sa = mfma16(qa0, kf[s][0], sa);     // S[query 16t+4g+r][key ki]
-            sa = mfma16(qa1, kf[s][1], sa);
-            dp = mfma16(da0, vf[s][0], dp);     // dP same layout
-            dp = mfma16(da1, vf[s][1], dp);
-  #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const float p = fast_exp2(fmaf(sa[r], sl2, -lq[r]));
-              pp[s][tt][r] = p;
-              ds[s][tt][r] = p * ((dp[r] - dd[r]) * scale);
-            }
-          }
-        }
-        bf16x8 pf[QB], dsf[QB];
-  #pragma unroll
-        for (int s = 0; s < QB; ++s) { pf[s] = pack8(pp[s][0], pp[s][1]); dsf[s] = pack8(ds[s][0], ds[s][1]); }
-  #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const bf16x8 a1 = frag_trr(do_rm, c, u, lane), a2 = frag_trr(q_rm, c, u, lane);
-  #pragma unroll
-          for (int s = 0; s < QB; ++s) {
-            dv[s][c] = mfma16(a1, pf[s], dv[s][c]);
-            dk[s][c] = mfma16(a2, dsf[s], dk[s][c]);
-          }
-        }
-      }
-  #pragma unroll
-      for (int s = 0; s < QB; ++s) {
-        if (key[s] < n) {
-          bf16_t* dkp = dqkv + ((int64_t)bi * n + key[s]) * tok_stride + inner + hi * DH;
-          bf16_t* dvp = dkp + inner;
-  #pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            bf16x4 a, b2;
-  #pragma unroll
-            for (int r = 0; r < 4; ++r) { a[r] = (bf16_t)dk[s][c][r]; b2[r] = (bf16_t)dv[s][c][r]; }
-            *(bf16x4*)(dkp + 16 * c + 4 * g) = a;
-            *(bf16x4*)(dvp + 16 * c + 4 * g) = b2;
-          }
-        }
-      }
-    }
+  ATTN_STAMP(4);
+  for (int kb = wave; kb < nblk; kb += nwaves) {   // ------------------------------------ phase 2: dK, dV
+    DkvOperands nx;
+    if (kb + nwaves < nblk) dkv_load(nx, qbase + inner, tok_stride, inner, kb + nwaves, lane, n);
+    dkv_block<NTP>(q_rm, do_rm, lse_s, d_s, xk, tok_stride, inner, dqkv + (int64_t)bi * n * tok_stride + inner + hi * DH, kb, lane, n, scale);
+    xk = nx;
   }
+  ATTN_STAMP(5);
 }
 
 template <typename K>
@@ -607,7 +532,8 @@ void set_smem(K kern, int bytes) {   // one attribute call per distinct kernel (
   if (ndone < 32) done[ndone++] = (const void*)kern;
 }
 
-inline int att_threads(int n) { (void)n; return 512; }   // 8 waves measured best (13 one-block waves: bwd 16 % slower)
+// 8 waves: 13 one-block waves measured 16 % slower in the backward; 7 waves (tools/probe_attn, r4s) the same forward and a 6 % slower backward
+inline int att_threads(int n) { (void)n; return 512; }
 inline int pick_ntp(int n) { return n <= 64 ? 4 : n <= 96 ? 6 : n <= 224 ? 14 : 18; }
 
 }  // namespace

@@ -9,7 +9,11 @@ namespace attn_lds {
 constexpr int DH = 64;
 constexpr int ROWB = DH * 2;  // 128-byte rows
 
+#ifdef VITX_ATTN_PROBE_NOEXP   // timing switch of tools/probe_attn (wrong results): what do the transcendentals cost?
+__device__ __forceinline__ float fast_exp2(float x) { return x; }
+#else
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }  // raw v_exp_f32 (inputs are <= 0 or masked)
+#endif
 
 // 16-B chunk swizzle of the 128-B rows.  The key moves in steps of TWO chunks (32 B) per row pair: the transpose reads
 // (ds_read_b64_tr_b16, 32-lane service groups touching 8 rows x 32 B) need rows r and r+2 in different 32-B bank groups -- with a
@@ -67,9 +71,17 @@ __device__ __forceinline__ bf16x8 pack8(const f32x4& a, const f32x4& b) {
   for (int e = 0; e < 4; ++e) { r[e] = (bf16_t)a[e]; r[4 + e] = (bf16_t)b[e]; }
   return r;
 }
+#ifdef VITX_ATTN_PROBE_NOMFMA  // timing switch of tools/probe_attn (wrong results): one VALU op per MFMA, operands kept alive
+__device__ __forceinline__ f32x4 mfma16(const bf16x8& a, const bf16x8& b, const f32x4& c) {
+  f32x4 r = c;
+  r[0] += (float)a[0] * (float)b[0];
+  return r;
+}
+#else
 __device__ __forceinline__ f32x4 mfma16(const bf16x8& a, const bf16x8& b, const f32x4& c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
+#endif
 
 
 }  // namespace attn_lds
