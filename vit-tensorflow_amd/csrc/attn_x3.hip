@@ -11,6 +11,7 @@
 //   layout: packed qkv [b, n, 3, h, 64] fp32 exactly as the to_qkv Dense emits it, output o [b, n, h*64] fp32 (vit.py:82).
 #include "kernels.h"
 #include "attn_lds.h"
+#include <type_traits>
 
 namespace {
 
@@ -101,7 +102,20 @@ __global__ __launch_bounds__(X3_THREADS) void attn_x3_fwd_kernel(const float* __
     float m[QB];
 #pragma unroll
     for (int s = 0; s < QB; ++s) m[s] = -INFINITY;
-    for (int t = 0; t < NTP && t * 16 < n; ++t) {
+    // the key mask (a compare + select per score) only on the tiles that reach past n
+    const int t_full = n >> 4;
+#pragma unroll 1
+    for (int t = 0; t < t_full; ++t) {
+      const P2 kf0 = frag_rm2(k_hi, k_lo, t * 16 + qi, g), kf1 = frag_rm2(k_hi, k_lo, t * 16 + qi, g + 4);
+      f32x4 a[QB];
+#pragma unroll
+      for (int s = 0; s < QB; ++s) a[s] = mfma3(kf0, qf[s][0], f32x4{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+      for (int s = 0; s < QB; ++s) a[s] = mfma3(kf1, qf[s][1], a[s]);
+#pragma unroll
+      for (int s = 0; s < QB; ++s) m[s] = fmaxf(fmaxf(m[s], fmaxf(a[s][0], a[s][1])), fmaxf(a[s][2], a[s][3]));
+    }
+    for (int t = t_full; t < NTP && t * 16 < n; ++t) {
       const P2 kf0 = frag_rm2(k_hi, k_lo, t * 16 + qi, g), kf1 = frag_rm2(k_hi, k_lo, t * 16 + qi, g + 4);
 #pragma unroll
       for (int s = 0; s < QB; ++s) {
@@ -127,21 +141,27 @@ __global__ __launch_bounds__(X3_THREADS) void attn_x3_fwd_kernel(const float* __
 #pragma unroll
       for (int c = 0; c < 4; ++c) oacc[s][c] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    const int u_end = min(NTP / 2, (n + 31) >> 5);
-#pragma unroll 1
-    for (int u = 0; u < u_end; ++u) {
+    const int u_full = n >> 5, u_end = min(NTP / 2, (n + 31) >> 5);   // at most one pair reaches past n
+    auto pair = [&](int u, auto masked_c) {
+      constexpr bool MASKED = decltype(masked_c)::value;
       f32x4 p[QB][2];
 #pragma unroll
       for (int tt = 0; tt < 2; ++tt) {
         const int t = 2 * u + tt;
         const P2 kf0 = frag_rm2(k_hi, k_lo, t * 16 + qi, g), kf1 = frag_rm2(k_hi, k_lo, t * 16 + qi, g + 4);
+        f32x4 a[QB];
+#pragma unroll
+        for (int s = 0; s < QB; ++s) a[s] = mfma3(kf0, qf[s][0], f32x4{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+        for (int s = 0; s < QB; ++s) a[s] = mfma3(kf1, qf[s][1], a[s]);
 #pragma unroll
         for (int s = 0; s < QB; ++s) {
-          f32x4 a = {0.f, 0.f, 0.f, 0.f};
-          a = mfma3(kf0, qf[s][0], a);
-          a = mfma3(kf1, qf[s][1], a);
+          const f32x4 e = a[s] * sl2 - m[s];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) p[s][tt][r] = (t * 16 + 4 * g + r) < n ? fast_exp2(fmaf(a[r], sl2, -m[s])) : 0.f;
+          for (int r = 0; r < 4; ++r) {
+            p[s][tt][r] = fast_exp2(e[r]);
+            if (MASKED) p[s][tt][r] = (t * 16 + 4 * g + r) < n ? p[s][tt][r] : 0.f;
+          }
           l[s] += (p[s][tt][0] + p[s][tt][1]) + (p[s][tt][2] + p[s][tt][3]);
         }
       }
@@ -154,7 +174,10 @@ __global__ __launch_bounds__(X3_THREADS) void attn_x3_fwd_kernel(const float* __
 #pragma unroll
         for (int s = 0; s < QB; ++s) oacc[s][c] = mfma3(vf, pf[s], oacc[s][c]);
       }
-    }
+    };
+#pragma unroll 1
+    for (int u = 0; u < u_full; ++u) pair(u, std::false_type{});
+    if (u_full < u_end) pair(u_full, std::true_type{});
 #pragma unroll
     for (int s = 0; s < QB; ++s) {
       float ls = l[s];
@@ -230,25 +253,34 @@ __global__ __launch_bounds__(X3_THREADS) void attn_x3_bwd_kernel(const float* __
 #pragma unroll
         for (int c = 0; c < 4; ++c) dq[s][c] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
-#pragma unroll 1
-      for (int u = 0; u < u_end; ++u) {
+      auto pair = [&](int u, auto masked_c) {
+        constexpr bool MASKED = decltype(masked_c)::value;
         f32x4 ds[QB][2];
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
           const int t = 2 * u + tt;
           const P2 kf0 = frag_rm2(a_hi, a_lo, t * 16 + qi, g), kf1 = frag_rm2(a_hi, a_lo, t * 16 + qi, g + 4);
           const P2 vf0 = frag_rm2(b_hi, b_lo, t * 16 + qi, g), vf1 = frag_rm2(b_hi, b_lo, t * 16 + qi, g + 4);
+          f32x4 sa[QB], dp[QB];
 #pragma unroll
           for (int s = 0; s < QB; ++s) {
-            f32x4 sa = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-            sa = mfma3(kf0, qf[s][0], sa);
-            sa = mfma3(kf1, qf[s][1], sa);
-            dp = mfma3(vf0, dof[s][0], dp);
-            dp = mfma3(vf1, dof[s][1], dp);
+            sa[s] = mfma3(kf0, qf[s][0], f32x4{0.f, 0.f, 0.f, 0.f});
+            dp[s] = mfma3(vf0, dof[s][0], f32x4{0.f, 0.f, 0.f, 0.f});
+          }
+#pragma unroll
+          for (int s = 0; s < QB; ++s) {
+            sa[s] = mfma3(kf1, qf[s][1], sa[s]);
+            dp[s] = mfma3(vf1, dof[s][1], dp[s]);
+          }
+#pragma unroll
+          for (int s = 0; s < QB; ++s) {
+            const f32x4 e = sa[s] * sl2 - l2[s];
+            const f32x4 w = dp[s] * scale + nds[s];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              const float p = (t * 16 + 4 * g + r) < n ? fast_exp2(fmaf(sa[r], sl2, -l2[s])) : 0.f;
-              ds[s][tt][r] = p * fmaf(dp[r], scale, nds[s]);
+              float p = fast_exp2(e[r]);
+              if (MASKED) p = (t * 16 + 4 * g + r) < n ? p : 0.f;
+              ds[s][tt][r] = p * w[r];
             }
           }
         }
@@ -261,7 +293,11 @@ __global__ __launch_bounds__(X3_THREADS) void attn_x3_bwd_kernel(const float* __
 #pragma unroll
           for (int s = 0; s < QB; ++s) dq[s][c] = mfma3(kt, dsf[s], dq[s][c]);
         }
-      }
+      };
+      const int u_full = n >> 5;
+#pragma unroll 1
+      for (int u = 0; u < u_full; ++u) pair(u, std::false_type{});
+      if (u_full < u_end) pair(u_full, std::true_type{});
 #pragma unroll
       for (int s = 0; s < QB; ++s)
         if (q[s] < n) {
