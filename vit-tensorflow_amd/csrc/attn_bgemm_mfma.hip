@@ -60,7 +60,12 @@ __device__ __forceinline__ void stage_canonical(const T* src, int64_t sr, int64_
 #pragma unroll
       for (int i = 0; i < 8; ++i) dst[(r0 + i) * pitch + c] = (bf16_t)v[i];
     }
-  } else {                                                                 // anything else: element by element
+  } else if (sr < sc) {                                                    // unaligned rows (DeepViT's 65-float score rows) with r the fast index in memory:
+    for (int e = tid; e < Rp * Cp; e += nthr) {                            // lanes along r (coalesced 4-B loads; DeepViT cfg4 -0.06 ms per step, r4u)
+      const int c = e / Rp, r = e - c * Rp;
+      dst[r * pitch + c] = (r < R && c < Cn) ? (bf16_t)(float)src[r * sr + c * sc] : (bf16_t)0.f;
+    }
+  } else {                                                                 // anything else: element by element, lanes along c
     for (int e = tid; e < Rp * Cp; e += nthr) {
       const int r = e / Cp, c = e - r * Cp;
       dst[r * pitch + c] = (r < R && c < Cn) ? (bf16_t)(float)src[r * sr + c * sc] : (bf16_t)0.f;
