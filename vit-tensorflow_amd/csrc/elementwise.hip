@@ -380,10 +380,8 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, in
 // ------------------------------------------------------------------ operand preparation
 // fp32 Keras kernel W[in][out] -> bf16 copies: wn[in][ldwn] (dgrad operand) and wt[out][ldwt] (forward operand)
 // 64 x 64 tiles: 16-B loads, 8-B (4 x bf16) stores in both orientations (128-B row segments per 16 lanes); edge tiles element-wise.
-__global__ __launch_bounds__(256) void convert_weight_kernel(const float* __restrict__ w, int in, int out, bf16_t* __restrict__ wn,
-                                                             int64_t ldwn, bf16_t* __restrict__ wt, int64_t ldwt) {
-  __shared__ float tile[64][65];
-  const int i0 = blockIdx.y * 64, o0 = blockIdx.x * 64;
+__device__ __forceinline__ void convert_weight_tile(const float* __restrict__ w, int in, int out, bf16_t* __restrict__ wn, int64_t ldwn,
+                                                    bf16_t* __restrict__ wt, int64_t ldwt, int i0, int o0, float (*tile)[65]) {
   const int c4 = (threadIdx.x & 15) * 4, r16 = threadIdx.x >> 4;   // 16 lanes x 4 columns, 16 row slots
   const bool full = i0 + 64 <= in && o0 + 64 <= out && (out & 3) == 0 && (ldwn & 3) == 0 && (ldwt & 3) == 0;
   if (full) {
@@ -417,6 +415,25 @@ __global__ __launch_bounds__(256) void convert_weight_kernel(const float* __rest
     const int o = e >> 6, i = e & 63;
     if (i0 + i < in && o0 + o < out) wt[(int64_t)(o0 + o) * ldwt + i0 + i] = (bf16_t)tile[i][o];
   }
+}
+__global__ __launch_bounds__(256) void convert_weight_kernel(const float* __restrict__ w, int in, int out, bf16_t* __restrict__ wn,
+                                                             int64_t ldwn, bf16_t* __restrict__ wt, int64_t ldwt) {
+  __shared__ float tile[64][65];
+  convert_weight_tile(w, in, out, wn, ldwn, wt, ldwt, blockIdx.y * 64, blockIdx.x * 64, tile);
+}
+// Every Dense kernel of a model in ONE launch (the per-step refresh of the bf16 operand copies): 49 launches of 144-576 blocks each left most
+// of the chip idle (0.24 ms per ViT-B/16 step at 2.9 TB/s).  blockIdx.x -> (matrix, tile) through the block-offset column of the table.
+__global__ __launch_bounds__(256) void convert_weights_batched_kernel(const ConvertDesc* __restrict__ d, int n) {
+  __shared__ float tile[64][65];
+  __shared__ int sel;
+  for (int t = threadIdx.x; t < n; t += 256) {                     // one table entry per thread: a single load latency, not a dependent scan
+    const int b0 = d[t].block0, b1 = t + 1 < n ? d[t + 1].block0 : 0x7fffffff;
+    if ((int)blockIdx.x >= b0 && (int)blockIdx.x < b1) sel = t;
+  }
+  __syncthreads();
+  const ConvertDesc c = d[sel];
+  const int local = (int)blockIdx.x - c.block0, by = local / c.tiles_x, bx = local - by * c.tiles_x;
+  convert_weight_tile(c.w, c.in, c.out, c.wn, c.ldwn, c.wt, c.ldwt, by * 64, bx * 64, tile);
 }
 
 // out[c][r] = in[r][c]  (bf16, 64x64 tiles through LDS); covers rows x cols exactly (both multiples of 64 by construction)
@@ -816,6 +833,9 @@ void launch_colsum(const void* x, int is_bf16, int64_t ld, int rows, int cols, f
 void launch_convert_weight(const float* w, int in, int out, bf16_t* wn, int64_t ldwn, bf16_t* wt, int64_t ldwt, hipStream_t s) {
   dim3 grid((unsigned)ceil_div(out, 64), (unsigned)ceil_div(in, 64)), block(256);
   hipLaunchKernelGGL(convert_weight_kernel, grid, block, 0, s, w, in, out, wn, ldwn, wt, ldwt);
+}
+void launch_convert_weights_batched(const ConvertDesc* descs_dev, int n, int total_blocks, hipStream_t s) {
+  if (n > 0 && total_blocks > 0) hipLaunchKernelGGL(convert_weights_batched_kernel, dim3((unsigned)total_blocks), dim3(256), 0, s, descs_dev, n);
 }
 void launch_transpose_bf16(const bf16_t* in, int64_t ldi, int rows, int cols, bf16_t* out, int64_t ldo, hipStream_t s) {
   dim3 grid((unsigned)ceil_div(cols, 64), (unsigned)ceil_div(rows, 64)), block(256);

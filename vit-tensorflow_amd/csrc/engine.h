@@ -112,6 +112,7 @@ struct vitx_engine {
   bool side_dirty = false;           // work was queued on the side stream since the last join
   SideRing rg_dh, rg_glp, rg_dqkv, rg_dbr;
   std::vector<hipEvent_t> side_events; size_t side_ev_next = 0;
+  void* conv_descs = nullptr; int conv_n = 0, conv_blocks = 0;   // device table of the batched bf16 operand refresh (built on first use)
   std::vector<PendingReady> side_ready;   // gradient-ready reports waiting for the side stream's share of their range
   float* params = nullptr;
   float* grads = nullptr;

@@ -211,16 +211,43 @@ static inline const float* dense_b(const vitx_engine* e, const Dense& w) { retur
 static inline float* dense_gw(const vitx_engine* e, const Dense& w) { return w.ext_gw ? w.ext_gw : e->grads + w.w; }
 static inline float* dense_gb(const vitx_engine* e, const Dense& w) { return w.ext_gb ? w.ext_gb : (w.b >= 0 ? e->grads + w.b : nullptr); }
 
+// device table of the batched operand refresh: a function of the model only (arena offsets and operand buffers never move); built once, at
+// creation (not inside a step, which may be under stream capture)
+static void build_convert_table(vitx_engine* e) {
+  if (!e->bf16 || e->conv_descs) return;
+  std::vector<ConvertDesc> t;
+  int blocks = 0;
+  auto add = [&](const Dense& w) {
+    if (w.w < 0 || !w.wt) return;
+    const int tx = (int)ceil_div(w.out, 64), ty = (int)ceil_div(w.in, 64);
+    t.push_back({e->params + w.w, w.wn, w.wt, w.out_k, w.in_k, w.in, w.out, tx, blocks});
+    blocks += tx * ty;
+  };
+  add(e->patch);
+  add(e->head);
+  for (auto& st : e->stages)
+    for (auto& b : st.bp) { add(b.qkv); add(b.q); add(b.kv); add(b.out); add(b.fc1); add(b.fc2); }
+  if (!t.empty() && hipMalloc(&e->conv_descs, t.size() * sizeof(ConvertDesc)) == hipSuccess) {
+    e->allocs.push_back(e->conv_descs);
+    (void)hipMemcpy(e->conv_descs, t.data(), t.size() * sizeof(ConvertDesc), hipMemcpyHostToDevice);
+    e->conv_n = (int)t.size();
+    e->conv_blocks = blocks;
+  }
+}
+
 void engine_refresh_weights(vitx_engine* e) {
   if (!e->bf16) { e->params_dirty = false; return; }
   Prof pr(e, "convert_weights", 0, (double)e->n_params * 8);
-  auto conv = [&](const Dense& w) {
-    if (w.w >= 0 && w.wt) launch_convert_weight(e->params + w.w, w.in, w.out, w.wn, w.out_k, w.wt, w.in_k, e->stream);
-  };
-  conv(e->patch);
-  conv(e->head);
-  for (auto& st : e->stages)
-    for (auto& b : st.bp) { conv(b.qkv); conv(b.q); conv(b.kv); conv(b.out); conv(b.fc1); conv(b.fc2); }
+  if (e->conv_descs) launch_convert_weights_batched((const ConvertDesc*)e->conv_descs, e->conv_n, e->conv_blocks, e->stream);
+  else {   // no table (allocation failed): one launch per matrix
+    auto conv = [&](const Dense& w) {
+      if (w.w >= 0 && w.wt) launch_convert_weight(e->params + w.w, w.in, w.out, w.wn, w.out_k, w.wt, w.in_k, e->stream);
+    };
+    conv(e->patch);
+    conv(e->head);
+    for (auto& st : e->stages)
+      for (auto& b : st.bp) { conv(b.qkv); conv(b.q); conv(b.kv); conv(b.out); conv(b.fc1); conv(b.fc2); }
+  }
   e->params_dirty = false;
 }
 
@@ -1372,6 +1399,7 @@ int engine_create(const vitx_config& cfg, vitx_engine** out, std::string& err) {
     engine_destroy(e);          // the stream and the object allocated before it
     return rc;
   }
+  build_convert_table(e);
   *out = e;
   return VITX_OK;
 }

@@ -106,6 +106,9 @@ void launch_reduce_partials(const float* partial, int nparts, int64_t stride, in
 void launch_reduce_partials3(const float* partial, int nparts, int64_t stride, int64_t seg, int nseg, float* out0, float* out1, float* out2,
                              float* ws2, float alpha, hipStream_t s);
 void launch_convert_weight(const float* w, int in, int out, bf16_t* wn, int64_t ldwn, bf16_t* wt, int64_t ldwt, hipStream_t s);
+// one table entry per Dense kernel; block0 = first block of this matrix in the batched launch (tiles of 64 x 64, tiles_x = ceil(out / 64))
+struct ConvertDesc { const float* w; bf16_t* wn; bf16_t* wt; int64_t ldwn, ldwt; int in, out, tiles_x, block0; };
+void launch_convert_weights_batched(const ConvertDesc* descs_dev, int n, int total_blocks, hipStream_t s);
 void launch_transpose_bf16(const bf16_t* in, int64_t ldi, int rows, int cols, bf16_t* out, int64_t ldo, hipStream_t s);
 void launch_convert(const float* in, int64_t ldi, void* out, int out_bf16, int64_t ldo, int rows, int cols, int64_t out_cols_zero_to,
                     hipStream_t s);
