@@ -759,9 +759,13 @@ void launch_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, const
 
 int64_t layernorm_bwd_ws_elems(int d) { return (int64_t)(LNB_BLOCKS + 32) * 3 * d; }
 
+// The parameter-gradient sums (dgamma, dbeta, the optional column sums of g_in) are a two-level reduction of per-block partials that nothing in
+// the backward chain consumes: with `deferred` != nullptr the main kernel(s) only are launched and *deferred receives the number of partial rows;
+// the caller then runs launch_layernorm_bwd_reduce on a stream of its choice (the engine: the side stream, beside the weight gradients).
 void launch_layernorm_bwd(const void* dy, int dy_bf16, int64_t lddy, const float* x, int64_t ldx, const float* mean, const float* rstd,
                           const float* gamma, const float* g_in, int64_t ldgi, float* g_out, int64_t ldgo, void* g_lp, int64_t ldglp,
-                          float* partial_ws, float* dgamma, float* dbeta, float* gsum, int rows, int d, hipStream_t s) {
+                          float* partial_ws, float* dgamma, float* dbeta, float* gsum, int rows, int d, hipStream_t s, int* deferred) {
+  if (deferred) *deferred = 0;
   if (rows == 0) return;
   const int want_gsum = (gsum != nullptr && g_in != nullptr) ? 1 : 0;
   if (!ln_vec_ok(d, {lddy, ldx, g_in ? ldgi : 0, ldgo, g_lp ? ldglp : 0}, {dy, x, gamma, g_in, g_out, g_lp})) {
@@ -778,7 +782,8 @@ void launch_layernorm_bwd(const void* dy, int dy_bf16, int64_t lddy, const float
                          (float*)g_lp, ldglp, rows, d);
     }
     // (the column kernel runs FIRST: g_out may alias g_in, which it reads)
-    launch_reduce_partials3(partial_ws, chunks, (int64_t)3 * d, d, want_gsum ? 3 : 2, dgamma, dbeta, gsum, partial_ws + (int64_t)LNB_BLOCKS * 3 * d, 1.0f, s);
+    if (deferred) *deferred = chunks;
+    else launch_layernorm_bwd_reduce(partial_ws, chunks, d, dgamma, dbeta, want_gsum ? gsum : nullptr, s);
     return;
   }
   const int nblk = (int)std::min<int64_t>(LNB_BLOCKS, ceil_div(rows, 8));
@@ -792,8 +797,12 @@ void launch_layernorm_bwd(const void* dy, int dy_bf16, int64_t lddy, const float
   VITX_VPL_DISPATCH(d, CALL);
 #undef CALL
   // partial layout [blk][3][d]: dgamma = sum_blk partial[blk][0], dbeta = sum_blk partial[blk][1]
-  launch_reduce_partials3(partial_ws, nblk, (int64_t)3 * d, d, want_gsum ? 3 : 2, dgamma, dbeta, gsum, partial_ws + (int64_t)LNB_BLOCKS * 3 * d,
-                          1.0f, s);
+  if (deferred) *deferred = nblk;
+  else launch_layernorm_bwd_reduce(partial_ws, nblk, d, dgamma, dbeta, want_gsum ? gsum : nullptr, s);
+}
+void launch_layernorm_bwd_reduce(float* partial_ws, int nparts, int d, float* dgamma, float* dbeta, float* gsum, hipStream_t s) {
+  if (nparts <= 0) return;
+  launch_reduce_partials3(partial_ws, nparts, (int64_t)3 * d, d, gsum ? 3 : 2, dgamma, dbeta, gsum, partial_ws + (int64_t)LNB_BLOCKS * 3 * d, 1.0f, s);
 }
 
 // level-2 scratch for the two-level path lives behind the level-1 partials (callers size their workspace with *_ws_elems)

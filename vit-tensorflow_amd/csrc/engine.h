@@ -78,10 +78,11 @@ struct ProfEvent {
 // Weight-gradient side stream (engine.hip, "side stream" section): a buffer the dgrad chain rewrites every block while a weight-gradient
 // GEMM queued on the side stream may still be reading it.  The chain writes into the next slot of a small ring instead; a slot is reused
 // only after the side-stream reader recorded on it has finished (an event wait on the main stream, normally already satisfied).
+constexpr int SIDE_RING_MAX = 8;
 struct SideRing {
-  void* slot[3] = {nullptr, nullptr, nullptr};
-  hipEvent_t rd[3] = {nullptr, nullptr, nullptr};
-  bool pend[3] = {false, false, false};
+  void* slot[SIDE_RING_MAX] = {};
+  hipEvent_t rd[SIDE_RING_MAX] = {};
+  bool pend[SIDE_RING_MAX] = {};
   int n = 0, cur = 0;
 };
 struct PendingReady { int64_t off, cnt; hipEvent_t ev; };
@@ -107,10 +108,13 @@ struct vitx_engine {
   hipStream_t own_stream = nullptr, stream = nullptr;
   // weight gradients (no consumer until the optimizer / the gradient exchange) run on `side`, forked from / joined into `stream` by events
   hipStream_t side = nullptr;
+  hipStream_t side2 = nullptr;   // the small reductions of the LayerNorm VJPs: they must not queue behind a block's weight-gradient GEMMs
   int side_mode = 1;                 // VITX_SIDE_STREAM=0: everything on one stream (A/B reference)
   bool side_live = false;            // inside a backward pass that uses the side stream
   bool side_dirty = false;           // work was queued on the side stream since the last join
-  SideRing rg_dh, rg_glp, rg_dqkv, rg_dbr;
+  SideRing rg_dh, rg_glp, rg_dqkv, rg_dbr, rg_lnp, rg_cs;
+  float* cs_part = nullptr;   // per-tile column sums of d hpre (fc1 bias gradient): same treatment
+  float* ln_part = nullptr;   // LayerNorm-VJP partial sums of the blocks, their own ring: the reduction runs on the side stream
   std::vector<hipEvent_t> side_events; size_t side_ev_next = 0;
   void* conv_descs = nullptr; int conv_n = 0, conv_blocks = 0;   // device table of the batched bf16 operand refresh (built on first use)
   std::vector<PendingReady> side_ready;   // gradient-ready reports waiting for the side stream's share of their range

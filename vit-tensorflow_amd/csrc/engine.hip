@@ -328,8 +328,8 @@ static void side_join(vitx_engine* e) {
     (void)hipStreamWaitEvent(e->stream, ev, 0);
     e->side_dirty = false;
   }
-  for (SideRing* r : {&e->rg_dh, &e->rg_glp, &e->rg_dqkv, &e->rg_dbr})
-    for (int i = 0; i < 3; ++i) r->pend[i] = false;
+  for (SideRing* r : {&e->rg_dh, &e->rg_glp, &e->rg_dqkv, &e->rg_dbr, &e->rg_lnp, &e->rg_cs})
+    for (int i = 0; i < SIDE_RING_MAX; ++i) r->pend[i] = false;
   side_flush_ready(e, 0);
 }
 // scope of a backward pass: decides whether this pass uses the side stream, joins on every way out
@@ -348,6 +348,43 @@ struct SideScope {
     e->side_live = false;
   }
 };
+
+// the small-reduction stream: behind everything queued on the main stream so far ...
+static void side2_begin(vitx_engine* e) {
+  hipEvent_t ev = side_event(e);
+  (void)hipEventRecord(ev, e->stream);
+  (void)hipStreamWaitEvent(e->side2, ev, 0);
+}
+// ... and, once its launches are queued: the ring slot they read is released by an event on that stream, and the weight-gradient stream is
+// ordered behind them, so that the join and the gradient-ready reports (events on that stream) cover them too
+static void side2_end(vitx_engine* e, SideRing& r) {
+  (void)hipEventRecord(r.rd[r.cur], e->side2);
+  r.pend[r.cur] = true;
+  (void)hipStreamWaitEvent(e->side, r.rd[r.cur], 0);
+  e->side_dirty = true;
+}
+static inline int side2_min_rows() {
+  static const int v = [] { const char* k = getenv("VITX_LN_REDUCE_SIDE_ROWS"); return k ? atoi(k) : 8192; }();
+  return v;
+}
+// LayerNorm VJP of a block: with the side stream live, the two small launches that reduce its per-block partials into dgamma / dbeta (/ a bias
+// gradient) leave the input-gradient chain -- 5 us each, 50 per ViT-B/16 step, nothing downstream reads their results.  They go to a stream of
+// their own: on the weight-gradient stream they queued behind a block's GEMMs and piled up in the tail after the chain had finished (CaiT cfg5
+// +0.2 .. 0.6 ms per step, r4x); here they run as soon as the VJP kernel is done, in whatever gaps the chip has.  The weight-gradient stream is
+// then ordered behind them, so that the join and the gradient-ready reports (events on that stream) cover them too.
+static void block_layernorm_bwd(vitx_engine* e, const void* dy, int T, int d, const float* x, const float* mean, const float* rstd, const float* gamma,
+                                const float* g_in, float* g_out, void* g_lp, float* dgamma, float* dbeta, float* gsum, int rows) {
+  if (!e->side_live || !e->side2 || e->rg_lnp.n == 0 || rows < side2_min_rows()) {   // short VJPs (CaiT's class-attention rows): three stream operations cost more than they hide
+    launch_layernorm_bwd(dy, T, d, x, d, mean, rstd, gamma, g_in, d, g_out, d, g_lp, d, e->red_ws, dgamma, dbeta, gsum, rows, d, e->stream);
+    return;
+  }
+  side_rotate(e, e->rg_lnp, e->ln_part);
+  int parts = 0;
+  launch_layernorm_bwd(dy, T, d, x, d, mean, rstd, gamma, g_in, d, g_out, d, g_lp, d, e->ln_part, dgamma, dbeta, gsum, rows, d, e->stream, &parts);
+  side2_begin(e);
+  launch_layernorm_bwd_reduce(e->ln_part, parts, d, dgamma, dbeta, (gsum && g_in) ? gsum : nullptr, e->side2);
+  side2_end(e, e->rg_lnp);
+}
 
 // ------------------------------------------------------------------------------------------------
 // Dense layer = x @ kernel[in,out] + bias (Keras nn.Dense; vit.py:39,42,59,63,143,156) and its VJPs
@@ -919,14 +956,21 @@ static int block_backward(vitx_engine* e, Stage& st, int si, int l, int b, int n
   {
     side_rotate(e, e->rg_dh, e->d_h);
     EpiParams ep; ep.out = e->d_h; ep.ldo = m; ep.aux = ba.hpre; ep.ldaux = m;
+    // with the side stream live the per-tile sums go to a ring slot of their own and their reduction to the small-reduction stream (as the
+    // LayerNorm VJP's: block_layernorm_bwd)
+    const bool cs_side = fc1_bias_fused && e->side_live && e->side2 && e->rg_cs.n && rows >= side2_min_rows();
+    if (cs_side) side_rotate(e, e->rg_cs, e->cs_part);
+    float* cs = cs_side ? e->cs_part : e->red_ws;
     if (fc1_bias_fused) {
-      HIPCHK(hipMemsetAsync(e->red_ws, 0, (size_t)cs_rows * m * 4, e->stream));   // rows the chosen tile shape does not reach stay 0
-      ep.colsum = e->red_ws; ep.ldcs = m;
+      HIPCHK(hipMemsetAsync(cs, 0, (size_t)cs_rows * m * 4, e->stream));   // rows the chosen tile shape does not reach stay 0
+      ep.colsum = cs; ep.ldcs = m;
     }
     dense_dgrad(e, dbranch, d, rows, bp.fc2, EPI_GELU_BWD, ep);             // d hpre = (d act) * gelu'(hpre)
     if (fc1_bias_fused) {
       Prof pr(e, "reduce_partials", 0, (double)(cs_rows + 1) * m * 4);
-      launch_reduce_partials3(e->red_ws, cs_rows, m, m, 1, e->grads + bp.fc1.b, nullptr, nullptr, e->red_ws + (int64_t)cs_rows * m, 1.0f, e->stream);
+      if (cs_side) side2_begin(e);
+      launch_reduce_partials3(cs, cs_rows, m, m, 1, e->grads + bp.fc1.b, nullptr, nullptr, cs + (int64_t)cs_rows * m, 1.0f, cs_side ? e->side2 : e->stream);
+      if (cs_side) side2_end(e, e->rg_cs);
     }
     if (drop > 0.f) {
       Prof pr(e, "dropout", 0, 0);
@@ -955,8 +999,8 @@ static int block_backward(vitx_engine* e, Stage& st, int si, int l, int b, int n
   {
     Prof pr(e, "layernorm_bwd", 0, lnb);
     void* ln_glp = next_glp();
-    launch_layernorm_bwd(e->d_y, T, d, ba.ln2_src ? ba.ln2_src : ba.x_mid, d, ba.mean2, ba.rstd2, e->params + bp.ln2_g, ln_gin, d, ln_gout, d, ln_glp, d,
-                         e->red_ws, e->grads + bp.ln2_g, e->grads + bp.ln2_b, fc2_bias_in_ln ? e->grads + bp.fc2.b : nullptr, rows, d, e->stream);
+    block_layernorm_bwd(e, e->d_y, T, d, ba.ln2_src ? ba.ln2_src : ba.x_mid, ba.mean2, ba.rstd2, e->params + bp.ln2_g, ln_gin, ln_gout, ln_glp,
+                        e->grads + bp.ln2_g, e->grads + bp.ln2_b, fc2_bias_in_ln ? e->grads + bp.fc2.b : nullptr, rows);
   }
   }   // !skip_mlp
   if (ba.skip_attn) {
@@ -1055,8 +1099,8 @@ static int block_backward(vitx_engine* e, Stage& st, int si, int l, int b, int n
   {
     Prof pr(e, "layernorm_bwd", 0, lnb);
     void* ln_glp = next_glp();
-    launch_layernorm_bwd(e->d_y, T, d, ba.ln1_src ? ba.ln1_src : ba.x_in, d, ba.mean1, ba.rstd1, e->params + bp.ln1_g, ln_gin, d, ln_gout, d, ln_glp, d,
-                         e->red_ws, e->grads + bp.ln1_g, e->grads + bp.ln1_b, out_bias_in_ln ? e->grads + bp.out.b : nullptr, rows, d, e->stream);
+    block_layernorm_bwd(e, e->d_y, T, d, ba.ln1_src ? ba.ln1_src : ba.x_in, ba.mean1, ba.rstd1, e->params + bp.ln1_g, ln_gin, ln_gout, ln_glp,
+                        e->grads + bp.ln1_g, e->grads + bp.ln1_b, out_bias_in_ln ? e->grads + bp.out.b : nullptr, rows);
   }
   report_ready(e, bp.p_begin, bp.p_end - bp.p_begin);
   return VITX_OK;
@@ -1128,6 +1172,7 @@ static int engine_create_body(vitx_engine* e, const vitx_config& cfg, std::strin
     int least = 0, greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
     HIPCHK(hipStreamCreateWithPriority(&e->side, hipStreamNonBlocking, e->side_mode == 2 ? greatest : least));
+    HIPCHK(hipStreamCreateWithPriority(&e->side2, hipStreamNonBlocking, greatest));
   }
 
   const int d = c.dim, inner = e->inner, m = c.mlp_dim, esz = e->esz;
@@ -1348,6 +1393,11 @@ static int engine_create_body(vitx_engine* e, const vitx_config& cfg, std::strin
     if ((rc = ring(e->rg_glp, e->g_lp, (size_t)rmax * d * esz, 3)) != VITX_OK) return rc;
     if ((rc = ring(e->rg_dqkv, e->d_qkv, (size_t)(rmax + 256) * 3 * inner * esz + (size_t)crow_max * 2 * inner * esz, 2)) != VITX_OK) return rc;
     if ((rc = ring(e->rg_dbr, e->d_br, (size_t)rmax * d * esz, 3)) != VITX_OK) return rc;
+    DALLOC(e->ln_part, (size_t)layernorm_bwd_ws_elems(d) * 4, false);
+    if ((rc = ring(e->rg_lnp, e->ln_part, (size_t)layernorm_bwd_ws_elems(d) * 4, 4)) != VITX_OK) return rc;
+    const size_t cs_bytes = (size_t)(ceil_div(rmax, 128) + 64) * m * 4;   // per-tile column sums + the second reduction level behind them
+    DALLOC(e->cs_part, cs_bytes, false);
+    if ((rc = ring(e->rg_cs, e->cs_part, cs_bytes, 4)) != VITX_OK) return rc;
   }
   DALLOC(e->dsum, (size_t)B * c.heads * e->ntok_cap * 4 + 16, false);
   DALLOC(e->zero_page, 256, false);
@@ -1383,11 +1433,13 @@ void engine_destroy(vitx_engine* e) {
   if (!e) return;
   (void)hipStreamSynchronize(e->stream);
   if (e->side) (void)hipStreamSynchronize(e->side);
+  if (e->side2) (void)hipStreamSynchronize(e->side2);
   for (void* p : e->allocs) (void)hipFree(p);
-  for (SideRing* r : {&e->rg_dh, &e->rg_glp, &e->rg_dqkv, &e->rg_dbr})
-    for (int i = 0; i < 3; ++i) if (r->rd[i]) (void)hipEventDestroy(r->rd[i]);
+  for (SideRing* r : {&e->rg_dh, &e->rg_glp, &e->rg_dqkv, &e->rg_dbr, &e->rg_lnp, &e->rg_cs})
+    for (int i = 0; i < SIDE_RING_MAX; ++i) if (r->rd[i]) (void)hipEventDestroy(r->rd[i]);
   for (auto ev : e->side_events) (void)hipEventDestroy(ev);
   if (e->side) (void)hipStreamDestroy(e->side);
+  if (e->side2) (void)hipStreamDestroy(e->side2);
   if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
   delete e;
 }

@@ -98,7 +98,8 @@ void launch_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, const
 void launch_layernorm_bwd(const void* dy, int dy_bf16, int64_t lddy, const float* x, int64_t ldx, const float* mean,
                           const float* rstd, const float* gamma, const float* g_in, int64_t ldgi, float* g_out, int64_t ldgo,
                           void* g_lp, int64_t ldglp, float* partial_ws, float* dgamma, float* dbeta, float* gsum, int rows, int d,
-                          hipStream_t s);   // gsum (optional): column sums of g_in
+                          hipStream_t s, int* deferred = nullptr);   // gsum (optional): column sums of g_in; deferred: see the definition
+void launch_layernorm_bwd_reduce(float* partial_ws, int nparts, int d, float* dgamma, float* dbeta, float* gsum, hipStream_t s);
 int64_t layernorm_bwd_ws_elems(int d);
 void launch_colsum(const void* x, int is_bf16, int64_t ld, int rows, int cols, float* partial_ws, float* out, hipStream_t s);
 int64_t colsum_ws_elems(int cols);
