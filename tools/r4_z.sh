@@ -1,0 +1,6 @@
+#!/bin/bash
+# round 4, call Z: colsum slot zeroing off the chain, embedding backward reordered -- full GPU tier, same-box A/B against the previous commit
+OUT=gpurun_out/r4z; mkdir -p $OUT; export TMPDIR=/tmp
+cd $GRAFT_REPO_ROOT 2>/dev/null || cd /root/repo
+timeout 1800 python -m pytest tests -m gpu -q --timeout 900 -p no:cacheprovider > $OUT/pytest_all.log 2>&1; grep -E "passed|failed" $OUT/pytest_all.log | tail -2
+timeout 900 python tools/ab_bench.py vit-tensorflow_amd/lib/libvitx_head.so vit-tensorflow_amd/lib/libvitx.so 3 > $OUT/ab.log 2>&1; grep "round" $OUT/ab.log; grep -A3 "\"step\"" $OUT/ab.log

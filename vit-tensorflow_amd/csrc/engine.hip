@@ -970,7 +970,7 @@ static int block_backward(vitx_engine* e, Stage& st, int si, int l, int b, int n
       Prof pr(e, "reduce_partials", 0, (double)(cs_rows + 1) * m * 4);
       if (cs_side) side2_begin(e);
       launch_reduce_partials3(cs, cs_rows, m, m, 1, e->grads + bp.fc1.b, nullptr, nullptr, cs + (int64_t)cs_rows * m, 1.0f, cs_side ? e->side2 : e->stream);
-      if (cs_side) side2_end(e, e->rg_cs);
+      if (cs_side) side2_end(e, e->rg_cs);   // (zeroing the slot here instead of on the chain: measured neutral, r4z)
     }
     if (drop > 0.f) {
       Prof pr(e, "dropout", 0, 0);
@@ -1815,14 +1815,18 @@ int engine_embed_backward(vitx_engine* e, const float* dtokens_dev, float* dimg_
   if (dtokens_dev != e->g) HIPCHK(hipMemcpyAsync(e->g, dtokens_dev, (size_t)b * ntok * d * 4, hipMemcpyDeviceToDevice, e->stream));
   {
     Prof pr(e, "embed_bwd", 0, (double)b * ntok * d * 4);
+    launch_extract_rows(e->g, b, ntok, 1, np, d, e->d_y, T, d, e->stream);                    // dE = g[:, 1:, :]
+  }
+  // the projection's weight gradient first: on the side stream it runs beside the batch sums below (which only read g) instead of behind them
+  dense_wgrad(e, e->patches, e->pd_k, e->d_y, d, b * np, e->patch);
+  {
+    Prof pr(e, "embed_bwd", 0, (double)b * ntok * d * 4);
     if (ntok < e->ntok_max)   // position rows the image did not reach (efficient.py:45 slices the table)
       launch_fill_zero(e->grads + e->pos + (int64_t)ntok * d, (int64_t)(e->ntok_max - ntok) * d * 4, e->stream);
     launch_batch_reduce(e->g, b, ntok, d, 0, ntok, e->grads + e->pos, e->stream);             // dpos[j] = sum_b g[b,j]
     launch_batch_reduce(e->g, b, ntok, d, 0, 1, e->grads + e->cls, e->stream);                // dcls = sum_b g[b,0]
     launch_sum_rows(e->grads + e->pos + d, np, d, e->grads + e->patch.b, e->stream);          // db = sum over patch rows
-    launch_extract_rows(e->g, b, ntok, 1, np, d, e->d_y, T, d, e->stream);                    // dE = g[:, 1:, :]
   }
-  dense_wgrad(e, e->patches, e->pd_k, e->d_y, d, b * np, e->patch);
   if (dimg_dev) {
     EpiParams ep; ep.out = e->tmp_f32; ep.ldo = e->pd;
     dense_dgrad(e, e->d_y, d, b * np, e->patch, EPI_STORE_F32, ep);
@@ -2035,16 +2039,20 @@ int engine_backward(vitx_engine* e, const float* dlogits_dev, float* dimg_dev, s
   }
 
   // ---- embedding: x0 = [cls | patches @ W + b] + pos   (vit.py:160-165; cait.py:181-184)
+  const int tok_off = no_cls ? 0 : 1;
+  {
+    Prof pr(e, "embed_bwd", 0, 0);
+    launch_extract_rows(e->g, b, ntok, tok_off, np, d, e->d_y, T, d, e->stream);        // dE = g[:, tok_off:, :]
+  }
+  // the projection's weight gradient first: on the side stream it runs beside the batch sums below (which only read g) instead of behind them
+  dense_wgrad(e, e->patches, e->pd_k, e->d_y, d, b * np, e->patch);
   {
     Prof pr(e, "embed_bwd", 0, (double)b * ntok * d * 4);
     launch_batch_reduce(e->g, b, ntok, d, 0, ntok - extra, e->grads + e->pos, e->stream);      // dpos[j] = sum_b g[b,j]
     if (extra && d_token_out_dev) launch_batch_reduce(e->g, b, ntok, d, ntok - 1, 1, d_token_out_dev, e->stream);   // d(distill token) = sum_b g[b,-1]
-    const int tok_off = no_cls ? 0 : 1;
     if (!no_cls) launch_batch_reduce(e->g, b, ntok, d, 0, 1, e->grads + e->cls, e->stream);   // dcls = sum_b g[b,0]
     launch_sum_rows(e->grads + e->pos + (int64_t)tok_off * d, np, d, e->grads + e->patch.b, e->stream);   // db = sum over patch rows
-    launch_extract_rows(e->g, b, ntok, tok_off, np, d, e->d_y, T, d, e->stream);        // dE = g[:, tok_off:, :]
   }
-  dense_wgrad(e, e->patches, e->pd_k, e->d_y, d, b * np, e->patch);
   if (dimg_dev) {
     EpiParams ep; ep.out = e->tmp_f32; ep.ldo = e->pd;
     dense_dgrad(e, e->d_y, d, b * np, e->patch, EPI_STORE_F32, ep);
