@@ -282,13 +282,26 @@ static hipEvent_t side_event(vitx_engine* e) {
   return ev;
 }
 // stream a weight gradient is launched on; forks the side stream behind everything queued on the main stream so far
-static hipStream_t side_fork(vitx_engine* e) {
+// (`pre`: an event recorded earlier on the main stream, at the point the operands of this weight gradient were complete -- side_prefork)
+static hipStream_t side_fork(vitx_engine* e, hipEvent_t pre = nullptr) {
   if (!e->side_live) return e->stream;
-  hipEvent_t ev = side_event(e);
-  (void)hipEventRecord(ev, e->stream);
+  hipEvent_t ev = pre;
+  if (!ev) {
+    ev = side_event(e);
+    (void)hipEventRecord(ev, e->stream);
+  }
   (void)hipStreamWaitEvent(e->side, ev, 0);
   e->side_dirty = true;
   return e->side;
+}
+// The engine queues a weight gradient BEHIND the input-gradient GEMMs that share its operands (they want the operand while the memory-side cache
+// still holds it); forked at its own place in the queue it would also wait for those GEMMs.  The fork point is therefore recorded where the
+// operands are complete, and handed to dense_wgrad later.  nullptr when the side stream is not in use.
+static hipEvent_t side_prefork(vitx_engine* e) {
+  if (!e->side_live) return nullptr;
+  hipEvent_t ev = side_event(e);
+  (void)hipEventRecord(ev, e->stream);
+  return ev;
 }
 // the current slot of `r` is being read by work just queued on the side stream
 static void side_note_read(vitx_engine* e, SideRing& r) {
@@ -454,12 +467,12 @@ static void dense_dgrad(vitx_engine* e, const void* dY, int64_t ldy, int rows, c
 }
 
 // dW[in,out] = X^T[in,rows] @ dY[rows,out]   (reduction over every token row of the batch)
-static void dense_wgrad(vitx_engine* e, const void* X, int64_t ldx, const void* dY, int64_t ldy, int rows, const Dense& w) {
+static void dense_wgrad(vitx_engine* e, const void* X, int64_t ldx, const void* dY, int64_t ldy, int rows, const Dense& w, hipEvent_t pre = nullptr) {
   float* dW = dense_gw(e, w);
   const double flops = 2.0 * rows * (double)w.out * w.in;
   const double bytes = (double)rows * w.in * e->esz + (double)rows * w.out * e->esz + (double)w.in * w.out * 4;
   if (e->bf16 && !e->force_generic_gemm) {
-    const hipStream_t ws = side_fork(e);        // the side stream inside a backward pass that uses it, else the main stream
+    const hipStream_t ws = side_fork(e, pre);   // the side stream inside a backward pass that uses it, else the main stream
     const int kext = (int)round_up(rows, 64);   // rows >= `rows` of both operands are zero (row-padding invariant)
     Bf16GemmArgs g;
     g.M = w.in; g.N = w.out; g.K = kext; g.kernel = e->gemm_kernel;
@@ -953,6 +966,8 @@ static int block_backward(vitx_engine* e, Stage& st, int si, int l, int b, int n
   // 310 MB output) whenever that GEMM runs an LDS-staged bf16 kernel and no dropout mask is applied to d hpre afterwards
   const bool fc1_bias_fused = e->bf16 && !e->force_generic_gemm && !(e->gemm_kernel & 256) && drop == 0.f && bp.fc1.b >= 0;
   const int cs_rows = (int)ceil_div(rows, 128);   // >= the M-tile count of every variant (128 / 256 / 320 rows per tile)
+  const hipEvent_t fork_fc2 = side_prefork(e);    // act and the branch gradient are complete here: the fc2 weight gradient may start
+  hipEvent_t fork_fc1 = nullptr;
   {
     side_rotate(e, e->rg_dh, e->d_h);
     EpiParams ep; ep.out = e->d_h; ep.ldo = m; ep.aux = ba.hpre; ep.ldaux = m;
@@ -976,13 +991,14 @@ static int block_backward(vitx_engine* e, Stage& st, int si, int l, int b, int n
       Prof pr(e, "dropout", 0, 0);
       launch_dropout(e->d_h, T, (int64_t)rows * m, drop, seed, site0 + 2, e->stream);   // mask of the post-GELU dropout (commutes)
     }
+    fork_fc1 = side_prefork(e);                   // d hpre is complete: the fc1 weight gradient need not wait for the fc1 input gradient
   }
   // Order: the two consumers of d hpre (310 MB at ViT-B/16, just written) run right behind its producer; the fc2 weight gradient,
   // which reads other tensors (act, the branch gradient), follows them instead of sitting in between and pushing d hpre out of the
   // memory-side cache.  VITX_MLP_BWD_ORDER=0: fc2 weight gradient first (the order of round 1; same results either way).
   const bool fc2_bias_in_ln = dbranch != e->d_br && !grouped;   // db_fc2 = column sums of g: fused into the LayerNorm backward pass below
   auto fc2_param_grads = [&]() {
-    dense_wgrad(e, ba.act, m, dbranch, d, rows, bp.fc2);
+    dense_wgrad(e, ba.act, m, dbranch, d, rows, bp.fc2, fork_fc2);
     side_note_read(e, dbranch == e->d_br ? e->rg_dbr : e->rg_glp);
     if (!fc2_bias_in_ln && !fc2_bias_done) bias_grad(e, dbranch == e->d_br ? (const void*)e->d_br : (const void*)e->g, dbranch == e->d_br ? T : 0, d, rows, bp.fc2);
   };
@@ -992,7 +1008,7 @@ static int block_backward(vitx_engine* e, Stage& st, int si, int l, int b, int n
     ep.nt_out = (e->nt_mask >> 4) & 1;   // d(y2) is read by the LayerNorm backward only after both weight gradients: keep d(hpre) cached instead
     dense_dgrad(e, e->d_h, m, rows, bp.fc1, EPI_STORE, ep);
   }
-  dense_wgrad(e, ba.y2, d, e->d_h, m, rows, bp.fc1);
+  dense_wgrad(e, ba.y2, d, e->d_h, m, rows, bp.fc1, fork_fc1);
   side_note_read(e, e->rg_dh);
   if (!fc1_bias_fused) bias_grad(e, e->d_h, T, m, rows, bp.fc1);
   if (e->mlp_bwd_consumers_first) fc2_param_grads();
@@ -1027,8 +1043,9 @@ static int block_backward(vitx_engine* e, Stage& st, int si, int l, int b, int n
   const void* d_o = dbranch;   // when to_out is the identity (vit.py:53) the branch gradient IS d(attn_out)
   if (bp.has_out) {
     EpiParams ep; ep.out = e->d_o; ep.ldo = inner;
+    const hipEvent_t fork_out = side_prefork(e);   // o and the branch gradient are complete
     dense_dgrad(e, dbranch, d, rows, bp.out, EPI_STORE, ep);
-    dense_wgrad(e, ba.o, inner, dbranch, d, rows, bp.out);
+    dense_wgrad(e, ba.o, inner, dbranch, d, rows, bp.out, fork_out);
     side_note_read(e, dbranch == e->d_br ? e->rg_dbr : e->rg_glp);
     out_bias_in_ln = dbranch != e->d_br && !grouped;
     if (!out_bias_in_ln && !out_bias_done) bias_grad(e, dbranch == e->d_br ? (const void*)e->d_br : (const void*)e->g, dbranch == e->d_br ? T : 0, d, rows, bp.out);
@@ -1092,8 +1109,9 @@ static int block_backward(vitx_engine* e, Stage& st, int si, int l, int b, int n
     }
     EpiParams ep; ep.out = e->d_y; ep.ldo = d;
     ep.nt_out = (e->nt_mask >> 4) & 1;
+    const hipEvent_t fork_qkv = side_prefork(e);   // d(q, k, v) is complete
     dense_dgrad(e, e->d_qkv, 3 * inner, rows, bp.qkv, EPI_STORE, ep);
-    dense_wgrad(e, ba.y1, d, e->d_qkv, 3 * inner, rows, bp.qkv);
+    dense_wgrad(e, ba.y1, d, e->d_qkv, 3 * inner, rows, bp.qkv, fork_qkv);
     side_note_read(e, e->rg_dqkv);
   }
   {
