@@ -1072,11 +1072,12 @@ static int block_backward(vitx_engine* e, Stage& st, int si, int l, int b, int n
     // to_q / to_kv VJPs
     const void* ctx = nc > 0 ? ba.ctx : ba.y1;
     EpiParams ep; ep.out = e->d_y; ep.ldo = d;
+    const hipEvent_t fork_qkv = side_prefork(e);                                // dq and dkv are complete
     dense_dgrad(e, dq, inner, rows, bp.q, EPI_STORE, ep);                       // d y1 (via q)
-    dense_wgrad(e, ba.y1, d, dq, inner, rows, bp.q);
+    dense_wgrad(e, ba.y1, d, dq, inner, rows, bp.q, fork_qkv);
     EpiParams ep2; ep2.out = e->d_ctx; ep2.ldo = d;
     dense_dgrad(e, dkv, 2 * inner, b * nk, bp.kv, EPI_STORE, ep2);              // d ctx (via k, v)
-    dense_wgrad(e, ctx, d, dkv, 2 * inner, b * nk, bp.kv);
+    dense_wgrad(e, ctx, d, dkv, 2 * inner, b * nk, bp.kv, fork_qkv);
     side_note_read(e, e->rg_dqkv);
     Prof pr(e, "ctx_bwd", 0, 0);
     if (nc > 0) {
@@ -1412,6 +1413,7 @@ static int engine_create_body(vitx_engine* e, const vitx_config& cfg, std::strin
     if ((rc = ring(e->rg_dqkv, e->d_qkv, (size_t)(rmax + 256) * 3 * inner * esz + (size_t)crow_max * 2 * inner * esz, 2)) != VITX_OK) return rc;
     if ((rc = ring(e->rg_dbr, e->d_br, (size_t)rmax * d * esz, 3)) != VITX_OK) return rc;
     DALLOC(e->ln_part, (size_t)layernorm_bwd_ws_elems(d) * 4, false);
+    // (one slot per use of a backward pass -- no wait for these on the chain at all -- measured the same as four: r4pg)
     if ((rc = ring(e->rg_lnp, e->ln_part, (size_t)layernorm_bwd_ws_elems(d) * 4, 4)) != VITX_OK) return rc;
     const size_t cs_bytes = (size_t)(ceil_div(rmax, 128) + 64) * m * 4;   // per-tile column sums + the second reduction level behind them
     DALLOC(e->cs_part, cs_bytes, false);
