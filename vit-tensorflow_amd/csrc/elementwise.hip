@@ -561,6 +561,62 @@ __global__ void batch_reduce4_kernel(const float* __restrict__ g, int b, int nto
   for (; bi < b; ++bi) { const float4 v = *(const float4*)(p + bi * stride); a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
   *(float4*)(out + j * d + c) = a;
 }
+// The same sum with the batch split over the 8 waves of a block (wave w takes images [w*bc, (w+1)*bc), four loads in flight; the partial sums
+// meet in LDS and are added in wave order): one thread per output walked b images in 64 dependent round trips (59 us at b = 256 whatever the
+// output size; these launches close the backward chain).
+__global__ __launch_bounds__(512) void batch_reduce4_split_kernel(const float* __restrict__ g, int b, int ntok, int d4, int j0, int nj,
+                                                                  float* __restrict__ out) {
+  __shared__ float4 red[8][64];
+  const int64_t total = (int64_t)nj * d4;
+  const int64_t e = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
+  const int w = threadIdx.x >> 6;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (e < total) {
+    const int64_t j = e / d4;
+    const int c = (int)(e - j * d4) * 4;
+    const int64_t d = (int64_t)d4 * 4;
+    const float* p = g + (j0 + j) * d + c;
+    const int64_t stride = (int64_t)ntok * d;
+    const int bc = (b + 7) / 8, b0 = w * bc, b1 = min(b, b0 + bc);
+    int bi = b0;
+    for (; bi + 4 <= b1; bi += 4) {
+      const float4 v0 = *(const float4*)(p + (bi + 0) * stride), v1 = *(const float4*)(p + (bi + 1) * stride);
+      const float4 v2 = *(const float4*)(p + (bi + 2) * stride), v3 = *(const float4*)(p + (bi + 3) * stride);
+      a.x += v0.x; a.y += v0.y; a.z += v0.z; a.w += v0.w;
+      a.x += v1.x; a.y += v1.y; a.z += v1.z; a.w += v1.w;
+      a.x += v2.x; a.y += v2.y; a.z += v2.z; a.w += v2.w;
+      a.x += v3.x; a.y += v3.y; a.z += v3.z; a.w += v3.w;
+    }
+    for (; bi < b1; ++bi) { const float4 v = *(const float4*)(p + bi * stride); a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
+  }
+  red[w][threadIdx.x & 63] = a;
+  __syncthreads();
+  if (w == 0 && e < total) {
+    float4 t = red[0][threadIdx.x];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) { const float4 v = red[k][threadIdx.x]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+    const int64_t j = e / d4;
+    *(float4*)(out + j * (int64_t)d4 * 4 + (e - j * d4) * 4) = t;
+  }
+}
+// column sums of a small [rows][d] matrix, rows split over the 4 waves of a block the same way (fixed order)
+__global__ __launch_bounds__(256) void sum_rows_split_kernel(const float* __restrict__ in, int rows, int d, float* __restrict__ out) {
+  __shared__ float red[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
+  float a = 0.f;
+  if (c < d) {
+    const int rc = (rows + 3) / 4, r0 = w * rc, r1 = min(rows, r0 + rc);
+    int r = r0;
+    for (; r + 4 <= r1; r += 4) {
+      const float v0 = in[(int64_t)r * d + c], v1 = in[(int64_t)(r + 1) * d + c], v2 = in[(int64_t)(r + 2) * d + c], v3 = in[(int64_t)(r + 3) * d + c];
+      a += v0; a += v1; a += v2; a += v3;
+    }
+    for (; r < r1; ++r) a += in[(int64_t)r * d + c];
+  }
+  red[w][threadIdx.x & 63] = a;
+  __syncthreads();
+  if (w == 0 && c < d) out[c] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+}
 __global__ void sum_rows_kernel(const float* __restrict__ in, int rows, int d, float* __restrict__ out) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= d) return;
@@ -875,7 +931,8 @@ void launch_mean_pool_bwd(const float* dp, int b, int ntok, int d, float* g, hip
 void launch_batch_reduce(const float* g, int b, int ntok, int d, int j0, int nj, float* out, hipStream_t s) {
   if (nj <= 0) return;
   if (d % 4 == 0 && ((uintptr_t)g) % 16 == 0 && ((uintptr_t)out) % 16 == 0) {
-    hipLaunchKernelGGL(batch_reduce4_kernel, dim3((unsigned)ceil_div((int64_t)nj * (d / 4), 64)), dim3(64), 0, s, g, b, ntok, d / 4, j0, nj, out);
+    if (b >= 32) hipLaunchKernelGGL(batch_reduce4_split_kernel, dim3((unsigned)ceil_div((int64_t)nj * (d / 4), 64)), dim3(512), 0, s, g, b, ntok, d / 4, j0, nj, out);
+    else hipLaunchKernelGGL(batch_reduce4_kernel, dim3((unsigned)ceil_div((int64_t)nj * (d / 4), 64)), dim3(64), 0, s, g, b, ntok, d / 4, j0, nj, out);
     return;
   }
   hipLaunchKernelGGL(batch_reduce_kernel, dim3(grid_for((int64_t)nj * d)), dim3(256), 0, s, g, b, ntok, d, j0, nj, out);
@@ -892,7 +949,8 @@ void launch_extract_rows(const float* g, int b, int ntok, int tok_off, int np, i
   else hipLaunchKernelGGL(extract_rows_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, g, b, ntok, tok_off, np, d, (float*)out, ldo);
 }
 void launch_sum_rows(const float* in, int rows, int d, float* out, hipStream_t s) {
-  hipLaunchKernelGGL(sum_rows_kernel, dim3((unsigned)ceil_div(d, 256)), dim3(256), 0, s, in, rows, d, out);
+  if (rows >= 32) hipLaunchKernelGGL(sum_rows_split_kernel, dim3((unsigned)ceil_div(d, 64)), dim3(256), 0, s, in, rows, d, out);
+  else hipLaunchKernelGGL(sum_rows_kernel, dim3((unsigned)ceil_div(d, 256)), dim3(256), 0, s, in, rows, d, out);
 }
 void launch_ce_grad(const float* logits, int64_t ld, const int32_t* labels, int b, int nc, float inv_batch, float* dlogits, float* loss,
                     hipStream_t s) {
