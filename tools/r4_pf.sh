@@ -1,6 +1,4 @@
 #!/bin/bash
-# round 4: batch sums of the embedding backward split over the waves of a block -- full GPU tier + A/B
-OUT=gpurun_out/r4ph; mkdir -p $OUT; export TMPDIR=/tmp
+OUT=gpurun_out/r4pi; mkdir -p $OUT; export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT 2>/dev/null || cd /root/repo
-timeout 1800 python -m pytest tests -m gpu -q --timeout 900 -p no:cacheprovider > $OUT/pytest_all.log 2>&1; grep -E "passed|failed" $OUT/pytest_all.log | tail -2
-timeout 900 python tools/ab_bench.py vit-tensorflow_amd/lib/libvitx_head.so vit-tensorflow_amd/lib/libvitx.so 4 > $OUT/ab.log 2>&1; grep "round" $OUT/ab.log; grep -A3 "\"step\"" $OUT/ab.log; grep -A4 "embed_bwd" $OUT/ab.log | head -6
+timeout 900 python tools/ab_env.py "VITX_SIDE_STREAM=1" "VITX_SIDE_STREAM=2" "VITX_SIDE_STREAM=0" --rounds 3 > $OUT/ab_env_side_mode.log 2>&1; tail -8 $OUT/ab_env_side_mode.log
