@@ -496,7 +496,8 @@ static void dense_wgrad(vitx_engine* e, const void* X, int64_t ldx, const void* 
     const int nk = kext / 64;
     // one wave of workgroups (these kernels run 1 WG/CU): split-K so that tiles*split ~ 256, fewer slices = less partial traffic
     // (finer slices -- 384 / 512 workgroups, so that a low-priority side-stream workgroup holds its CU for less long -- measured +2.5 / +1.6 ms per step:
-    //  profiles/r4/ab_weight_gradient_slices_r4o_not_kept.log)
+    //  profiles/r4/ab_weight_gradient_slices_r4o_not_kept.log; coarser ones -- 192 / 128 workgroups, less partial traffic -- +0.3 / +0.8 ms:
+    //  ab_weight_gradient_coarser_slices_r4pj_not_kept.log)
     int split = (int)std::max<int64_t>(1, std::min<int64_t>(ceil_div(nk, 4), std::max<int64_t>(1, 256 / tiles)));
     while (split > 1 && (int64_t)split * w.in * w.out > e->partial_elems) --split;
     if (!e->wgrad_via_transpose) {
