@@ -16,8 +16,12 @@ CONFIGS.setdefault("cait_side_mid", ("cait", dict(image_size=128, patch_size=16,
 CONFIGS.setdefault("deepvit_side_mid", ("deepvit", dict(image_size=128, patch_size=16, num_classes=100, dim=256, depth=4, heads=4, mlp_dim=512)))
 
 
-def _run(name, b, steps, monkeypatch, side, dropout=0.0):
+def _run(name, b, steps, monkeypatch, side, dropout=0.0, reduce_rows=None):
     monkeypatch.setenv("VITX_SIDE_STREAM", side)
+    if reduce_rows is None:
+        monkeypatch.delenv("VITX_LN_REDUCE_SIDE_ROWS", raising=False)
+    else:
+        monkeypatch.setenv("VITX_LN_REDUCE_SIDE_ROWS", str(reduce_rows))   # row threshold of the third stream (small reductions): 0 = always
     cfg = oracle_cfg(name)
     P = spec.init_params(cfg, seed=5, randomize_all=True)
     v, kw = CONFIGS[name]
@@ -46,6 +50,18 @@ def test_side_stream_gradients_are_bit_identical_to_the_one_stream_order(name, b
             assert np.array_equal(d0, d1), f"step {s}: d(img) differs (mode {mode})"
             for k in g0:
                 assert np.array_equal(g0[k], g1[k]), f"step {s}: gradient {k} differs (mode {mode})"
+
+
+@pytest.mark.parametrize("name,b", [("vit_side_mid", 16), ("cait_side_mid", 32), ("deepvit_side_mid", 32)])
+def test_small_reductions_on_the_third_stream_are_bit_identical_at_any_row_count(name, b, monkeypatch):
+    """The LayerNorm-VJP / fc1-bias partial reductions leave the chain for a third stream only above a row threshold (default 8192); forced on for
+    every VJP -- CaiT's 32-row class-attention layers included -- the gradients are still exactly those of the one-stream order."""
+    ref = _run(name, b, 2, monkeypatch, "0")
+    got = _run(name, b, 2, monkeypatch, "1", reduce_rows=0)
+    for s, ((l0, g0, d0), (l1, g1, d1)) in enumerate(zip(ref, got)):
+        assert np.array_equal(l0, l1) and np.array_equal(d0, d1), f"step {s}"
+        for k in g0:
+            assert np.array_equal(g0[k], g1[k]), f"step {s}: gradient {k} differs"
 
 
 def test_side_stream_composes_with_the_gradient_ready_callback(monkeypatch):

@@ -108,6 +108,7 @@ struct vitx_engine {
   hipStream_t own_stream = nullptr, stream = nullptr;
   // weight gradients (no consumer until the optimizer / the gradient exchange) run on `side`, forked from / joined into `stream` by events
   hipStream_t side = nullptr;
+  int side2_min_rows = 8192;     // VITX_LN_REDUCE_SIDE_ROWS (read once per handle): VJPs of fewer rows keep their reductions on the main stream
   hipStream_t side2 = nullptr;   // the small reductions of the LayerNorm VJPs: they must not queue behind a block's weight-gradient GEMMs
   int side_mode = 1;                 // VITX_SIDE_STREAM=0: everything on one stream (A/B reference)
   bool side_live = false;            // inside a backward pass that uses the side stream

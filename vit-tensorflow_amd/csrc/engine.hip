@@ -376,10 +376,6 @@ static void side2_end(vitx_engine* e, SideRing& r) {
   (void)hipStreamWaitEvent(e->side, r.rd[r.cur], 0);
   e->side_dirty = true;
 }
-static inline int side2_min_rows() {
-  static const int v = [] { const char* k = getenv("VITX_LN_REDUCE_SIDE_ROWS"); return k ? atoi(k) : 8192; }();
-  return v;
-}
 // LayerNorm VJP of a block: with the side stream live, the two small launches that reduce its per-block partials into dgamma / dbeta (/ a bias
 // gradient) leave the input-gradient chain -- 5 us each, 50 per ViT-B/16 step, nothing downstream reads their results.  They go to a stream of
 // their own: on the weight-gradient stream they queued behind a block's GEMMs and piled up in the tail after the chain had finished (CaiT cfg5
@@ -387,7 +383,7 @@ static inline int side2_min_rows() {
 // then ordered behind them, so that the join and the gradient-ready reports (events on that stream) cover them too.
 static void block_layernorm_bwd(vitx_engine* e, const void* dy, int T, int d, const float* x, const float* mean, const float* rstd, const float* gamma,
                                 const float* g_in, float* g_out, void* g_lp, float* dgamma, float* dbeta, float* gsum, int rows) {
-  if (!e->side_live || !e->side2 || e->rg_lnp.n == 0 || rows < side2_min_rows()) {   // short VJPs (CaiT's class-attention rows): three stream operations cost more than they hide
+  if (!e->side_live || !e->side2 || e->rg_lnp.n == 0 || rows < e->side2_min_rows) {   // short VJPs (CaiT's class-attention rows): three stream operations cost more than they hide
     launch_layernorm_bwd(dy, T, d, x, d, mean, rstd, gamma, g_in, d, g_out, d, g_lp, d, e->red_ws, dgamma, dbeta, gsum, rows, d, e->stream);
     return;
   }
@@ -974,7 +970,7 @@ static int block_backward(vitx_engine* e, Stage& st, int si, int l, int b, int n
     EpiParams ep; ep.out = e->d_h; ep.ldo = m; ep.aux = ba.hpre; ep.ldaux = m;
     // with the side stream live the per-tile sums go to a ring slot of their own and their reduction to the small-reduction stream (as the
     // LayerNorm VJP's: block_layernorm_bwd)
-    const bool cs_side = fc1_bias_fused && e->side_live && e->side2 && e->rg_cs.n && rows >= side2_min_rows();
+    const bool cs_side = fc1_bias_fused && e->side_live && e->side2 && e->rg_cs.n && rows >= e->side2_min_rows;
     if (cs_side) side_rotate(e, e->rg_cs, e->cs_part);
     float* cs = cs_side ? e->cs_part : e->red_ws;
     if (fc1_bias_fused) {
@@ -1187,6 +1183,7 @@ static int engine_create_body(vitx_engine* e, const vitx_config& cfg, std::strin
   HIPCHK(hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking));
   e->stream = e->own_stream;
   if (const char* k = getenv("VITX_SIDE_STREAM")) e->side_mode = atoi(k);
+  if (const char* k = getenv("VITX_LN_REDUCE_SIDE_ROWS")) e->side2_min_rows = atoi(k);
   if (e->bf16 && e->side_mode) {
     // lowest priority: the input-gradient chain is the critical path, the weight gradients fill what it leaves free (VITX_SIDE_STREAM=2: same priority)
     int least = 0, greatest = 0;
