@@ -23,7 +23,11 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-res
 # per-source additions.  attn_bf16.hip / attn_x3.hip: the running row maxima come straight out of MFMA accumulators; with NaNs honoured every fmaxf first
 # canonicalises its operands (v_max_f32 x, x, x: 8 extra VALU instructions per key tile in a VALU-bound loop).  No NaN is produced or
 # consumed on that path (masked keys are -inf selects, never arithmetic on NaN).
-EXTRA_FLAGS = {"attn_bf16.hip": ["-fno-honor-nans"], "attn_x3.hip": ["-fno-honor-nans"]}
+# gemm_bf16_tn.hip: the machine scheduler's max-ILP strategy orders the transpose reads / MFMAs of the weight-gradient K loop 1.6 % faster
+# (8.06 -> 7.93 ms per step as a class, `profiles/r4/ab_gemm_sched_strategy_max_ilp_r4st.log`; the NT kernel does not move and one of its
+# instantiations then fails tools/isa_check.py, so it keeps the default).
+EXTRA_FLAGS = {"attn_bf16.hip": ["-fno-honor-nans"], "attn_x3.hip": ["-fno-honor-nans"],
+               "gemm_bf16_tn.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]}
 
 
 def _deps_mtime() -> float:
