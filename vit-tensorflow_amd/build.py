@@ -26,7 +26,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-res
 # gemm_bf16_tn.hip: the machine scheduler's max-ILP strategy orders the transpose reads / MFMAs of the weight-gradient K loop 1.6 % faster
 # (8.06 -> 7.93 ms per step as a class, `profiles/r4/ab_gemm_sched_strategy_max_ilp_r4st.log`; the NT kernel does not move and one of its
 # instantiations then fails tools/isa_check.py, so it keeps the default).
-EXTRA_FLAGS = {"attn_bf16.hip": ["-fno-honor-nans"], "attn_x3.hip": ["-fno-honor-nans"],
+EXTRA_FLAGS = {"attn_bf16.hip": ["-fno-honor-nans"], "attn_x3.hip": ["-fno-honor-nans", "-mllvm", "-amdgpu-sched-strategy=max-ilp"],   # (attn_x3: -0.3 ms per BF16X3 step)
                "gemm_bf16_tn.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"],
                # gemm_bf16x3.hip (VALU-bound split arithmetic around three MFMAs per product): the max-memory-clause strategy, BF16X3 step at batch 256
                # 108.9 -> 105.5 ms on the same box (max-ilp 107.4, iterative-minreg 106.9; `profiles/r4/ab_bf16x3_gemm_sched_strategies_r4st.log`)
