@@ -114,10 +114,16 @@ def test_mae_wrapper_passes_training_to_the_encoder():
     from vit_tensorflow import ViT
     from vit_tensorflow.mae import MAE
     enc = ViT(image_size=64, patch_size=16, num_classes=10, dim=64, depth=2, heads=2, mlp_dim=128, dim_head=32, dropout=0.3, compute="fp32", max_batch=2, seed=1)
-    mae = MAE(image_size=64, encoder=enc, decoder_dim=32, masking_ratio=0.5, decoder_depth=1, decoder_heads=2, decoder_dim_head=16, literal_loss=False)
+    # seed: the wrapper's own weights (decoder, mask token) are drawn from it -- unseeded, the loss gaps below are a random draw per run and
+    # came out below the thresholds about once in thirty runs
+    mae = MAE(image_size=64, encoder=enc, decoder_dim=32, masking_ratio=0.5, decoder_depth=1, decoder_heads=2, decoder_dim_head=16, literal_loss=False,
+              seed=11)
     img = np.random.default_rng(0).standard_normal((2, 64, 64, 3)).astype(np.float32)
     idx = np.stack([np.random.default_rng(i).permutation(16) for i in range(2)]).astype(np.int32)
     l_eval = [float(mae(img, training=False, indices=idx)) for _ in range(2)]
-    l_a, l_a2, l_b = (float(mae(img, training=True, indices=idx, seed=s)) for s in (5, 5, 6))
+    l_a, l_a2 = (float(mae(img, training=True, indices=idx, seed=5)) for _ in range(2))
+    l_other = [float(mae(img, training=True, indices=idx, seed=s)) for s in (6, 7, 8, 9)]
     assert l_eval[0] == l_eval[1] and l_a == l_a2
-    assert abs(l_a - l_eval[0]) > 1e-4 and abs(l_a - l_b) > 1e-5
+    # dropout 0.3 moves the loss by ~1e-3 for most masks: at least one of five seeds is clearly off the inference loss, and the seeds differ
+    assert max(abs(l - l_eval[0]) for l in [l_a] + l_other) > 1e-4, (l_eval, l_a, l_other)
+    assert len({l_a, *l_other}) >= 4, (l_a, l_other)
