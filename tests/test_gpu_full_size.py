@@ -19,7 +19,8 @@ M_TOKENS = 256 * 197
 
 # (N, K, epilogues): 1 = bias + fp32 residual, 2 = bias + GELU (act and gelu' in bf16), 3 = bf16 store, 4 = x stored gelu' + fused column sums
 NT_LAUNCHES = [(3072, 768, (2, 4, 3)), (768, 3072, (1, 3)), (768, 768, (1, 3)), (2304, 768, (3,)), (768, 2304, (3,))]
-NT_VARIANTS = (6, 7, 11, 13)   # the persistent variants: lockstep 256 / 320 rows (fall-back beyond 2 GiB operands), pipelined + wave-private epilogue 320 / 256 rows
+NT_VARIANTS = (6, 7, 9, 10, 11, 13)   # the persistent variants: lockstep 256 / 320 rows (fall-back beyond 2 GiB operands), pipelined + wave-private epilogue 320 / 256 rows,
+                                    # 9 / 10: the pipelined kernel with 192 x 128 tiles on 4 waves, two workgroups per CU (persistent / one tile per workgroup)
 BF16_OUT_TOL = 1.1e-2    # ~2x observed (5.2e-3 = one bf16 ulp): the two kernels add in different orders, a value on a rounding boundary flips one ulp
 GELU_OUT2_TOL = 1.5e-2   # gelu'(h) / gelu(h) of a pre-activation that flipped (observed 7.2e-3)
 F32_OUT_TOL = 1e-3

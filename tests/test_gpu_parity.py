@@ -267,14 +267,14 @@ def test_bf16_mfma_gemm_equals_fp32_fma_gemm():
     avg, err = C.c_float(), C.c_float()
     # 1-3: one tile per workgroup (128^2, 256^2, 256x128); 5: 320x256; 6/7: persistent 256^2 / 320x256 (cross-tile prefetch);
     # 13 / 11: software-pipelined persistent kernel (register double-buffered fragments, DMA pieces spread over the K-tile, wave-private epilogue),
-    # 256 / 320-row tiles;
+    # 256 / 320-row tiles; 9 / 10: the same kernel with 192 x 128 tiles on 4 waves (two workgroups per CU), persistent / one tile per workgroup;
     # +256: direct epilogue; +512: LDS-staged epilogue; 0: automatic (measured) choice.  (Bits 4-5 are the timing-experiment
     # switches -- invalid results by design -- and vitx_bench_gemm refuses them without VITX_GEMM_XP, checked below.)
-    for kern in (0, 1, 2, 3, 5, 6, 7, 11, 13, 1 + 256, 2 + 256, 3 + 256, 5 + 256, 6 + 256, 7 + 256, 2 + 512):
+    for kern in (0, 1, 2, 3, 5, 6, 7, 9, 10, 11, 13, 1 + 256, 2 + 256, 3 + 256, 5 + 256, 6 + 256, 7 + 256, 2 + 512):
         for (M, Nn, K) in [(256, 256, 64), (300, 200, 192), (1000, 768, 768), (197 * 4, 2304, 768), (30001, 1000, 128)]:
             N.check(N.lib().vitx_bench_gemm(m._handle, M, Nn, K, kern, 0, 1, C.byref(avg), C.byref(err)))
             assert 0 <= err.value <= 2e-3 * np.sqrt(K), (kern, M, Nn, K, err.value)
-    for kern in (0, 6, 7, 11, 13):   # every fused epilogue of the persistent variants, > 256 tiles so workgroups walk several tiles
+    for kern in (0, 6, 7, 9, 10, 11, 13):   # every fused epilogue of the persistent variants, > 256 tiles so workgroups walk several tiles
         for epi in (1, 2, 3):
             N.check(N.lib().vitx_bench_gemm(m._handle, 30208, 1024, 192, kern, epi, 1, C.byref(avg), C.byref(err)))
             assert 0 <= err.value <= 2e-3 * np.sqrt(192) + 2e-2, (kern, epi, err.value)

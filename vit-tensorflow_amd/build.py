@@ -1,4 +1,4 @@
-"""Build libvitx.so (the C-ABI HIP library) and the oracle's C pieces, in-tree, for gfx950.
+"""Build libvitx.so (the C-ABI HIP library), in-tree, for gfx950 (the oracle is numpy / torch: nothing of it is compiled).
 
     python vit-tensorflow_amd/build.py [--force]
 
@@ -36,7 +36,45 @@ EXTRA_FLAGS = {"attn_bf16.hip": ["-fno-honor-nans"], "attn_x3.hip": ["-fno-honor
 def _deps_mtime() -> float:
     hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     hdrs.append(os.path.join(HERE, "..", "include", "vitx.h"))
+    hdrs.append(os.path.abspath(__file__))   # FLAGS / EXTRA_FLAGS live here: an edited flag set rebuilds every object
     return max(os.path.getmtime(h) for h in hdrs)
+
+
+def flags_id() -> str:
+    """Digest of the compile flags (part of kernel_source_id(): tuned GEMM profiles / PMC traffic files are refused when it changes)."""
+    import hashlib
+    return hashlib.sha256(repr((FLAGS, sorted(EXTRA_FLAGS.items()))).encode()).hexdigest()[:12]
+
+
+# Objects whose K loops issue LDS-DMA from inline asm and keep M0 alive between the pieces of a group (common.h, vitx_dma16 / vitx_dma16_cont):
+# hipcc does not model M0 across asm statements (an "m0" clobber only draws `inline asm clobber list contains reserved registers`), so the
+# guarantee is checked on the ISA of EVERY build instead of trusted: no M0 write but the DMA statements' own, no compiler vmcnt wait and no
+# scratch access inside a K loop (tools/isa_check.py).  A compiler that breaks either fails the build here, not a run on the GPU.
+ISA_CHECKED = ["gemm_bf16_pipe.hip", "gemm_bf16_tn.hip"]
+
+
+def _isa_gate(objs) -> None:
+    import importlib.util
+    tool = os.path.join(HERE, "..", "tools", "isa_check.py")
+    if not os.path.exists(tool):
+        return
+    spec = importlib.util.spec_from_file_location("vitx_isa_check", tool)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    for src, obj in objs:
+        stamp = obj + ".isa_ok"
+        if os.path.exists(stamp) and os.path.getmtime(stamp) >= os.path.getmtime(obj):
+            continue
+        bad = []
+        for name, body in mod.kernels(mod.disassemble(obj)):
+            if "nt_pipe_kernel" not in name and "gemm_bf16_tn_kernel" not in name:
+                continue
+            r = mod.check(name, body)
+            if r is not None and not r[0]:
+                bad.append(r[1])
+        if bad:
+            raise RuntimeError(f"ISA check failed for {src} (tools/isa_check.py):\n" + "\n".join(bad))
+        open(stamp, "w").write("ok\n")
 
 
 ASAN_FLAGS = ["-fsanitize=address", "-shared-libsan", "-fno-gpu-sanitize", "-g"]   # host code only (the device side needs xnack+ targets)
@@ -69,6 +107,7 @@ def build(force: bool = False) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
     with ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
         objs = list(ex.map(lambda s: _compile(s, force), SOURCES))
+    _isa_gate([(s, o) for s, o in zip(SOURCES, objs) if s in ISA_CHECKED])
     if force or not os.path.exists(LIB) or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs):
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs, "-ldl"]
         r = subprocess.run(cmd, capture_output=True, text=True)

@@ -962,7 +962,7 @@ static int block_backward(vitx_engine* e, Stage& st, int si, int l, int b, int n
   // fc1 bias gradient = column sums of d hpre: produced per M-tile by the fc2-dgrad epilogue itself (no second pass over the
   // 310 MB output) whenever that GEMM runs an LDS-staged bf16 kernel and no dropout mask is applied to d hpre afterwards
   const bool fc1_bias_fused = e->bf16 && !e->force_generic_gemm && !(e->gemm_kernel & 256) && drop == 0.f && bp.fc1.b >= 0;
-  const int cs_rows = (int)ceil_div(rows, 128);   // >= the M-tile count of every variant (128 / 256 / 320 rows per tile)
+  const int cs_rows = (int)ceil_div(rows, 96);    // >= the number of wave rows of every variant (96 / 128 / 160 rows per wave row, 128 per tile of the lockstep kernels)
   const hipEvent_t fork_fc2 = side_prefork(e);    // act and the branch gradient are complete here: the fc2 weight gradient may start
   hipEvent_t fork_fc1 = nullptr;
   {
@@ -1413,7 +1413,7 @@ static int engine_create_body(vitx_engine* e, const vitx_config& cfg, std::strin
     DALLOC(e->ln_part, (size_t)layernorm_bwd_ws_elems(d) * 4, false);
     // (one slot per use of a backward pass -- no wait for these on the chain at all -- measured the same as four: r4pg)
     if ((rc = ring(e->rg_lnp, e->ln_part, (size_t)layernorm_bwd_ws_elems(d) * 4, 4)) != VITX_OK) return rc;
-    const size_t cs_bytes = (size_t)(ceil_div(rmax, 128) + 64) * m * 4;   // per-tile column sums + the second reduction level behind them
+    const size_t cs_bytes = (size_t)(ceil_div(rmax, 96) + 64) * m * 4;   // per-tile column sums + the second reduction level behind them
     DALLOC(e->cs_part, cs_bytes, false);
     if ((rc = ring(e->rg_cs, e->cs_part, cs_bytes, 4)) != VITX_OK) return rc;
   }
@@ -1438,7 +1438,7 @@ static int engine_create_body(vitx_engine* e, const vitx_config& cfg, std::strin
   }
   // (+ per-M-tile column sums of the fc2-dgrad epilogue: one row per 256 token rows, 32 second-level rows)
   e->red_elems = std::max<int64_t>({layernorm_bwd_ws_elems(d), colsum_ws_elems((int)maxfeat), headmix_ws_elems((int)B, c.heads, 1, 1),
-                                    (int64_t)256 * 2 * 32, (int64_t)(1024 + 64) * d, (ceil_div(std::max<int64_t>(e->mp, e->mpp), 128) + 40) * (int64_t)m,
+                                    (int64_t)256 * 2 * 32, (int64_t)(1024 + 64) * d, (ceil_div(std::max<int64_t>(e->mp, e->mpp), 96) + 40) * (int64_t)m,
                                     headchain_ws_elems(c.heads), deepvit_point_ws_elems((int)B, c.heads, e->ntok_cap),
                                     deepvit_point_bwd_ws_elems(c.heads)});
   DALLOC(e->red_ws, (size_t)e->red_elems * 4, false);
@@ -2106,7 +2106,7 @@ int engine_check_gemm(vitx_engine* e, int kind, int M, int N, int K, int kernel,
     const int64_t Mp = round_up(M, 1280), Np = round_up(N, 256);
     bf16_t *A, *B, *T1[2], *T2[2], *aux; float *F[2], *bias, *R, *cs[2];
     if (alloc((void**)&A, (size_t)Mp * K * 2) || alloc((void**)&B, (size_t)Np * K * 2) || alloc((void**)&bias, (size_t)Np * 4) || alloc((void**)&R, (size_t)Mp * Np * 4) ||
-        alloc((void**)&aux, (size_t)Mp * Np * 2) || alloc((void**)&cs[0], (size_t)(Mp / 128 + 8) * Np * 4) || alloc((void**)&cs[1], (size_t)Np * 4 * 64)) { cleanup(); err = "check_gemm: out of memory"; return VITX_ERR_HIP; }
+        alloc((void**)&aux, (size_t)Mp * Np * 2) || alloc((void**)&cs[0], (size_t)(Mp / 96 + 8) * Np * 4) || alloc((void**)&cs[1], (size_t)Np * 4 * 64)) { cleanup(); err = "check_gemm: out of memory"; return VITX_ERR_HIP; }
     for (int i = 0; i < 2; ++i)
       if (alloc((void**)&T1[i], (size_t)Mp * Np * 2) || alloc((void**)&T2[i], (size_t)Mp * Np * 2) || alloc((void**)&F[i], (size_t)Mp * Np * 4)) { cleanup(); err = "check_gemm: out of memory"; return VITX_ERR_HIP; }
     launch_fill_random_bf16(A, (int64_t)M * K, 11u, 1.0f, e->stream);          // rows >= M stay zero (row padding invariant)
@@ -2143,7 +2143,7 @@ int engine_check_gemm(vitx_engine* e, int kind, int M, int N, int K, int kernel,
     else launch_max_rel_diff(T1[0], T1[1], 1, M, N, Np, Np, dmax, e->stream);
     if (epilogue == 2) launch_max_rel_diff(T2[0], T2[1], 1, M, N, Np, Np, dmax + 1, e->stream);
     if (epilogue == 4) {   // fused column sums (one partial row per M-tile -- or per wave row of a tile -- of the launch; unwritten rows are zero)
-      const int nt = (int)ceil_div(M, 128);
+      const int nt = (int)ceil_div(M, 96);   // >= the wave rows of every variant (rows no variant writes are zero)
       float* ws;
       if (alloc((void**)&ws, (size_t)std::max<int64_t>(colsum_ws_elems(N), (int64_t)nt * Np) * 4)) { cleanup(); err = "check_gemm: out of memory"; return VITX_ERR_HIP; }
       if (g.kernel == 0) { cleanup(); err = "check_gemm: epilogue 4 needs an explicit kernel variant (the column-sum rows follow its tile height)"; return VITX_ERR_INVALID; }
@@ -2243,8 +2243,8 @@ int engine_bench_gemm(vitx_engine* e, int M, int N, int K, int kernel, int epilo
   launch_gemm_bf16(g, ep, mode, e->stream);   // warm-up (+ attribute setup)
   unsigned long long* stamps = nullptr;
   if (getenv("VITX_GEMM_STAMPS")) {
-    HIPCHK(hipMalloc((void**)&stamps, 256 * 16 * 4 * 8));
-    HIPCHK(hipMemsetAsync(stamps, 0, 256 * 16 * 4 * 8, e->stream));
+    HIPCHK(hipMalloc((void**)&stamps, 512 * 16 * 4 * 8));
+    HIPCHK(hipMemsetAsync(stamps, 0, 512 * 16 * 4 * 8, e->stream));
     g.stamps = stamps;
   }
   hipEvent_t e0, e1;
@@ -2258,17 +2258,26 @@ int engine_bench_gemm(vitx_engine* e, int M, int N, int K, int kernel, int epilo
   HIPCHK(hipEventElapsedTime(&ms, e0, e1));
   *avg_ms = ms / std::max(1, iters);
   if (stamps) {   // phase durations of the last launch, averaged over the workgroups, per tile index (cycles of the shader clock counter)
-    std::vector<unsigned long long> hs(256 * 16 * 4);
+    std::vector<unsigned long long> hs(512 * 16 * 4);
     HIPCHK(hipMemcpy(hs.data(), stamps, hs.size() * 8, hipMemcpyDeviceToHost));
     (void)hipFree(stamps);
     g.stamps = nullptr;
-    for (int t = 0; t < 16; ++t) {
+    if (atoi(getenv("VITX_GEMM_STAMPS")) == 2) {   // raw rows: workgroup, placement (xcc, HW_ID), then (tile start, K loop end, epilogue end, refill end) per tile
+      for (int w = 0; w < 512; ++w) {
+        const unsigned long long* p = &hs[(size_t)w * 16 * 4];
+        if (!p[0]) continue;
+        fprintf(stderr, "[stamps-raw] wg %d xcc %llu hwid 0x%08llx", w, p[15 * 4] >> 32, p[15 * 4] & 0xffffffffull);
+        for (int t = 0; t < 15 && p[t * 4]; ++t) fprintf(stderr, " | %llu %llu %llu %llu", p[t * 4], p[t * 4 + 1], p[t * 4 + 2], p[t * 4 + 3]);
+        fprintf(stderr, "\n");
+      }
+    }
+    for (int t = 0; t < 15; ++t) {
       double kl = 0, ep_ = 0, dr = 0, gap = 0; int n = 0, ng = 0;
-      for (int w = 0; w < 256; ++w) {
+      for (int w = 0; w < 512; ++w) {
         const unsigned long long* p = &hs[((size_t)w * 16 + t) * 4];
         if (!p[0] || !p[3]) continue;
         kl += (double)(p[1] - p[0]); ep_ += (double)(p[2] - p[1]); dr += (double)(p[3] - p[2]); ++n;
-        if (t + 1 < 16) { const unsigned long long* q = &hs[((size_t)w * 16 + t + 1) * 4]; if (q[0]) { gap += (double)(q[0] - p[3]); ++ng; } }
+        if (t + 1 < 15) { const unsigned long long* q = &hs[((size_t)w * 16 + t + 1) * 4]; if (q[0]) { gap += (double)(q[0] - p[3]); ++ng; } }
       }
       if (n) fprintf(stderr, "[stamps] tile %2d (%3d WGs): k-loop %8.0f  epilogue %8.0f  drain+refill %8.0f  gap %6.0f cycles\n", t, n, kl / n, ep_ / n, dr / n,
                      ng ? gap / ng : 0.0);

@@ -311,7 +311,7 @@ void launch_mode(const Bf16GemmArgs& g, const EpiParams& ep, hipStream_t s) {
   const bool bf16_out = (MODE == EPI_STORE || MODE == EPI_BIAS_GELU || MODE == EPI_GELU_BWD);
   // (8-B per-lane pieces) are staged; with 32-row staging rounds (variants 5-8) staging wins for fp32 outputs too.
   const bool direct = (g.kernel & 256) ? true : ((g.kernel & 512) ? false : (!bf16_out && k < 5));
-  if (k == 11 || k == 13) { launch_gemm_bf16_pipe(k, MODE, g, ep, s); return; }   // gemm_bf16_pipe.hip
+  if (k == 9 || k == 10 || k == 11 || k == 13) { launch_gemm_bf16_pipe(k, MODE, g, ep, s); return; }   // gemm_bf16_pipe.hip
   if (direct) {
     if (k == 1) launch_variant<128, 128, 2, 2, MODE, false>(g, ep, s);
     else if (k == 3) launch_variant<256, 128, 4, 2, MODE, false>(g, ep, s);
@@ -345,12 +345,12 @@ int gemm_bf16_pick(int M, int N) {
 int gemm_bf16_tile_m(int kernel, int M, int N) {
   kernel &= 15;
   if (kernel == 0) kernel = gemm_bf16_pick(M, N);
-  return kernel == 1 ? 128 : ((kernel == 5 || kernel == 7 || kernel == 11) ? 320 : 256);
+  return kernel == 1 ? 128 : ((kernel == 9 || kernel == 10) ? 192 : ((kernel == 5 || kernel == 7 || kernel == 11) ? 320 : 256));
 }
 int gemm_bf16_tile_n(int kernel, int M, int N) {
   kernel &= 15;
   if (kernel == 0) kernel = gemm_bf16_pick(M, N);
-  return (kernel == 1 || kernel == 3) ? 128 : 256;
+  return (kernel == 1 || kernel == 3 || kernel == 9 || kernel == 10) ? 128 : 256;
 }
 void gemm_bf16_allow_320(int on) { g_allow_320 = on; }
 void gemm_bf16_set_shared_gpu(int on) { g_shared_gpu = on; }
@@ -447,7 +447,7 @@ void launch_gemm_bf16(const Bf16GemmArgs& g0, const EpiParams& ep, int mode, hip
     // The candidates have different tile heights and each stores its per-tile column sums (EPI_GELU_BWD) with '=' into rows the caller
     // zeroed ONCE: rows a taller-tiled winner does not write would keep what a shorter-tiled candidate left there, and the reduction behind
     // the launch adds every row (the fc1 bias gradient of the first step of a process was wrong by that much).  Clear them again.
-    if (ep.colsum != nullptr) (void)hipMemsetAsync(ep.colsum, 0, (size_t)ceil_div(g0.M, 128) * ep.ldcs * sizeof(float), s);
+    if (ep.colsum != nullptr) (void)hipMemsetAsync(ep.colsum, 0, (size_t)ceil_div(g0.M, 96) * ep.ldcs * sizeof(float), s);
     std::lock_guard<std::mutex> lk(g_tune_mu);
     g_tuned[key] = best;
   }

@@ -16,6 +16,15 @@ __device__ __forceinline__ int wp_lane() {
   return l;
 }
 
+// 16-byte output store by cache policy: 0 plain, 1 non-temporal.  (Write-through `sc1` stores -- the line is not kept in the XCD's L2 -- were measured in
+// round 5 as a way to keep operand panels L2-resident across a workgroup's tiles: FETCH_SIZE -5 %, time unchanged, 20-40 more SGPR spills in the GELU
+// instantiation; not kept, profiles/r5/ab_write_through_stores_*_r5c_not_kept.log.)
+template <int POL>
+__device__ __forceinline__ void wp_store16(bf16_t* base, uint32_t elem_off, bf16x8 v) {
+  if constexpr (POL == 1) __builtin_nontemporal_store(v, (bf16x8*)(base + elem_off));
+  else *(bf16x8*)(base + elem_off) = v;
+}
+
 // ---- GELU by table (the fc1 epilogue, 256-row tiles).  The pre-activation is rounded to bf16 BEFORE the activation is applied (what a bf16
 // tensor of it would hold), so gelu / gelu' are functions of a 16-bit pattern: for 2^-12 <= |x| < 8 (15 binades x 128 mantissas x 2 signs = 3840
 // patterns) they are read from a 15-KiB LDS table; smaller |x| take the first entry of their sign (Phi = 1/2, gelu' = 1/2 to bf16 precision), larger
@@ -61,7 +70,7 @@ const uint32_t* gelu_table_dev() {   // one copy per device (one process may dri
 //     the epilogue of the current one starts).
 //   * the epilogue is wave-private (no workgroup barrier): see the epilogue section.
 template <int BM, int BN, int WM, int WN, int MODE>
-__global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_pipe_kernel(Bf16GemmArgs g, EpiParams ep, int tiles_m, int tiles_n,
+__global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_nt_pipe_kernel(Bf16GemmArgs g, EpiParams ep, int tiles_m, int tiles_n,
                                                                          int kt_per_split, const uint32_t* __restrict__ gelu_tab) {
   constexpr int NW = WM * WN;
   constexpr int WTM = BM / WM, WTN = BN / WN;
@@ -69,14 +78,23 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_pipe_kernel(Bf16Gem
   constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
   constexpr int A_INSTR = BM / 8 / NW, B_INSTR = BN / 8 / NW;
   static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile rows must split evenly over the waves");
-  static_assert(BN == 256, "256-column tiles");
+  static_assert(BN == 256 || BN == 128, "256-column tiles (8 waves) or 128-column tiles (4 waves, two workgroups per CU)");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int nwg = gridDim.x, bid = blockIdx.x;
   const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
   const int logical0 = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
   const int total_tiles = tiles_m * tiles_n;
-  if (logical0 >= total_tiles) return;
+  // ---- the workgroup's tile list: indices w_first, w_first + w_stride, ... < w_limit of a walk.
+  // walk 0: the XCD-interleaved chunks of the global list (decode_tile: row-major, or bands of 4 row tiles for wide outputs).
+  // walk 2 (wide outputs, full persistent grid; the launcher decides): every XCD OWNS a contiguous range of row tiles and its workgroups walk it in
+  // bands of 8 row tiles, column-major inside a band -- the 32 tiles an XCD works on at any time are 8 rows x 4 columns of ONE band, and the band's
+  // 8 A panels (3 MiB at K = 768) stay in that XCD's L2 across the band's rounds instead of every round fetching 4 + 8 fresh panels
+  // (PMC, round 5: fc1 / qkv / fc2-dgrad fetched their A operand 4-5 times through the L2s; profiles/r5/fetch_by_shape_*.txt).
+  const bool xw = BM == 256 && g.walk == 2;   // (256-row tiles only: the 320-row instantiations serve 768-wide outputs and have no register to spare)
+  const int w_r0 = xw ? (tiles_m * xcd) >> 3 : 0, w_nr = xw ? ((tiles_m * (xcd + 1)) >> 3) - w_r0 : tiles_m;
+  const int w_first = xw ? (bid >> 3) : logical0, w_stride = xw ? (nwg >> 3) : nwg, w_limit = xw ? w_nr * tiles_n : total_tiles;
+  if (w_first >= w_limit) return;
   const int z = blockIdx.y;
   const int kt0 = z * kt_per_split;
   const int nk = min(kt_per_split, g.K / BK - kt0);
@@ -109,7 +127,16 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_pipe_kernel(Bf16Gem
 
   const int gm = ((tiles_n >= 8 && g.stagger != 8) ? 4 : 1) * (g.reverse_m ? -1 : 1);   // (stagger 8: row-major order, A/B switch of the micro-benchmark)
   // ---- issue cursor over this workgroup's K-tile stream (tile, kt); LDS buffer of stream item i = i & 1
-  int i_logical = logical0, i_k = 0, issued = 0;
+  auto tile_of = [&](int idx, int& tm, int& tn) {
+    if (xw) {
+      decode_tile_fwd(idx, w_nr, tiles_n, 8, tm, tn);
+      tm += w_r0;
+      if (g.reverse_m) tm = tiles_m - 1 - tm;
+    } else {
+      decode_tile(idx, tiles_m, tiles_n, gm, tm, tn);
+    }
+  };
+  int i_logical = w_first, i_k = 0, issued = 0;
   bool i_more = nk > 0;
   // DMA addressing: buffer_load ... lds with one resource per operand (SGPRs), the tile / K offset in the scalar offset and a
   // loop-invariant 32-bit lane offset -- no per-piece VALU address arithmetic and one address dword per lane instead of two
@@ -122,7 +149,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_pipe_kernel(Bf16Gem
   uint32_t a_soff = 0, b_soff = 0;       // byte offset of the cursor tile's first K-tile inside A / B
   auto i_set_tile = [&]() {
     int tm, tn;
-    decode_tile(i_logical, tiles_m, tiles_n, gm, tm, tn);
+    tile_of(i_logical, tm, tn);
     a_soff = (uint32_t)(((int64_t)tm * BM * g.lda + (int64_t)kt0 * BK) * 2);
     b_soff = (uint32_t)(((int64_t)tn * BN * g.ldb + (int64_t)kt0 * BK) * 2);
     {
@@ -159,8 +186,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_pipe_kernel(Bf16Gem
     ++issued;
     if (++i_k == nk) {
       i_k = 0;
-      i_logical += nwg;
-      i_more = persistent && i_logical < total_tiles;
+      i_logical += w_stride;
+      i_more = persistent && i_logical < w_limit;
       if (i_more) i_set_tile();
     }
   };
@@ -220,17 +247,25 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_pipe_kernel(Bf16Gem
   load_frags(fa[0], fb[0], smem, 0);
   int it = 0;   // consumed K-tile counter of the stream
   int tile_idx = 0;
-  constexpr bool kStamps = false;   // cycle stamps of the tile phases (diagnostic build only: the stores leave VMEM state pending across the K loop)
+#ifndef VITX_GEMM_STAMPS_BUILD
+#define VITX_GEMM_STAMPS_BUILD 0
+#endif
+  constexpr bool kStamps = VITX_GEMM_STAMPS_BUILD != 0;   // tools/build_variant.sh stamps "-DVITX_GEMM_STAMPS_BUILD=1" gemm_bf16_pipe.hip; cycle stamps of the tile phases (diagnostic build only: the stores leave VMEM state pending across the K loop)
   auto stamp = [&](int k) {
     if constexpr (kStamps)
-      if (g.stamps && tid == 0 && bid < 256 && tile_idx < 16) g.stamps[((int64_t)bid * 16 + tile_idx) * 4 + k] = __builtin_readcyclecounter();
+      if (g.stamps && tid == 0 && bid < 512 && tile_idx < 15) {
+        g.stamps[((int64_t)bid * 16 + tile_idx) * 4 + k] = __builtin_readcyclecounter();
+        // where this workgroup runs (HW_ID: CU / SE; XCC_ID), record 15 of its row: which workgroups share a CU is read from here
+        if (tile_idx == 0 && k == 0)
+          g.stamps[((int64_t)bid * 16 + 15) * 4] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+      }
   };
   // (the ONLY back edge of this loop runs through handover(): on any other path the compiler's scoreboard would carry the epilogue's
   //  bias / residual loads into the K loop as "pending" and protect their registers with vmcnt waits there -- see handover())
-  for (int logical = logical0;; logical += nwg, ++tile_idx) {
+  for (int logical = w_first;; logical += w_stride, ++tile_idx) {
     int tile_m, tile_n;
-    decode_tile(logical, tiles_m, tiles_n, gm, tile_m, tile_n);
-    const bool has_next = persistent && logical + nwg < total_tiles;
+    tile_of(logical, tile_m, tile_n);
+    const bool has_next = persistent && logical + w_stride < w_limit;
     stamp(0);
 #pragma unroll
     for (int i = 0; i < MT; ++i)
@@ -305,7 +340,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_pipe_kernel(Bf16Gem
       //   bf16 staging (plain store, GELU): a 32 x 64 block is 4 KiB -- area 0 / area 1 alternate (GELU: gelu' in area 0, gelu in area 1).
       //   fp32 staging (residual, GELU VJP): columns 0..31 in area 0, 32..63 in area 1 with rows and chunk parity flipped (row ^ 1, chunk ^ 1) so that
       //   the 16 lanes of a row-contiguous read hit 64 different banks; 16-B chunks are XOR-swizzled with (row >> 1) & 7 in both layouts.
-      static_assert((BM == 256 || BM == 320) && A_INSTR >= 4 && B_INSTR == 4 && WTN == 64 && MT * 32 == WTM && NT == 2, "wave-private epilogue: 256 / 320 x 256 tiles, 2 x 4 waves");
+      static_assert((BM == 256 || BM == 320 || BM == 192) && A_INSTR >= 4 && B_INSTR == 4 && WTN == 64 && MT * 32 == WTM && NT == 2, "wave-private epilogue: 256 / 320 x 256 tiles, 2 x 4 waves");
       if constexpr (MODE == EPI_STORE || MODE == EPI_BIAS_GELU || MODE == EPI_BIAS_RESID || MODE == EPI_GELU_BWD) {
         const bool wp_ok = interior && (MODE == EPI_BIAS_RESID || ep.wide_ok) && !(MODE == EPI_STORE && has_bias);
         if (wp_ok) {
@@ -333,7 +368,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_pipe_kernel(Bf16Gem
             bf16_t* const outp = (bf16_t*)ep.out + out_off + (int64_t)row_w * ep.ldo + col_w;
             const uint32_t ldo = (uint32_t)ep.ldo, ooff = (uint32_t)(le >> 3) * ldo + (uint32_t)(le & 7) * 8u;
             auto run = [&](auto nt_c) {
-              constexpr bool NTS = decltype(nt_c)::value;
+              constexpr int POL = decltype(nt_c)::value;
               static_for<MT>([&](auto i_c) {
                 constexpr int i0 = decltype(i_c)::value;
                 char* const ar = (i0 & 1) ? sb : sa;
@@ -350,15 +385,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_pipe_kernel(Bf16Gem
                   v[k] = *(const bf16x8*)(ar + r * 128 + (((le & 7) ^ ((r >> 1) & 7)) << 4));
                 }
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                  bf16x8* dst = (bf16x8*)(outp + (ooff + (uint32_t)(i0 * 32 + k * 8) * ldo));
-                  if constexpr (NTS) __builtin_nontemporal_store(v[k], dst);
-                  else *dst = v[k];
-                }
+                for (int k = 0; k < 4; ++k) wp_store16<POL>(outp, ooff + (uint32_t)(i0 * 32 + k * 8) * ldo, v[k]);
               });
             };
-            if (ep.nt_out) run(std::true_type{});
-            else run(std::false_type{});
+            if (ep.nt_out) run(ic<1>{});
+            else run(ic<0>{});
           } else if constexpr (MODE == EPI_BIAS_GELU) {
             // (the bias values of a 32-column block are re-read for every 32 x 32 accumulator block -- L1 hits -- instead of living in 32 registers
             //  through the epilogue: with them the table form spilled, and a scratch reload is a VMEM load the compiler waits for inside the K loop)
@@ -370,7 +401,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_pipe_kernel(Bf16Gem
             const bool use_tab = GTAB && gelu_tab != nullptr;
             const char* const gt = smem + 2 * STAGE;
             auto run = [&](auto nt_c, auto tab_c) {
-              constexpr bool NTS = decltype(nt_c)::value, TAB = decltype(tab_c)::value;
+              constexpr int POL = decltype(nt_c)::value;
+              constexpr bool TAB = decltype(tab_c)::value;
               static_for<MT>([&](auto i_c) {
                 constexpr int i0 = decltype(i_c)::value;
 #pragma unroll
@@ -419,20 +451,18 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_pipe_kernel(Bf16Gem
                 }
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                  bf16x8* d1 = (bf16x8*)(o1 + (o1off + (uint32_t)(i0 * 32 + k * 8) * ldo));
-                  if constexpr (NTS) __builtin_nontemporal_store(vd[k], d1);
-                  else *d1 = vd[k];
-                  *(bf16x8*)(o2 + (o2off + (uint32_t)(i0 * 32 + k * 8) * ldo2)) = vg[k];
+                  wp_store16<POL>(o1, o1off + (uint32_t)(i0 * 32 + k * 8) * ldo, vd[k]);
+                  wp_store16<0>(o2, o2off + (uint32_t)(i0 * 32 + k * 8) * ldo2, vg[k]);
                 }
               });
             };
             if constexpr (GTAB) {
-              if (use_tab) { if (ep.nt_out) run(std::true_type{}, std::true_type{}); else run(std::false_type{}, std::true_type{}); }
-              else if (ep.nt_out) run(std::true_type{}, std::false_type{});
-              else run(std::false_type{}, std::false_type{});
+              if (use_tab) { if (ep.nt_out) run(ic<1>{}, std::true_type{}); else run(ic<0>{}, std::true_type{}); }
+              else if (ep.nt_out) run(ic<1>{}, std::false_type{});
+              else run(ic<0>{}, std::false_type{});
             } else {
-              if (ep.nt_out) run(std::true_type{}, std::false_type{});
-              else run(std::false_type{}, std::false_type{});
+              if (ep.nt_out) run(ic<1>{}, std::false_type{});
+              else run(ic<0>{}, std::false_type{});
             }
           } else if constexpr (MODE == EPI_BIAS_RESID) {
             // out[f32] = resid + (acc + bias) [* scale]; LayerScale (cait.py:47-48) also keeps f = acc + bias in out2 (epilogue_fast4's arithmetic).
@@ -452,7 +482,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_pipe_kernel(Bf16Gem
               // the 32 rows in steps of 16 (320-row tiles: 8 -- 160 accumulator registers leave room for less); the residual rows of a step are
               // requested before the LDS round trip / under the stores of the step before (a missing bias / scale is the exact identity: + 0, x 1 --
               // one instruction stream for the four combinations)
-              constexpr int RS = BM == 256 ? 16 : 8, NR = RS / 4, NS = 32 / RS;
+              constexpr int RS = BM == 320 ? 8 : 16, NR = RS / 4, NS = 32 / RS;
               float4 x[NR], v[NR];
 #pragma unroll
               for (int k = 0; k < NR; ++k) x[k] = *(const float4*)(rp + (roff + (uint32_t)(i0 * 32 + k * 4) * ldr));
@@ -505,7 +535,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_pipe_kernel(Bf16Gem
                 const float4 a = va[k], b = vb[k];
                 const bf16x8 o = pack_bf16x8(make_float4(a.x * (float)x[k][0], a.y * (float)x[k][1], a.z * (float)x[k][2], a.w * (float)x[k][3]),
                                              make_float4(b.x * (float)x[k][4], b.y * (float)x[k][5], b.z * (float)x[k][6], b.w * (float)x[k][7]));
-                *(bf16x8*)(op + (ooff + (uint32_t)(i0 * 32 + k * 8) * ldo)) = o;
+                wp_store16<0>(op, ooff + (uint32_t)(i0 * 32 + k * 8) * ldo, o);
                 cs.x += (float)o[0]; cs.y += (float)o[1]; cs.z += (float)o[2]; cs.w += (float)o[3];       // as stored (rounded to bf16)
                 cs2.x += (float)o[4]; cs2.y += (float)o[5]; cs2.z += (float)o[6]; cs2.w += (float)o[7];
               }
@@ -582,7 +612,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_pipe_kernel(Bf16Gem
 }
 
 template <int BM, int BN, int WM, int WN, int MODE>
-void launch_pipe(const Bf16GemmArgs& g, const EpiParams& ep, hipStream_t s) {
+void launch_pipe(const Bf16GemmArgs& g, const EpiParams& ep, hipStream_t s, bool one_tile_per_wg = false) {
   constexpr int SMEM = 2 * (BM + BN) * BK * 2 + ((MODE == EPI_BIAS_GELU && BM == 256) ? GT_BYTES : 0);
   // buffer-addressed DMA: 31-bit byte offsets inside each operand; larger operands take the flat-addressed persistent kernel
   if (((int64_t)ceil_div(g.M, BM) * BM * g.lda + g.K) * 2 >= (1LL << 31) || ((int64_t)ceil_div(g.N, BN) * BN * g.ldb + g.K) * 2 >= (1LL << 31)) {
@@ -603,12 +633,17 @@ void launch_pipe(const Bf16GemmArgs& g, const EpiParams& ep, hipStream_t s) {
   static const int phase_env = [] { const char* v = getenv("VITX_GEMM_PHASE"); return v ? atoi(v) : 0; }();
   Bf16GemmArgs gp = g;
   if (gp.phase == 0) gp.phase = phase_env;
-  static const int grid_cap = [] { const char* v = getenv("VITX_GEMM_GRID"); return v ? atoi(v) : 256; }();   // experiment: fewer persistent workgroups
+  static const int walk_env = [] { const char* v = getenv("VITX_GEMM_WALK"); return v ? atoi(v) : -1; }();   // A/B: 0 = interleaved chunks everywhere
+  // (4-wave tiles: 80 KiB of LDS and <= 256 registers per wave, i.e. TWO workgroups per CU -- one's epilogue runs under the other's K loop)
+  static const int grid_cap = [] { const char* v = getenv("VITX_GEMM_GRID"); return v ? atoi(v) : 256 * (WM * WN == 4 ? 2 : 1); }();   // experiment: fewer persistent workgroups
   // Beside collectives (data parallel: RCCL's workgroups hold CUs for as long as a collective runs) a persistent grid with static tile lists waits
   // for the workgroups that could not be placed; one tile per workgroup lets the hardware dispatcher balance.  Same kernel: a workgroup whose tile
   // list has one entry simply never takes the cross-tile path.
-  const unsigned gx = (zs == 1 && !gemm_bf16_shared_gpu()) ? (unsigned)std::min(tiles_m * tiles_n, grid_cap) : (unsigned)(tiles_m * tiles_n);
+  const unsigned gx = (zs == 1 && !gemm_bf16_shared_gpu() && !one_tile_per_wg) ? (unsigned)std::min(tiles_m * tiles_n, grid_cap) : (unsigned)(tiles_m * tiles_n);
   dim3 grid(gx, (unsigned)zs), block(WM * WN * 64);
+  // XCD-owned row bands (walk 2): wide outputs on the full persistent grid with enough row tiles for 8-row bands per XCD
+  const bool walk2_ok = BM == 256 && zs == 1 && gx == (unsigned)grid_cap && (gx & 7) == 0 && gx < (unsigned)(tiles_m * tiles_n) && tiles_n >= 8 && tiles_m >= 64 && g.stagger != 8;
+  gp.walk = (walk2_ok && walk_env != 0) ? 2 : 0;
   static const int gelu_table_on = [] { const char* v = getenv("VITX_GELU_TABLE"); return v ? atoi(v) : 1; }();   // 0: the polynomial form everywhere (A/B)
   const uint32_t* gtab = (MODE == EPI_BIAS_GELU && BM == 256 && gelu_table_on) ? gelu_table_dev() : nullptr;
   hipLaunchKernelGGL(kern, grid, block, SMEM, s, gp, ep, tiles_m, tiles_n, per, gtab);
@@ -617,6 +652,8 @@ void launch_pipe(const Bf16GemmArgs& g, const EpiParams& ep, hipStream_t s) {
 template <int MODE>
 void pipe_mode(int variant, const Bf16GemmArgs& g, const EpiParams& ep, hipStream_t s) {
   switch (variant) {
+    case 9: launch_pipe<192, 128, 2, 2, MODE>(g, ep, s); break;          // two 4-wave workgroups per CU (80 KiB of LDS each), persistent: 512 workgroups
+    case 10: launch_pipe<192, 128, 2, 2, MODE>(g, ep, s, true); break;   // the same, one tile per workgroup (the hardware dispatcher balances the tail)
     case 11: launch_pipe<320, 256, 2, 4, MODE>(g, ep, s); break;   // fewer, taller tiles: 768-wide outputs (474 instead of 591 tiles at 50k rows: 1.85 rounds of 256 CUs)
     default: launch_pipe<256, 256, 2, 4, MODE>(g, ep, s); break;   // 13
   }

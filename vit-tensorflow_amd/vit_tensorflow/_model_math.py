@@ -42,4 +42,12 @@ def kernel_source_id() -> str:
     for f in files:
         with open(f, "rb") as fh:
             h.update(os.path.basename(f).encode() + b"\0" + fh.read())
+    try:   # the compile flags are part of what was built (per-source scheduler strategies, -fno-honor-nans): build.py's own digest of them
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("vitx_build_flags", os.path.join(_HERE, "..", "build.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        h.update(b"flags\0" + mod.flags_id().encode())
+    except Exception:   # a tree without build.py (pre-built library only): the sources alone
+        pass
     return h.hexdigest()[:16]
