@@ -112,6 +112,9 @@ def main():
     ap.add_argument("--graph", action="store_true", help="replay the step as one HIP graph (single GPU; the default launches kernel by kernel)")
     ap.add_argument("--bucket-mb", type=float, default=48.0)
     ap.add_argument("--grad-wire", default="fp32", choices=["fp32", "bf16"], help="dtype of the gradient all-reduce on the wire (N > 1)")
+    ap.add_argument("--dp-impl", default="native", choices=["native", "torch"],
+                    help="gradient exchange (N > 1): native = the library's own bucketed RCCL exchange on its communication stream (csrc/comm.hip); "
+                         "torch = torch.distributed all-reduce per bucket from the gradient-ready callback (vit_tensorflow/parallel.py)")
     args = ap.parse_args()
 
     # The contract is ONE JSON line on stdout.  Native libraries (RCCL prints a version banner through C stdio, flushed at exit)
@@ -124,7 +127,9 @@ def main():
     import torch.distributed as dist
 
     force_dp = bool(os.environ.get("VITX_FORCE_DP"))   # exercise the whole DP path (RCCL group of 1) on a single GPU
-    rank, local, world = init_from_env(force=force_dp)
+    native_dp = args.dp_impl == "native"
+    # native exchange: torch.distributed only carries the rendezvous (RCCL id, initial weights), the barrier and the max over ranks -- gloo on the CPU
+    rank, local, world = init_from_env(backend="gloo" if native_dp else None, force=force_dp)
     if world != args.gpus and rank == 0:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
     if not torch.cuda.is_available():
@@ -154,7 +159,21 @@ def main():
     sync = None
     cb = None
     dp = world > 1 or force_dp
-    if dp:
+    if dp and native_dp:
+        # every rank starts from rank 0's weights (the packed host blob; one-time, over gloo), joins the RCCL group, and from then on the library
+        # exchanges the gradient buckets itself while the backward pass runs
+        blob = np.empty(model._n, dtype=np.float32)
+        N.check(lib.vitx_get_params(h, blob.ctypes.data_as(C.c_void_p), model._n))
+        uid = torch.zeros(128, dtype=torch.uint8)
+        if rank == 0:
+            uid = torch.frombuffer(bytearray(model.comm_unique_id()), dtype=torch.uint8).clone()
+        if world > 1:
+            wt = torch.from_numpy(blob)
+            dist.broadcast(wt, src=0)
+            dist.broadcast(uid, src=0)
+            N.check(lib.vitx_set_params(h, blob.ctypes.data_as(C.c_void_p), model._n))
+        model.comm_init(rank, world, bytes(uid.numpy().tobytes()), overlap=True, bucket_mb=args.bucket_mb, wire=args.grad_wire)
+    elif dp:
         # The engine must run on the stream RCCL orders itself against.  torch's default stream has handle 0, which the C ABI
         # reads as "use the library's own stream", so the data-parallel path runs under an explicit side stream.
         dp_stream = torch.cuda.Stream(device=dev)
@@ -184,6 +203,8 @@ def main():
         N.check(lib.vitx_backward_dev(h, None, None))
         if sync:
             sync.finish()
+        elif dp:
+            N.check(lib.vitx_allreduce_grads(h))   # sends what the backward pass has not, orders the compute stream behind the last bucket
 
     def full_sync():
         N.check(lib.vitx_sync(h))
@@ -215,7 +236,7 @@ def main():
     full_sync()
     el = time.perf_counter() - t0
     if dist.is_initialized():
-        t = torch.tensor([el], device=dev, dtype=torch.float64)
+        t = torch.tensor([el], device=torch.device("cpu") if native_dp else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
 
@@ -228,17 +249,24 @@ def main():
         "dtype": {"bf16": "bf16", "fp32": "f32", "bf16x3": "bf16x3 (fp32 storage, split-operand bf16 MFMA GEMMs)"}[args.compute], "data": "synthetic",
         "config": {"workload": f"{args.workload} fwd+bwd, batch {b}/GPU, N(0,1) NHWC images resident in HBM, random-init weights, "
                                f"softmax-CE cotangent, dropout 0", "global_batch": b * world,
-                   "parallelism": f"dp{world}", "compute": args.compute, **({"launch": "hip_graph"} if (args.graph and not dp) else {}), **({"grad_wire": args.grad_wire} if dp else {})},
+                   "parallelism": f"dp{world}", "compute": args.compute, **({"launch": "hip_graph"} if (args.graph and not dp) else {}), **({"grad_wire": args.grad_wire, "dp_impl": args.dp_impl} if dp else {})},
         "path_mfma_frac": round(value / world * fpi / MFMA_BF16_PEAK, 4),
         "flops_per_image": fpi,
     }
     if priming:
         out["priming_steps"] = priming
+    if dp and native_dp:
+        st = (C.c_int64 * 4)()
+        N.check(lib.vitx_comm_stats(h, st))
+        out["config"]["exchange"] = {"buckets": int(st[0]), "sent_during_backward": int(st[1]), "bucket_mib": round(st[2] * 4 / (1 << 20), 1),
+                                     "dense_launches_beside_a_collective": int(st[3])}
 
     if rank == 0 and not args.no_profile:
         try:   # per-kernel-class HIP-event timing of two more steps (outside the timed region)
             if sync:
                 N.check(lib.vitx_set_grad_ready_callback(h, C.cast(None, N.GRAD_READY_FN), None))
+            elif dp:
+                N.check(lib.vitx_comm_overlap(h, 0, 0, 0))   # the per-class timing below is of the compute kernels alone
             psteps = 2
             N.check(lib.vitx_profile_begin(h))
             for _ in range(psteps):

@@ -228,7 +228,15 @@ int32_t vitx_graph_destroy(void* graph_exec);
 int32_t vitx_set_grad_ready_callback(vitx_handle h, vitx_grad_ready_fn fn, void* user);
 int32_t vitx_comm_unique_id(void* out_128_bytes);
 int32_t vitx_comm_init(vitx_handle h, int32_t rank, int32_t world, const void* unique_id_128_bytes);
-int32_t vitx_allreduce_grads(vitx_handle h); /* RCCL sum over ranks, then x 1/world */
+/* Overlapped exchange (SURVEY.md 8(e), Appendix B "grads live in one contiguous arena ... buckets are contiguous slices; side stream + events"):
+ * enable != 0 -> from the next backward on, every bucket of the gradient arena is all-reduced (and scaled by 1/world) on the handle's own
+ * communication stream the moment the backward pass has enqueued its last producer; vitx_allreduce_grads then only sends what is left and orders the
+ * compute stream behind the last bucket.  bucket_bytes: fp32 bytes per bucket (0 = 32 MiB); wire_bf16 != 0: the collective moves bf16 copies
+ * (half the xGMI bytes; each rank's addend is rounded once).  Call after vitx_comm_init, between steps. */
+int32_t vitx_comm_overlap(vitx_handle h, int32_t enable, int64_t bucket_bytes, int32_t wire_bf16);
+/* out4 = {buckets, buckets the last exchange sent from inside the backward pass, elements per bucket, Dense launches that found a collective in flight} */
+int32_t vitx_comm_stats(vitx_handle h, int64_t* out4);
+int32_t vitx_allreduce_grads(vitx_handle h); /* RCCL mean over ranks of the gradient arena (bucketed; finishes an overlapped exchange) */
 
 /* ---- measurement / debugging */
 int32_t vitx_profile_begin(vitx_handle h);

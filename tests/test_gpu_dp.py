@@ -154,3 +154,96 @@ def test_native_comm_entry_points_group_of_one():
     N.check(lib.vitx_get_grads(h, g.ctypes.data_as(C.c_void_p), m._n))
     for n, s, o in m._table:
         assert np.array_equal(g[o:o + int(np.prod(s))].reshape(s), before[n]), n
+
+
+# ------------------------------------------------------------------------------------------------ the library's own overlapped exchange (csrc/comm.hip)
+@pytest.mark.parametrize("wire", ["fp32", "bf16"])
+def test_native_overlapped_exchange_group_of_one(wire):
+    """vitx_comm_overlap: buckets of the gradient arena go out on the handle's communication stream from INSIDE the backward pass (the engine's own
+    gradient-ready points; no Python, no torch.distributed), vitx_allreduce_grads sends the rest and orders the compute stream behind the last one.
+    Group of one: the exchanged gradients equal the plain ones (fp32 wire: bit for bit; bf16 wire: one rounding per value)."""
+    import ctypes as C
+    from vit_tensorflow import ViT, _native as N
+    kw = dict(image_size=64, patch_size=16, num_classes=10, dim=128, depth=3, heads=2, mlp_dim=256, dim_head=64)
+    rng = np.random.default_rng(3)
+    img = rng.standard_normal((4, 64, 64, 3)).astype(np.float32)
+    dl = (rng.standard_normal((4, 10)) / 4).astype(np.float32)
+    plain = ViT(**kw, compute="bf16", max_batch=4, seed=5)
+    plain(img, training=False)
+    ref, _ = plain.backward(dl)
+    m = ViT(**kw, compute="bf16", max_batch=4, seed=5)
+    m.build((4,))
+    m.comm_init(0, 1, ViT.comm_unique_id(), overlap=True, bucket_mb=64 / 1024, wire=wire)   # 64-KiB buckets: dozens per backward pass
+    st = (C.c_int64 * 4)()
+    for _ in range(2):                                                                     # twice: the bucket state resets between steps
+        m(img, training=False)
+        got, _ = m.backward(dl)                                                            # finishes the exchange (vitx_allreduce_grads)
+        N.check(N.lib().vitx_comm_stats(m._handle, st))
+        assert st[0] >= 8 and st[2] == 64 * 1024 // 4, list(st)
+        assert st[1] >= st[0] // 2, f"only {st[1]} of {st[0]} buckets left during the backward pass"
+        for k in ref:
+            if wire == "fp32":
+                assert np.array_equal(got[k], ref[k]), k
+            else:
+                assert np.abs(got[k] - ref[k]).max() <= 2.0 ** -8 * np.abs(ref[k]).max() + 1e-30, k
+    # misuse: a second backward before the exchange of the first is finished is reported by the next vitx_allreduce_grads, and the state recovers
+    lib, h = N.lib(), m._handle
+    dlc = np.ascontiguousarray(dl)
+    m(img, training=False)
+    N.check(lib.vitx_backward(h, dlc.ctypes.data_as(C.c_void_p), None))
+    N.check(lib.vitx_backward(h, dlc.ctypes.data_as(C.c_void_p), None))
+    with pytest.raises(N.VitxError, match="one vitx_allreduce_grads per backward"):
+        N.check(lib.vitx_allreduce_grads(h))
+    m(img, training=False)
+    got, _ = m.backward(dl)
+    for k in ref:
+        assert np.abs(got[k] - ref[k]).max() <= 2.0 ** -8 * np.abs(ref[k]).max() + 1e-30, k
+
+
+NATIVE_WORKER = r'''
+import ctypes as C, os, sys, time
+import numpy as np
+root, out, gb = sys.argv[1], sys.argv[2], int(sys.argv[3])
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+sys.path[:0] = [root, os.path.join(root, "vit-tensorflow_amd"), os.path.join(root, "tests")]
+from vit_tensorflow import ViT, _native as N
+kw = dict(image_size=64, patch_size=16, num_classes=10, dim=128, depth=3, heads=2, mlp_dim=256, dim_head=64)
+b = gb // world
+m = ViT(**kw, compute="bf16", max_batch=b, device=rank, seed=1)          # same seed: identical replicas (the RCCL id travels through a file)
+m.build((b,))
+uid_path = os.path.join(out, "uid.bin")
+if rank == 0:
+    open(uid_path + ".tmp", "wb").write(ViT.comm_unique_id()); os.replace(uid_path + ".tmp", uid_path)
+while not os.path.exists(uid_path): time.sleep(0.05)
+m.comm_init(rank, world, open(uid_path, "rb").read(), overlap=True, bucket_mb=0.25, wire="fp32")
+rng = np.random.Generator(np.random.PCG64(5))
+img_all = rng.standard_normal((gb, 64, 64, 3)).astype(np.float32)
+lab_all = rng.integers(0, 10, gb)
+sl = slice(rank * b, (rank + 1) * b)
+for _ in range(2):
+    logits = np.asarray(m(img_all[sl], training=False), np.float64)
+    p = np.exp(logits - logits.max(-1, keepdims=True)); p /= p.sum(-1, keepdims=True)
+    dl = ((p - np.eye(10)[lab_all[sl]]) / b).astype(np.float32)           # mean over the LOCAL batch; the exchange averages over the ranks
+    grads, _ = m.backward(dl)
+np.save(os.path.join(out, f"native_grads_rank{rank}.npy"), np.concatenate([grads[n].reshape(-1) for n, _, _ in m._table]))
+if rank == 0:
+    np.save(os.path.join(out, "params.npy"), np.concatenate([m.state_dict()[n].reshape(-1) for n, _, _ in m._table]))
+    np.save(os.path.join(out, "img.npy"), img_all); np.save(os.path.join(out, "lab.npy"), lab_all)
+'''
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two visible GPUs (the round-end multi-GPU node)")
+def test_native_exchange_two_ranks_equals_one_rank(tmp_path):
+    """The library's own exchange over a real two-rank RCCL group: 2 ranks x 2 images, per-rank mean gradients averaged over the ranks == 1 rank x 4."""
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, "-c", NATIVE_WORKER, ROOT, str(tmp_path), "4"], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    for p in procs:
+        out, _ = p.communicate(timeout=600)
+        assert p.returncode == 0, out[-3000:]
+    g0, g1 = np.load(tmp_path / "native_grads_rank0.npy"), np.load(tmp_path / "native_grads_rank1.npy")
+    assert np.array_equal(g0, g1), "ranks must hold identical reduced gradients"
+    ref = _single_process_gradient(tmp_path)
+    assert np.abs(g0 - ref).max() <= 2e-2 * np.abs(ref).max()

@@ -657,62 +657,46 @@ int32_t vitx_set_grad_ready_callback(vitx_handle h, vitx_grad_ready_fn fn, void*
   return VITX_OK;
 }
 
-// ---- RCCL (loaded lazily: libvitx itself does not link against it)
-struct uid128_t { char b[128]; };   // ncclUniqueId (NCCL_UNIQUE_ID_BYTES = 128), passed by value to ncclCommInitRank
-static void* rccl_handle() {
-  static void* lib = nullptr;
-  if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
-  if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
-  if (!lib) lib = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_LOCAL);
-  return lib;
-}
-
+// ---- data parallel: the library's own RCCL exchange (comm.hip; librccl is dlopen'ed, libvitx does not link against it)
 int32_t vitx_comm_unique_id(void* out128) {
   CAPI_TRY
-  void* lib = rccl_handle();
-  if (!lib) return fail(VITX_ERR_COMM, "cannot dlopen librccl.so");
-  auto get = (int (*)(uid128_t*))dlsym(lib, "ncclGetUniqueId");
-  if (!get) return fail(VITX_ERR_COMM, "ncclGetUniqueId not found");
-  uid128_t id;
-  if (get(&id) != 0) return fail(VITX_ERR_COMM, "ncclGetUniqueId failed");
-  std::memcpy(out128, &id, 128);
-  return VITX_OK;
+  if (!out128) return fail(VITX_ERR_INVALID, "null argument");
+  std::string err;
+  const int rc = comm_unique_id(out128, err);
+  return rc == VITX_OK ? VITX_OK : fail(rc, err);
   CAPI_CATCH
 }
 
 int32_t vitx_comm_init(vitx_handle h, int32_t rank, int32_t world, const void* uid) {
   CAPI_TRY
   if (!h || !uid) return fail(VITX_ERR_INVALID, "null argument");
-  void* lib = rccl_handle();
-  if (!lib) return fail(VITX_ERR_COMM, "cannot dlopen librccl.so");
-  auto init = (int (*)(void**, int, uid128_t, int))dlsym(lib, "ncclCommInitRank");
-  if (!init) return fail(VITX_ERR_COMM, "ncclCommInitRank not found");
-  uid128_t id;
-  std::memcpy(&id, uid, 128);
-  CAPI_HIP(hipSetDevice(h->cfg.device_id));
-  void* comm = nullptr;
-  if (init(&comm, world, id, rank) != 0) return fail(VITX_ERR_COMM, "ncclCommInitRank failed");
-  h->rccl_lib = lib;
-  h->comm = comm;
-  h->rank = rank;
-  h->world = world;
-  return VITX_OK;
+  std::string err;
+  const int rc = comm_init(h, rank, world, uid, err);
+  return rc == VITX_OK ? VITX_OK : fail(rc, err);
   CAPI_CATCH
+}
+
+int32_t vitx_comm_overlap(vitx_handle h, int32_t enable, int64_t bucket_bytes, int32_t wire_bf16) {
+  CAPI_TRY
+  if (!h) return fail(VITX_ERR_INVALID, "null handle");
+  std::string err;
+  const int rc = comm_overlap(h, enable, bucket_bytes, wire_bf16, err);
+  return rc == VITX_OK ? VITX_OK : fail(rc, err);
+  CAPI_CATCH
+}
+
+int32_t vitx_comm_stats(vitx_handle h, int64_t* out4) {
+  if (!h || !out4) return fail(VITX_ERR_INVALID, "null argument");
+  comm_stats(h, out4);
+  return VITX_OK;
 }
 
 int32_t vitx_allreduce_grads(vitx_handle h) {
   CAPI_TRY
   if (!h) return fail(VITX_ERR_INVALID, "null handle");
-  if (!h->comm) return fail(VITX_ERR_STATE, "vitx_comm_init has not been called");
-  // ncclAllReduce(sendbuff, recvbuff, count, ncclFloat32 = 7, ncclSum = 0, comm, stream)
-  auto ar = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))dlsym(h->rccl_lib, "ncclAllReduce");
-  if (!ar) return fail(VITX_ERR_COMM, "ncclAllReduce not found");
-  if (ar(h->grads, h->grads, (size_t)h->n_arena, 7, 0, h->comm, h->stream) != 0) return fail(VITX_ERR_COMM, "ncclAllReduce failed");
-  if (h->world > 1) {
-    // x 1/world: reuse the partial reducer as a scale kernel (nparts = 1)
-    launch_reduce_partials(h->grads, 1, 0, h->n_arena, h->grads, 1.0f / (float)h->world, h->stream);
-  }
-  return VITX_OK;
+  std::string err;
+  const int rc = comm_finish(h, err);
+  return rc == VITX_OK ? VITX_OK : fail(rc, err);
   CAPI_CATCH
 }
 

@@ -1,0 +1,259 @@
+// Native data-parallel gradient exchange (SURVEY.md 8(b) "handle owns its ... RCCL communicator", 8(e), Appendix B): batch-sharded replicas, ONE
+// exchange step per training step -- the mean of the gradient arena over the ranks -- done by the library itself:
+//   * the arena is cut into fixed buckets (contiguous slices; the arena is laid out in reverse execution order of the backward, so buckets complete
+//     front to back of the backward pass and no pack copy is needed);
+//   * the engine reports arena ranges as their last producing kernel is enqueued (report_ready, engine.hip -- the same points the Python callback of
+//     vit_tensorflow/parallel.py hangs on); the moment a bucket is fully covered, an event is recorded on the compute stream, the COMMUNICATION stream
+//     waits for it and runs [fp32 -> bf16 wire copy] -> ncclAllReduce (RCCL, in place) -> [widen + x 1/world | x 1/world] for that bucket, so the
+//     collective of block i runs under the backward of blocks i-1, i-2, ...;
+//   * vitx_allreduce_grads() launches whatever was not reported, then makes the compute stream wait for the last bucket.
+// Without vitx_comm_overlap the same entry point is the one-shot exchange behind the backward (every bucket at once).
+// The reference has no distributed code: semantics are by equivalence -- N ranks x b/N images with mean-reduced gradients == one
+// device on the concatenated batch.  xGMI is point-to-point (7 links x ~153 GB/s per GPU): buckets are tens of MB so that RCCL spreads each one over all
+// links / channels instead of paying per-message latency; the bf16 wire halves the bytes (173 instead of 346 MB at ViT-B/16).
+// librccl is dlopen'ed (libvitx does not link against it); torch.distributed is NOT involved on this path.
+#include <dlfcn.h>
+
+#include <cstring>
+
+#include "engine.h"
+
+#define HIPCHK_ERR(x, err)                                                 \
+  do {                                                                     \
+    hipError_t e_ = (x);                                                   \
+    if (e_ != hipSuccess) {                                                \
+      (err) = std::string(#x) + ": " + hipGetErrorString(e_);              \
+      return VITX_ERR_HIP;                                                 \
+    }                                                                      \
+  } while (0)
+
+namespace {
+
+struct uid128_t { char b[128]; };   // ncclUniqueId (NCCL_UNIQUE_ID_BYTES = 128), passed by value to ncclCommInitRank
+constexpr int NCCL_FLOAT32 = 7, NCCL_BFLOAT16 = 9, NCCL_SUM = 0;   // ncclDataType_t / ncclRedOp_t values of RCCL's nccl.h
+typedef int (*all_reduce_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
+
+void* rccl_handle() {
+  static void* lib = nullptr;
+  if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+  if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+  if (!lib) lib = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_LOCAL);
+  return lib;
+}
+
+__global__ __launch_bounds__(256) void comm_to_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int64_t n4) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const float4 v = *(const float4*)(src + 4 * i);
+    st4<bf16_t>(dst + 4 * i, v);
+  }
+}
+__global__ __launch_bounds__(256) void comm_from_bf16_kernel(const bf16_t* __restrict__ src, float* __restrict__ dst, int64_t n4, float alpha) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const float4 v = ld4<bf16_t>(src + 4 * i);
+    *(float4*)(dst + 4 * i) = make_float4(v.x * alpha, v.y * alpha, v.z * alpha, v.w * alpha);
+  }
+}
+__global__ __launch_bounds__(256) void comm_scale_kernel(float* __restrict__ x, int64_t n4, float alpha) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    float4 v = *(float4*)(x + 4 * i);
+    *(float4*)(x + 4 * i) = make_float4(v.x * alpha, v.y * alpha, v.z * alpha, v.w * alpha);
+  }
+}
+inline unsigned grid_for(int64_t n4) { return (unsigned)std::min<int64_t>(2048, std::max<int64_t>(1, (n4 + 255) / 256)); }
+
+int64_t bucket_size(const vitx_engine* e, int i) { return std::min<int64_t>(e->cm.bucket, e->n_arena - (int64_t)i * e->cm.bucket); }
+
+// bucket i is final on the compute stream: hand it to the communication stream
+int launch_bucket(vitx_engine* e, int i, std::string& err) {
+  CommState& c = e->cm;
+  if (c.launched[(size_t)i]) return VITX_OK;
+  c.launched[(size_t)i] = 1;
+  auto ar = (all_reduce_fn)c.all_reduce;
+  const int64_t lo = (int64_t)i * c.bucket, n = bucket_size(e, i);   // n_arena and the bucket size are multiples of 4 elements
+  float* g = e->grads + lo;
+  HIPCHK_ERR(hipEventRecord(c.ready_ev[(size_t)i], e->stream), err);
+  HIPCHK_ERR(hipStreamWaitEvent(c.stream, c.ready_ev[(size_t)i], 0), err);
+  const float alpha = 1.0f / (float)e->world;
+  if (c.wire_bf16) {
+    bf16_t* w = c.wire + lo;
+    hipLaunchKernelGGL(comm_to_bf16_kernel, dim3(grid_for(n / 4)), dim3(256), 0, c.stream, g, w, n / 4);
+    if (ar(w, w, (size_t)n, NCCL_BFLOAT16, NCCL_SUM, e->comm, c.stream) != 0) { err = "ncclAllReduce (bf16 wire) failed"; return VITX_ERR_COMM; }
+    hipLaunchKernelGGL(comm_from_bf16_kernel, dim3(grid_for(n / 4)), dim3(256), 0, c.stream, w, g, n / 4, alpha);
+  } else {
+    if (ar(g, g, (size_t)n, NCCL_FLOAT32, NCCL_SUM, e->comm, c.stream) != 0) { err = "ncclAllReduce failed"; return VITX_ERR_COMM; }
+    if (e->world > 1) hipLaunchKernelGGL(comm_scale_kernel, dim3(grid_for(n / 4)), dim3(256), 0, c.stream, g, n / 4, alpha);
+  }
+  HIPCHK_ERR(hipEventRecord(c.done_ev[(size_t)i], c.stream), err);
+  c.last_launched = i;
+  ++c.n_launched;
+  return VITX_OK;
+}
+
+int ensure_state(vitx_engine* e, std::string& err) {
+  CommState& c = e->cm;
+  if (!c.all_reduce) {
+    c.all_reduce = dlsym(e->rccl_lib, "ncclAllReduce");
+    if (!c.all_reduce) { err = "ncclAllReduce not found"; return VITX_ERR_COMM; }
+  }
+  if (!c.stream) {
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);   // (numerically lowest = highest priority): the few workgroups of a collective should not queue behind a GEMM's
+    HIPCHK_ERR(hipStreamCreateWithPriority(&c.stream, hipStreamNonBlocking, hi), err);
+  }
+  if (c.bucket <= 0) c.bucket = 8LL << 20;   // 32 MiB of fp32
+  const int nb = (int)((e->n_arena + c.bucket - 1) / c.bucket);
+  if ((int)c.launched.size() != nb) {
+    for (auto ev : c.ready_ev) (void)hipEventDestroy(ev);
+    for (auto ev : c.done_ev) (void)hipEventDestroy(ev);
+    c.ready_ev.assign((size_t)nb, nullptr);
+    c.done_ev.assign((size_t)nb, nullptr);
+    for (int i = 0; i < nb; ++i) {
+      HIPCHK_ERR(hipEventCreateWithFlags(&c.ready_ev[(size_t)i], hipEventDisableTiming), err);
+      HIPCHK_ERR(hipEventCreateWithFlags(&c.done_ev[(size_t)i], hipEventDisableTiming), err);
+    }
+    c.covered.assign((size_t)nb, 0);
+    c.launched.assign((size_t)nb, 0);
+    c.last_launched = -1;
+    c.n_launched = 0;
+  }
+  if (c.wire_bf16 && !c.wire) {
+    HIPCHK_ERR(hipMalloc((void**)&c.wire, (size_t)e->n_arena * sizeof(bf16_t)), err);
+  }
+  return VITX_OK;
+}
+
+}  // namespace
+
+int comm_unique_id(void* out128, std::string& err) {
+  void* lib = rccl_handle();
+  if (!lib) { err = "cannot dlopen librccl.so"; return VITX_ERR_COMM; }
+  auto get = (int (*)(uid128_t*))dlsym(lib, "ncclGetUniqueId");
+  if (!get) { err = "ncclGetUniqueId not found"; return VITX_ERR_COMM; }
+  uid128_t id;
+  if (get(&id) != 0) { err = "ncclGetUniqueId failed"; return VITX_ERR_COMM; }
+  std::memcpy(out128, &id, 128);
+  return VITX_OK;
+}
+
+int comm_init(vitx_engine* e, int rank, int world, const void* uid, std::string& err) {
+  if (world < 1 || rank < 0 || rank >= world) { err = "vitx_comm_init: need 0 <= rank < world"; return VITX_ERR_INVALID; }
+  if (e->comm) { err = "vitx_comm_init: this handle already has a communicator"; return VITX_ERR_STATE; }
+  void* lib = rccl_handle();
+  if (!lib) { err = "cannot dlopen librccl.so"; return VITX_ERR_COMM; }
+  auto init = (int (*)(void**, int, uid128_t, int))dlsym(lib, "ncclCommInitRank");
+  if (!init) { err = "ncclCommInitRank not found"; return VITX_ERR_COMM; }
+  uid128_t id;
+  std::memcpy(&id, uid, 128);
+  HIPCHK_ERR(hipSetDevice(e->cfg.device_id), err);
+  void* comm = nullptr;
+  if (init(&comm, world, id, rank) != 0) { err = "ncclCommInitRank failed"; return VITX_ERR_COMM; }
+  e->rccl_lib = lib;
+  e->comm = comm;
+  e->rank = rank;
+  e->world = world;
+  return VITX_OK;
+}
+
+// enable != 0: buckets are exchanged from inside the backward pass as they complete.  bucket_bytes: fp32 bytes per bucket (0 = 32 MiB); wire_bf16: the
+// collective moves bf16 (rounded once per rank: 2^-9 relative per addend -- the usual price of a compressed gradient exchange; default fp32).
+int comm_overlap(vitx_engine* e, int enable, int64_t bucket_bytes, int wire_bf16, std::string& err) {
+  if (!e->comm) { err = "vitx_comm_init has not been called"; return VITX_ERR_STATE; }
+  CommState& c = e->cm;
+  if (c.n_launched) { err = "vitx_comm_overlap: an exchange is in progress (call vitx_allreduce_grads first)"; return VITX_ERR_STATE; }
+  if (bucket_bytes < 0 || (bucket_bytes > 0 && bucket_bytes < 4096)) { err = "vitx_comm_overlap: bucket_bytes must be 0 (default) or >= 4096"; return VITX_ERR_INVALID; }
+  const int64_t bucket = bucket_bytes > 0 ? (bucket_bytes / 4 + 3) / 4 * 4 : (8LL << 20);
+  if (bucket != c.bucket) { c.bucket = bucket; c.launched.clear(); }   // (re-sized in ensure_state)
+  c.wire_bf16 = wire_bf16 != 0;
+  const int rc = ensure_state(e, err);
+  if (rc != VITX_OK) return rc;
+  std::fill(c.covered.begin(), c.covered.end(), 0);
+  c.overlap = enable != 0;
+  return VITX_OK;
+}
+
+// engine.hip, report_ready: arena range [off, off + cnt) is final on the compute stream (every producing kernel has been enqueued there)
+void comm_on_ready(vitx_engine* e, int64_t off, int64_t cnt) {
+  CommState& c = e->cm;
+  if (!c.overlap || c.launched.empty()) return;
+  const int64_t lo = std::max<int64_t>(0, off), hi = std::min<int64_t>(e->n_arena, off + cnt);
+  if (hi <= lo) return;
+  std::string err;
+  for (int64_t i = lo / c.bucket; i <= (hi - 1) / c.bucket; ++i) {
+    const int64_t b0 = i * c.bucket, b1 = b0 + bucket_size(e, (int)i);
+    if (c.launched[(size_t)i]) {   // this bucket has already gone out: a second backward pass ran before the exchange of the first was finished
+      c.failed = "a backward pass ran before vitx_allreduce_grads finished the exchange of the previous one (one vitx_allreduce_grads per backward)";
+      return;
+    }
+    c.covered[(size_t)i] += std::max<int64_t>(0, std::min(hi, b1) - std::max(lo, b0));
+    if (c.covered[(size_t)i] >= b1 - b0)
+      if (launch_bucket(e, (int)i, err) != VITX_OK) { c.failed = err; return; }
+  }
+}
+
+// 1 while a collective launched by this handle may still hold CUs (the newest bucket's completion event has not fired): the Dense launches next to it
+// use one-tile-per-workgroup grids (a persistent grid with static tile lists would wait for the workgroups RCCL's kernels keep off their CUs)
+int comm_busy(vitx_engine* e) {
+  CommState& c = e->cm;
+  if (!c.overlap || c.last_launched < 0) return 0;
+  static const int honour = [] { const char* v = getenv("VITX_COMM_SHARED"); return v ? atoi(v) : 1; }();   // 0: persistent grids even beside a collective (A/B)
+  if (!honour) return 0;
+  const int busy = hipEventQuery(c.done_ev[(size_t)c.last_launched]) == hipErrorNotReady ? 1 : 0;
+  c.busy_hits += busy;
+  return busy;
+}
+
+// vitx_allreduce_grads: finish (overlapped mode) or perform (one-shot mode) the exchange; on return the compute stream is ordered behind it
+int comm_finish(vitx_engine* e, std::string& err) {
+  if (!e->comm) { err = "vitx_comm_init has not been called"; return VITX_ERR_STATE; }
+  int rc = ensure_state(e, err);
+  if (rc != VITX_OK) return rc;
+  CommState& c = e->cm;
+  if (!c.failed.empty()) {
+    err = c.failed;
+    c.failed.clear();
+    (void)hipStreamSynchronize(c.stream);
+    std::fill(c.covered.begin(), c.covered.end(), 0);
+    std::fill(c.launched.begin(), c.launched.end(), 0);
+    c.last_launched = -1;
+    c.n_launched = 0;
+    return VITX_ERR_COMM;
+  }
+  const int nb = (int)c.launched.size();
+  c.last_overlapped = c.n_launched;   // buckets that went out from inside the backward pass
+  for (int i = 0; i < nb; ++i)
+    if ((rc = launch_bucket(e, i, err)) != VITX_OK) return rc;
+  // the communication stream runs its buckets in order: the newest completion event covers them all
+  if (c.last_launched >= 0) HIPCHK_ERR(hipStreamWaitEvent(e->stream, c.done_ev[(size_t)c.last_launched], 0), err);
+  std::fill(c.covered.begin(), c.covered.end(), 0);
+  std::fill(c.launched.begin(), c.launched.end(), 0);
+  c.last_launched = -1;
+  c.n_launched = 0;
+  return VITX_OK;
+}
+
+// {buckets, buckets the last exchange sent from inside the backward pass, elements per bucket, Dense launches that found a collective in flight}
+void comm_stats(vitx_engine* e, int64_t* out4) {
+  const CommState& c = e->cm;
+  out4[0] = (int64_t)c.launched.size();
+  out4[1] = c.last_overlapped;
+  out4[2] = c.bucket;
+  out4[3] = c.busy_hits;
+}
+
+void comm_destroy(vitx_engine* e) {
+  CommState& c = e->cm;
+  if (c.stream) (void)hipStreamSynchronize(c.stream);
+  for (auto ev : c.ready_ev) (void)hipEventDestroy(ev);
+  for (auto ev : c.done_ev) (void)hipEventDestroy(ev);
+  c.ready_ev.clear();
+  c.done_ev.clear();
+  if (c.wire) (void)hipFree(c.wire);
+  c.wire = nullptr;
+  if (c.stream) (void)hipStreamDestroy(c.stream);
+  c.stream = nullptr;
+  if (e->comm && e->rccl_lib) {
+    auto destroy = (int (*)(void*))dlsym(e->rccl_lib, "ncclCommDestroy");
+    if (destroy) (void)destroy(e->comm);
+  }
+  e->comm = nullptr;
+}

@@ -19,6 +19,22 @@ struct ParamDesc {
 // Returns "" on success or the reference's assertion text on an invalid config.
 std::string build_param_table(const vitx_config& c, std::vector<ParamDesc>& out);
 
+// native data-parallel exchange (comm.hip)
+struct CommState {
+  hipStream_t stream = nullptr;      // the collectives' stream (high priority)
+  void* all_reduce = nullptr;        // ncclAllReduce (dlsym)
+  int overlap = 0;                   // 1: buckets are launched from inside the backward pass as they complete
+  int64_t bucket = 0;                // elements per bucket (multiple of 4)
+  int wire_bf16 = 0;
+  bf16_t* wire = nullptr;            // [n_arena] bf16 wire copies (allocated on first use)
+  std::vector<int64_t> covered;      // per bucket: elements reported final
+  std::vector<char> launched;
+  std::vector<hipEvent_t> ready_ev, done_ev;
+  int last_launched = -1, n_launched = 0, last_overlapped = 0;
+  int64_t busy_hits = 0;
+  std::string failed;                // error of a launch made from inside the backward (surfaced by the next vitx_allreduce_grads)
+};
+
 struct Dense {
   int in = 0, out = 0;
   int in_k = 0, out_k = 0;          // padded to 64 (K extents of the bf16 GEMMs)
@@ -208,7 +224,18 @@ struct vitx_engine {
   // data parallel
   vitx_grad_ready_fn grad_cb = nullptr; void* grad_cb_user = nullptr;
   void* rccl_lib = nullptr; void* comm = nullptr; int rank = 0, world = 1;
+  CommState cm;
 };
+
+// comm.hip: the library's own gradient exchange (RCCL, dlopen'ed)
+int comm_unique_id(void* out128, std::string& err);
+int comm_init(vitx_engine* e, int rank, int world, const void* uid, std::string& err);
+int comm_overlap(vitx_engine* e, int enable, int64_t bucket_bytes, int wire_bf16, std::string& err);
+void comm_on_ready(vitx_engine* e, int64_t off, int64_t cnt);
+int comm_busy(vitx_engine* e);
+int comm_finish(vitx_engine* e, std::string& err);
+void comm_stats(vitx_engine* e, int64_t* out4);
+void comm_destroy(vitx_engine* e);
 
 int engine_create(const vitx_config& cfg, vitx_engine** out, std::string& err);
 void engine_destroy(vitx_engine* e);

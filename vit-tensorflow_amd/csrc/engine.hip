@@ -317,18 +317,23 @@ static void side_rotate(vitx_engine* e, SideRing& r, P*& ptr) {
   if (r.pend[r.cur]) { (void)hipStreamWaitEvent(e->stream, r.rd[r.cur], 0); r.pend[r.cur] = false; }
   ptr = (P*)r.slot[r.cur];
 }
+// an arena range is final on the compute stream: the library's own bucketed exchange (comm.hip) and / or the caller's callback
+static void notify_ready(vitx_engine* e, int64_t off, int64_t cnt) {
+  if (e->cm.overlap) comm_on_ready(e, off, cnt);
+  if (e->grad_cb) e->grad_cb(e->grad_cb_user, off, cnt);
+}
 static void side_flush_ready(vitx_engine* e, size_t keep) {
   while (e->side_ready.size() > keep) {
     PendingReady pr = e->side_ready.front();
     e->side_ready.erase(e->side_ready.begin());
     (void)hipStreamWaitEvent(e->stream, pr.ev, 0);
-    if (e->grad_cb) e->grad_cb(e->grad_cb_user, pr.off, pr.cnt);
+    notify_ready(e, pr.off, pr.cnt);
   }
 }
 // gradient-ready report of an arena range whose weight gradients may still be queued on the side stream
 static void report_ready(vitx_engine* e, int64_t off, int64_t cnt) {
-  if (!e->grad_cb) return;
-  if (!e->side_live) { e->grad_cb(e->grad_cb_user, off, cnt); return; }
+  if (!e->grad_cb && !e->cm.overlap) return;
+  if (!e->side_live) { notify_ready(e, off, cnt); return; }
   hipEvent_t ev = side_event(e);
   (void)hipEventRecord(ev, e->side);
   e->side_ready.push_back({off, cnt, ev});
@@ -398,13 +403,31 @@ static void block_layernorm_bwd(vitx_engine* e, const void* dy, int T, int d, co
 // ------------------------------------------------------------------------------------------------
 // Dense layer = x @ kernel[in,out] + bias (Keras nn.Dense; vit.py:39,42,59,63,143,156) and its VJPs
 
+
+// Algorithmic HBM bytes of one fused Dense launch: every operand read once and every output written once AT ITS STORAGE WIDTH, the operands of the
+// fused epilogue included (the fp32 residual read + fp32 result of vit.py:101-102, the two bf16 outputs of the fc1 epilogue, the stored gelu' the
+// fc2 input gradient multiplies by).  Until round 4 this was A + W + one bf16 output for every launch, which under-counted the fused launches by
+// 1.4x (423 against 306 MB per launch of the family at ViT-B/16, batch 256) -- and made the PMC traffic look 1.8x "wasted" where it is 1.3x.
+static double dense_launch_bytes(const vitx_engine* e, int mode, const EpiParams& ep, double rows, double k, double n) {
+  const double esz = e->esz;
+  double b = rows * k * esz + k * n * esz;                      // A, W
+  switch (mode) {
+    case EPI_BIAS_GELU: b += 2.0 * rows * n * esz; break;        // act (or h) and gelu'(h)
+    case EPI_BIAS_RESID: b += 2.0 * rows * n * 4.0 + ((ep.scale && ep.out2) ? rows * n * esz : 0.0); break;   // fp32 residual in, fp32 out (+ LayerScale's f)
+    case EPI_GELU_BWD: b += 2.0 * rows * n * esz; break;         // stored gelu' (or h) in, d h out
+    case EPI_STORE_F32: case EPI_PATCH: b += rows * n * 4.0; break;
+    default: b += rows * n * esz; break;
+  }
+  return b;
+}
+
 // ------------------------------------------------------------------------------------------------
 static void dense_fwd(vitx_engine* e, const void* X, int64_t ldx, int rows, const Dense& w, int mode, EpiParams ep) {
   ep.M = rows;
   ep.N = w.out;
   if (mode != EPI_GELU_BWD) ep.bias = dense_b(e, w);
   const double flops = 2.0 * rows * (double)w.out * w.in;
-  const double bytes = (double)rows * w.in * e->esz + (double)rows * w.out * e->esz + (double)w.in * w.out * e->esz;
+  const double bytes = dense_launch_bytes(e, mode, ep, rows, w.in, w.out);
   if (e->bf16 && !e->force_generic_gemm) {
     Bf16GemmArgs g;
     g.A = (const bf16_t*)X; g.lda = ldx;
@@ -412,6 +435,7 @@ static void dense_fwd(vitx_engine* e, const void* X, int64_t ldx, int rows, cons
     g.M = rows; g.N = w.out; g.K = w.in_k; g.kernel = e->gemm_kernel;
     g.reverse_m = (e->reverse_mask & 1) && (int64_t)rows * w.in_k * 2 > e->reverse_min_bytes;   // A larger than the memory-side cache, just written
     g.stagger = (mode == EPI_BIAS_GELU || mode == EPI_BIAS_RESID || mode == EPI_PATCH) ? e->gemm_stagger : 0;
+    g.shared_gpu = comm_busy(e);
     ep.zero_pad = 1;
     finalize_epi(ep);
     char shape[48];
@@ -436,7 +460,7 @@ static void dense_dgrad(vitx_engine* e, const void* dY, int64_t ldy, int rows, c
   ep.N = w.in;
   ep.bias = nullptr;
   const double flops = 2.0 * rows * (double)w.out * w.in;
-  const double bytes = (double)rows * w.in * e->esz + (double)rows * w.out * e->esz + (double)w.in * w.out * e->esz;
+  const double bytes = dense_launch_bytes(e, mode, ep, rows, w.out, w.in);
   if (e->bf16 && !e->force_generic_gemm) {
     Bf16GemmArgs g;
     g.A = (const bf16_t*)dY; g.lda = ldy;
@@ -444,6 +468,7 @@ static void dense_dgrad(vitx_engine* e, const void* dY, int64_t ldy, int rows, c
     g.M = rows; g.N = w.in; g.K = w.out_k; g.kernel = e->gemm_kernel;
     g.reverse_m = (e->reverse_mask & 2) && (int64_t)rows * w.out_k * 2 > e->reverse_min_bytes;
     g.stagger = (mode == EPI_GELU_BWD) ? e->gemm_stagger : 0;
+    g.shared_gpu = comm_busy(e);   // a bucket's collective may be running beside this launch (native exchange, comm.hip)
     ep.zero_pad = 1;
     finalize_epi(ep);
     char shape[48];
@@ -1452,6 +1477,7 @@ void engine_destroy(vitx_engine* e) {
   (void)hipStreamSynchronize(e->stream);
   if (e->side) (void)hipStreamSynchronize(e->side);
   if (e->side2) (void)hipStreamSynchronize(e->side2);
+  comm_destroy(e);
   for (void* p : e->allocs) (void)hipFree(p);
   for (SideRing* r : {&e->rg_dh, &e->rg_glp, &e->rg_dqkv, &e->rg_dbr, &e->rg_lnp, &e->rg_cs})
     for (int i = 0; i < SIDE_RING_MAX; ++i) if (r->rd[i]) (void)hipEventDestroy(r->rd[i]);

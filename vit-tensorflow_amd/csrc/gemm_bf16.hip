@@ -397,7 +397,7 @@ void launch_gemm_bf16(const Bf16GemmArgs& g0, const EpiParams& ep, int mode, hip
   const bool tunable = g0.kernel == 0 && autotune_enabled() && (g0.N % 256 == 0 || g0.N > 512) && (work >= 2.0e9 || (few_tiles && work >= 1.0e8)) &&
                        !(mode == EPI_BIAS_RESID && ep.out == (void*)ep.resid);
   if (!tunable) { dispatch_gemm_bf16(g0, ep, mode, s); return; }
-  const std::array<int64_t, 6> key = {mode, g0.M, g0.N, g0.K, g0.split_k > 1 ? g0.split_k : 1, (ep.scale != nullptr) + 2 * g_shared_gpu};
+  const std::array<int64_t, 6> key = {mode, g0.M, g0.N, g0.K, g0.split_k > 1 ? g0.split_k : 1, (ep.scale != nullptr) + 2 * (g_shared_gpu | (g0.shared_gpu != 0))};
   int best = -1;
   {
     std::lock_guard<std::mutex> lk(g_tune_mu);
@@ -424,7 +424,7 @@ void launch_gemm_bf16(const Bf16GemmArgs& g0, const EpiParams& ep, int mode, hip
       const bool is320 = c == 5 || c == 11;
       if (is320 && !g_allow_320) continue;
       if ((c == 1 || c == 3) && !small_m) continue;
-      if (!g_shared_gpu && (c == 2 || c == 5)) continue;   // beside collectives the pipelined kernel runs one tile per workgroup too (launch_pipe) and competes with 2 / 5
+      if (!(g_shared_gpu || g0.shared_gpu) && (c == 2 || c == 5)) continue;   // beside collectives the pipelined kernel runs one tile per workgroup too (launch_pipe) and competes with 2 / 5
       g.kernel = c;
       dispatch_gemm_bf16(g, ep, mode, s);   // warm-up (first-use attribute setup, instruction cache)
       (void)hipEventRecord(ev[0], s);

@@ -639,7 +639,7 @@ void launch_pipe(const Bf16GemmArgs& g, const EpiParams& ep, hipStream_t s, bool
   // Beside collectives (data parallel: RCCL's workgroups hold CUs for as long as a collective runs) a persistent grid with static tile lists waits
   // for the workgroups that could not be placed; one tile per workgroup lets the hardware dispatcher balance.  Same kernel: a workgroup whose tile
   // list has one entry simply never takes the cross-tile path.
-  const unsigned gx = (zs == 1 && !gemm_bf16_shared_gpu() && !one_tile_per_wg) ? (unsigned)std::min(tiles_m * tiles_n, grid_cap) : (unsigned)(tiles_m * tiles_n);
+  const unsigned gx = (zs == 1 && !gemm_bf16_shared_gpu() && !g.shared_gpu && !one_tile_per_wg) ? (unsigned)std::min(tiles_m * tiles_n, grid_cap) : (unsigned)(tiles_m * tiles_n);
   dim3 grid(gx, (unsigned)zs), block(WM * WN * 64);
   // XCD-owned row bands (walk 2): wide outputs on the full persistent grid with enough row tiles for 8-row bands per XCD
   const bool walk2_ok = BM == 256 && zs == 1 && gx == (unsigned)grid_cap && (gx & 7) == 0 && gx < (unsigned)(tiles_m * tiles_n) && tiles_n >= 8 && tiles_m >= 64 && g.stagger != 8;

@@ -59,6 +59,7 @@ struct Bf16GemmArgs {
   unsigned long long* stamps = nullptr;   // diagnostics (VITX_GEMM_STAMPS=1 in vitx_bench_gemm): cycle stamps of the tile phases, [256 WGs][16 tiles][4]
   int phase = 0;             // persistent pipelined kernels: workgroup i starts ((i >> 3) & 7) * phase * 4096 cycles late (de-phases the tile loops)
   int reverse_m = 0;         // 1: row tiles are walked from the last to the first (see decode_tile)
+  int shared_gpu = 0;        // 1: a collective of this handle may hold CUs while this launch runs (comm_busy): one tile per workgroup instead of a persistent grid
   int walk = 0;              // set by the launcher of the pipelined kernel: 2 = XCD-owned row bands (see gemm_bf16_nt_pipe_kernel)
   int stagger = 0;           // >0: first-wave workgroups start (cu_slot & 3) * stagger * 2048 cycles late (de-phases store-heavy epilogues)
 };

@@ -406,10 +406,33 @@ class VitxModel:
             dimg = np.empty(self._last_img_shape(), dtype=np.float32)
             dimg_p = dimg.ctypes.data_as(C.c_void_p)
         N.check(N.lib().vitx_backward(self._handle, d.ctypes.data_as(C.c_void_p), dimg_p))
+        if getattr(self, "_comm_world", 0):   # data parallel: the gradients every rank sees are the mean over the ranks (comm_init below)
+            N.check(N.lib().vitx_allreduce_grads(self._handle))
         g = np.empty(self._n, dtype=np.float32)
         N.check(N.lib().vitx_get_grads(self._handle, g.ctypes.data_as(C.c_void_p), self._n))
         grads = {n: g[o:o + int(np.prod(s))].reshape(s) for n, s, o in self._table}
         return grads, dimg
+
+    # ---- data parallel (no reference counterpart): one process per GPU, parameters replicated, images sharded, ONE exchange per step --
+    # the mean of the gradient arena over the ranks, done by the library itself over RCCL (csrc/comm.hip; no torch.distributed involved)
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        """128-byte RCCL id: make it on rank 0 and hand the same bytes to every rank's comm_init (file, socket, MPI, torch store ...)."""
+        uid = (C.c_char * 128)()
+        N.check(N.lib().vitx_comm_unique_id(uid))
+        return bytes(uid)
+
+    def comm_init(self, rank: int, world: int, unique_id: bytes, overlap: bool = True, bucket_mb: float = 32.0, wire: str = "fp32") -> None:
+        """Join the RCCL group.  From then on backward() returns the gradients averaged over the ranks (feed every rank its own shard of the
+        batch, dlogits scaled by 1/local batch).  overlap: buckets of `bucket_mb` MiB are all-reduced on the handle's communication stream
+        while the rest of the backward pass runs; wire "bf16" halves the bytes on xGMI (each rank's addend rounded once)."""
+        if self._handle is None:
+            raise N.VitxError(N.ERR_STATE, "comm_init needs a built model (call build() or run a forward first)")
+        assert wire in ("fp32", "bf16") and len(unique_id) == 128
+        buf = (C.c_char * 128).from_buffer_copy(unique_id)
+        N.check(N.lib().vitx_comm_init(self._handle, int(rank), int(world), buf))
+        N.check(N.lib().vitx_comm_overlap(self._handle, 1 if overlap else 0, int(bucket_mb * (1 << 20)), 1 if wire == "bf16" else 0))
+        self._comm_world = int(world)
 
     def apply_gradients(self, optimizer: str = "adamw", lr: float = 1e-3, beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-7,
                         weight_decay: float = 0.0, momentum: float = 0.0) -> None:
