@@ -22,7 +22,7 @@ CASES = {
 LOGIT_TOL, GRAD_RTOL = 3.4e-2, 6.0e-2
 # fused against launch-per-op: same rounding points (bf16 q/k/v, fp32 scores, bf16 normalised scores into A V), different exp
 FUSED_VS_UNFUSED_LOGIT, FUSED_VS_UNFUSED_GRAD = 1e-2, 1.5e-2     # observed 0 .. 4.5e-3 (a bf16 rounding of o flips, or not), 0 .. 4.1e-3
-FUSED_AWAY = ()     # kernel classes that must not appear next to the fused kernels (filled in as the backward gets fused)
+FUSED_AWAY = ("attn_headchain", "attn_generic_headops", "attn_generic_softmax")   # kernel classes that must not appear next to the fused kernels
 
 
 def _run(kw, b, fused, monkeypatch):
@@ -56,6 +56,22 @@ def test_fused_reattention_matches_oracle_and_unfused_path(case, monkeypatch):
     assert worst[0] <= GRAD_RTOL, worst
     assert d_log <= FUSED_VS_UNFUSED_LOGIT
     assert d_g[0] <= FUSED_VS_UNFUSED_GRAD, d_g
+
+
+@pytest.mark.parametrize("case", list(CASES))
+def test_fused_backward_matches_the_launch_per_op_backward(case, monkeypatch):
+    """Same fused forward (same kept softmax / normalised scores), the backward once as ONE kernel up to d(q) + the (dK, dV) pair and once as
+    batched GEMMs + point kernel + partial reductions + softmax row kernel (VITX_DEEPVIT_FUSED_BWD=0).  Rounding points that differ: d(attn')
+    never leaves the chip (fp32 either way), d(dots) enters the dq product as bf16 from LDS instead of being converted by the GEMM's loader."""
+    kw, b = CASES[case]
+    monkeypatch.setenv("VITX_DEEPVIT_FUSED_BWD", "1")
+    _, _, _, _, lg_a, g_a = _run(kw, b, True, monkeypatch)
+    monkeypatch.setenv("VITX_DEEPVIT_FUSED_BWD", "0")
+    _, _, _, _, lg_b, g_b = _run(kw, b, True, monkeypatch)
+    assert np.array_equal(lg_a, lg_b)
+    d_g = max(((rel_max_err(g_a[k], np.asarray(g_b[k], np.float64)), k) for k in g_b))
+    print(f"[{case}] fused backward vs launch-per-op backward: worst grad {d_g[0]:.3e} at {d_g[1]}")
+    assert d_g[0] <= 5e-3, d_g
 
 
 @pytest.mark.parametrize("cpi", ["1", "2"])
@@ -92,6 +108,8 @@ def test_fused_kernel_is_the_one_that_runs(monkeypatch):
     N.check(lib.vitx_profile_end(h, stats, 64, C.byref(ns)))
     names = {stats[i].name.decode(): stats[i].launches for i in range(ns.value)}
     assert names.get("attn_deepvit_fused_fwd") == kw["depth"], names
+    assert names.get("attn_deepvit_fused_bwd") == kw["depth"], names      # round 5: the chain's VJP up to d(q) is one kernel too
+    assert names.get("attn_bgemm_mfma") == kw["depth"], names             # ... followed by ONE paired launch (dK, dV) per block
     for gone in FUSED_AWAY:
         assert gone not in names, (gone, names)
 

@@ -780,6 +780,22 @@ static void attn_generic_bwd(vitx_engine* e, const BlockParams& bp, const AttnVi
   float* const* sc = kept ? keep->sc_keep : e->sc;
   const int pi = kept ? keep->sc_pi : attn_generic_scores(e, bp, a, b, true, e->sc);
   float* dA = e->sc[3];
+  if (T && e->cfg.variant == VITX_VARIANT_DEEPVIT && e->deepvit_fused && e->deepvit_fused_bwd && kept && keep->sc_no_mixed && !e->unfused_headops &&
+      !e->force_generic_gemm && deepvit_attn_fused_supported(h, dh, a.nq, a.nk)) {
+    // deepvit.py:79-88 backwards in ONE kernel up to d(q) (attn_deepvit_fused.hip): d(attn') = dO v^T, LayerNorm-over-heads VJP, mix VJP (+ dW, dgamma,
+    // dbeta), softmax VJP, dq = scale d(dots) k.  d(dots) leaves the chip once (fp32, into dA) for the product that needs every query tile of an image:
+    // dK = scale d(dots)^T q; dV = attn'^T dO reads the normalised scores the forward kept.
+    {
+      const double pts = (double)b * h * a.nq * a.nk;
+      Prof pr(e, "attn_deepvit_fused_bwd", 4.0 * pts * dh + 4.0 * pts * h, ((double)b * a.nq * 3 * h * dh + 2.0 * (double)b * a.nq * h * dh) * 2 + 8.0 * pts);
+      launch_deepvit_attn_bwd((const bf16_t*)a.q, (const bf16_t*)a.k, (const bf16_t*)a.v, a.ldq, a.ldk, a.ldv, a.qb, a.kb, a.vb, (const bf16_t*)gr.d_o, gr.ldo,
+                              gr.ob, sc[0], e->params + bp.re_w, e->params + bp.re_g, dA, (bf16_t*)gr.dq, gr.lddq, gr.dqb, e->red_ws, e->grads + bp.re_w,
+                              e->grads + bp.re_g, e->grads + bp.re_b, b, h, a.nq, a.nk, ld, scale, e->cfg.ln_eps, (const bf16_t*)e->zero_page, e->stream);
+    }
+    bgemm_pair(e, BgemmCall{sc[pi], 0, 1, ld, bs, hs, gr.d_o, T, gr.ldo, 1, gr.ob, dh, a.nk, dh, a.nq, b, h, EPI_STORE, T, gr.dv, gr.lddv, gr.dvb, dh, 1.0f},
+               BgemmCall{dA, 0, 1, ld, bs, hs, a.q, T, a.ldq, 1, a.qb, dh, a.nk, dh, a.nq, b, h, EPI_STORE, T, gr.dk, gr.lddk, gr.dkb, dh, scale});
+    return;
+  }
   // d(attn) = dO v^T ; dV = attn^T dO
   bgemm_pair(e, BgemmCall{gr.d_o, T, gr.ldo, 1, gr.ob, dh, a.v, T, 1, a.ldv, a.vb, dh, a.nq, a.nk, dh, b, h, EPI_STORE_F32, 0, dA, ld, bs, hs, 1.0f},
              BgemmCall{sc[pi], 0, 1, ld, bs, hs, gr.d_o, T, gr.ldo, 1, gr.ob, dh, a.nk, dh, a.nq, b, h, EPI_STORE, T, gr.dv, gr.lddv, gr.dvb, dh, 1.0f});
@@ -1188,6 +1204,7 @@ static int engine_create_body(vitx_engine* e, const vitx_config& cfg, std::strin
   e->force_generic_gemm = env_flag("VITX_GENERIC_GEMM");
   e->force_generic_attn = env_flag("VITX_GENERIC_ATTN");
   if (const char* k = getenv("VITX_DEEPVIT_FUSED")) e->deepvit_fused = atoi(k) != 0;
+  if (const char* k = getenv("VITX_DEEPVIT_FUSED_BWD")) e->deepvit_fused_bwd = atoi(k) != 0;
   if (const char* k = getenv("VITX_MLP_BWD_ORDER")) e->mlp_bwd_consumers_first = atoi(k) != 0;
   if (const char* k = getenv("VITX_NT")) e->nt_mask = atoi(k);
   if (const char* k = getenv("VITX_BGEMM_PAIRS")) e->bgemm_pairs = atoi(k) != 0;
@@ -1465,7 +1482,7 @@ static int engine_create_body(vitx_engine* e, const vitx_config& cfg, std::strin
   e->red_elems = std::max<int64_t>({layernorm_bwd_ws_elems(d), colsum_ws_elems((int)maxfeat), headmix_ws_elems((int)B, c.heads, 1, 1),
                                     (int64_t)256 * 2 * 32, (int64_t)(1024 + 64) * d, (ceil_div(std::max<int64_t>(e->mp, e->mpp), 96) + 40) * (int64_t)m,
                                     headchain_ws_elems(c.heads), deepvit_point_ws_elems((int)B, c.heads, e->ntok_cap),
-                                    deepvit_point_bwd_ws_elems(c.heads)});
+                                    deepvit_point_bwd_ws_elems(c.heads), deepvit_attn_bwd_ws_elems((int)B, c.heads, e->ntok_cap)});
   DALLOC(e->red_ws, (size_t)e->red_elems * 4, false);
   HIPCHK(hipStreamSynchronize(e->stream));
   

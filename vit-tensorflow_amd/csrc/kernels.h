@@ -146,6 +146,12 @@ void launch_deepvit_point_bwd(const float* a0, float* da_inout, const float* w, 
                               float* dgamma, float* dbeta, int b, int h, int nq, int nk, int64_t ld, float eps, hipStream_t s);
 // attn_deepvit_fused.hip: the whole Re-attention forward (deepvit.py:79-88) in one kernel, bf16 mode, nk <= 80
 bool deepvit_attn_fused_supported(int h, int dim_head, int nq, int nk);
+// the VJP of the same chain up to d(q) in one kernel (d(dots) leaves as fp32 for the d(k) product; P = what the fused forward kept)
+int64_t deepvit_attn_bwd_ws_elems(int b, int h, int nq);
+void launch_deepvit_attn_bwd(const bf16_t* q, const bf16_t* k, const bf16_t* v, int64_t ldq, int64_t ldk, int64_t ldv, int64_t qb, int64_t kb, int64_t vb,
+                             const bf16_t* d_o, int64_t ldo, int64_t ob, const float* p_keep, const float* w, const float* gamma, float* ds_out,
+                             bf16_t* dq, int64_t lddq, int64_t dqb, float* ws, float* dw, float* dgamma, float* dbeta, int b, int h, int nq, int nk,
+                             int64_t ld, float scale, float eps, const bf16_t* zero_page, hipStream_t s);
 void launch_deepvit_attn_fwd(const bf16_t* q, const bf16_t* k, const bf16_t* v, int64_t ldq, int64_t ldk, int64_t ldv, int64_t qb,
                              int64_t kb, int64_t vb, bf16_t* o, int64_t ldo, int64_t ob, const float* w, const float* gamma,
                              const float* beta, float* p_keep, float* a2_keep, int keep, int b, int h, int nq,
