@@ -86,6 +86,29 @@ __global__ __launch_bounds__(DV_THREADS) void deepvit_attn_fwd_kernel(
   };
   load_q(t_begin, qf);
 
+  // stage-2 roles (see the backward kernel): key slot jl, head quad hq; the mixing matrix as the A operand of v_mfma_f32_16x16x4_f32
+  const int jl = lane & 15, hq = lane >> 4;
+  float WA[4], gm[4], bt[4];
+  bool hv[4];
+#pragma unroll
+  for (int st = 0; st < 4; ++st) {
+    const int hh = 4 * hq + st;
+    hv[st] = hh < H;
+    WA[st] = (hh < H && jl < H) ? w[hh * H + jl] : 0.f;
+    gm[st] = hh < H ? gamma[hh] : 0.f;
+    bt[st] = hh < H ? beta[hh] : 0.f;
+  }
+  auto qsum = [](float x) {        // sum over the four head quads of a key (lanes l, l ^ 16, l ^ 32, l ^ 48)
+    const unsigned u = __builtin_bit_cast(unsigned, x);
+    const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    const float t = __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+    const unsigned v2 = __builtin_bit_cast(unsigned, t);
+    const auto s2 = __builtin_amdgcn_permlane32_swap(v2, v2, false, false);
+    return __builtin_bit_cast(float, (unsigned)s2[0]) + __builtin_bit_cast(float, (unsigned)s2[1]);
+  };
+  const __amdgpu_buffer_rsrc_t rsA2 = __builtin_amdgcn_make_buffer_rsrc((void*)(a2_keep + (int64_t)bi * H * plane), 0, (int)(H * plane * 4), 0x00020000);
+  const int plane4 = (int)plane * 4;
+
   for (int tile = t_begin; tile < t_end; ++tile) {
     const int q0 = tile * 16;
     // ---------------------------------------------------------------- stage 1: S^T, softmax (deepvit.py:79-80)
@@ -139,51 +162,41 @@ __global__ __launch_bounds__(DV_THREADS) void deepvit_attn_fwd_kernel(
     __syncthreads();
 
     // -------------------------------------------------------------- stage 2: re-attention mix + LayerNorm over heads (deepvit.py:83-84)
-    // one thread per (query, key) point, exactly the 16 nk valid ones: the VALU work (H^2 FMAs per point) is spread evenly over
-    // the waves; with 4-key groups and padded columns it took two waves on one SIMD 5 us per tile
-    for (int p = tid; p < ((xp & 2) ? 0 : 16 * nk); p += DV_THREADS) {
-      const int i = p / nk, j = p - i * nk;
-      float y[H], vv[H];
+    // Round 5: the H x H mix runs on the fp32 matrix pipe with the mixing matrix in registers (lane = (key slot jl, head quad hq), a lane owns heads
+    // 4 hq + r of its key; see the backward kernel below for the operand roles) -- wave w takes queries w and w + 8 in groups of 16 keys.  The
+    // one-thread-per-point form it replaces read W through scalar loads (2 x H row round trips per point batch: 5 us per tile).
+    if (!(xp & 2)) {
+#pragma unroll 1
+      for (int rr = 0; rr < 2; ++rr) {
+        const int i = wave + 8 * rr;
+        const bool rv = (q0 + i) < nq;
 #pragma unroll
-      for (int hh = 0; hh < H; ++hh) y[hh] = Pl[(hh * 16 + i) * DV_PP + j];
-      // vv[g] = sum_h y[h] W[h][g], accumulated over h in ascending order for every g (the FMA chain of the backward's
-      // recomputation in deepvit_point_bwd_kernel: same bits).  W is read with wave-uniform addresses (scalar loads, SGPR operands)
-      // one ROW at a time, the next row requested before the current one is used; the scheduling barriers keep the compiler from
-      // requesting all H rows at once -- H^2 SGPRs do not exist and it parks them in VGPR lanes (2231 v_readlane per point).
-      const float* wm = w + opaque_zero();
+        for (int gk = 0; gk < DV_NT; ++gk) {
+          if (gk < nt) {
+            const int j = 16 * gk + jl;
+            const bool valid = rv && j < nk;
+            float y[4];
 #pragma unroll
-      for (int gg = 0; gg < H; ++gg) vv[gg] = 0.f;
-      float wc[H], wn[H];
+            for (int r = 0; r < 4; ++r) { const float t = Pl[(min(4 * hq + r, H - 1) * 16 + i) * DV_PP + j]; y[r] = (valid && hv[r]) ? t : 0.f; }
+            f32x4 vv = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int gg = 0; gg < H; ++gg) wc[gg] = wm[gg];
+            for (int st = 0; st < 4; ++st) vv = __builtin_amdgcn_mfma_f32_16x16x4f32(WA[st], y[st], vv, 0, 0, 0);   // mixed scores of heads 4 hq + r
+            const float mu = qsum((vv[0] + vv[1]) + (vv[2] + vv[3])) * (1.0f / (float)H);   // (rows >= H of the mix are exact zeros)
+            float xh[4], var = 0.f;
 #pragma unroll
-      for (int hh = 0; hh < H; ++hh) {
-        if (hh + 1 < H) {
+            for (int r = 0; r < 4; ++r) { xh[r] = hv[r] ? vv[r] - mu : 0.f; var += xh[r] * xh[r]; }
+            const float rs = rsqrtf(qsum(var) * (1.0f / (float)H) + eps);
 #pragma unroll
-          for (int gg = 0; gg < H; ++gg) wn[gg] = wm[(hh + 1) * H + gg];
+            for (int r = 0; r < 4; ++r) {
+              const int hh = 4 * hq + r;
+              const float a2 = xh[r] * rs * gm[r] + bt[r];
+              if (hv[r]) Al[(hh * 16 + i) * DV_AP + j] = valid ? (bf16_t)a2 : (bf16_t)0.f;   // (keys nk .. 16 nt - 1 multiply zero rows of V)
+              // kept for the backward: valid points only; everything else is sent out of the descriptor's range (dropped)
+              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, a2), rsA2,
+                                                    (keep && valid && hv[r]) ? (4 * hq * (int)plane + (q0 + i) * (int)ld + j) * 4 : 0x7ffffff0, r * plane4, 0);
+            }
+          }
         }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int gg = 0; gg < H; ++gg) vv[gg] = fmaf(y[hh], wc[gg], vv[gg]);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int gg = 0; gg < H; ++gg) wc[gg] = wn[gg];
-      }
-      float mu = 0.f;
-#pragma unroll
-      for (int gg = 0; gg < H; ++gg) mu += vv[gg];
-      mu /= (float)H;
-      float var = 0.f;
-#pragma unroll
-      for (int gg = 0; gg < H; ++gg) var += (vv[gg] - mu) * (vv[gg] - mu);
-      const float rs = rsqrtf(var / (float)H + eps);
-      const bool st = keep && (q0 + i) < nq;
-      float* arow = a2_keep + (int64_t)bi * H * plane + (int64_t)(q0 + i) * ld + j;
-#pragma unroll
-      for (int gg = 0; gg < H; ++gg) {
-        const float a2 = (vv[gg] - mu) * rs * gamma[gg] + beta[gg];
-        Al[(gg * 16 + i) * DV_AP + j] = (bf16_t)a2;
-        if (st) arow[gg * plane] = a2;
       }
     }
     __syncthreads();
