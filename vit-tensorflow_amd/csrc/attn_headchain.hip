@@ -196,6 +196,200 @@ __global__ __launch_bounds__(64 * HC_WAVES) void cait_chain_bwd_kernel(const flo
   store_dw<H>(acc_pre, pw + H * H, lane);
 }
 
+
+// ------------------------------------------------------------------------------------------------ CaiT, head mixes on the fp32 matrix pipe (round 5)
+// Same chains, other lane roles: a wave still owns one (image, query) row, but a lane is (key slot jl = lane & 15, head quad hq = lane >> 4) and holds
+// the values of heads 4 hq + r (r < 4) of its key, a row being NG groups of 16 keys.  Both h x h mixes of a group are then four
+// v_mfma_f32_16x16x4_f32 each (D[m][n] += sum_k A[m][k] B[k][n], n = the group's 16 keys, k <-> the head a lane holds in register st) with the mixing
+// matrix sitting in registers as the A operand:
+//   out[key][g] = sum_h in[key][h] W[h][g]   (forward mixes):  A[m = g][k] = W[4 hq + st][g = jl],  B = in  of head 4 hq + st
+//   din[key][h] = sum_g dout[key][g] W[h][g] (their VJPs):     A[m = h][k] = W[h = jl][4 hq + st],  B = dout of head 4 hq + st
+// and the result lands in the same ownership (D: lane (n = jl, rows 4 hq + r)).  The fp32 MFMA multiplies exactly and accumulates in fp32 like the
+// FMA chains it replaces (other summation order: 1e-7 relative).  Why: as in-lane FMAs the mixes need all H values of a key in one lane and the
+// matrix re-read through scalar loads for every row (2 x H row round trips of ~200 cycles, H-element register arrays); here a lane holds 4 values
+// per tensor, the matrices cost 8-16 registers, and the kernels run at the speed of their three / four [b, h, n, n] fp32 streams.
+// The softmax over the keys = in-lane over the groups + a 16-lane DPP row reduction; everything the VJP needs stays in registers.
+template <int H>
+__device__ __forceinline__ void mix_operands(const float* __restrict__ w, int jl, int hq, float (&wa)[4], float (&wb)[4]) {
+#pragma unroll
+  for (int st = 0; st < 4; ++st) {
+    const int hh = 4 * hq + st;
+    wa[st] = (hh < H && jl < H) ? w[hh * H + jl] : 0.f;
+    wb[st] = (hh < H && jl < H) ? w[jl * H + hh] : 0.f;
+  }
+}
+__device__ __forceinline__ f32x4 mix4(const float (&a)[4], const float (&b)[4]) {
+  f32x4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int st = 0; st < 4; ++st) d = __builtin_amdgcn_mfma_f32_16x16x4f32(a[st], b[st], d, 0, 0, 0);
+  return d;
+}
+#define HC_DPP(OP, v, ctrl) v = OP(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), (ctrl), 0xF, 0xF, false)))
+__device__ __forceinline__ float row16_sum(float v) {   // over the 16 key slots of a head quad (one DPP row); every lane of the row gets the total
+  HC_DPP(vitx_addf, v, 0xB1); HC_DPP(vitx_addf, v, 0x4E); HC_DPP(vitx_addf, v, 0x124); HC_DPP(vitx_addf, v, 0x128);
+  return v;
+}
+__device__ __forceinline__ float row16_max(float v) {
+  HC_DPP(fmaxf, v, 0xB1); HC_DPP(fmaxf, v, 0x4E); HC_DPP(fmaxf, v, 0x124); HC_DPP(fmaxf, v, 0x128);
+  return v;
+}
+#undef HC_DPP
+// dW[hh][g] += sum over a group's 16 keys of xv[hh] dv[g] (xv / dv: this lane's 4 heads of its key), transposed through the per-wave scratch
+__device__ __forceinline__ void outer_accumulate16(f32x4& acc, const float (&xv)[4], const float (&dv)[4], float* xs, float* ys, int jl, int hq) {
+  *(float4*)(xs + jl * HC_PITCH + 4 * hq) = make_float4(xv[0], xv[1], xv[2], xv[3]);
+  *(float4*)(ys + jl * HC_PITCH + 4 * hq) = make_float4(dv[0], dv[1], dv[2], dv[3]);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  float ta[4], tb[4];
+#pragma unroll
+  for (int st = 0; st < 4; ++st) { ta[st] = xs[(4 * st + hq) * HC_PITCH + jl]; tb[st] = ys[(4 * st + hq) * HC_PITCH + jl]; }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int st = 0; st < 4; ++st) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ta[st], tb[st], acc, 0, 0, 0);
+}
+
+constexpr int HC_NG = 4;   // 16-key groups of a row: nk <= 64.  Group c = the keys 4 jl + c, so that a lane's four groups are ONE 16-byte access per head and
+                           // tensor (16 lanes x 16 B = a contiguous 256-B row piece per instruction instead of four 64-B pieces)
+
+template <int H>
+__global__ __launch_bounds__(64 * HC_WAVES) void cait_chain_fwd_mfma_kernel(const float* __restrict__ s0, const float* __restrict__ wpre,
+                                                                            const float* __restrict__ wpost, float* __restrict__ a1,
+                                                                            float* __restrict__ a2, int64_t rows, int nq, int nk, int64_t ld) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, jl = lane & 15, hq = lane >> 4;
+  const int64_t plane = (int64_t)nq * ld;
+  const bool in_row = 4 * jl < ld;                     // this lane's 16 bytes lie inside the row
+  const int jo = in_row ? 4 * jl : 0;                  // (loads are unconditional from a clamped address and masked afterwards)
+  float wa_pre[4], wa_post[4], unused[4];
+  mix_operands<H>(wpre, jl, hq, wa_pre, unused);
+  mix_operands<H>(wpost, jl, hq, wa_post, unused);
+  bool hv[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) hv[r] = 4 * hq + r < H;
+  for (int64_t row = (int64_t)blockIdx.x * HC_WAVES + wave; row < rows; row += (int64_t)gridDim.x * HC_WAVES) {
+    const int64_t bi = row / nq, i = row - bi * nq;
+    const int64_t base0 = bi * H * plane + i * ld + jo;
+    float4 xin[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) xin[r] = *(const float4*)(s0 + base0 + (int64_t)min(4 * hq + r, H - 1) * plane);
+    float y[HC_NG][4];
+    float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+    for (int c = 0; c < HC_NG; ++c) {
+      const bool valid = 4 * jl + c < nk;
+      float x[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { const float t = c == 0 ? xin[r].x : (c == 1 ? xin[r].y : (c == 2 ? xin[r].z : xin[r].w)); x[r] = (valid && hv[r]) ? t : 0.f; }
+      const f32x4 v = mix4(wa_pre, x);                                   // cait.py:123
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { y[c][r] = v[r]; if (valid) m[r] = fmaxf(m[r], v[r]); }
+    }
+    float inv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {                                        // softmax over the keys (cait.py:124)
+      m[r] = row16_max(m[r]);
+      float sacc = 0.f;
+#pragma unroll
+      for (int c = 0; c < HC_NG; ++c) {
+        const float e = (4 * jl + c < nk) ? expf(y[c][r] - m[r]) : 0.f;
+        y[c][r] = e;
+        sacc += e;
+      }
+      inv[r] = 1.0f / row16_sum(sacc);
+    }
+    float p[HC_NG][4], z[HC_NG][4];
+#pragma unroll
+    for (int c = 0; c < HC_NG; ++c) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) p[c][r] = y[c][r] * inv[r];
+      const f32x4 v = mix4(wa_post, p[c]);                               // cait.py:125
+#pragma unroll
+      for (int r = 0; r < 4; ++r) z[c][r] = v[r];
+    }
+    if (in_row) {                                                        // (columns nk .. ld - 1: zeros)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (hv[r]) {
+          const int64_t o = base0 + (int64_t)(4 * hq + r) * plane;
+          if (a1 != nullptr) *(float4*)(a1 + o) = make_float4(p[0][r], p[1][r], p[2][r], p[3][r]);
+          *(float4*)(a2 + o) = make_float4(z[0][r], z[1][r], z[2][r], z[3][r]);
+        }
+      }
+    }
+  }
+}
+
+// d(A2) in `da` -> d(S0) written back into `da`; partial[wave][0] = dW_post, partial[wave][1] = dW_pre
+template <int H>
+__global__ __launch_bounds__(64 * HC_WAVES) void cait_chain_bwd_mfma_kernel(const float* __restrict__ s0, const float* __restrict__ a1,
+                                                                            float* __restrict__ da, const float* __restrict__ wpre,
+                                                                            const float* __restrict__ wpost, float* __restrict__ partial,
+                                                                            int64_t rows, int nq, int nk, int64_t ld) {
+  __shared__ __attribute__((aligned(16))) float scratch[HC_WAVES][2][16 * HC_PITCH];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, jl = lane & 15, hq = lane >> 4;
+  float* xs = scratch[wave][0];
+  float* ys = scratch[wave][1];
+  const int64_t plane = (int64_t)nq * ld;
+  const bool in_row = 4 * jl < ld;
+  const int jo = in_row ? 4 * jl : 0;
+  float wb_pre[4], wb_post[4], unused[4];
+  mix_operands<H>(wpre, jl, hq, unused, wb_pre);
+  mix_operands<H>(wpost, jl, hq, unused, wb_post);
+  bool hv[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) hv[r] = 4 * hq + r < H;
+  f32x4 acc_post = {0.f, 0.f, 0.f, 0.f}, acc_pre = {0.f, 0.f, 0.f, 0.f};
+  auto comp = [](const float4& t, int c) { return c == 0 ? t.x : (c == 1 ? t.y : (c == 2 ? t.z : t.w)); };
+  for (int64_t row = (int64_t)blockIdx.x * HC_WAVES + wave; row < rows; row += (int64_t)gridDim.x * HC_WAVES) {
+    const int64_t bi = row / nq, i = row - bi * nq;
+    const int64_t base0 = bi * H * plane + i * ld + jo;
+    float4 a1in[4], dain[4], s0in[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int64_t o = base0 + (int64_t)min(4 * hq + r, H - 1) * plane;
+      a1in[r] = *(const float4*)(a1 + o);
+      dain[r] = *(const float4*)(da + o);
+      s0in[r] = *(const float4*)(s0 + o);
+    }
+    float av[HC_NG][4], d1[HC_NG][4];
+    float sdot[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < HC_NG; ++c) {
+      const bool valid = 4 * jl + c < nk;
+      float dz[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        av[c][r] = (valid && hv[r]) ? comp(a1in[r], c) : 0.f;
+        dz[r] = (valid && hv[r]) ? comp(dain[r], c) : 0.f;
+      }
+      outer_accumulate16(acc_post, av[c], dz, xs, ys, jl, hq);           // dW_post[hh][g] += A1[hh] * dA2[g]
+      const f32x4 v = mix4(wb_post, dz);                                  // dA1
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { d1[c][r] = v[r]; sdot[r] += av[c][r] * v[r]; }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sdot[r] = row16_sum(sdot[r]);             // softmax VJP: dS1 = A1 * (dA1 - sum_j A1 dA1)
+    float dso[HC_NG][4];
+#pragma unroll
+    for (int c = 0; c < HC_NG; ++c) {
+      const bool valid = 4 * jl + c < nk;
+      float ds1[4], x0[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { ds1[r] = av[c][r] * (d1[c][r] - sdot[r]); x0[r] = (valid && hv[r]) ? comp(s0in[r], c) : 0.f; }
+      outer_accumulate16(acc_pre, x0, ds1, xs, ys, jl, hq);              // dW_pre[hh][g] += S0[hh] * dS1[g]
+      const f32x4 v = mix4(wb_pre, ds1);                                 // dS0
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dso[c][r] = valid ? v[r] : 0.f;
+    }
+    if (in_row) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (hv[r]) *(float4*)(da + base0 + (int64_t)(4 * hq + r) * plane) = make_float4(dso[0][r], dso[1][r], dso[2][r], dso[3][r]);
+    }
+  }
+  float* pw = partial + ((int64_t)blockIdx.x * HC_WAVES + wave) * 2 * H * H;
+  store_dw<H>(acc_post, pw, lane);
+  store_dw<H>(acc_pre, pw + H * H, lane);
+}
+
 // ------------------------------------------------------------------------------------------------ DeepViT
 template <int H, int NP>
 __global__ __launch_bounds__(64 * HC_WAVES) void deepvit_chain_fwd_kernel(float* __restrict__ s0 /* in: scores; out: softmax (if keep) */,
@@ -362,6 +556,13 @@ void launch_cait_chain_fwd(const float* s0, const float* wpre, const float* wpos
                            int64_t ld, hipStream_t s) {
   const int64_t rows = (int64_t)b * nq;
   const dim3 grid(chain_blocks(rows)), block(64 * HC_WAVES);
+  static const int mfma_mix = [] { const char* v = getenv("VITX_CHAIN_MFMA"); return v ? atoi(v) : 1; }();   // 0: the in-lane FMA form (A/B reference)
+  if (mfma_mix) {
+#define CALL(H) hipLaunchKernelGGL((cait_chain_fwd_mfma_kernel<H>), grid, block, 0, s, s0, wpre, wpost, a1_or_null, a2, rows, nq, nk, ld)
+    HC_DISPATCH(h, CALL);
+#undef CALL
+    return;
+  }
 #define CALL(H) hipLaunchKernelGGL((cait_chain_fwd_kernel<H, 1>), grid, block, 0, s, s0, wpre, wpost, a1_or_null, a2, rows, nq, nk, ld)
   HC_DISPATCH(h, CALL);
 #undef CALL
@@ -371,9 +572,16 @@ void launch_cait_chain_bwd(const float* s0, const float* a1, float* da_inout, co
   const int64_t rows = (int64_t)b * nq;
   const int nblk = chain_blocks(rows);
   const dim3 grid(nblk), block(64 * HC_WAVES);
-#define CALL(H) hipLaunchKernelGGL((cait_chain_bwd_kernel<H, 1>), grid, block, 0, s, s0, a1, da_inout, wpre, wpost, ws, rows, nq, nk, ld)
-  HC_DISPATCH(h, CALL);
+  static const int mfma_mix = [] { const char* v = getenv("VITX_CHAIN_MFMA"); return v ? atoi(v) : 1; }();
+  if (mfma_mix) {
+#define CALL(H) hipLaunchKernelGGL((cait_chain_bwd_mfma_kernel<H>), grid, block, 0, s, s0, a1, da_inout, wpre, wpost, ws, rows, nq, nk, ld)
+    HC_DISPATCH(h, CALL);
 #undef CALL
+  } else {
+#define CALL(H) hipLaunchKernelGGL((cait_chain_bwd_kernel<H, 1>), grid, block, 0, s, s0, a1, da_inout, wpre, wpost, ws, rows, nq, nk, ld)
+    HC_DISPATCH(h, CALL);
+#undef CALL
+  }
   const int nparts = nblk * HC_WAVES;
   const int64_t stride = 2 * (int64_t)h * h;
   float* ws2 = ws + (int64_t)nparts * stride;
