@@ -487,6 +487,44 @@ static void dense_dgrad(vitx_engine* e, const void* dY, int64_t ldy, int rows, c
   }
 }
 
+static void dense_wgrad_generic(vitx_engine* e, const void* X, int64_t ldx, const void* dY, int64_t ldy, int rows, const Dense& w) {
+  float* dW = dense_gw(e, w);
+  const double flops = 2.0 * rows * (double)w.out * w.in;
+  const double bytes = (double)rows * w.in * e->esz + (double)rows * w.out * e->esz + (double)w.in * w.out * 4;
+  {
+    GenericGemmArgs g;
+    g.A = X; g.B = dY;
+    g.M = w.in; g.N = w.out; g.K = rows;
+    g.sam = 1; g.sak = ldx; g.sbk = ldy; g.sbn = 1; g.x3 = e->x3;
+    EpiParams ep;
+    ep.out = dW; ep.ldo = w.out; ep.M = w.in; ep.N = w.out;
+    // BF16X3 mode: a weight gradient is a handful of 128 x 128 tiles over tens of thousands of token rows -- split the rows into slices (the batch
+    // index of the kernel) so that tiles x slices fills the chip twice over, fp32 partials + the reduction pass of the bf16 mode
+    int slices = 1;
+    if (e->x3 && e->partial_ws && gemm_bf16x3_supported(g, 0, 0, 0)) {
+      const int64_t tiles = ceil_div(w.in, 128) * ceil_div(w.out, 128);
+      int64_t want = std::min<int64_t>({std::max<int64_t>(1, 1024 / tiles), std::max<int64_t>(1, rows / 256), e->partial_elems / ((int64_t)w.in * w.out), 32});   // (<= 32: the two-level reduction)
+      if (want > 1) {
+        const int ks = (int)round_up(ceil_div(rows, want), 32);
+        slices = (int)ceil_div(rows, ks);
+        if (slices > 1) {
+          g.K = ks; g.nb = slices; g.sAb = (int64_t)ks * ldx; g.sBb = (int64_t)ks * ldy; g.k_last = rows - (slices - 1) * ks;
+          ep.out = e->partial_ws; ep.out_batch_stride = (int64_t)w.in * w.out;
+        }
+      }
+    }
+    finalize_epi(ep);
+    {
+      Prof pr(e, f32_gemm_class(g, e->bf16, e->bf16, 0), flops, bytes);   // the class of the kernel that runs
+      launch_gemm_generic(g, ep, EPI_STORE_F32, e->bf16, e->bf16, 0, e->stream);
+    }
+    if (slices > 1) {
+      Prof pr(e, "reduce_partials", 0, (double)(slices + 1) * w.in * w.out * 4);
+      launch_reduce_partials(e->partial_ws, slices, (int64_t)w.in * w.out, (int64_t)w.in * w.out, dW, 1.0f, e->stream);
+    }
+  }
+}
+
 // dW[in,out] = X^T[in,rows] @ dY[rows,out]   (reduction over every token row of the batch)
 static void dense_wgrad(vitx_engine* e, const void* X, int64_t ldx, const void* dY, int64_t ldy, int rows, const Dense& w, hipEvent_t pre = nullptr) {
   float* dW = dense_gw(e, w);
@@ -526,6 +564,12 @@ static void dense_wgrad(vitx_engine* e, const void* X, int64_t ldx, const void* 
       // 2 GiB -- more slices if it would not (never at the shapes of the models here: 50k rows x 4096 features is 0.4 GB)
       const int64_t max_rows = (((1LL << 31) - (1 << 20)) / (2 * std::max<int64_t>(ldx, ldy))) / 64 * 64;
       split = (int)std::max<int64_t>(split, ceil_div(kext, std::max<int64_t>(64, max_rows)));
+      //  the raised slice count must still fit the partial buffer: if it does not, this one launch takes the strided fp32-FMA kernel
+      // (64-bit addressing, no partial buffer; slow and correct -- beyond 262k token rows x 4096 features, no model of the reference gets there)
+      if (split > 1 && (int64_t)split * w.in * w.out > e->partial_elems) {
+        dense_wgrad_generic(e, X, ldx, dY, ldy, rows, w);
+        return;
+      }
     }
     g.split_k = split;
     const int slices = gemm_bf16_num_slices(kext, split);
@@ -546,36 +590,7 @@ static void dense_wgrad(vitx_engine* e, const void* X, int64_t ldx, const void* 
       launch_reduce_partials(e->partial_ws, slices, (int64_t)w.in * w.out, (int64_t)w.in * w.out, dW, 1.0f, ws);
     }
   } else {
-    GenericGemmArgs g;
-    g.A = X; g.B = dY;
-    g.M = w.in; g.N = w.out; g.K = rows;
-    g.sam = 1; g.sak = ldx; g.sbk = ldy; g.sbn = 1; g.x3 = e->x3;
-    EpiParams ep;
-    ep.out = dW; ep.ldo = w.out; ep.M = w.in; ep.N = w.out;
-    // BF16X3 mode: a weight gradient is a handful of 128 x 128 tiles over tens of thousands of token rows -- split the rows into slices (the batch
-    // index of the kernel) so that tiles x slices fills the chip twice over, fp32 partials + the reduction pass of the bf16 mode
-    int slices = 1;
-    if (e->x3 && e->partial_ws && gemm_bf16x3_supported(g, 0, 0, 0)) {
-      const int64_t tiles = ceil_div(w.in, 128) * ceil_div(w.out, 128);
-      int64_t want = std::min<int64_t>({std::max<int64_t>(1, 1024 / tiles), std::max<int64_t>(1, rows / 256), e->partial_elems / ((int64_t)w.in * w.out), 32});   // (<= 32: the two-level reduction)
-      if (want > 1) {
-        const int ks = (int)round_up(ceil_div(rows, want), 32);
-        slices = (int)ceil_div(rows, ks);
-        if (slices > 1) {
-          g.K = ks; g.nb = slices; g.sAb = (int64_t)ks * ldx; g.sBb = (int64_t)ks * ldy; g.k_last = rows - (slices - 1) * ks;
-          ep.out = e->partial_ws; ep.out_batch_stride = (int64_t)w.in * w.out;
-        }
-      }
-    }
-    finalize_epi(ep);
-    {
-      Prof pr(e, f32_gemm_class(g, e->bf16, e->bf16, 0), flops, bytes);   // the class of the kernel that runs
-      launch_gemm_generic(g, ep, EPI_STORE_F32, e->bf16, e->bf16, 0, e->stream);
-    }
-    if (slices > 1) {
-      Prof pr(e, "reduce_partials", 0, (double)(slices + 1) * w.in * w.out * 4);
-      launch_reduce_partials(e->partial_ws, slices, (int64_t)w.in * w.out, (int64_t)w.in * w.out, dW, 1.0f, e->stream);
-    }
+    dense_wgrad_generic(e, X, ldx, dY, ldy, rows, w);
   }
 }
 

@@ -236,9 +236,11 @@ void launch_gemm_bf16_tn(const Bf16GemmArgs& g0, const EpiParams& ep, hipStream_
     const int nk = g.K / BK, split = g.split_k > 1 ? g.split_k : 1;
     const int64_t slice_rows = ceil_div(nk, split) * BK;
     if ((slice_rows * std::max(g.lda, g.ldb) + 256) * 2 >= (1LL << 31)) {
-      fprintf(stderr, "[vitx] launch_gemm_bf16_tn: a K slice of %lld rows x %lld features exceeds the 2 GiB buffer range -- more slices needed\n",
+      // (no abort() from inside a library.)  dense_wgrad never gets here -- it raises the slice count or takes the transpose path; a caller
+      // that does is told so and gets no launch (its output keeps whatever it held: the C ABI's gradient buffers are zero-initialised)
+      fprintf(stderr, "[vitx] launch_gemm_bf16_tn: a K slice of %lld rows x %lld features exceeds the 2 GiB buffer range -- NOT launched; use more slices\n",
               (long long)slice_rows, (long long)std::max(g.lda, g.ldb));
-      abort();
+      return;
     }
   }
   if (gemm_bf16_tn_tile(g.kernel, g.M, g.N) == 128) launch_tn_variant<128, 2, 2>(g, ep, s);

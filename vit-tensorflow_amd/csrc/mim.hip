@@ -70,16 +70,19 @@ int64_t add_param(vitx_mim* m, const std::string& name, std::vector<int64_t> sha
   return p.aoff;
 }
 
-// the wrappers' parameter order follows the attribute order of the reference constructors (mae.py:41-45, simmim.py:83-84)
+// ONE ordering rule for every parameter list of this library: a model's OWN variables first, then its sub-layers in
+// the attribute order of the reference constructor, kernel before bias -- what Keras 2's Layer.trainable_weights does (`self._trainable_weights +
+// children's`), as far as it can be stated without TensorFlow here (oracle/gen_ref_fixtures.py --real-tf prints the comparison where it exists).
+// Shapes are the reference variables' own: MPP's mask token is [1, 1, c p^2] (mpp.py:159), MAE's / SimMIM's are vectors (mae.py:42, simmim.py:83).
 void build_mim_table(vitx_mim* m) {
   m->table.clear(); m->n_params = m->n_arena = 0;
-  if (m->mpp) {   // attribute order of MPP.__init__ (mpp.py:149,159)
+  if (m->mpp) {   // mpp.py:159 (variable), mpp.py:149 (to_bits)
+    m->mask_tok = add_param(m, "mask_token", {1, 1, m->pd});
     m->w_px = add_param(m, "to_bits.kernel", {m->d, m->po});
     m->b_px = add_param(m, "to_bits.bias", {m->po});
-    m->mask_tok = add_param(m, "mask_token", {m->pd});
-  } else if (m->mae) {
-    if (m->project) { m->w_ed = add_param(m, "enc_to_dec.kernel", {m->d, m->dd}); m->b_ed = add_param(m, "enc_to_dec.bias", {m->dd}); }
+  } else if (m->mae) {   // mae.py:42 (variable), then mae.py:41,44,45
     m->mask_tok = add_param(m, "mask_token", {m->dd});
+    if (m->project) { m->w_ed = add_param(m, "enc_to_dec.kernel", {m->d, m->dd}); m->b_ed = add_param(m, "enc_to_dec.bias", {m->dd}); }
     // num_patches is read off pos_embedding.shape[-2] (mae.py:37), i.e. it counts the cls row: the table has np + 1 rows
     m->dpos = add_param(m, "decoder_pos_emb.embeddings", {m->np_max + 1, m->dd});
     m->w_px = add_param(m, "to_pixels.kernel", {m->dd, m->pd});

@@ -152,7 +152,8 @@ class MimWrapper:
         assert len(weights) == len(self._table), f"expected {len(self._table)} arrays, got {len(weights)}"
         for w, (n, s, o) in zip(weights, self._table):
             a = np.asarray(w, dtype=np.float32)
-            assert a.shape == tuple(s), f"{n}: expected shape {tuple(s)}, got {a.shape}"
+            # the reference's own shape, or the same values without / with singleton axes (MPP's mask token is [1, 1, c p^2], mpp.py:159)
+            assert tuple(d for d in a.shape if d != 1) == tuple(d for d in s if d != 1), f"{n}: expected shape {tuple(s)}, got {a.shape}"
             self._blob[o:o + a.size] = a.reshape(-1)
         self._push_params()
 

@@ -315,9 +315,12 @@ class VitxModel:
 
     def save_weights(self, path: str, format: str = "named") -> None:
         """format="named" (default): weights by engine parameter name in one .npz.  format="keras_list": the arrays of `get_weights()` in
-        order as arr_0, arr_1, ... -- exactly what `np.savez(path, *keras_model.get_weights())` writes on the TensorFlow side, so a list
-        exported there loads here and the other way round (order: model variables first -- pos_embedding, cls_token -- then the layers in
-        attribute order, kernel before bias, gamma before beta).  NOT the TF-checkpoint / H5 files the reference's
+        order as arr_0, arr_1, ... -- the form `np.savez(path, *keras_model.get_weights())` writes on the TensorFlow side.  The order is
+        this library's one rule: a model's own variables first -- pos_embedding, cls_token -- then its layers in the
+        attribute order of the reference constructor, kernel before bias, gamma before beta.  That is Keras 2's `Layer.trainable_weights`
+        as far as it can be stated WITHOUT TensorFlow in this environment -- unverified; a list in another order fails set_weights' shape
+        checks rather than loading silently, and `python -m oracle.gen_ref_fixtures --real-tf` prints Keras' actual order next to this one
+        wherever TensorFlow exists.  The by-name form ("named") does not depend on any order.  NOT the TF-checkpoint / H5 files the reference's
         inherited Model.save_weights writes: those formats need TensorFlow / h5py, neither of which exists in this environment."""
         if format == "keras_list":
             np.savez(self._npz_path(path), *self.get_weights())
