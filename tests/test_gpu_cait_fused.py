@@ -1,0 +1,96 @@
+"""GPU tier: the one-kernel CaiT talking-heads attention forward (attn_cait_fused.hip; cait.py:109-129) against (a) the oracle (exact
+restatement of cait.py, pinned by tests/golden/ref_cait_*.npz) and (b) the launch-per-op path it replaces (VITX_CAIT_FUSED=0: batched QK^T
+GEMM -> mix / softmax / mix chain kernel -> batched A V GEMM) on the same weights and inputs.  Shapes cover every head-count instance
+(4, 8, 12, 16), patch counts that are not multiples of the 16-row MFMA tile (36, 49) or of the 4-float score pitch (49), the BASELINE.json
+cfg5 geometry (64 patches, 16 heads) and the 80-key limit (5 x 16).  The class-attention stage (1 query, n + 1 keys) stays on the
+launch-per-op path in both runs."""
+import numpy as np
+import pytest
+
+from oracle import ref_torch, spec
+from util import rel_max_err
+
+pytestmark = pytest.mark.gpu
+
+CASES = {
+    # name: (kwargs, batch)
+    "h4_n16": (dict(image_size=64, patch_size=16, num_classes=10, dim=128, depth=2, cls_depth=1, heads=4, mlp_dim=256, dim_head=64), 3),
+    "h12_n36": (dict(image_size=96, patch_size=16, num_classes=10, dim=192, depth=2, cls_depth=1, heads=12, mlp_dim=256, dim_head=64), 2),
+    "h8_n49": (dict(image_size=112, patch_size=16, num_classes=10, dim=128, depth=1, cls_depth=2, heads=8, mlp_dim=256, dim_head=64), 2),
+    "h16_n64": (dict(image_size=128, patch_size=16, num_classes=10, dim=256, depth=2, cls_depth=2, heads=16, mlp_dim=512, dim_head=64), 5),
+    "h16_n80": (dict(image_size=(128, 160), patch_size=16, num_classes=10, dim=256, depth=1, cls_depth=1, heads=16, mlp_dim=512, dim_head=64), 2),
+}
+# bf16 mode against the EXACT oracle: the tolerances of the other bf16 parity tests (tests/test_gpu_parity.py)
+LOGIT_TOL, GRAD_RTOL = 3.4e-2, 6.0e-2
+# fused against launch-per-op: same rounding points (bf16 q/k/v, fp32 scores and mixes, bf16 mixed softmax into A V), different exp
+FUSED_VS_UNFUSED_LOGIT, FUSED_VS_UNFUSED_GRAD = 1e-2, 1.5e-2
+
+
+def _run(kw, b, fused, monkeypatch):
+    from vit_tensorflow.cait import CaiT
+    monkeypatch.setenv("VITX_CAIT_FUSED", "1" if fused else "0")
+    cfg = spec.make_config("cait", **kw)
+    P = spec.init_params(cfg, 1, randomize_all=True)
+    m = CaiT(**kw, compute="bf16", max_batch=b, seed=0)
+    m.load_state_dict({k: v.astype(np.float32) for k, v in P.items()})
+    rng = np.random.Generator(np.random.PCG64(3))
+    hw = kw["image_size"] if isinstance(kw["image_size"], tuple) else (kw["image_size"], kw["image_size"])
+    img = rng.standard_normal((b, hw[0], hw[1], 3)).astype(np.float32)
+    dl = (rng.standard_normal((b, kw["num_classes"])) / 2).astype(np.float32)
+    logits = np.asarray(m(img, training=True))
+    grads, _ = m.backward(dl)
+    return cfg, P, img, dl, logits, grads
+
+
+@pytest.mark.parametrize("case", list(CASES))
+def test_fused_talking_heads_matches_oracle_and_unfused_path(case, monkeypatch):
+    kw, b = CASES[case]
+    cfg, P, img, dl, lg_f, g_f = _run(kw, b, True, monkeypatch)
+    _, _, _, _, lg_u, g_u = _run(kw, b, False, monkeypatch)
+    ref_logits, ref_g, _ = ref_torch.forward_backward(cfg, P, img, dl)
+    e_log = np.abs(lg_f - ref_logits).max() / max(1.0, ref_logits.std())
+    worst = max(((rel_max_err(g_f[k], ref_g[k]), k) for k in ref_g))
+    d_log = np.abs(lg_f - lg_u).max()
+    d_g = max(((rel_max_err(g_f[k], np.asarray(g_u[k], np.float64)), k) for k in g_u))
+    print(f"[{case}] fused vs oracle: logits {e_log:.3e}, worst grad {worst[0]:.3e} at {worst[1]}; fused vs unfused: logits {d_log:.3e}, "
+          f"worst grad {d_g[0]:.3e} at {d_g[1]}")
+    assert e_log <= LOGIT_TOL
+    assert worst[0] <= GRAD_RTOL, worst
+    assert d_log <= FUSED_VS_UNFUSED_LOGIT
+    assert d_g[0] <= FUSED_VS_UNFUSED_GRAD, d_g
+
+
+def test_inference_forward_keeps_nothing_and_gives_the_same_logits(monkeypatch):
+    """training=False: no score tensor leaves the chip (the kept-tensor descriptors are empty); same logits as the training forward."""
+    from vit_tensorflow.cait import CaiT
+    monkeypatch.setenv("VITX_CAIT_FUSED", "1")
+    kw, b = CASES["h16_n64"]
+    m = CaiT(**kw, compute="bf16", max_batch=b, seed=0)
+    rng = np.random.Generator(np.random.PCG64(5))
+    img = rng.standard_normal((b, kw["image_size"], kw["image_size"], 3)).astype(np.float32)
+    a = np.asarray(m(img, training=False))
+    t = np.asarray(m(img, training=True))
+    assert np.array_equal(a, t)
+
+
+def test_fused_kernel_is_the_one_that_runs(monkeypatch):
+    """The profile of one forward + backward names the fused kernel once per patch-stage block; the chain kernel's forward only runs in the
+    class-attention blocks."""
+    import ctypes as C
+    from vit_tensorflow import _native as N
+    from vit_tensorflow.cait import CaiT
+    monkeypatch.setenv("VITX_CAIT_FUSED", "1")
+    kw, b = CASES["h16_n64"]
+    m = CaiT(**kw, compute="bf16", max_batch=b, seed=0)
+    rng = np.random.Generator(np.random.PCG64(3))
+    img = rng.standard_normal((b, kw["image_size"], kw["image_size"], 3)).astype(np.float32)
+    m(img, training=True)
+    lib, h = N.lib(), m._handle
+    N.check(lib.vitx_profile_begin(h))
+    m(img, training=True)
+    stats = (N.KernelStat * 64)()
+    ns = C.c_int32()
+    N.check(lib.vitx_profile_end(h, stats, 64, C.byref(ns)))
+    names = {stats[i].name.decode(): stats[i].launches for i in range(ns.value)}
+    assert names.get("attn_cait_fused_fwd") == kw["depth"], names
+    assert names.get("attn_headchain", 0) + names.get("attn_generic_headops", 0) <= kw["cls_depth"], names

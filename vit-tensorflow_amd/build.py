@@ -17,7 +17,7 @@ CSRC = os.path.join(HERE, "csrc")
 BUILD = os.path.join(HERE, "build")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libvitx.so")
-SOURCES = ["elementwise.hip", "gemm_generic.hip", "gemm_f32_mfma.hip", "gemm_bf16x3.hip", "gemm_bf16.hip", "gemm_bf16_pipe.hip", "gemm_bf16_tn.hip", "attn_bf16.hip", "attn_x3.hip", "attn_generic.hip", "attn_bgemm_mfma.hip", "attn_headchain.hip", "attn_deepvit_fused.hip", "mim_ops.hip", "mim.hip", "distill.hip", "comm.hip", "engine.hip", "capi.hip"]
+SOURCES = ["elementwise.hip", "gemm_generic.hip", "gemm_f32_mfma.hip", "gemm_bf16x3.hip", "gemm_bf16.hip", "gemm_bf16_pipe.hip", "gemm_bf16_tn.hip", "attn_bf16.hip", "attn_x3.hip", "attn_generic.hip", "attn_bgemm_mfma.hip", "attn_headchain.hip", "attn_deepvit_fused.hip", "attn_cait_fused.hip", "mim_ops.hip", "mim.hip", "distill.hip", "comm.hip", "engine.hip", "capi.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
 # per-source additions.  attn_bf16.hip / attn_x3.hip: the running row maxima come straight out of MFMA accumulators; with NaNs honoured every fmaxf first

@@ -772,6 +772,18 @@ static void attn_generic_fwd(vitx_engine* e, const BlockParams& bp, const AttnVi
     if (keep) { keep->sc_geom = score_geom(b, a.nq, a.nk); keep->sc_pi = 2; keep->sc_no_mixed = true; }
     return;
   }
+  if (T && e->cfg.variant == VITX_VARIANT_CAIT && e->cait_fused && !e->unfused_headops && !e->force_generic_gemm &&
+      cait_attn_fused_supported(h, dh, a.nq, a.nk)) {
+    // cait.py:121-128 in one kernel (attn_cait_fused.hip); the score tensors are written once, for this block's backward only (the class-attention
+    // stage, one query per image, keeps the launch-per-op path)
+    const double pts = (double)b * h * a.nq * a.nk;
+    Prof pr(e, "attn_cait_fused_fwd", 4.0 * pts * dh + 4.0 * pts * h, ((double)b * a.nq * 3 * h * dh + (double)b * a.nq * h * dh) * 2 + (keep ? 12.0 * pts : 0.0));
+    launch_cait_attn_fwd((const bf16_t*)a.q, (const bf16_t*)a.k, (const bf16_t*)a.v, a.ldq, a.ldk, a.ldv, a.qb, a.kb, a.vb, (bf16_t*)a.o, a.ldo, a.ob,
+                         e->params + bp.mix_pre, e->params + bp.mix_post, sc[0], sc[1], sc[2], keep != nullptr, b, h, a.nq, a.nk, ld,
+                         1.0f / std::sqrt((float)dh), (const bf16_t*)e->zero_page, e->stream);
+    if (keep) { keep->sc_geom = score_geom(b, a.nq, a.nk); keep->sc_pi = 2; keep->sc_no_mixed = false; }
+    return;
+  }
   const int pi = attn_generic_scores(e, bp, a, b, keep != nullptr, sc);
   if (keep) { keep->sc_geom = score_geom(b, a.nq, a.nk); keep->sc_pi = pi; keep->sc_no_mixed = false; }
   // out = attn v   (vit.py:81, deepvit.py:87, cait.py:127)
@@ -1220,6 +1232,7 @@ static int engine_create_body(vitx_engine* e, const vitx_config& cfg, std::strin
   e->force_generic_attn = env_flag("VITX_GENERIC_ATTN");
   if (const char* k = getenv("VITX_DEEPVIT_FUSED")) e->deepvit_fused = atoi(k) != 0;
   if (const char* k = getenv("VITX_DEEPVIT_FUSED_BWD")) e->deepvit_fused_bwd = atoi(k) != 0;
+  if (const char* k = getenv("VITX_CAIT_FUSED")) e->cait_fused = atoi(k) != 0;
   if (const char* k = getenv("VITX_MLP_BWD_ORDER")) e->mlp_bwd_consumers_first = atoi(k) != 0;
   if (const char* k = getenv("VITX_NT")) e->nt_mask = atoi(k);
   if (const char* k = getenv("VITX_BGEMM_PAIRS")) e->bgemm_pairs = atoi(k) != 0;

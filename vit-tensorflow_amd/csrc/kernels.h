@@ -146,6 +146,11 @@ void launch_deepvit_point_bwd(const float* a0, float* da_inout, const float* w, 
                               float* dgamma, float* dbeta, int b, int h, int nq, int nk, int64_t ld, float eps, hipStream_t s);
 // attn_deepvit_fused.hip: the whole Re-attention forward (deepvit.py:79-88) in one kernel, bf16 mode, nk <= 80
 bool deepvit_attn_fused_supported(int h, int dim_head, int nq, int nk);
+// cait.py:121-128 forward in one kernel (attn_cait_fused.hip): raw scaled scores / softmax / mixed softmax are written (fp32 [b][h][nq][ld]) only when keep
+bool cait_attn_fused_supported(int h, int dim_head, int nq, int nk);
+void launch_cait_attn_fwd(const bf16_t* q, const bf16_t* k, const bf16_t* v, int64_t ldq, int64_t ldk, int64_t ldv, int64_t qb, int64_t kb, int64_t vb,
+                          bf16_t* o, int64_t ldo, int64_t ob, const float* wpre, const float* wpost, float* s0_keep, float* a1_keep, float* a2_keep,
+                          int keep, int b, int h, int nq, int nk, int64_t ld, float scale, const bf16_t* zero_page, hipStream_t s);
 // the VJP of the same chain up to d(q) in one kernel (d(dots) leaves as fp32 for the d(k) product; P = what the fused forward kept)
 int64_t deepvit_attn_bwd_ws_elems(int b, int h, int nq);
 void launch_deepvit_attn_bwd(const bf16_t* q, const bf16_t* k, const bf16_t* v, int64_t ldq, int64_t ldk, int64_t ldv, int64_t qb, int64_t kb, int64_t vb,
