@@ -105,8 +105,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_nt_pipe_kernel(Bf16
   const int wm = wave / WN, wn = wave - wm * WN;
 
   if (g.phase > 0 && persistent) {   // de-phase the workgroups of an XCD: their store-heavy epilogues stop coinciding
-    const int ph = (bid >> 3) & 7;
-    for (int i = 0; i < ph * g.phase; ++i) __builtin_amdgcn_s_sleep(64);
+    // phase < 100: eight phases, ((bid >> 3) & 7) * phase * 4096 cycles; phase >= 100: two phases, every other CU slot of an XCD starts
+    // (phase - 100) * 4096 cycles late (about half a tile period: half the chip is in its K loop while the other half stores)
+    const int n = g.phase >= 100 ? ((bid >> 3) & 1) * (g.phase - 100) : ((bid >> 3) & 7) * g.phase;
+    for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(64);
   }
 
   // per-lane DMA source offsets in BYTES, unsigned: address = uniform 64-bit base (SGPR pair) + zero-extended 32-bit lane offset,
