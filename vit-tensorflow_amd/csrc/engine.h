@@ -213,6 +213,7 @@ struct vitx_engine {
                                          // weight-gradient operand loads -- 10.8 -> 11.25 ms per step.)
   bool mlp_bwd_consumers_first = true;   // VITX_MLP_BWD_ORDER=0: fc2 weight gradient between the producer and the consumers of d hpre
   bool deepvit_fused_bwd = true;     // VITX_DEEPVIT_FUSED_BWD=0: the backward of that kernel as batched GEMMs + point / row kernels (A/B reference)
+  bool glp_skip = true;             // LayerNorm VJPs skip the bf16 copy of the residual gradient when no branch reads it (all blocks have LayerScale); VITX_GLP_SKIP=0: always written
   bool cait_fused = true;           // cait.py:121-128 forward as one kernel in the bf16 mode (attn_cait_fused.hip); VITX_CAIT_FUSED=0 disables
   bool deepvit_fused = true;         // VITX_DEEPVIT_FUSED=0: DeepViT attention forward as batched GEMMs + head-axis kernels (A/B reference)
   bool unfused_headops = false;      // VITX_UNFUSED_HEADOPS=1: separate mix / softmax / LayerNorm-over-heads kernels (A/B reference)

@@ -1003,7 +1003,12 @@ static int block_backward(vitx_engine* e, Stage& st, int si, int l, int b, int n
   const bool grouped = ba.par_first || ba.par_last || ba.ln1_src || ba.ln2_src;
   const float* ln_gin = (!grouped || ba.par_first) ? e->g : e->g2;
   float* ln_gout = (!grouped || ba.par_last) ? e->g : e->g2;
-  const bool ln_writes_glp = T && (!grouped || ba.par_last);
+  // (round 5) every branch with a LayerScale takes its input gradient from the scale VJP pass (d_br), never from g_lp: when all blocks have one
+  // (CaiT) the LayerNorm VJPs do not write the bf16 copy at all -- 2 bytes per element of the residual stream per VJP, 52 per cfg5 step
+  bool glp_dead = e->glp_skip;
+  for (const Stage& sx : e->stages)
+    for (const BlockParams& bx : sx.bp) glp_dead = glp_dead && bx.a_scale >= 0 && bx.m_scale >= 0;
+  const bool ln_writes_glp = T && (!grouped || ba.par_last) && !glp_dead;
   // the bf16 residual gradient a LayerNorm VJP writes: the next ring slot while weight gradients on the side stream may still read the current one
   auto next_glp = [&]() -> void* {
     if (!ln_writes_glp) return nullptr;
@@ -1233,6 +1238,7 @@ static int engine_create_body(vitx_engine* e, const vitx_config& cfg, std::strin
   if (const char* k = getenv("VITX_DEEPVIT_FUSED")) e->deepvit_fused = atoi(k) != 0;
   if (const char* k = getenv("VITX_DEEPVIT_FUSED_BWD")) e->deepvit_fused_bwd = atoi(k) != 0;
   if (const char* k = getenv("VITX_CAIT_FUSED")) e->cait_fused = atoi(k) != 0;
+  if (const char* k = getenv("VITX_GLP_SKIP")) e->glp_skip = atoi(k) != 0;
   if (const char* k = getenv("VITX_MLP_BWD_ORDER")) e->mlp_bwd_consumers_first = atoi(k) != 0;
   if (const char* k = getenv("VITX_NT")) e->nt_mask = atoi(k);
   if (const char* k = getenv("VITX_BGEMM_PAIRS")) e->bgemm_pairs = atoi(k) != 0;
