@@ -71,7 +71,8 @@ def test_cfg5_cait_24_plus_2_batch_256_bf16_against_the_torch_oracle_on_the_gpu(
 def test_recompute_fallback_of_the_kept_scores_gives_the_same_gradients(name, monkeypatch):
     """The materialised-attention backward keeps each block's score tensors from the forward (GBs at batch 256) up to a budget and RECOMPUTES
     them for the blocks beyond it.  With the budget forced low the fallback runs for most blocks; it must reproduce the kept path's gradients:
-    bit-identical for CaiT (the same kernels produce the kept and the recomputed tensors); for DeepViT the kept tensors come from the one-kernel
+    bit-identical for CaiT (the same kernel produces the kept and the recomputed tensors: the one-kernel talking-heads forward, run without its
+    A V stage by the backward); for DeepViT the kept tensors come from the one-kernel
     Re-attention forward and the recomputed ones from the batched-GEMM + head-axis kernels, which round their bf16 operands at different points
     (observed 3.4e-3 of a tensor's max, the size of every other bf16 gate)."""
     b = 64

@@ -184,7 +184,7 @@ __global__ __launch_bounds__(CA_THREADS) void cait_attn_fwd_kernel(
     __syncthreads();
 
     // ---------------------------------------------------------------- stage 3: out = attn' v, merged heads (cait.py:127-128)
-    {
+    if (o != nullptr) {   // (o == nullptr: the backward of a block whose score tensors were not kept recomputes them with this kernel: stages 1-2 only)
       char* vbuf = smem + wave * CA_VBYTES;
 #pragma unroll
       for (int s = 0; s < HPW; ++s) {

@@ -805,7 +805,20 @@ static void attn_generic_bwd(vitx_engine* e, const BlockParams& bp, const AttnVi
   // the forward chain: as the block's forward left it, or recomputed (kept tensors absent / describing another geometry)
   const bool kept = keep && keep->sc_keep[0] && keep->sc_geom == score_geom(b, a.nq, a.nk);
   float* const* sc = kept ? keep->sc_keep : e->sc;
-  const int pi = kept ? keep->sc_pi : attn_generic_scores(e, bp, a, b, true, e->sc);
+  int pi;
+  if (kept) {
+    pi = keep->sc_pi;
+  } else if (T && e->cfg.variant == VITX_VARIANT_CAIT && e->cait_fused && !e->unfused_headops && !e->force_generic_gemm &&
+             cait_attn_fused_supported(h, dh, a.nq, a.nk)) {
+    // score tensors not kept (budget): recomputed by the kernel that produced them in the forward (same bits as the kept ones), without its A V stage
+    Prof pr(e, "attn_cait_fused_fwd", 0, 0);
+    launch_cait_attn_fwd((const bf16_t*)a.q, (const bf16_t*)a.k, (const bf16_t*)a.v, a.ldq, a.ldk, a.ldv, a.qb, a.kb, a.vb, nullptr, 0, 0,
+                         e->params + bp.mix_pre, e->params + bp.mix_post, e->sc[0], e->sc[1], e->sc[2], 1, b, h, a.nq, a.nk, ld,
+                         1.0f / std::sqrt((float)dh), (const bf16_t*)e->zero_page, e->stream);
+    pi = 2;
+  } else {
+    pi = attn_generic_scores(e, bp, a, b, true, e->sc);
+  }
   float* dA = e->sc[3];
   if (T && e->cfg.variant == VITX_VARIANT_DEEPVIT && e->deepvit_fused && e->deepvit_fused_bwd && kept && keep->sc_no_mixed && !e->unfused_headops &&
       !e->force_generic_gemm && deepvit_attn_fused_supported(h, dh, a.nq, a.nk)) {
