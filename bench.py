@@ -192,7 +192,9 @@ def main():
                         wire_dtype=torch.bfloat16 if args.grad_wire == "bf16" else None)
         cb = N.GRAD_READY_FN(lambda _u, off, cnt: sync.on_ready(int(off), int(cnt)))
         N.check(lib.vitx_set_grad_ready_callback(h, cb, None))
-    inv_global = 1.0 / float(b * world)   # dlogits carry 1/global_batch, so the all-reduce is a plain sum
+    # torch exchange: dlogits carry 1/global_batch and the all-reduce is a plain sum; native exchange: vitx_allreduce_grads AVERAGES over the
+    # ranks (sum x 1/world), so each rank's dlogits carry 1/local batch -- the same gradient of the global mean loss either way
+    inv_global = 1.0 / float(b) if (dp and not sync) else 1.0 / float(b * world)
 
     def step():
         N.check(lib.vitx_params_changed(h))    # a training step sees updated fp32 weights: re-derive bf16 operands

@@ -168,8 +168,11 @@ __device__ __forceinline__ int opaque_zero() {
 // `s_waitcnt vmcnt(N)` of the schedule (issuing wave) + the workgroup barrier in front of the first read of the buffer.  Ordinary loads and
 // stores the compiler counts itself only become more conservative (hidden pieces add to the hardware counter, never to the compiler's).
 //   dst  = wave-uniform LDS byte address (lane i lands at dst + 16 i);  rsrc = buffer resource of the operand (kernel-argument pointer);
-//   voff = per-lane byte offset;  soff = wave-uniform byte offset.  M0 is written inside the statement (the compiler does not preserve it
-//   around asm) and nothing else in these kernels uses M0 once the builtins are gone.
+//   voff = per-lane byte offset;  soff = wave-uniform byte offset.  M0 is written inside the statement and nothing else in these kernels uses M0
+//   once the builtins are gone.  An "m0" entry in the clobber list does not make that a compiler guarantee: M0 is a reserved register to hipcc,
+//   which answers "inline asm clobber list contains reserved registers: m0 ... may not be preserved across the asm statement" (-Winline-asm) and
+//   generates the same code.  The guarantee is the ISA gate: build.py disassembles these kernels after every compile and fails the build if
+//   anything but these statements writes M0 (tools/isa_check.py; tests/test_isa.py repeats it on the shipped objects).
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ i32x4 vitx_make_rsrc(const void* p) {
   const uint64_t a = (uint64_t)p;

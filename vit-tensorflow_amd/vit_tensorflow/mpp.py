@@ -11,7 +11,10 @@ reference computes when it runs (tests/golden/ref_mpp_*.npz are produced by its 
   * MPPLoss.call (mpp.py:112,125) clamps the target to [max_pixel_val, max_pixel_val] and passes (predictions, labels) to
     tf.nn.softmax_cross_entropy_with_logits(labels, logits) in swapped order: the loss as written is log(2^(bits c)) * mean_i sum_j logits_ij.
     `literal_loss=False` selects what the code evidently means: softmax cross-entropy of the masked positions' logits against the
-    discretised mean colour of their patches (target clamped to [0, max_pixel_val])."""
+    discretised mean colour of their patches (target clamped to [0, max_pixel_val]).
+    Only the literal LOSS VALUE is pinned to the reference: its gradient here is that of the shim's broadcasting cross-entropy, which real
+    TensorFlow's registered gradient (on the un-broadcast labels) may not reproduce, and the literal loss is linear in the logits -- unbounded
+    below.  To TRAIN, pass literal_loss=False."""
 import math
 
 import numpy as np
