@@ -201,29 +201,40 @@ __global__ __launch_bounds__(256) void layernorm_bwd_any_cols_kernel(const TD* _
   p[c] = ag; p[d + c] = ab; p[2 * d + c] = as;
 }
 
+#ifndef VITX_LNB_FUSE_WAVES
+#define VITX_LNB_FUSE_WAVES 3
+#endif
 constexpr int LNB_BLOCKS = 512;
 constexpr int LNB_THREADS = 512;   // 8 waves per block: 4096 waves in flight with only 512 partial rows to reduce
 
 // dx = r * (g*gamma - mean_d(g*gamma) - xhat * mean_d(g*gamma*xhat));  dgamma += g*xhat; dbeta += g
 // VPL = 4 (d = 1024) lands on 134 VGPRs by itself = 3 waves per SIMD = ONE 8-wave block per CU where d = 768 runs two; asking for
 // 4 waves per SIMD caps it at 128 (ViT-L / DeepViT / CaiT: 3.9 -> 5.5 TB/s)
-template <typename TD, typename TL, int VPL>
-__global__ __launch_bounds__(LNB_THREADS, (VPL == 4 ? 4 : 1)) void layernorm_bwd_kernel(const TD* __restrict__ dy, int64_t lddy, const float* __restrict__ x,
+// FUSE (round 5; CaiT, cait.py:47-48): the residual gradient this pass produces is what the NEXT branch of the backward chain -- the one whose output
+// f = Dense(...) was scaled by a LayerScale vector `nscale` and added to the stream -- needs for its LayerScale VJP: g_lp receives g * nscale (the
+// gradient entering that branch's last Dense, in T), and two more partial rows hold column sums of g (x nscale = that Dense's bias gradient) and of
+// g * f (= d nscale).  Replaces a pass of its own over g (fp32), f and the branch gradient (134 MB per branch at cfg5) by one more read of f here.
+template <typename TD, typename TL, int VPL, bool FUSE>
+__global__ __launch_bounds__(LNB_THREADS, (VPL == 4 ? (FUSE ? VITX_LNB_FUSE_WAVES : 4) : 1)) void layernorm_bwd_kernel(const TD* __restrict__ dy, int64_t lddy, const float* __restrict__ x,
                                                             int64_t ldx, const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             const float* __restrict__ gamma, const float* g_in, int64_t ldgi,
                                                             float* g_out, int64_t ldgo, TL* g_lp, int64_t ldglp,
-                                                            float* __restrict__ partial, int rows, int d, int want_gsum) {
+                                                            float* __restrict__ partial, int rows, int d, int want_gsum,
+                                                            const TL* __restrict__ nf, int64_t ldnf, const float* __restrict__ nscale) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int wib = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int nw = blockDim.x >> 6;
-  float4 ag[VPL], ab[VPL], gm[VPL], as[VPL];   // as: column sums of g_in (= bias gradient of the branch's last Dense)
+  constexpr int NSEG = FUSE ? 4 : 3;
+  float4 ag[VPL], ab[VPL], gm[VPL], as[VPL];   // as: column sums of g_in (= bias gradient of the branch's last Dense); FUSE: of g_out
+  float4 asc[FUSE ? VPL : 1];                  // FUSE: column sums of g_out * f
 #pragma unroll
   for (int i = 0; i < VPL; ++i) {
     ag[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     ab[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     as[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (FUSE) asc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     const int c = (lane + 64 * i) * 4;
-    gm[i] = (c < d) ? *(const float4*)(gamma + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    gm[i] = (!FUSE && c < d) ? *(const float4*)(gamma + c) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
   const float invd = 1.0f / (float)d;
   for (int row = blockIdx.x * nw + wib; row < rows; row += gridDim.x * nw) {
@@ -231,6 +242,7 @@ __global__ __launch_bounds__(LNB_THREADS, (VPL == 4 ? 4 : 1)) void layernorm_bwd
     const float* xr = x + (int64_t)row * ldx;
     const TD* dr = dy + (int64_t)row * lddy;
     float4 xh[VPL], gg[VPL];
+    float4 gip[FUSE ? VPL : 1], fvp[FUSE ? VPL : 1];   // FUSE: g_in and f of this row, requested with x and dy (not behind the two wave reductions)
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
@@ -238,10 +250,15 @@ __global__ __launch_bounds__(LNB_THREADS, (VPL == 4 ? 4 : 1)) void layernorm_bwd
       if (c < d) {
         const float4 xv = *(const float4*)(xr + c);
         const float4 dv = ld4<TD>(dr + c);
+        if (FUSE) {
+          gip[i] = g_in ? *(const float4*)(g_in + (int64_t)row * ldgi + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+          fvp[i] = ld4<TL>(nf + (int64_t)row * ldnf + c);
+        }
         xh[i] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
         ab[i].x += dv.x; ab[i].y += dv.y; ab[i].z += dv.z; ab[i].w += dv.w;
         ag[i].x += dv.x * xh[i].x; ag[i].y += dv.y * xh[i].y; ag[i].z += dv.z * xh[i].z; ag[i].w += dv.w * xh[i].w;
-        gg[i] = make_float4(dv.x * gm[i].x, dv.y * gm[i].y, dv.z * gm[i].z, dv.w * gm[i].w);
+        const float4 gmv = FUSE ? *(const float4*)(gamma + c) : gm[i];   // FUSE: gamma from L1 per row (16 registers the two extra accumulators need)
+        gg[i] = make_float4(dv.x * gmv.x, dv.y * gmv.y, dv.z * gmv.z, dv.w * gmv.w);
         s1 += (gg[i].x + gg[i].y) + (gg[i].z + gg[i].w);
         s2 += (gg[i].x * xh[i].x + gg[i].y * xh[i].y) + (gg[i].z * xh[i].z + gg[i].w * xh[i].w);
       }
@@ -254,20 +271,30 @@ __global__ __launch_bounds__(LNB_THREADS, (VPL == 4 ? 4 : 1)) void layernorm_bwd
       if (c < d) {
         float4 dx = make_float4(rs * (gg[i].x - s1 - xh[i].x * s2), rs * (gg[i].y - s1 - xh[i].y * s2),
                                 rs * (gg[i].z - s1 - xh[i].z * s2), rs * (gg[i].w - s1 - xh[i].w * s2));
-        if (g_in) {
+        if (FUSE) {
+          dx.x += gip[i].x; dx.y += gip[i].y; dx.z += gip[i].z; dx.w += gip[i].w;
+        } else if (g_in) {
           const float4 gi = *(const float4*)(g_in + (int64_t)row * ldgi + c);
           as[i].x += gi.x; as[i].y += gi.y; as[i].z += gi.z; as[i].w += gi.w;
           dx.x += gi.x; dx.y += gi.y; dx.z += gi.z; dx.w += gi.w;
         }
         *(float4*)(g_out + (int64_t)row * ldgo + c) = dx;
-        if (g_lp) st4<TL>(g_lp + (int64_t)row * ldglp + c, dx);
+        if (FUSE) {
+          const float4 fv = fvp[i];
+          const float4 sc = *(const float4*)(nscale + c);          // (4 KiB, L1-resident: not worth 16 registers at d = 1024)
+          as[i].x += dx.x; as[i].y += dx.y; as[i].z += dx.z; as[i].w += dx.w;
+          asc[i].x += dx.x * fv.x; asc[i].y += dx.y * fv.y; asc[i].z += dx.z * fv.z; asc[i].w += dx.w * fv.w;
+          st4<TL>(g_lp + (int64_t)row * ldglp + c, make_float4(dx.x * sc.x, dx.y * sc.y, dx.z * sc.z, dx.w * sc.w));
+        } else if (g_lp) {
+          st4<TL>(g_lp + (int64_t)row * ldglp + c, dx);
+        }
       }
     }
   }
   // fixed-order combine of the block's waves: dgamma, dbeta (, column sums of g_in), through LDS [nw][d]
   // (three explicit passes: selecting the accumulator array with a run-time pass index made the compiler keep all three arrays in
   //  scratch memory for the whole kernel -- 18 KB of scratch traffic per row next to 12 KB of useful HBM traffic)
-  auto combine = [&](const float4(&acc)[VPL], int pass) {
+  auto combine = [&](const auto& acc, int pass) {
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
@@ -278,12 +305,13 @@ __global__ __launch_bounds__(LNB_THREADS, (VPL == 4 ? 4 : 1)) void layernorm_bwd
     for (int c = threadIdx.x; c < d; c += blockDim.x) {
       float a = 0.f;
       for (int w = 0; w < nw; ++w) a += lds[(int64_t)w * d + c];
-      partial[((int64_t)blockIdx.x * 3 + pass) * d + c] = a;
+      partial[((int64_t)blockIdx.x * NSEG + pass) * d + c] = a;
     }
   };
   combine(ag, 0);
   combine(ab, 1);
-  if (want_gsum) combine(as, 2);
+  if (FUSE) { combine(as, 2); combine(asc, 3); }
+  else if (want_gsum) combine(as, 2);
 }
 
 // out[c] = alpha * sum_p partial[p*stride + c]; 64 columns x 4 part-groups per block, fixed order.
@@ -813,7 +841,7 @@ void launch_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, const
 #undef CALL
 }
 
-int64_t layernorm_bwd_ws_elems(int d) { return (int64_t)(LNB_BLOCKS + 32) * 3 * d; }
+int64_t layernorm_bwd_ws_elems(int d) { return (int64_t)(LNB_BLOCKS + 32) * 4 * d; }   // (4 partial rows per block: the LayerScale-fused form)
 
 // The parameter-gradient sums (dgamma, dbeta, the optional column sums of g_in) are a two-level reduction of per-block partials that nothing in
 // the backward chain consumes: with `deferred` != nullptr the main kernel(s) only are launched and *deferred receives the number of partial rows;
@@ -846,16 +874,53 @@ void launch_layernorm_bwd(const void* dy, int dy_bf16, int64_t lddy, const float
   dim3 grid(nblk), block(LNB_THREADS);
   const size_t shm = (size_t)(LNB_THREADS / 64) * d * sizeof(float);
 #define CALL(V)                                                                                                                  \
-  if (dy_bf16) hipLaunchKernelGGL((layernorm_bwd_kernel<bf16_t, bf16_t, V>), grid, block, shm, s, (const bf16_t*)dy, lddy, x, ldx, \
-                                  mean, rstd, gamma, g_in, ldgi, g_out, ldgo, (bf16_t*)g_lp, ldglp, partial_ws, rows, d, want_gsum); \
-  else hipLaunchKernelGGL((layernorm_bwd_kernel<float, float, V>), grid, block, shm, s, (const float*)dy, lddy, x, ldx, mean, rstd, \
-                          gamma, g_in, ldgi, g_out, ldgo, (float*)g_lp, ldglp, partial_ws, rows, d, want_gsum)
+  if (dy_bf16) hipLaunchKernelGGL((layernorm_bwd_kernel<bf16_t, bf16_t, V, false>), grid, block, shm, s, (const bf16_t*)dy, lddy, x, ldx, \
+                                  mean, rstd, gamma, g_in, ldgi, g_out, ldgo, (bf16_t*)g_lp, ldglp, partial_ws, rows, d, want_gsum, \
+                                  (const bf16_t*)nullptr, (int64_t)0, (const float*)nullptr); \
+  else hipLaunchKernelGGL((layernorm_bwd_kernel<float, float, V, false>), grid, block, shm, s, (const float*)dy, lddy, x, ldx, mean, rstd, \
+                          gamma, g_in, ldgi, g_out, ldgo, (float*)g_lp, ldglp, partial_ws, rows, d, want_gsum, (const float*)nullptr, (int64_t)0, \
+                          (const float*)nullptr)
   VITX_VPL_DISPATCH(d, CALL);
 #undef CALL
   // partial layout [blk][3][d]: dgamma = sum_blk partial[blk][0], dbeta = sum_blk partial[blk][1]
   if (deferred) *deferred = nblk;
   else launch_layernorm_bwd_reduce(partial_ws, nblk, d, dgamma, dbeta, want_gsum ? gsum : nullptr, s);
 }
+// ---- LayerNorm VJP + the LayerScale VJP of the branch that consumes its result (bf16 mode; see layernorm_bwd_kernel, FUSE)
+bool layernorm_bwd_scale_ok(int d) { return d % 4 == 0 && d <= 8 * 256; }
+void launch_layernorm_bwd_scale(const bf16_t* dy, int64_t lddy, const float* x, int64_t ldx, const float* mean, const float* rstd, const float* gamma,
+                                const float* g_in, int64_t ldgi, float* g_out, int64_t ldgo, bf16_t* dbr, int64_t lddbr, const bf16_t* nf, int64_t ldnf,
+                                const float* nscale, float* partial_ws, int rows, int d, hipStream_t s, int* nparts) {
+  *nparts = 0;
+  if (rows == 0) return;
+  const int nblk = (int)std::min<int64_t>(LNB_BLOCKS, ceil_div(rows, 8));
+  dim3 grid(nblk), block(LNB_THREADS);
+  const size_t shm = (size_t)(LNB_THREADS / 64) * d * sizeof(float);
+#define CALL(V)                                                                                                                              \
+  hipLaunchKernelGGL((layernorm_bwd_kernel<bf16_t, bf16_t, V, true>), grid, block, shm, s, dy, lddy, x, ldx, mean, rstd, gamma, g_in, ldgi, g_out, \
+                     ldgo, dbr, lddbr, partial_ws, rows, d, 0, nf, ldnf, nscale)
+  VITX_VPL_DISPATCH(d, CALL);
+#undef CALL
+  *nparts = nblk;
+}
+__global__ void mul_vec_kernel(float* __restrict__ a, const float* __restrict__ b, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) a[i] *= b[i];
+}
+// partial layout [blk][4][d]: dgamma, dbeta, column sums of g, column sums of g * f; dbias (optional) = nscale * colsum(g)
+void launch_layernorm_bwd_scale_reduce(float* partial_ws, int nparts, int d, float* dgamma, float* dbeta, float* dscale, float* dbias, const float* nscale,
+                                       hipStream_t s) {
+  if (nparts <= 0) return;
+  float* ws2 = partial_ws + (int64_t)LNB_BLOCKS * 4 * d;
+  launch_reduce_partials3(partial_ws, nparts, (int64_t)4 * d, d, 2, dgamma, dbeta, nullptr, ws2, 1.0f, s);
+  if (dbias) {
+    launch_reduce_partials3(partial_ws + 2 * (int64_t)d, nparts, (int64_t)4 * d, d, 2, dbias, dscale, nullptr, ws2, 1.0f, s);
+    hipLaunchKernelGGL(mul_vec_kernel, dim3((unsigned)ceil_div(d, 256)), dim3(256), 0, s, dbias, nscale, d);
+  } else {
+    launch_reduce_partials3(partial_ws + 3 * (int64_t)d, nparts, (int64_t)4 * d, d, 1, dscale, nullptr, nullptr, ws2, 1.0f, s);
+  }
+}
+
 void launch_layernorm_bwd_reduce(float* partial_ws, int nparts, int d, float* dgamma, float* dbeta, float* gsum, hipStream_t s) {
   if (nparts <= 0) return;
   launch_reduce_partials3(partial_ws, nparts, (int64_t)3 * d, d, gsum ? 3 : 2, dgamma, dbeta, gsum, partial_ws + (int64_t)LNB_BLOCKS * 3 * d, 1.0f, s);

@@ -214,6 +214,8 @@ struct vitx_engine {
   bool mlp_bwd_consumers_first = true;   // VITX_MLP_BWD_ORDER=0: fc2 weight gradient between the producer and the consumers of d hpre
   bool deepvit_fused_bwd = true;     // VITX_DEEPVIT_FUSED_BWD=0: the backward of that kernel as batched GEMMs + point / row kernels (A/B reference)
   bool glp_skip = true;             // LayerNorm VJPs skip the bf16 copy of the residual gradient when no branch reads it (all blocks have LayerScale); VITX_GLP_SKIP=0: always written
+  bool ln_scale_fused = true;       // CaiT: a LayerNorm VJP also runs the LayerScale VJP of the branch that consumes its result (VITX_LN_SCALE_FUSED=0: a pass of its own)
+  int64_t dbr_ready = 0;            // branch_key of the branch whose gradient e->d_br already holds (set by that LayerNorm VJP, cleared by the branch)
   bool cait_fused = true;           // cait.py:121-128 forward as one kernel in the bf16 mode (attn_cait_fused.hip); VITX_CAIT_FUSED=0 disables
   bool deepvit_fused = true;         // VITX_DEEPVIT_FUSED=0: DeepViT attention forward as batched GEMMs + head-axis kernels (A/B reference)
   bool unfused_headops = false;      // VITX_UNFUSED_HEADOPS=1: separate mix / softmax / LayerNorm-over-heads kernels (A/B reference)

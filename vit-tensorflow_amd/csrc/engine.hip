@@ -386,8 +386,24 @@ static void side2_end(vitx_engine* e, SideRing& r) {
 // their own: on the weight-gradient stream they queued behind a block's GEMMs and piled up in the tail after the chain had finished (CaiT cfg5
 // +0.2 .. 0.6 ms per step, r4x); here they run as soon as the VJP kernel is done, in whatever gaps the chip has.  The weight-gradient stream is
 // then ordered behind them, so that the join and the gradient-ready reports (events on that stream) cover them too.
+// (round 5) `nb` != null: the branch that consumes this VJP's result has a LayerScale (CaiT) -- its VJP rides on this pass (layernorm_bwd_kernel, FUSE):
+// e->d_br receives g * scale, the scale gradient and that branch's bias gradient come out of two more partial rows
+struct NextBranch { const void* f; const float* scale; float* dscale; float* dbias; };
 static void block_layernorm_bwd(vitx_engine* e, const void* dy, int T, int d, const float* x, const float* mean, const float* rstd, const float* gamma,
-                                const float* g_in, float* g_out, void* g_lp, float* dgamma, float* dbeta, float* gsum, int rows) {
+                                const float* g_in, float* g_out, void* g_lp, float* dgamma, float* dbeta, float* gsum, int rows,
+                                const NextBranch* nb = nullptr) {
+  if (nb) {
+    const bool side = e->side_live && e->side2 && e->rg_lnp.n != 0 && rows >= e->side2_min_rows;
+    if (side) side_rotate(e, e->rg_lnp, e->ln_part);
+    float* part = side ? e->ln_part : e->red_ws;
+    int parts = 0;
+    launch_layernorm_bwd_scale((const bf16_t*)dy, d, x, d, mean, rstd, gamma, g_in, d, g_out, d, (bf16_t*)e->d_br, d, (const bf16_t*)nb->f, d, nb->scale,
+                               part, rows, d, e->stream, &parts);
+    if (side) side2_begin(e);
+    launch_layernorm_bwd_scale_reduce(part, parts, d, dgamma, dbeta, nb->dscale, nb->dbias, nb->scale, side ? e->side2 : e->stream);
+    if (side) side2_end(e, e->rg_lnp);
+    return;
+  }
   if (!e->side_live || !e->side2 || e->rg_lnp.n == 0 || rows < e->side2_min_rows) {   // short VJPs (CaiT's class-attention rows): three stream operations cost more than they hide
     launch_layernorm_bwd(dy, T, d, x, d, mean, rstd, gamma, g_in, d, g_out, d, g_lp, d, e->red_ws, dgamma, dbeta, gsum, rows, d, e->stream);
     return;
@@ -1001,7 +1017,10 @@ static int block_forward(vitx_engine* e, Stage& st, int si, int l, int b, int nq
 }
 
 // g (fp32 [rows,d]) holds dL/dx_out on entry and dL/dx_in on exit; g_lp is its T copy (bf16 mode).
-static int block_backward(vitx_engine* e, Stage& st, int si, int l, int b, int nq, int nc, float drop, uint64_t seed, std::string& err) {
+static inline int64_t branch_key(int si, int l, int mlp) { return (((int64_t)si + 1) << 32) | ((int64_t)l << 1) | mlp; }
+// next_l: the layer of the same stage (same token rows) whose backward runs right after this one, or -1 -- lets this block's last LayerNorm VJP carry
+// the LayerScale VJP of that layer's MLP branch (block_layernorm_bwd, NextBranch)
+static int block_backward(vitx_engine* e, Stage& st, int si, int l, int b, int nq, int nc, float drop, uint64_t seed, std::string& err, int next_l = -1) {
   const uint32_t site0 = (uint32_t)((si * 1000 + l) * 4);
   const BlockParams& bp = st.bp[l];
   BlockActs& ba = st.ba[l];
@@ -1031,9 +1050,14 @@ static int block_backward(vitx_engine* e, Stage& st, int si, int l, int b, int n
 
   const void* dbranch = gT;
   bool fc2_bias_done = false, out_bias_done = false;   // bias gradient already produced by the LayerScale VJP pass
+  const int64_t key_mlp = branch_key(si, l, 1), key_attn = branch_key(si, l, 0);
   if (!ba.skip_mlp) {
   // ---- MLP branch: x_out = x_mid + scale * fc2(gelu(fc1(LN(x_mid))))
-  if (bp.m_scale >= 0 || drop > 0.f) {   // LayerScale VJP (cait.py:47-48): dscale = sum g*f(x), d f = g*scale; Dropout VJP: same mask
+  if (e->dbr_ready == key_mlp) {           // the LayerNorm VJP of the layer above has already run this branch's LayerScale VJP (block_layernorm_bwd, nb)
+    e->dbr_ready = 0;
+    dbranch = e->d_br;
+    fc2_bias_done = dense_gb(e, bp.fc2) != nullptr;
+  } else if (bp.m_scale >= 0 || drop > 0.f) {   // LayerScale VJP (cait.py:47-48): dscale = sum g*f(x), d f = g*scale; Dropout VJP: same mask
     Prof pr(e, "branch_grad", 0, 0);
     // LayerScale without dropout: one pass over g gives dscale AND the branch gradient g * scale
     const bool one_pass = bp.m_scale >= 0 && drop == 0.f && d % 4 == 0;
@@ -1097,9 +1121,15 @@ static int block_backward(vitx_engine* e, Stage& st, int si, int l, int b, int n
   if (e->mlp_bwd_consumers_first) fc2_param_grads();
   {
     Prof pr(e, "layernorm_bwd", 0, lnb);
-    void* ln_glp = next_glp();
+    // the attention branch of this block is next: its LayerScale VJP on this pass where it has one (and no dropout mask to apply)
+    NextBranch nb{ba.fa, bp.a_scale >= 0 ? e->params + bp.a_scale : nullptr, bp.a_scale >= 0 ? e->grads + bp.a_scale : nullptr,
+                  (bp.has_out && dense_gb(e, bp.out)) ? dense_gb(e, bp.out) : nullptr};
+    const bool fuse = e->ln_scale_fused && T && !grouped && !ba.skip_attn && bp.a_scale >= 0 && (bp.has_out ? drop : 0.f) == 0.f && !fc2_bias_in_ln &&
+                      layernorm_bwd_scale_ok(d);
+    void* ln_glp = fuse ? nullptr : next_glp();
+    if (fuse) { side_rotate(e, e->rg_dbr, e->d_br); e->dbr_ready = key_attn; }
     block_layernorm_bwd(e, e->d_y, T, d, ba.ln2_src ? ba.ln2_src : ba.x_mid, ba.mean2, ba.rstd2, e->params + bp.ln2_g, ln_gin, ln_gout, ln_glp,
-                        e->grads + bp.ln2_g, e->grads + bp.ln2_b, fc2_bias_in_ln ? e->grads + bp.fc2.b : nullptr, rows);
+                        e->grads + bp.ln2_g, e->grads + bp.ln2_b, fc2_bias_in_ln ? e->grads + bp.fc2.b : nullptr, rows, fuse ? &nb : nullptr);
   }
   }   // !skip_mlp
   if (ba.skip_attn) {
@@ -1110,7 +1140,11 @@ static int block_backward(vitx_engine* e, Stage& st, int si, int l, int b, int n
   // ---- attention branch: x_mid = x_in + scale * to_out(attn(LN(x_in)))
   gT = T ? e->g_lp : (const void*)e->g;
   dbranch = gT;
-  if (bp.a_scale >= 0 || (drop > 0.f && bp.has_out)) {
+  if (e->dbr_ready == key_attn) {
+    e->dbr_ready = 0;
+    dbranch = e->d_br;
+    out_bias_done = bp.has_out && dense_gb(e, bp.out) != nullptr;
+  } else if (bp.a_scale >= 0 || (drop > 0.f && bp.has_out)) {
     Prof pr(e, "branch_grad", 0, 0);
     const float adrop = bp.has_out ? drop : 0.f;
     const bool one_pass = bp.a_scale >= 0 && adrop == 0.f && d % 4 == 0;
@@ -1200,9 +1234,21 @@ static int block_backward(vitx_engine* e, Stage& st, int si, int l, int b, int n
   }
   {
     Prof pr(e, "layernorm_bwd", 0, lnb);
-    void* ln_glp = next_glp();
+    // the MLP branch of the layer below is next
+    NextBranch nb{nullptr, nullptr, nullptr, nullptr};
+    bool fuse = false;
+    if (next_l >= 0 && e->ln_scale_fused && T && !grouped && drop == 0.f && !out_bias_in_ln && layernorm_bwd_scale_ok(d)) {
+      const BlockParams& np_ = st.bp[(size_t)next_l];
+      const BlockActs& na = st.ba[(size_t)next_l];
+      if (np_.m_scale >= 0 && !na.skip_mlp && !(na.par_first || na.par_last || na.ln1_src || na.ln2_src)) {
+        nb = NextBranch{na.fm, e->params + np_.m_scale, e->grads + np_.m_scale, dense_gb(e, np_.fc2)};
+        fuse = true;
+      }
+    }
+    void* ln_glp = fuse ? nullptr : next_glp();
+    if (fuse) { side_rotate(e, e->rg_dbr, e->d_br); e->dbr_ready = branch_key(si, next_l, 1); }
     block_layernorm_bwd(e, e->d_y, T, d, ba.ln1_src ? ba.ln1_src : ba.x_in, ba.mean1, ba.rstd1, e->params + bp.ln1_g, ln_gin, ln_gout, ln_glp,
-                        e->grads + bp.ln1_g, e->grads + bp.ln1_b, out_bias_in_ln ? e->grads + bp.out.b : nullptr, rows);
+                        e->grads + bp.ln1_g, e->grads + bp.ln1_b, out_bias_in_ln ? e->grads + bp.out.b : nullptr, rows, fuse ? &nb : nullptr);
   }
   report_ready(e, bp.p_begin, bp.p_end - bp.p_begin);
   return VITX_OK;
@@ -1252,6 +1298,7 @@ static int engine_create_body(vitx_engine* e, const vitx_config& cfg, std::strin
   if (const char* k = getenv("VITX_DEEPVIT_FUSED_BWD")) e->deepvit_fused_bwd = atoi(k) != 0;
   if (const char* k = getenv("VITX_CAIT_FUSED")) e->cait_fused = atoi(k) != 0;
   if (const char* k = getenv("VITX_GLP_SKIP")) e->glp_skip = atoi(k) != 0;
+  if (const char* k = getenv("VITX_LN_SCALE_FUSED")) e->ln_scale_fused = atoi(k) != 0;
   if (const char* k = getenv("VITX_MLP_BWD_ORDER")) e->mlp_bwd_consumers_first = atoi(k) != 0;
   if (const char* k = getenv("VITX_NT")) e->nt_mask = atoi(k);
   if (const char* k = getenv("VITX_BGEMM_PAIRS")) e->bgemm_pairs = atoi(k) != 0;
@@ -1983,8 +2030,9 @@ int engine_transformer_backward(vitx_engine* e, const float* dout_dev, float* dt
   if (T) launch_convert(e->g, d, e->g_lp, 1, d, b * n, d, d, e->stream);
   int rc;
   SideScope side_scope(e, true);
+  e->dbr_ready = 0;
   for (int l = s0.depth - 1; l >= 0; --l)
-    if ((rc = block_backward(e, s0, 0, l, b, n, 0, e->tf_drop, e->tf_seed, err)) != VITX_OK) return rc;
+    if ((rc = block_backward(e, s0, 0, l, b, n, 0, e->tf_drop, e->tf_seed, err, l - 1)) != VITX_OK) return rc;
   if (dtokens_dev) HIPCHK(hipMemcpyAsync(dtokens_dev, e->g, bytes, hipMemcpyDeviceToDevice, e->stream));
   return VITX_OK;
 }
@@ -2123,11 +2171,16 @@ int engine_backward(vitx_engine* e, const float* dlogits_dev, float* dimg_dev, s
   report_ready(e, e->head_g, e->n_arena - e->head_g);
 
   int rc;
+  e->dbr_ready = 0;
+  auto next_kept = [&](int si, int l) {   // the next lower layer of the stage that survived layer dropout in this forward (cait.py:17-31), or -1
+    for (int j = l - 1; j >= 0; --j) if (e->layer_kept[(size_t)si][(size_t)j]) return j;
+    return -1;
+  };
   if (cait) {
     Stage& s1 = e->stages[1];
     launch_fill_zero(e->g_ctx, (int64_t)b * np * d * 4, e->stream);
     for (int l = s1.depth - 1; l >= 0; --l)
-      if (e->layer_kept[1][(size_t)l] && (rc = block_backward(e, s1, 1, l, b, 1, np, drop, e->last_seed, err)) != VITX_OK) return rc;
+      if (e->layer_kept[1][(size_t)l] && (rc = block_backward(e, s1, 1, l, b, 1, np, drop, e->last_seed, err, next_kept(1, l))) != VITX_OK) return rc;
     {
       Prof pr(e, "embed_bwd", 0, 0);
       launch_batch_reduce(e->g, b, 1, d, 0, 1, e->grads + e->cls, e->stream);          // dcls = sum_b g (cait.py:189 VJP)
@@ -2139,7 +2192,8 @@ int engine_backward(vitx_engine* e, const float* dlogits_dev, float* dimg_dev, s
   for (int l = s0.depth - 1; l >= 0; --l) {
     if (merging && l == e->merge_after && (rc = merger_backward(e, s0.ba[l].x_out, b, ntok, err)) != VITX_OK) return rc;
     const int rows_tok = (merging && l > e->merge_after) ? e->merge_t : ntok;
-    if (e->layer_kept[0][(size_t)l] && (rc = block_backward(e, s0, 0, l, b, rows_tok, 0, drop, e->last_seed, err)) != VITX_OK) return rc;
+    if (e->layer_kept[0][(size_t)l] && (rc = block_backward(e, s0, 0, l, b, rows_tok, 0, drop, e->last_seed, err, merging ? -1 : next_kept(0, l))) != VITX_OK)
+      return rc;
   }
   if (e->last_training && c.emb_dropout > 0.f) {
     Prof pr(e, "dropout", 0, 0);

@@ -103,6 +103,14 @@ void launch_layernorm_bwd(const void* dy, int dy_bf16, int64_t lddy, const float
                           hipStream_t s, int* deferred = nullptr);   // gsum (optional): column sums of g_in; deferred: see the definition
 void launch_layernorm_bwd_reduce(float* partial_ws, int nparts, int d, float* dgamma, float* dbeta, float* gsum, hipStream_t s);
 int64_t layernorm_bwd_ws_elems(int d);
+// LayerNorm VJP that also runs the LayerScale VJP of the branch consuming its result (bf16 mode, CaiT): dbr = g_out * nscale, partial rows for
+// d nscale = colsum(g_out * nf) and that branch's bias gradient nscale * colsum(g_out); the caller runs the reduction on a stream of its choice
+bool layernorm_bwd_scale_ok(int d);   // (every operand 16-B aligned with row strides that are multiples of 4: true of the engine's own buffers)
+void launch_layernorm_bwd_scale(const bf16_t* dy, int64_t lddy, const float* x, int64_t ldx, const float* mean, const float* rstd, const float* gamma,
+                                const float* g_in, int64_t ldgi, float* g_out, int64_t ldgo, bf16_t* dbr, int64_t lddbr, const bf16_t* nf, int64_t ldnf,
+                                const float* nscale, float* partial_ws, int rows, int d, hipStream_t s, int* nparts);
+void launch_layernorm_bwd_scale_reduce(float* partial_ws, int nparts, int d, float* dgamma, float* dbeta, float* dscale, float* dbias, const float* nscale,
+                                       hipStream_t s);
 void launch_colsum(const void* x, int is_bf16, int64_t ld, int rows, int cols, float* partial_ws, float* out, hipStream_t s);
 int64_t colsum_ws_elems(int cols);
 void launch_reduce_partials(const float* partial, int nparts, int64_t stride, int64_t n, float* out, float alpha, hipStream_t s);
