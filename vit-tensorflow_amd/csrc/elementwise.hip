@@ -242,7 +242,8 @@ __global__ __launch_bounds__(LNB_THREADS, (VPL == 4 ? (FUSE ? VITX_LNB_FUSE_WAVE
     const float* xr = x + (int64_t)row * ldx;
     const TD* dr = dy + (int64_t)row * lddy;
     float4 xh[VPL], gg[VPL];
-    float4 gip[FUSE ? VPL : 1], fvp[FUSE ? VPL : 1];   // FUSE: g_in and f of this row, requested with x and dy (not behind the two wave reductions)
+    constexpr bool PRE = FUSE;   // (requesting g_in early in the plain form as well: 2.74 vs 2.72 ms per ViT-B/16 step, neutral -- profiles/r5/ab_layernorm_vjp_prefetch_r5q_neutral.log)
+    float4 gip[PRE ? VPL : 1], fvp[FUSE ? VPL : 1];   // g_in (and f) of this row, requested with x and dy (not behind the two wave reductions)
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
@@ -250,10 +251,8 @@ __global__ __launch_bounds__(LNB_THREADS, (VPL == 4 ? (FUSE ? VITX_LNB_FUSE_WAVE
       if (c < d) {
         const float4 xv = *(const float4*)(xr + c);
         const float4 dv = ld4<TD>(dr + c);
-        if (FUSE) {
-          gip[i] = g_in ? *(const float4*)(g_in + (int64_t)row * ldgi + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-          fvp[i] = ld4<TL>(nf + (int64_t)row * ldnf + c);
-        }
+        if (PRE) gip[i] = g_in ? *(const float4*)(g_in + (int64_t)row * ldgi + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (FUSE) fvp[i] = ld4<TL>(nf + (int64_t)row * ldnf + c);
         xh[i] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
         ab[i].x += dv.x; ab[i].y += dv.y; ab[i].z += dv.z; ab[i].w += dv.w;
         ag[i].x += dv.x * xh[i].x; ag[i].y += dv.y * xh[i].y; ag[i].z += dv.z * xh[i].z; ag[i].w += dv.w * xh[i].w;
@@ -271,7 +270,8 @@ __global__ __launch_bounds__(LNB_THREADS, (VPL == 4 ? (FUSE ? VITX_LNB_FUSE_WAVE
       if (c < d) {
         float4 dx = make_float4(rs * (gg[i].x - s1 - xh[i].x * s2), rs * (gg[i].y - s1 - xh[i].y * s2),
                                 rs * (gg[i].z - s1 - xh[i].z * s2), rs * (gg[i].w - s1 - xh[i].w * s2));
-        if (FUSE) {
+        if (PRE) {
+          if (!FUSE) { as[i].x += gip[i].x; as[i].y += gip[i].y; as[i].z += gip[i].z; as[i].w += gip[i].w; }
           dx.x += gip[i].x; dx.y += gip[i].y; dx.z += gip[i].z; dx.w += gip[i].w;
         } else if (g_in) {
           const float4 gi = *(const float4*)(g_in + (int64_t)row * ldgi + c);
