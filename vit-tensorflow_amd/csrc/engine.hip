@@ -573,7 +573,13 @@ static void dense_wgrad(vitx_engine* e, const void* X, int64_t ldx, const void* 
     // (finer slices -- 384 / 512 workgroups, so that a low-priority side-stream workgroup holds its CU for less long -- measured +2.5 / +1.6 ms per step:
     //  profiles/r4/ab_weight_gradient_slices_r4o_not_kept.log; coarser ones -- 192 / 128 workgroups, less partial traffic -- +0.3 / +0.8 ms:
     //  ab_weight_gradient_coarser_slices_r4pj_not_kept.log)
-    int split = (int)std::max<int64_t>(1, std::min<int64_t>(ceil_div(nk, 4), std::max<int64_t>(1, 256 / tiles)));
+    // (round 5) with few token rows -- 16 k rows: CaiT / DeepViT at 256 x 64 tokens -- a full wave of workgroups means 16 K-tiles per slice, a partial
+    //  buffer as large as the operands, and a launch that takes every CU from the input-gradient GEMMs it runs beside; HALF a wave leaves those
+    //  their CUs and halves the partial traffic: CaiT cfg5 38.4 -> 36.7 ms, README config -2 %, DeepViT cfg4 neutral; at 50 k rows (ViT-B / L) it
+    //  costs 1.0 / 2.0 ms (profiles/r5/sweep_weight_gradient_workgroups_r5t.log).  VITX_WGRAD_WGS=n overrides.
+    static const int wg_env = [] { const char* v = getenv("VITX_WGRAD_WGS"); return v ? std::max(1, atoi(v)) : 0; }();
+    const int wg_target = wg_env ? wg_env : (rows <= 24576 ? 128 : 256);
+    int split = (int)std::max<int64_t>(1, std::min<int64_t>(ceil_div(nk, 4), std::max<int64_t>(1, wg_target / tiles)));
     while (split > 1 && (int64_t)split * w.in * w.out > e->partial_elems) --split;
     if (!e->wgrad_via_transpose) {
       // the weight-gradient kernel addresses a K slice of each operand through a buffer resource (31-bit byte offsets): a slice must stay below
