@@ -127,6 +127,7 @@ __global__ __launch_bounds__(CA_THREADS) void cait_attn_fwd_kernel(
     for (int rr = 0; rr < 2; ++rr) {
       const int i = wave + 8 * rr;
       const bool rv = (q0 + i) < nq;
+      if (!rv) continue;   // (wave-uniform) a query row past the end: nothing of it is stored
       const int voff = (4 * hq * (int)plane + (q0 + i) * (int)ld + jl) * 4;
       float y[CA_NT][4];
       float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};

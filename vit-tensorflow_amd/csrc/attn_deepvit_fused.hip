@@ -170,6 +170,7 @@ __global__ __launch_bounds__(DV_THREADS) void deepvit_attn_fwd_kernel(
       for (int rr = 0; rr < 2; ++rr) {
         const int i = wave + 8 * rr;
         const bool rv = (q0 + i) < nq;
+        if (!rv) continue;   // (wave-uniform) a query row past the end -- 15 of the last tile's 16 at 65 tokens: its column of O^T is never stored
 #pragma unroll
         for (int gk = 0; gk < DV_NT; ++gk) {
           if (gk < nt) {
@@ -416,6 +417,7 @@ __global__ __launch_bounds__(DVB_THREADS) void deepvit_attn_bwd_kernel(
 #pragma unroll
           for (int r = 0; r < 4; ++r) y[kb][r] = yn[kb][r];
         if (rr + 1 < RPW) load_p(tile, rr + 1, yn); else load_p(tile + 1, 0, yn);   // the next row's P, in flight under this row's arithmetic
+        if (!rv) continue;   // (wave-uniform) a query row past the end: contributes nothing to dW / dgamma / dbeta, and its column of dq^T is never stored
 #pragma unroll
         for (int kb = 0; kb < DV_NT; ++kb) {
           if (kb < nt) {
