@@ -134,12 +134,13 @@ __global__ __launch_bounds__(256) void bgemm_mfma_pair_kernel(GenericGemmArgs g1
 bool bgemm_mfma_supported(const GenericGemmArgs& g, int ta, int tb, int to, int mode) {
   if (g.M > 128 || g.N > 128 || g.K > 128 || g.M < 1 || g.N < 1 || g.K < 1) return false;
   if (tb != 1) return false;                                           // B operand: bf16 q / k / v / dO head slices
-  if (!((ta == 1 && to == 0 && mode == EPI_STORE_F32) || (ta == 0 && to == 1 && mode == EPI_STORE))) return false;
+  // A: bf16 head slices (q, k, v, dO) or bf16 score tensors kept by the one-kernel forwards (round 5) -> fp32 scores or bf16 rows; or fp32 scores -> bf16 rows
+  if (!((ta == 1 && to == 0 && mode == EPI_STORE_F32) || (to == 1 && mode == EPI_STORE))) return false;
   return true;
 }
 
-void launch_bgemm_mfma_pair(const GenericGemmArgs& g1, const EpiParams& ep1, int ta1, const GenericGemmArgs& g2, const EpiParams& ep2, int ta2,
-                            hipStream_t s) {
+void launch_bgemm_mfma_pair(const GenericGemmArgs& g1, const EpiParams& ep1, int ta1, int to1, const GenericGemmArgs& g2, const EpiParams& ep2, int ta2,
+                            int to2, hipStream_t s) {
   const int Mp1 = (int)round_up(g1.M, 16), Np1 = (int)round_up(g1.N, 16), Kp1 = (int)round_up(g1.K, 32);
   const int Mp2 = (int)round_up(g2.M, 16), Np2 = (int)round_up(g2.N, 16), Kp2 = (int)round_up(g2.K, 32);
   const size_t smem = std::max((size_t)(Mp1 + Np1) * (Kp1 + PAD) * 2, (size_t)(Mp2 + Np2) * (Kp2 + PAD) * 2);
@@ -151,18 +152,25 @@ void launch_bgemm_mfma_pair(const GenericGemmArgs& g1, const EpiParams& ep1, int
     if (!set) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); set = true; } \
     hipLaunchKernelGGL(kern, grid, block, smem, s, g1, ep1, Mp1, Np1, Kp1, g2, ep2, Mp2, Np2, Kp2);                                \
   }
-  if (ta1 && !ta2) VITX_PAIR(bf16_t, float, float, bf16_t)
+  if (ta1 && to1 && ta2 && to2) VITX_PAIR(bf16_t, bf16_t, bf16_t, bf16_t)      // (dV = A'^T dO, dK = dS^T q) / (dQ = dS k, dK = dS^T q) on bf16 score tensors
+  else if (ta1 && !to1 && ta2 && to2) VITX_PAIR(bf16_t, float, bf16_t, bf16_t)   // (dA = dO v^T, dV = A'^T dO) with A' kept as bf16
+  else if (ta1 && !ta2) VITX_PAIR(bf16_t, float, float, bf16_t)
   else if (!ta1 && !ta2) VITX_PAIR(float, bf16_t, float, bf16_t)
   else if (ta1 && ta2) VITX_PAIR(bf16_t, float, bf16_t, float)
   else VITX_PAIR(float, bf16_t, bf16_t, float)
 #undef VITX_PAIR
 }
 
-void launch_bgemm_mfma(const GenericGemmArgs& g, const EpiParams& ep, int ta, hipStream_t s) {
+void launch_bgemm_mfma(const GenericGemmArgs& g, const EpiParams& ep, int ta, int to, hipStream_t s) {
   const int Mp = (int)round_up(g.M, 16), Np = (int)round_up(g.N, 16), Kp = (int)round_up(g.K, 32);
   const size_t smem = (size_t)(Mp + Np) * (Kp + PAD) * 2;
   dim3 grid((unsigned)(g.nb * g.nh)), block(256);
-  if (ta) {
+  if (ta && to) {
+    auto kern = bgemm_mfma_kernel<bf16_t, bf16_t>;
+    static bool set = false;
+    if (!set) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); set = true; }
+    hipLaunchKernelGGL(kern, grid, block, smem, s, g, ep, Mp, Np, Kp);
+  } else if (ta) {
     auto kern = bgemm_mfma_kernel<bf16_t, float>;
     static bool set = false;
     if (!set) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); set = true; }

@@ -106,8 +106,14 @@ __global__ __launch_bounds__(DV_THREADS) void deepvit_attn_fwd_kernel(
     const auto s2 = __builtin_amdgcn_permlane32_swap(v2, v2, false, false);
     return __builtin_bit_cast(float, (unsigned)s2[0]) + __builtin_bit_cast(float, (unsigned)s2[1]);
   };
-  const __amdgpu_buffer_rsrc_t rsA2 = __builtin_amdgcn_make_buffer_rsrc((void*)(a2_keep + (int64_t)bi * H * plane), 0, (int)(H * plane * 4), 0x00020000);
-  const int plane4 = (int)plane * 4;
+  // keep == 2 (round 5): the normalised scores are kept as bf16 [H][nq][ld2], ld2 = nk rounded up to 8 -- their only reader is the dV product, whose
+  // loader rounds them to bf16 anyway (same bits, half the bytes written here and read there)
+  const bool a2_lp = keep == 2;
+  const int ld2 = (nk + 7) & ~7;
+  const int64_t plane2 = (int64_t)nq * ld2;
+  const __amdgpu_buffer_rsrc_t rsA2 = a2_lp ? __builtin_amdgcn_make_buffer_rsrc((void*)((bf16_t*)a2_keep + (int64_t)bi * H * plane2), 0, (int)(H * plane2 * 2), 0x00020000)
+                                            : __builtin_amdgcn_make_buffer_rsrc((void*)(a2_keep + (int64_t)bi * H * plane), 0, (int)(H * plane * 4), 0x00020000);
+  const int plane4 = a2_lp ? (int)plane2 * 2 : (int)plane * 4;
 
   for (int tile = t_begin; tile < t_end; ++tile) {
     const int q0 = tile * 16;
@@ -193,8 +199,12 @@ __global__ __launch_bounds__(DV_THREADS) void deepvit_attn_fwd_kernel(
               const float a2 = xh[r] * rs * gm[r] + bt[r];
               if (hv[r]) Al[(hh * 16 + i) * DV_AP + j] = valid ? (bf16_t)a2 : (bf16_t)0.f;   // (keys nk .. 16 nt - 1 multiply zero rows of V)
               // kept for the backward: valid points only; everything else is sent out of the descriptor's range (dropped)
-              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, a2), rsA2,
-                                                    (keep && valid && hv[r]) ? (4 * hq * (int)plane + (q0 + i) * (int)ld + j) * 4 : 0x7ffffff0, r * plane4, 0);
+              if (a2_lp)
+                __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, (bf16_t)a2), rsA2,
+                                                      (valid && hv[r]) ? (4 * hq * (int)plane2 + (q0 + i) * ld2 + j) * 2 : 0x7ffffff0, r * plane4, 0);
+              else
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, a2), rsA2,
+                                                      (keep && valid && hv[r]) ? (4 * hq * (int)plane + (q0 + i) * (int)ld + j) * 4 : 0x7ffffff0, r * plane4, 0);
             }
           }
         }
@@ -274,7 +284,7 @@ __global__ __launch_bounds__(DVB_THREADS) void deepvit_attn_bwd_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, int64_t ldq, int64_t ldk, int64_t ldv, int64_t qb,
     int64_t kb, int64_t vb, const bf16_t* __restrict__ d_o, int64_t ldo, int64_t ob, const float* __restrict__ p_keep, const float* __restrict__ w,
     const float* __restrict__ gamma, float* __restrict__ ds_out, bf16_t* __restrict__ dq, int64_t lddq, int64_t dqb, float* __restrict__ partial,
-    int nq, int nk, int64_t ld, float scale, float eps, const bf16_t* __restrict__ zero_page, int ntile, int cpi, int xp) {
+    int nq, int nk, int64_t ld, float scale, float eps, const bf16_t* __restrict__ zero_page, int ntile, int cpi, int xp, int ds_bf16) {
   constexpr int HPW = (H + DVB_WAVES - 1) / DVB_WAVES;   // heads per wave (stages 1, 3)
   constexpr int RPW = 16 / DVB_WAVES;                    // query rows per wave (stage 2)
   constexpr int R0 = dv_bwd_r0<H>();
@@ -363,8 +373,12 @@ __global__ __launch_bounds__(DVB_THREADS) void deepvit_attn_bwd_kernel(
   // under a per-lane condition becomes a branch around it with a full `s_waitcnt vmcnt(0)` behind each (twenty serialised memory round trips per
   // row in the first version); reads past the block return zero, the rest is masked afterwards
   const __amdgpu_buffer_rsrc_t rsP = __builtin_amdgcn_make_buffer_rsrc((void*)(p_keep + (int64_t)bi * H * plane), 0, (int)(H * plane * 4), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc((void*)(ds_out + (int64_t)bi * H * plane), 0, (int)(H * plane * 4), 0x00020000);
-  const int plane4 = (int)plane * 4;
+  // ds_bf16 (round 5): d(dots) leaves as bf16 [H][nq][ld2], ld2 = nk rounded up to 8 -- its only reader is the dK product, whose loader rounds it anyway
+  const int ld2 = (nk + 7) & ~7;
+  const int64_t plane2 = (int64_t)nq * ld2;
+  const __amdgpu_buffer_rsrc_t rsD = ds_bf16 ? __builtin_amdgcn_make_buffer_rsrc((void*)((bf16_t*)ds_out + (int64_t)bi * H * plane2), 0, (int)(H * plane2 * 2), 0x00020000)
+                                             : __builtin_amdgcn_make_buffer_rsrc((void*)(ds_out + (int64_t)bi * H * plane), 0, (int)(H * plane * 4), 0x00020000);
+  const int plane4 = (int)plane * 4, planeD = ds_bf16 ? (int)plane2 * 2 : (int)plane * 4;
   auto load_p = [&](int tile_, int rr_, float (&dst)[DV_NT][4]) {
     const int i_ = wave + DVB_WAVES * rr_, qrow = tile_ * 16 + i_;
     const bool rv_ = tile_ < t_end && qrow < nq;
@@ -479,8 +493,12 @@ __global__ __launch_bounds__(DVB_THREADS) void deepvit_attn_bwd_kernel(
               const float ds = y[kb][r] * (dp[kb][r] - rsum[r]);      // 0 for masked keys / rows / heads (P = 0)
               if (hv[r]) sl[hh * DV_AP + j] = (bf16_t)ds;
               // columns nk .. ld - 1 get their zeros; everything else (padding rows / columns / heads) is sent out of the descriptor's range: dropped
-              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, ds), rsD,
-                                                    (rv && j < ld && hv[r] && !(xp & 16)) ? (4 * hq * (int)plane + (q0 + i) * (int)ld + j) * 4 : 0x7ffffff0, r * plane4, 0);
+              if (ds_bf16)
+                __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, (bf16_t)ds), rsD,
+                                                      (rv && j < ld2 && hv[r] && !(xp & 16)) ? (4 * hq * (int)plane2 + (q0 + i) * ld2 + j) * 2 : 0x7ffffff0, r * planeD, 0);
+              else
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, ds), rsD,
+                                                      (rv && j < ld && hv[r] && !(xp & 16)) ? (4 * hq * (int)plane + (q0 + i) * (int)ld + j) * 4 : 0x7ffffff0, r * planeD, 0);
             }
           }
         }
@@ -601,7 +619,7 @@ int64_t deepvit_attn_bwd_ws_elems(int b, int h, int nq) {
 void launch_deepvit_attn_bwd(const bf16_t* q, const bf16_t* k, const bf16_t* v, int64_t ldq, int64_t ldk, int64_t ldv, int64_t qb, int64_t kb, int64_t vb,
                              const bf16_t* d_o, int64_t ldo, int64_t ob, const float* p_keep, const float* w, const float* gamma, float* ds_out,
                              bf16_t* dq, int64_t lddq, int64_t dqb, float* ws, float* dw, float* dgamma, float* dbeta, int b, int h, int nq, int nk,
-                             int64_t ld, float scale, float eps, const bf16_t* zero_page, hipStream_t s) {
+                             int64_t ld, float scale, float eps, const bf16_t* zero_page, hipStream_t s, int ds_bf16) {
   const int ntile = (nq + 15) / 16;
   const int cpi = dv_bwd_cpi(b, ntile);
   static const int xp = [] { const char* e = getenv("VITX_DVB_XP"); return e ? atoi(e) : 0; }();   // timing experiments (WRONG results): 1 / 2 / 4 / 8 = without stage 1 / 2 / 2b / 3
@@ -609,7 +627,7 @@ void launch_deepvit_attn_bwd(const bf16_t* q, const bf16_t* k, const bf16_t* v, 
   {                                                                                                                                    \
     dv_set_smem(deepvit_attn_bwd_kernel<HT>, dv_bwd_smem<HT>());                                                                       \
     hipLaunchKernelGGL(deepvit_attn_bwd_kernel<HT>, dim3(b * cpi), dim3(DVB_THREADS), dv_bwd_smem<HT>(), s, q, k, v, ldq, ldk, ldv, qb, \
-                       kb, vb, d_o, ldo, ob, p_keep, w, gamma, ds_out, dq, lddq, dqb, ws, nq, nk, ld, scale, eps, zero_page, ntile, cpi, xp); \
+                       kb, vb, d_o, ldo, ob, p_keep, w, gamma, ds_out, dq, lddq, dqb, ws, nq, nk, ld, scale, eps, zero_page, ntile, cpi, xp, ds_bf16); \
   }
   if (h == 4) CALL(4) else if (h == 8) CALL(8) else if (h == 12) CALL(12) else CALL(16)
 #undef CALL

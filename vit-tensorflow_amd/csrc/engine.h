@@ -73,6 +73,7 @@ struct BlockActs {
   int64_t sc_geom = -1;             // (b, nq, nk) the kept tensors describe
   int sc_pi = 0;                    // index of the tensor that multiplies V
   bool sc_no_mixed = false;         // kept by the one-kernel DeepViT forward: sc_keep[1] (the mixed scores) was not written
+  bool sc_a2_bf16 = false;   // sc_keep[2] holds bf16 [nq][round_up(nk, 8)] planes (one-kernel forward with the one-kernel backward as its reader)
   int par_first = 0, par_last = 0;   // backward order inside a group of parallel half-blocks: first / last one processed (1 + 1 = alone)
 };
 
@@ -216,6 +217,7 @@ struct vitx_engine {
   bool glp_skip = true;             // LayerNorm VJPs skip the bf16 copy of the residual gradient when no branch reads it (all blocks have LayerScale); VITX_GLP_SKIP=0: always written
   bool ln_scale_fused = true;       // CaiT: a LayerNorm VJP also runs the LayerScale VJP of the branch that consumes its result (VITX_LN_SCALE_FUSED=0: a pass of its own)
   int64_t dbr_ready = 0;            // branch_key of the branch whose gradient e->d_br already holds (set by that LayerNorm VJP, cleared by the branch)
+  bool score_bf16 = true;           // score tensors whose only reader is a batched product are kept / written as bf16 by the one-kernel attention paths (VITX_SCORE_BF16=0: fp32)
   bool cait_fused = true;           // cait.py:121-128 forward as one kernel in the bf16 mode (attn_cait_fused.hip); VITX_CAIT_FUSED=0 disables
   bool deepvit_fused = true;         // VITX_DEEPVIT_FUSED=0: DeepViT attention forward as batched GEMMs + head-axis kernels (A/B reference)
   bool unfused_headops = false;      // VITX_UNFUSED_HEADOPS=1: separate mix / softmax / LayerNorm-over-heads kernels (A/B reference)

@@ -697,7 +697,7 @@ static void bgemm_pair(vitx_engine* e, const BgemmCall& c1, const BgemmCall& c2)
   if (e->bf16 && !e->force_generic_gemm && e->bgemm_pairs && c1.nb == c2.nb && c1.nh == c2.nh && bgemm_mfma_supported(g1, c1.ta, c1.tb, c1.to, c1.mode) &&
       bgemm_mfma_supported(g2, c2.ta, c2.tb, c2.to, c2.mode)) {
     Prof pr(e, "attn_bgemm_mfma", 2.0 * c1.nb * c1.nh * ((double)c1.M * c1.N * c1.K + (double)c2.M * c2.N * c2.K), 0);
-    launch_bgemm_mfma_pair(g1, ep1, c1.ta, g2, ep2, c2.ta, e->stream);
+    launch_bgemm_mfma_pair(g1, ep1, c1.ta, c1.to, g2, ep2, c2.ta, c2.to, e->stream);
     return;
   }
   for (const BgemmCall* c : {&c1, &c2})
@@ -718,7 +718,7 @@ static void bgemm(vitx_engine* e, const void* A, int ta, int64_t sam, int64_t sa
   finalize_epi(ep);
   if (e->bf16 && !e->force_generic_gemm && bgemm_mfma_supported(g, ta, tb, to, mode)) {
     Prof pr(e, "attn_bgemm_mfma", 2.0 * M * (double)N * K * nb * nh, 0);
-    launch_bgemm_mfma(g, ep, ta, e->stream);
+    launch_bgemm_mfma(g, ep, ta, to, e->stream);
     return;
   }
   Prof pr(e, "attn_generic_bgemm", 2.0 * M * (double)N * K * nb * nh, 0);
@@ -787,11 +787,13 @@ static void attn_generic_fwd(vitx_engine* e, const BlockParams& bp, const AttnVi
       deepvit_attn_fused_supported(h, dh, a.nq, a.nk)) {
     // deepvit.py:79-88 in one kernel; the three score tensors only leave the chip when this block's backward will read them
     const double pts = (double)b * h * a.nq * a.nk;
+    // (round 5) the normalised scores are kept as bf16 when the one-kernel backward will be their reader (its dV product rounds them anyway)
+    const bool lp = e->deepvit_fused_bwd && e->score_bf16;
     Prof pr(e, "attn_deepvit_fused_fwd", 4.0 * pts * dh + 2.0 * pts * h, ((double)b * a.nq * 3 * h * dh + (double)b * a.nq * h * dh) * 2 + (keep ? 8.0 * pts : 0.0));
     launch_deepvit_attn_fwd((const bf16_t*)a.q, (const bf16_t*)a.k, (const bf16_t*)a.v, a.ldq, a.ldk, a.ldv, a.qb, a.kb, a.vb, (bf16_t*)a.o,
-                            a.ldo, a.ob, e->params + bp.re_w, e->params + bp.re_g, e->params + bp.re_b, sc[0], sc[2], keep != nullptr,
+                            a.ldo, a.ob, e->params + bp.re_w, e->params + bp.re_g, e->params + bp.re_b, sc[0], sc[2], keep ? (lp ? 2 : 1) : 0,
                             b, h, a.nq, a.nk, ld, 1.0f / std::sqrt((float)dh), e->cfg.ln_eps, (const bf16_t*)e->zero_page, e->stream);
-    if (keep) { keep->sc_geom = score_geom(b, a.nq, a.nk); keep->sc_pi = 2; keep->sc_no_mixed = true; }
+    if (keep) { keep->sc_geom = score_geom(b, a.nq, a.nk); keep->sc_pi = 2; keep->sc_no_mixed = true; keep->sc_a2_bf16 = lp; }
     return;
   }
   if (T && e->cfg.variant == VITX_VARIANT_CAIT && e->cait_fused && !e->unfused_headops && !e->force_generic_gemm &&
@@ -852,10 +854,14 @@ static void attn_generic_bwd(vitx_engine* e, const BlockParams& bp, const AttnVi
       Prof pr(e, "attn_deepvit_fused_bwd", 4.0 * pts * dh + 4.0 * pts * h, ((double)b * a.nq * 3 * h * dh + 2.0 * (double)b * a.nq * h * dh) * 2 + 8.0 * pts);
       launch_deepvit_attn_bwd((const bf16_t*)a.q, (const bf16_t*)a.k, (const bf16_t*)a.v, a.ldq, a.ldk, a.ldv, a.qb, a.kb, a.vb, (const bf16_t*)gr.d_o, gr.ldo,
                               gr.ob, sc[0], e->params + bp.re_w, e->params + bp.re_g, dA, (bf16_t*)gr.dq, gr.lddq, gr.dqb, e->red_ws, e->grads + bp.re_w,
-                              e->grads + bp.re_g, e->grads + bp.re_b, b, h, a.nq, a.nk, ld, scale, e->cfg.ln_eps, (const bf16_t*)e->zero_page, e->stream);
+                              e->grads + bp.re_g, e->grads + bp.re_b, b, h, a.nq, a.nk, ld, scale, e->cfg.ln_eps, (const bf16_t*)e->zero_page, e->stream,
+                              keep->sc_a2_bf16 ? 1 : 0);
     }
-    bgemm_pair(e, BgemmCall{sc[pi], 0, 1, ld, bs, hs, gr.d_o, T, gr.ldo, 1, gr.ob, dh, a.nk, dh, a.nq, b, h, EPI_STORE, T, gr.dv, gr.lddv, gr.dvb, dh, 1.0f},
-               BgemmCall{dA, 0, 1, ld, bs, hs, a.q, T, a.ldq, 1, a.qb, dh, a.nk, dh, a.nq, b, h, EPI_STORE, T, gr.dk, gr.lddk, gr.dkb, dh, scale});
+    // fp32 [nq][ld] score planes, or (kept as / written as bf16) [nq][ld2] planes with ld2 = nk rounded up to 8
+    const int lp = keep->sc_a2_bf16 ? 1 : 0;
+    const int64_t ldp = lp ? round_up(a.nk, 8) : ld, hsp = (int64_t)a.nq * ldp, bsp = (int64_t)h * hsp;
+    bgemm_pair(e, BgemmCall{sc[pi], lp, 1, ldp, bsp, hsp, gr.d_o, T, gr.ldo, 1, gr.ob, dh, a.nk, dh, a.nq, b, h, EPI_STORE, T, gr.dv, gr.lddv, gr.dvb, dh, 1.0f},
+               BgemmCall{dA, lp, 1, ldp, bsp, hsp, a.q, T, a.ldq, 1, a.qb, dh, a.nk, dh, a.nq, b, h, EPI_STORE, T, gr.dk, gr.lddk, gr.dkb, dh, scale});
     return;
   }
   // d(attn) = dO v^T ; dV = attn^T dO
@@ -1304,6 +1310,7 @@ static int engine_create_body(vitx_engine* e, const vitx_config& cfg, std::strin
   if (const char* k = getenv("VITX_DEEPVIT_FUSED_BWD")) e->deepvit_fused_bwd = atoi(k) != 0;
   if (const char* k = getenv("VITX_CAIT_FUSED")) e->cait_fused = atoi(k) != 0;
   if (const char* k = getenv("VITX_GLP_SKIP")) e->glp_skip = atoi(k) != 0;
+  if (const char* k = getenv("VITX_SCORE_BF16")) e->score_bf16 = atoi(k) != 0;
   if (const char* k = getenv("VITX_LN_SCALE_FUSED")) e->ln_scale_fused = atoi(k) != 0;
   if (const char* k = getenv("VITX_MLP_BWD_ORDER")) e->mlp_bwd_consumers_first = atoi(k) != 0;
   if (const char* k = getenv("VITX_NT")) e->nt_mask = atoi(k);

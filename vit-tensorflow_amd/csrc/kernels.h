@@ -43,9 +43,9 @@ void launch_deepvit_chain_bwd(const float* a0, const float* mixed, float* da_ino
 // ---------------------------------------------------------------- attn_bgemm_mfma.hip
 // batched small GEMM (M, N, K <= 128 per (image, head)) on MFMA for the materialised attention path in bf16 mode
 bool bgemm_mfma_supported(const GenericGemmArgs& g, int ta, int tb, int to, int mode);
-void launch_bgemm_mfma(const GenericGemmArgs& g, const EpiParams& ep, int ta, hipStream_t s);
-void launch_bgemm_mfma_pair(const GenericGemmArgs& g1, const EpiParams& ep1, int ta1, const GenericGemmArgs& g2, const EpiParams& ep2, int ta2,
-                            hipStream_t s);   // two products of the same (image, head) back to back in one launch (same nb, nh)
+void launch_bgemm_mfma(const GenericGemmArgs& g, const EpiParams& ep, int ta, int to, hipStream_t s);
+void launch_bgemm_mfma_pair(const GenericGemmArgs& g1, const EpiParams& ep1, int ta1, int to1, const GenericGemmArgs& g2, const EpiParams& ep2, int ta2,
+                            int to2, hipStream_t s);   // two products of the same (image, head) back to back in one launch (same nb, nh)
 
 // ---------------------------------------------------------------- gemm_bf16.hip
 // C[M,N] = A[M,K] * B[N,K]^T, bf16 operands (K contiguous), fp32 MFMA accumulation.
@@ -164,7 +164,7 @@ int64_t deepvit_attn_bwd_ws_elems(int b, int h, int nq);
 void launch_deepvit_attn_bwd(const bf16_t* q, const bf16_t* k, const bf16_t* v, int64_t ldq, int64_t ldk, int64_t ldv, int64_t qb, int64_t kb, int64_t vb,
                              const bf16_t* d_o, int64_t ldo, int64_t ob, const float* p_keep, const float* w, const float* gamma, float* ds_out,
                              bf16_t* dq, int64_t lddq, int64_t dqb, float* ws, float* dw, float* dgamma, float* dbeta, int b, int h, int nq, int nk,
-                             int64_t ld, float scale, float eps, const bf16_t* zero_page, hipStream_t s);
+                             int64_t ld, float scale, float eps, const bf16_t* zero_page, hipStream_t s, int ds_bf16 = 0);
 void launch_deepvit_attn_fwd(const bf16_t* q, const bf16_t* k, const bf16_t* v, int64_t ldq, int64_t ldk, int64_t ldv, int64_t qb,
                              int64_t kb, int64_t vb, bf16_t* o, int64_t ldo, int64_t ob, const float* w, const float* gamma,
                              const float* beta, float* p_keep, float* a2_keep, int keep, int b, int h, int nq,
