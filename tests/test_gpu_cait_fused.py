@@ -123,3 +123,33 @@ def test_layerscale_vjp_on_the_layernorm_pass_equals_the_separate_pass(case, lay
     worst = max(((rel_max_err(out[0][1][k], np.asarray(out[1][1][k], np.float64)), k) for k in out[1][1]))
     print(f"[{case}, layer dropout {layer_dropout}] LayerScale VJP fused into the LayerNorm VJP vs separate: worst grad {worst[0]:.3e} at {worst[1]}")
     assert worst[0] <= 8e-3, worst     # observed 3.5e-3 (an fc2 bias gradient: fp32 column sums against sums of bf16-rounded addends)
+
+
+@pytest.mark.parametrize("variant, case", [("cait", "h16_n64"), ("cait", "h8_n49"), ("deepvit", "h16_n65"), ("deepvit", "h12_n37")])
+def test_bf16_score_planes_give_the_same_bits_as_fp32_planes(variant, case, monkeypatch):
+    """The mixed / normalised scores the one-kernel forwards keep for the dV product, and d(dots) on its way to the dQ / dK products, are stored as
+    bf16 (VITX_SCORE_BF16=1, the default) or as fp32 (0).  The batched products round their score operand to bf16 while staging it, with the same
+    round-to-nearest-even the kernels apply when they store bf16 themselves: every gradient must come out bit-identical."""
+    import test_gpu_deepvit_fused as dvt
+    if variant == "cait":
+        from vit_tensorflow.cait import CaiT as Model
+        kw, b = CASES[case]
+    else:
+        from vit_tensorflow.deepvit import DeepViT as Model
+        kw, b = dvt.CASES[case]
+    cfg = spec.make_config(variant, **kw)
+    P = spec.init_params(cfg, 1, randomize_all=True)
+    rng = np.random.Generator(np.random.PCG64(17))
+    img = rng.standard_normal((b, kw["image_size"], kw["image_size"], 3)).astype(np.float32)
+    dl = (rng.standard_normal((b, kw["num_classes"])) / 2).astype(np.float32)
+    out = []
+    for lp in ("1", "0"):
+        monkeypatch.setenv("VITX_SCORE_BF16", lp)
+        m = Model(**kw, compute="bf16", max_batch=b, seed=5)
+        m.load_state_dict({k: v.astype(np.float32) for k, v in P.items()})
+        logits = np.asarray(m(img, training=True))
+        grads, _ = m.backward(dl)
+        out.append((logits, grads))
+    assert np.array_equal(out[0][0], out[1][0])
+    for k in out[0][1]:
+        assert np.array_equal(out[0][1][k], out[1][1][k]), k

@@ -98,8 +98,14 @@ __global__ __launch_bounds__(CA_THREADS) void cait_attn_fwd_kernel(
   const int64_t img_off = (int64_t)bi * H * plane;
   const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc((void*)(s0_keep + img_off), 0, keep ? (int)(H * plane * 4) : 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsA1 = __builtin_amdgcn_make_buffer_rsrc((void*)(a1_keep + img_off), 0, keep ? (int)(H * plane * 4) : 0, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsA2 = __builtin_amdgcn_make_buffer_rsrc((void*)(a2_keep + img_off), 0, keep ? (int)(H * plane * 4) : 0, 0x00020000);
-  const int plane4 = (int)plane * 4;
+  // keep == 2: the mixed softmax is kept as bf16 [H][nq][ld2], ld2 = nk rounded up to 8 -- its only reader is the dV product, whose loader rounds it
+  // to bf16 anyway (same bits, half the bytes)
+  const bool a2_lp = keep == 2;
+  const int ld2 = (nk + 7) & ~7;
+  const int64_t plane2 = (int64_t)nq * ld2;
+  const __amdgpu_buffer_rsrc_t rsA2 = a2_lp ? __builtin_amdgcn_make_buffer_rsrc((void*)((bf16_t*)a2_keep + (int64_t)bi * H * plane2), 0, (int)(H * plane2 * 2), 0x00020000)
+                                            : __builtin_amdgcn_make_buffer_rsrc((void*)(a2_keep + img_off), 0, keep ? (int)(H * plane * 4) : 0, 0x00020000);
+  const int plane4 = (int)plane * 4, planeA2 = a2_lp ? (int)plane2 * 2 : (int)plane * 4;
 
   for (int tile = t_begin; tile < t_end; ++tile) {
     const int q0 = tile * 16;
@@ -176,7 +182,11 @@ __global__ __launch_bounds__(CA_THREADS) void cait_attn_fwd_kernel(
           for (int r = 0; r < 4; ++r) {
             const int off = (rv && j < ld && hv[r]) ? voff + 64 * gk : 0x7ffffff0;
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, p[r]), rsA1, off, r * plane4, 0);
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, j < nk ? z[r] : 0.f), rsA2, off, r * plane4, 0);
+            if (a2_lp)
+              __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, (bf16_t)(j < nk ? z[r] : 0.f)), rsA2,
+                                                    (j < ld2 && hv[r]) ? (4 * hq * (int)plane2 + (q0 + i) * ld2 + j) * 2 : 0x7ffffff0, r * planeA2, 0);
+            else
+              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, j < nk ? z[r] : 0.f), rsA2, off, r * planeA2, 0);
             if (hv[r]) Al[((4 * hq + r) * 16 + i) * CA_AP + j] = (j < nk) ? (bf16_t)z[r] : (bf16_t)0.f;   // (keys nk .. 16 nt - 1 multiply zero rows of V)
           }
         }

@@ -322,12 +322,16 @@ template <int H>
 __global__ __launch_bounds__(64 * HC_WAVES) void cait_chain_bwd_mfma_kernel(const float* __restrict__ s0, const float* __restrict__ a1,
                                                                             float* __restrict__ da, const float* __restrict__ wpre,
                                                                             const float* __restrict__ wpost, float* __restrict__ partial,
-                                                                            int64_t rows, int nq, int nk, int64_t ld) {
+                                                                            int64_t rows, int nq, int nk, int64_t ld, bf16_t* __restrict__ ds_lp) {
   __shared__ __attribute__((aligned(16))) float scratch[HC_WAVES][2][16 * HC_PITCH];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, jl = lane & 15, hq = lane >> 4;
   float* xs = scratch[wave][0];
   float* ys = scratch[wave][1];
   const int64_t plane = (int64_t)nq * ld;
+  // ds_lp != null (round 5): d(dots) goes out as bf16 [H][nq][ld2] planes (ld2 = nk rounded up to 8) into a buffer of its own instead of over d(attn') in
+  // fp32 -- its only readers are the dQ / dK products, whose loaders round it to bf16 anyway
+  const int ld2 = (nk + 7) & ~7;
+  const int64_t plane2 = (int64_t)nq * ld2;
   const bool in_row = 4 * jl < ld;
   const int jo = in_row ? 4 * jl : 0;
   float wb_pre[4], wb_post[4], unused[4];
@@ -379,7 +383,13 @@ __global__ __launch_bounds__(64 * HC_WAVES) void cait_chain_bwd_mfma_kernel(cons
 #pragma unroll
       for (int r = 0; r < 4; ++r) dso[c][r] = valid ? v[r] : 0.f;
     }
-    if (in_row) {
+    if (ds_lp) {
+      if (4 * jl < ld2) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (hv[r]) *(bf16x4*)(ds_lp + (bi * H + 4 * hq + r) * plane2 + i * ld2 + 4 * jl) = bf16x4{(bf16_t)dso[0][r], (bf16_t)dso[1][r], (bf16_t)dso[2][r], (bf16_t)dso[3][r]};
+      }
+    } else if (in_row) {
 #pragma unroll
       for (int r = 0; r < 4; ++r)
         if (hv[r]) *(float4*)(da + base0 + (int64_t)(4 * hq + r) * plane) = make_float4(dso[0][r], dso[1][r], dso[2][r], dso[3][r]);
@@ -567,14 +577,19 @@ void launch_cait_chain_fwd(const float* s0, const float* wpre, const float* wpos
   HC_DISPATCH(h, CALL);
 #undef CALL
 }
+static int chain_mfma_mix() {
+  static const int v = [] { const char* e = getenv("VITX_CHAIN_MFMA"); return e ? atoi(e) : 1; }();
+  return v;
+}
+bool cait_chain_bwd_bf16_out_ok() { return chain_mfma_mix() != 0; }   // (only the MFMA form of the kernel has the bf16 output)
 void launch_cait_chain_bwd(const float* s0, const float* a1, float* da_inout, const float* wpre, const float* wpost, float* ws, float* dwpre,
-                           float* dwpost, int b, int h, int nq, int nk, int64_t ld, hipStream_t s) {
+                           float* dwpost, int b, int h, int nq, int nk, int64_t ld, hipStream_t s, bf16_t* ds_lp) {
   const int64_t rows = (int64_t)b * nq;
   const int nblk = chain_blocks(rows);
   const dim3 grid(nblk), block(64 * HC_WAVES);
-  static const int mfma_mix = [] { const char* v = getenv("VITX_CHAIN_MFMA"); return v ? atoi(v) : 1; }();
+  const int mfma_mix = chain_mfma_mix();
   if (mfma_mix) {
-#define CALL(H) hipLaunchKernelGGL((cait_chain_bwd_mfma_kernel<H>), grid, block, 0, s, s0, a1, da_inout, wpre, wpost, ws, rows, nq, nk, ld)
+#define CALL(H) hipLaunchKernelGGL((cait_chain_bwd_mfma_kernel<H>), grid, block, 0, s, s0, a1, da_inout, wpre, wpost, ws, rows, nq, nk, ld, ds_lp)
     HC_DISPATCH(h, CALL);
 #undef CALL
   } else {

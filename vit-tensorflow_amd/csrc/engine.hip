@@ -803,13 +803,13 @@ static void attn_generic_fwd(vitx_engine* e, const BlockParams& bp, const AttnVi
     const double pts = (double)b * h * a.nq * a.nk;
     Prof pr(e, "attn_cait_fused_fwd", 4.0 * pts * dh + 4.0 * pts * h, ((double)b * a.nq * 3 * h * dh + (double)b * a.nq * h * dh) * 2 + (keep ? 12.0 * pts : 0.0));
     launch_cait_attn_fwd((const bf16_t*)a.q, (const bf16_t*)a.k, (const bf16_t*)a.v, a.ldq, a.ldk, a.ldv, a.qb, a.kb, a.vb, (bf16_t*)a.o, a.ldo, a.ob,
-                         e->params + bp.mix_pre, e->params + bp.mix_post, sc[0], sc[1], sc[2], keep != nullptr, b, h, a.nq, a.nk, ld,
+                         e->params + bp.mix_pre, e->params + bp.mix_post, sc[0], sc[1], sc[2], keep ? (e->score_bf16 ? 2 : 1) : 0, b, h, a.nq, a.nk, ld,
                          1.0f / std::sqrt((float)dh), (const bf16_t*)e->zero_page, e->stream);
-    if (keep) { keep->sc_geom = score_geom(b, a.nq, a.nk); keep->sc_pi = 2; keep->sc_no_mixed = false; }
+    if (keep) { keep->sc_geom = score_geom(b, a.nq, a.nk); keep->sc_pi = 2; keep->sc_no_mixed = false; keep->sc_a2_bf16 = e->score_bf16; }
     return;
   }
   const int pi = attn_generic_scores(e, bp, a, b, keep != nullptr, sc);
-  if (keep) { keep->sc_geom = score_geom(b, a.nq, a.nk); keep->sc_pi = pi; keep->sc_no_mixed = false; }
+  if (keep) { keep->sc_geom = score_geom(b, a.nq, a.nk); keep->sc_pi = pi; keep->sc_no_mixed = false; keep->sc_a2_bf16 = false; }
   // out = attn v   (vit.py:81, deepvit.py:87, cait.py:127)
   bgemm(e, sc[pi], 0, ld, 1, bs, hs, a.v, T, a.ldv, 1, a.vb, dh, a.nq, dh, a.nk, b, h, EPI_STORE, T, a.o, a.ldo, a.ob, dh, 1.0f);
 }
@@ -830,6 +830,7 @@ static void attn_generic_bwd(vitx_engine* e, const BlockParams& bp, const AttnVi
   const bool kept = keep && keep->sc_keep[0] && keep->sc_geom == score_geom(b, a.nq, a.nk);
   float* const* sc = kept ? keep->sc_keep : e->sc;
   int pi;
+  bool a2_lp = kept && keep->sc_a2_bf16;   // sc[pi] holds bf16 [nq][ld2] planes (the one-kernel forwards; DeepViT's is consumed by its own branch below)
   if (kept) {
     pi = keep->sc_pi;
   } else if (T && e->cfg.variant == VITX_VARIANT_CAIT && e->cait_fused && !e->unfused_headops && !e->force_generic_gemm &&
@@ -837,9 +838,10 @@ static void attn_generic_bwd(vitx_engine* e, const BlockParams& bp, const AttnVi
     // score tensors not kept (budget): recomputed by the kernel that produced them in the forward (same bits as the kept ones), without its A V stage
     Prof pr(e, "attn_cait_fused_fwd", 0, 0);
     launch_cait_attn_fwd((const bf16_t*)a.q, (const bf16_t*)a.k, (const bf16_t*)a.v, a.ldq, a.ldk, a.ldv, a.qb, a.kb, a.vb, nullptr, 0, 0,
-                         e->params + bp.mix_pre, e->params + bp.mix_post, e->sc[0], e->sc[1], e->sc[2], 1, b, h, a.nq, a.nk, ld,
+                         e->params + bp.mix_pre, e->params + bp.mix_post, e->sc[0], e->sc[1], e->sc[2], e->score_bf16 ? 2 : 1, b, h, a.nq, a.nk, ld,
                          1.0f / std::sqrt((float)dh), (const bf16_t*)e->zero_page, e->stream);
     pi = 2;
+    a2_lp = e->score_bf16;
   } else {
     pi = attn_generic_scores(e, bp, a, b, true, e->sc);
   }
@@ -865,14 +867,19 @@ static void attn_generic_bwd(vitx_engine* e, const BlockParams& bp, const AttnVi
     return;
   }
   // d(attn) = dO v^T ; dV = attn^T dO
+  const int64_t ld2 = round_up(a.nk, 8), hs2 = (int64_t)a.nq * ld2, bs2 = (int64_t)h * hs2;   // bf16 score planes (a2_lp, ds_lp)
   bgemm_pair(e, BgemmCall{gr.d_o, T, gr.ldo, 1, gr.ob, dh, a.v, T, 1, a.ldv, a.vb, dh, a.nq, a.nk, dh, b, h, EPI_STORE_F32, 0, dA, ld, bs, hs, 1.0f},
-             BgemmCall{sc[pi], 0, 1, ld, bs, hs, gr.d_o, T, gr.ldo, 1, gr.ob, dh, a.nk, dh, a.nq, b, h, EPI_STORE, T, gr.dv, gr.lddv, gr.dvb, dh, 1.0f});
+             a2_lp ? BgemmCall{sc[pi], 1, 1, ld2, bs2, hs2, gr.d_o, T, gr.ldo, 1, gr.ob, dh, a.nk, dh, a.nq, b, h, EPI_STORE, T, gr.dv, gr.lddv, gr.dvb, dh, 1.0f}
+                   : BgemmCall{sc[pi], 0, 1, ld, bs, hs, gr.d_o, T, gr.ldo, 1, gr.ob, dh, a.nk, dh, a.nq, b, h, EPI_STORE, T, gr.dv, gr.lddv, gr.dvb, dh, 1.0f});
+  // (round 5, CaiT) d(dots) as bf16 into the buffer of the mixed softmax, which the dV product above was the last to read
+  bf16_t* ds_lp = nullptr;
   // (the row-per-wave DeepViT chain reads the mixed scores; tensors kept by the one-kernel forward go to the point kernel, which recomputes them)
   const bool chain = !e->unfused_headops && headchain_supported(h, a.nk) && !(kept && keep->sc_no_mixed);
   if (chain && e->cfg.variant == VITX_VARIANT_CAIT) {
     Prof pr(e, "attn_headchain", 0, 0);
+    if (T && a2_lp && e->score_bf16 && cait_chain_bwd_bf16_out_ok()) ds_lp = (bf16_t*)sc[pi];
     launch_cait_chain_bwd(sc[0], sc[1], dA, e->params + bp.mix_pre, e->params + bp.mix_post, e->red_ws, e->grads + bp.mix_pre,
-                          e->grads + bp.mix_post, b, h, a.nq, a.nk, ld, e->stream);
+                          e->grads + bp.mix_post, b, h, a.nq, a.nk, ld, e->stream, ds_lp);
   } else if (chain && e->cfg.variant == VITX_VARIANT_DEEPVIT) {
     Prof pr(e, "attn_headchain", 0, 0);
     launch_deepvit_chain_bwd(sc[0], sc[1], dA, e->params + bp.re_w, e->params + bp.re_g, e->red_ws, e->grads + bp.re_w, e->grads + bp.re_g,
@@ -897,6 +904,11 @@ static void attn_generic_bwd(vitx_engine* e, const BlockParams& bp, const AttnVi
     }
   }
   // dQ = scale dS k ; dK = scale dS^T q
+  if (ds_lp) {
+    bgemm_pair(e, BgemmCall{ds_lp, 1, ld2, 1, bs2, hs2, a.k, T, a.ldk, 1, a.kb, dh, a.nq, dh, a.nk, b, h, EPI_STORE, T, gr.dq, gr.lddq, gr.dqb, dh, scale},
+               BgemmCall{ds_lp, 1, 1, ld2, bs2, hs2, a.q, T, a.ldq, 1, a.qb, dh, a.nk, dh, a.nq, b, h, EPI_STORE, T, gr.dk, gr.lddk, gr.dkb, dh, scale});
+    return;
+  }
   bgemm_pair(e, BgemmCall{dA, 0, ld, 1, bs, hs, a.k, T, a.ldk, 1, a.kb, dh, a.nq, dh, a.nk, b, h, EPI_STORE, T, gr.dq, gr.lddq, gr.dqb, dh, scale},
              BgemmCall{dA, 0, 1, ld, bs, hs, a.q, T, a.ldq, 1, a.qb, dh, a.nk, dh, a.nq, b, h, EPI_STORE, T, gr.dk, gr.lddk, gr.dkb, dh, scale});
 }

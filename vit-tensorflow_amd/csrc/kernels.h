@@ -34,7 +34,8 @@ int64_t headchain_ws_elems(int h);
 void launch_cait_chain_fwd(const float* s0, const float* wpre, const float* wpost, float* a1_or_null, float* a2, int b, int h, int nq, int nk,
                            int64_t ld, hipStream_t s);
 void launch_cait_chain_bwd(const float* s0, const float* a1, float* da_inout, const float* wpre, const float* wpost, float* ws, float* dwpre,
-                           float* dwpost, int b, int h, int nq, int nk, int64_t ld, hipStream_t s);
+                           float* dwpost, int b, int h, int nq, int nk, int64_t ld, hipStream_t s, bf16_t* ds_lp = nullptr);
+bool cait_chain_bwd_bf16_out_ok();
 void launch_deepvit_chain_fwd(float* s0_inout, const float* wre, const float* gamma, const float* beta, float* mixed_or_null, float* a2, int keep,
                               int b, int h, int nq, int nk, int64_t ld, float eps, hipStream_t s);
 void launch_deepvit_chain_bwd(const float* a0, const float* mixed, float* da_inout, const float* wre, const float* gamma, float* ws, float* dwre,
