@@ -153,3 +153,30 @@ def test_bf16_score_planes_give_the_same_bits_as_fp32_planes(variant, case, monk
     assert np.array_equal(out[0][0], out[1][0])
     for k in out[0][1]:
         assert np.array_equal(out[0][1][k], out[1][1][k]), k
+
+
+@pytest.mark.parametrize("case", ["h4_n16", "h16_n64"])
+def test_q_and_kv_projections_as_one_dense_equal_two(case, monkeypatch):
+    """Patch stage (cait.py:109-116 with context = None): to_q and to_kv read the same tokens and run as ONE Dense on concatenated bf16 operand copies
+    (VITX_CAIT_QKV_CAT=1, the default) or as two (0).  Same dot products forward (bit-identical logits); backward, d(y1) comes out of one GEMM over
+    d(q | k | v) instead of two GEMMs and a bf16 add (one rounding less).  Parameters and gradients stay two tensors either way."""
+    from vit_tensorflow.cait import CaiT
+    kw, b = CASES[case]
+    cfg = spec.make_config("cait", **kw)
+    P = spec.init_params(cfg, 1, randomize_all=True)
+    rng = np.random.Generator(np.random.PCG64(23))
+    img = rng.standard_normal((b, kw["image_size"], kw["image_size"], 3)).astype(np.float32)
+    dl = (rng.standard_normal((b, kw["num_classes"])) / 2).astype(np.float32)
+    out = []
+    for cat in ("1", "0"):
+        monkeypatch.setenv("VITX_CAIT_QKV_CAT", cat)
+        m = CaiT(**kw, compute="bf16", max_batch=b, seed=5)
+        m.load_state_dict({k: v.astype(np.float32) for k, v in P.items()})
+        logits = np.asarray(m(img, training=True))
+        grads, _ = m.backward(dl)
+        out.append((logits, grads))
+    assert np.array_equal(out[0][0], out[1][0])
+    assert set(out[0][1]) == set(out[1][1])
+    worst = max(((rel_max_err(out[0][1][k], np.asarray(out[1][1][k], np.float64)), k) for k in out[1][1]))
+    print(f"[{case}] q / kv as one Dense vs two: worst grad {worst[0]:.3e} at {worst[1]}")
+    assert worst[0] <= 8e-3, worst

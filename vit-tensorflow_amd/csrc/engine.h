@@ -49,6 +49,7 @@ struct Dense {
 struct BlockParams {
   int64_t a_scale = -1, ln1_g = -1, ln1_b = -1;
   Dense qkv, q, kv, out;
+  Dense qkvcat;   // CaiT patch stage, bf16 mode: operand copies of [to_q | to_kv] side by side (w = -1: no parameter of its own)
   bool has_out = true;
   int64_t mix_pre = -1, mix_post = -1, re_w = -1, re_g = -1, re_b = -1;
   int64_t m_scale = -1, ln2_g = -1, ln2_b = -1;
@@ -218,6 +219,7 @@ struct vitx_engine {
   bool ln_scale_fused = true;       // CaiT: a LayerNorm VJP also runs the LayerScale VJP of the branch that consumes its result (VITX_LN_SCALE_FUSED=0: a pass of its own)
   int64_t dbr_ready = 0;            // branch_key of the branch whose gradient e->d_br already holds (set by that LayerNorm VJP, cleared by the branch)
   bool score_bf16 = true;           // score tensors whose only reader is a batched product are kept / written as bf16 by the one-kernel attention paths (VITX_SCORE_BF16=0: fp32)
+  bool cait_qkv_cat = true;         // CaiT patch stage: to_q and to_kv as one Dense on concatenated operand copies (VITX_CAIT_QKV_CAT=0: two launches each way)
   bool cait_fused = true;           // cait.py:121-128 forward as one kernel in the bf16 mode (attn_cait_fused.hip); VITX_CAIT_FUSED=0 disables
   bool deepvit_fused = true;         // VITX_DEEPVIT_FUSED=0: DeepViT attention forward as batched GEMMs + head-axis kernels (A/B reference)
   bool unfused_headops = false;      // VITX_UNFUSED_HEADOPS=1: separate mix / softmax / LayerNorm-over-heads kernels (A/B reference)

@@ -191,7 +191,8 @@ static int64_t find_param(const vitx_engine* e, const std::string& name) {
   return -1;
 }
 
-static int init_dense(vitx_engine* e, Dense& w, const std::string& kname, const std::string& bname, int in, int out, std::string& err) {
+static int init_dense(vitx_engine* e, Dense& w, const std::string& kname, const std::string& bname, int in, int out, std::string& err,
+                      bool operand_copies = true) {
   w.in = in;
   w.out = out;
   w.in_k = (int)round_up(in, 64);
@@ -199,7 +200,7 @@ static int init_dense(vitx_engine* e, Dense& w, const std::string& kname, const 
   w.w = find_param(e, kname);
   w.b = bname.empty() ? -1 : find_param(e, bname);
   if (w.w < 0) { err = "missing parameter " + kname; return VITX_ERR_INVALID; }
-  if (e->bf16) {
+  if (e->bf16 && operand_copies) {
     DALLOC(w.wt, (size_t)round_up(out, 256) * w.in_k * 2, false);
     DALLOC(w.wn, (size_t)round_up(in, 256) * w.out_k * 2, false);
   }
@@ -223,10 +224,23 @@ static void build_convert_table(vitx_engine* e) {
     t.push_back({e->params + w.w, w.wn, w.wt, w.out_k, w.in_k, w.in, w.out, tx, blocks});
     blocks += tx * ty;
   };
+  // CaiT patch stage: to_q and to_kv read the same tokens (cait.py:109-116 with context = None) and run as ONE Dense on the concatenated operand
+  // copies [to_q | to_kv]; parameters and gradients stay two tensors
+  auto add_cat = [&](const BlockParams& b) {
+    if (!b.qkvcat.wt) return;
+    const Dense& c = b.qkvcat;
+    int col = 0;
+    for (const Dense* w : {&b.q, &b.kv}) {
+      const int tx = (int)ceil_div(w->out, 64), ty = (int)ceil_div(w->in, 64);
+      t.push_back({e->params + w->w, c.wn + col, c.wt + (int64_t)col * c.in_k, c.out_k, c.in_k, w->in, w->out, tx, blocks});
+      blocks += tx * ty;
+      col += w->out;
+    }
+  };
   add(e->patch);
   add(e->head);
   for (auto& st : e->stages)
-    for (auto& b : st.bp) { add(b.qkv); add(b.q); add(b.kv); add(b.out); add(b.fc1); add(b.fc2); }
+    for (auto& b : st.bp) { add(b.qkv); add(b.q); add(b.kv); add_cat(b); add(b.out); add(b.fc1); add(b.fc2); }
   if (!t.empty() && hipMalloc(&e->conv_descs, t.size() * sizeof(ConvertDesc)) == hipSuccess) {
     e->allocs.push_back(e->conv_descs);
     (void)hipMemcpy(e->conv_descs, t.data(), t.size() * sizeof(ConvertDesc), hipMemcpyHostToDevice);
@@ -246,7 +260,14 @@ void engine_refresh_weights(vitx_engine* e) {
     conv(e->patch);
     conv(e->head);
     for (auto& st : e->stages)
-      for (auto& b : st.bp) { conv(b.qkv); conv(b.q); conv(b.kv); conv(b.out); conv(b.fc1); conv(b.fc2); }
+      for (auto& b : st.bp) {
+        conv(b.qkv); conv(b.q); conv(b.kv); conv(b.out); conv(b.fc1); conv(b.fc2);
+        if (b.qkvcat.wt) {   // [to_q | to_kv] into the concatenated copies
+          const Dense& c = b.qkvcat;
+          launch_convert_weight(e->params + b.q.w, b.q.in, b.q.out, c.wn, c.out_k, c.wt, c.in_k, e->stream);
+          launch_convert_weight(e->params + b.kv.w, b.kv.in, b.kv.out, c.wn + b.q.out, c.out_k, c.wt + (int64_t)b.q.out * c.in_k, c.in_k, e->stream);
+        }
+      }
   }
   e->params_dirty = false;
 }
@@ -943,7 +964,13 @@ static int block_forward(vitx_engine* e, Stage& st, int si, int l, int b, int nq
   }
   AttnView av;
   av.nq = nq; av.nk = nk; av.o = ba.o; av.ldo = inner; av.ob = (int64_t)nq * inner;
-  if (c.variant == VITX_VARIANT_CAIT) {
+  if (c.variant == VITX_VARIANT_CAIT && bp.qkvcat.wt) {
+    EpiParams ep; ep.out = ba.qkv; ep.ldo = 3 * inner;
+    dense_fwd(e, ba.y1, d, rows, bp.qkvcat, EPI_STORE, ep);                  // cait.py:114-115 with context = x: q and kv of the same tokens, one launch
+    av.q = ba.qkv; av.k = boff(ba.qkv, inner, esz); av.v = boff(ba.qkv, 2 * inner, esz);
+    av.ldq = av.ldk = av.ldv = 3 * inner;
+    av.qb = av.kb = av.vb = (int64_t)nq * 3 * inner;
+  } else if (c.variant == VITX_VARIANT_CAIT) {
     EpiParams ep; ep.out = ba.q; ep.ldo = inner;
     dense_fwd(e, ba.y1, d, rows, bp.q, EPI_STORE, ep);                       // cait.py:114
     const void* ctx = ba.y1;
@@ -1197,7 +1224,25 @@ static int block_backward(vitx_engine* e, Stage& st, int si, int l, int b, int n
   av.nq = nq; av.nk = nk; av.o = ba.o; av.ldo = inner; av.ob = (int64_t)nq * inner;
   AttnGrad ag;
   ag.d_o = d_o; ag.ldo = inner; ag.ob = (int64_t)nq * inner;
-  if (c.variant == VITX_VARIANT_CAIT) {
+  if (c.variant == VITX_VARIANT_CAIT && bp.qkvcat.wt) {
+    // patch stage, concatenated [to_q | to_kv] operands: d(q | k | v) rows as one matrix -> ONE input-gradient GEMM straight into d(y1) (no second
+    // GEMM + add pass), two weight gradients reading their column blocks of it
+    av.q = ba.qkv; av.k = boff(ba.qkv, inner, esz); av.v = boff(ba.qkv, 2 * inner, esz);
+    av.ldq = av.ldk = av.ldv = 3 * inner;
+    av.qb = av.kb = av.vb = (int64_t)nq * 3 * inner;
+    ag.dq = e->d_qkv; ag.dk = boff(e->d_qkv, inner, esz); ag.dv = boff(e->d_qkv, 2 * inner, esz);
+    ag.lddq = ag.lddk = ag.lddv = 3 * inner;
+    ag.dqb = ag.dkb = ag.dvb = (int64_t)nq * 3 * inner;
+    int rc = ensure_scores(e, 4, (int64_t)b * c.heads * nq * round_up(nk, 4), err);
+    if (rc != VITX_OK) return rc;
+    attn_generic_bwd(e, bp, av, ag, b, &ba);
+    EpiParams ep; ep.out = e->d_y; ep.ldo = d;
+    const hipEvent_t fork_qkv = side_prefork(e);                                // d(q | k | v) is complete
+    dense_dgrad(e, e->d_qkv, 3 * inner, rows, bp.qkvcat, EPI_STORE, ep);
+    dense_wgrad(e, ba.y1, d, ag.dq, 3 * inner, rows, bp.q, fork_qkv);
+    dense_wgrad(e, ba.y1, d, ag.dk, 3 * inner, rows, bp.kv, fork_qkv);
+    side_note_read(e, e->rg_dqkv);
+  } else if (c.variant == VITX_VARIANT_CAIT) {
     av.q = ba.q; av.ldq = inner; av.qb = (int64_t)nq * inner;
     av.k = ba.kv; av.ldk = 2 * inner; av.kb = (int64_t)nk * 2 * inner;
     av.v = boff(ba.kv, inner, esz); av.ldv = 2 * inner; av.vb = av.kb;
@@ -1321,6 +1366,7 @@ static int engine_create_body(vitx_engine* e, const vitx_config& cfg, std::strin
   if (const char* k = getenv("VITX_DEEPVIT_FUSED")) e->deepvit_fused = atoi(k) != 0;
   if (const char* k = getenv("VITX_DEEPVIT_FUSED_BWD")) e->deepvit_fused_bwd = atoi(k) != 0;
   if (const char* k = getenv("VITX_CAIT_FUSED")) e->cait_fused = atoi(k) != 0;
+  if (const char* k = getenv("VITX_CAIT_QKV_CAT")) e->cait_qkv_cat = atoi(k) != 0;
   if (const char* k = getenv("VITX_GLP_SKIP")) e->glp_skip = atoi(k) != 0;
   if (const char* k = getenv("VITX_SCORE_BF16")) e->score_bf16 = atoi(k) != 0;
   if (const char* k = getenv("VITX_LN_SCALE_FUSED")) e->ln_scale_fused = atoi(k) != 0;
@@ -1387,8 +1433,16 @@ static int engine_create_body(vitx_engine* e, const vitx_config& cfg, std::strin
       bp.ln1_g = find_param(e, pre + ".attn.norm.gamma");
       bp.ln1_b = find_param(e, pre + ".attn.norm.beta");
       if (cait) {
-        if ((rc = init_dense(e, bp.q, pre + ".attn.to_q.kernel", "", d, inner, err)) != VITX_OK) return rc;
-        if ((rc = init_dense(e, bp.kv, pre + ".attn.to_kv.kernel", "", d, 2 * inner, err)) != VITX_OK) return rc;
+        // patch stage (no context tokens) in bf16 mode: one Dense on the concatenated operand copies of to_q and to_kv (build_convert_table)
+        const bool cat = e->bf16 && nc == 0 && e->cait_qkv_cat && inner % 64 == 0 && !e->force_generic_gemm;   // (the fp32-FMA debug path reads the parameter tensors themselves)
+        if ((rc = init_dense(e, bp.q, pre + ".attn.to_q.kernel", "", d, inner, err, !cat)) != VITX_OK) return rc;
+        if ((rc = init_dense(e, bp.kv, pre + ".attn.to_kv.kernel", "", d, 2 * inner, err, !cat)) != VITX_OK) return rc;
+        if (cat) {
+          Dense& w = bp.qkvcat;
+          w.in = d; w.out = 3 * inner; w.in_k = (int)round_up(d, 64); w.out_k = (int)round_up(3 * inner, 64);
+          DALLOC(w.wt, (size_t)round_up(w.out, 256) * w.in_k * 2, true);
+          DALLOC(w.wn, (size_t)round_up(w.in, 256) * w.out_k * 2, true);
+        }
         bp.mix_pre = find_param(e, pre + ".attn.mix_heads_pre_attn");
         bp.mix_post = find_param(e, pre + ".attn.mix_heads_post_attn");
       } else {
@@ -1413,7 +1467,11 @@ static int engine_create_body(vitx_engine* e, const vitx_config& cfg, std::strin
       DALLOC(ba.x_out, (size_t)rows * d * 4, false);
       x_prev = ba.x_out;
       DALLOC(ba.y1, (size_t)rows * d * esz, true);
-      if (cait) {
+      if (cait && bp.qkvcat.wt) {
+        DALLOC(ba.qkv, (size_t)rows * 3 * inner * esz, true);   // [q | k | v] per token row, as vit.py's to_qkv would lay them out
+        DALLOC(ba.fa, (size_t)rows * d * esz, true);
+        DALLOC(ba.fm, (size_t)rows * d * esz, true);
+      } else if (cait) {
         DALLOC(ba.q, (size_t)rows * inner * esz, true);
         DALLOC(ba.kv, (size_t)crow * 2 * inner * esz, true);
         if (nc > 0) DALLOC(ba.ctx, (size_t)crow * d * esz, true);
