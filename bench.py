@@ -128,6 +128,7 @@ def main():
 
     force_dp = bool(os.environ.get("VITX_FORCE_DP"))   # exercise the whole DP path (RCCL group of 1) on a single GPU
     native_dp = args.dp_impl == "native"
+    gloo_default = native_dp   # the default process group carries CPU tensors only (rendezvous, barrier, max of the timing)
     # native exchange: torch.distributed only carries the rendezvous (RCCL id, initial weights), the barrier and the max over ranks -- gloo on the CPU
     rank, local, world = init_from_env(backend="gloo" if native_dp else None, force=force_dp)
     if world != args.gpus and rank == 0:
@@ -158,6 +159,7 @@ def main():
 
     sync = None
     cb = None
+    dp_group = None   # torch exchange: the default group (RCCL), or an NCCL group of its own when it is the fallback of the native exchange (default group = gloo)
     dp = world > 1 or force_dp
     if dp and native_dp:
         # every rank starts from rank 0's weights (the packed host blob; one-time, over gloo), joins the RCCL group, and from then on the library
@@ -172,8 +174,24 @@ def main():
             dist.broadcast(wt, src=0)
             dist.broadcast(uid, src=0)
             N.check(lib.vitx_set_params(h, blob.ctypes.data_as(C.c_void_p), model._n))
-        model.comm_init(rank, world, bytes(uid.numpy().tobytes()), overlap=True, bucket_mb=args.bucket_mb, wire=args.grad_wire)
-    elif dp:
+        # a rank whose librccl cannot be opened or initialised reports an error here (a hang inside RCCL cannot be caught): every rank then
+        # agrees, over gloo, to fall back to the torch exchange on an NCCL group of its own instead of leaving the run without a number
+        ok = 1
+        try:
+            if os.environ.get("VITX_BENCH_SIMULATE_NATIVE_FAILURE"):   # tests: exercise the fallback below
+                raise RuntimeError("simulated")
+            model.comm_init(rank, world, bytes(uid.numpy().tobytes()), overlap=True, bucket_mb=args.bucket_mb, wire=args.grad_wire)
+        except Exception as ex:   # noqa: BLE001
+            ok = 0
+            print(f"[bench] rank {rank}: native exchange unavailable ({ex}); falling back to --dp-impl torch", file=sys.stderr)
+        if world > 1:
+            flag = torch.tensor([ok], dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok = int(flag.item())
+        if not ok:
+            native_dp = False
+            dp_group = dist.new_group(backend="nccl") if dist.is_initialized() else None
+    if dp and not native_dp:
         # The engine must run on the stream RCCL orders itself against.  torch's default stream has handle 0, which the C ABI
         # reads as "use the library's own stream", so the data-parallel path runs under an explicit side stream.
         dp_stream = torch.cuda.Stream(device=dev)
@@ -186,9 +204,9 @@ def main():
         N.check(lib.vitx_bind_arenas(h, C.c_void_p(params_t.data_ptr()), C.c_void_p(grads_t.data_ptr())))
         # engine work must be ordered with RCCL through torch's current stream
         N.check(lib.vitx_set_stream(h, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
-        broadcast_params(params_t, 0)
+        broadcast_params(params_t, 0, group=dp_group)
         N.check(lib.vitx_params_changed(h))
-        sync = GradSync(grads_t, bucket_elems=int(args.bucket_mb * (1 << 20) / 4), average=False, always_reduce=force_dp,
+        sync = GradSync(grads_t, bucket_elems=int(args.bucket_mb * (1 << 20) / 4), group=dp_group, average=False, always_reduce=force_dp,
                         wire_dtype=torch.bfloat16 if args.grad_wire == "bf16" else None)
         cb = N.GRAD_READY_FN(lambda _u, off, cnt: sync.on_ready(int(off), int(cnt)))
         N.check(lib.vitx_set_grad_ready_callback(h, cb, None))
@@ -238,7 +256,7 @@ def main():
     full_sync()
     el = time.perf_counter() - t0
     if dist.is_initialized():
-        t = torch.tensor([el], device=torch.device("cpu") if native_dp else dev, dtype=torch.float64)
+        t = torch.tensor([el], device=torch.device("cpu") if gloo_default else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
 
@@ -251,7 +269,7 @@ def main():
         "dtype": {"bf16": "bf16", "fp32": "f32", "bf16x3": "bf16x3 (fp32 storage, split-operand bf16 MFMA GEMMs)"}[args.compute], "data": "synthetic",
         "config": {"workload": f"{args.workload} fwd+bwd, batch {b}/GPU, N(0,1) NHWC images resident in HBM, random-init weights, "
                                f"softmax-CE cotangent, dropout 0", "global_batch": b * world,
-                   "parallelism": f"dp{world}", "compute": args.compute, **({"launch": "hip_graph"} if (args.graph and not dp) else {}), **({"grad_wire": args.grad_wire, "dp_impl": args.dp_impl} if dp else {})},
+                   "parallelism": f"dp{world}", "compute": args.compute, **({"launch": "hip_graph"} if (args.graph and not dp) else {}), **({"grad_wire": args.grad_wire, "dp_impl": args.dp_impl if (native_dp or args.dp_impl == "torch") else "torch (native exchange unavailable)"} if dp else {})},
         "path_mfma_frac": round(value / world * fpi / MFMA_BF16_PEAK, 4),
         "flops_per_image": fpi,
     }

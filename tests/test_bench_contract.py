@@ -53,18 +53,23 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("impl", ["native", "torch"])
+@pytest.mark.parametrize("impl", ["native", "torch", "native-unavailable"])
 def test_bench_data_parallel_path_on_a_group_of_one(impl):
     """The N > 1 code path of bench.py (rendezvous, weight broadcast, the gradient exchange overlapped with the backward pass, the join) on the one GPU
     a test box has: VITX_FORCE_DP=1 forms an RCCL group of one.  native = the library's own bucketed exchange (csrc/comm.hip), torch = GradSync."""
     env = dict(os.environ, VITX_FORCE_DP="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29641", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    if impl == "native-unavailable":   # the native exchange reports an error at start-up: every rank falls back to the torch exchange (own NCCL group)
+        env["VITX_BENCH_SIMULATE_NATIVE_FAILURE"] = "1"
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "8", "--no-cpu-baseline", "--no-profile",
-                          "--bucket-mb", "16", "--dp-impl", impl], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+                          "--bucket-mb", "16", "--dp-impl", "torch" if impl == "torch" else "native"], capture_output=True, text=True, timeout=600, cwd=ROOT,
+                         env=env)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, out.stdout
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["scaling"] == "weak"
+    if impl == "native-unavailable":
+        assert "unavailable" in d["config"]["dp_impl"] and "exchange" not in d["config"]
     if impl == "native":
         ex = d["config"]["exchange"]
         assert ex["buckets"] >= 2 and 1 <= ex["sent_during_backward"] <= ex["buckets"], ex   # 346 MB of gradients in 16-MiB buckets, most sent early
