@@ -236,6 +236,9 @@ int32_t vitx_comm_init(vitx_handle h, int32_t rank, int32_t world, const void* u
 int32_t vitx_comm_overlap(vitx_handle h, int32_t enable, int64_t bucket_bytes, int32_t wire_bf16);
 /* out4 = {buckets, buckets the last exchange sent from inside the backward pass, elements per bucket, Dense launches that found a collective in flight} */
 int32_t vitx_comm_stats(vitx_handle h, int64_t* out4);
+/* leave the group: the communicator, the communication stream and the wire buffer are released and the handle is single-rank again (a later
+ * vitx_comm_init may join another group).  Call between steps -- an exchange in progress is joined first. */
+int32_t vitx_comm_destroy(vitx_handle h);
 int32_t vitx_allreduce_grads(vitx_handle h); /* RCCL mean over ranks of the gradient arena (bucketed; finishes an overlapped exchange) */
 
 /* ---- measurement / debugging */

@@ -180,3 +180,23 @@ def test_q_and_kv_projections_as_one_dense_equal_two(case, monkeypatch):
     worst = max(((rel_max_err(out[0][1][k], np.asarray(out[1][1][k], np.float64)), k) for k in out[1][1]))
     print(f"[{case}] q / kv as one Dense vs two: worst grad {worst[0]:.3e} at {worst[1]}")
     assert worst[0] <= 8e-3, worst
+
+
+@pytest.mark.parametrize("case", ["h4_n16", "h16_n64"])
+def test_second_backward_on_the_same_forward_gives_the_same_gradients(case, monkeypatch):
+    """ The bf16 talking-heads backward writes d(dots) over the forward's kept mixed softmax.  A second backward on the same forward is
+    allowed by the API: it must notice that the kept tensor is gone and recompute the scores, not read d(dots) as attention weights."""
+    from vit_tensorflow.cait import CaiT
+    monkeypatch.setenv("VITX_CAIT_FUSED", "1")
+    kw, b = CASES[case]
+    m = CaiT(**kw, compute="bf16", max_batch=b, seed=0)
+    rng = np.random.Generator(np.random.PCG64(11))
+    img = rng.standard_normal((b, kw["image_size"], kw["image_size"], 3)).astype(np.float32)
+    dl = (rng.standard_normal((b, kw["num_classes"])) / 2).astype(np.float32)
+    m(img, training=True)
+    g1, _ = m.backward(dl)
+    g1 = {k: np.array(v, copy=True) for k, v in g1.items()}
+    g2, _ = m.backward(dl)
+    worst = max(((rel_max_err(g2[k], np.asarray(g1[k], np.float64)), k) for k in g1))
+    print(f"[{case}] second backward vs first: worst {worst[0]:.3e} at {worst[1]}")
+    assert worst[0] <= 1e-5, worst   # recomputed scores have the forward's bits; only reduction order could differ

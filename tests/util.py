@@ -71,3 +71,16 @@ def report_gates() -> None:
     for k, (e, t, what) in sorted(_OBSERVED.items()):
         print(f"[gate] {k}: worst observed {e:.3e} (gate {t:.1e}, at {what})")
     _OBSERVED.clear()
+
+
+def fake_rccl_lib() -> str:
+    """tests/fake_rccl/libfake_rccl.so (test infrastructure: ncclGetUniqueId / ncclCommInitRank / ncclAllReduce / ncclCommDestroy over a POSIX
+    shared-memory segment, stream-ordered with hipLaunchHostFunc), compiled on first use; point csrc/comm.hip at it with VITX_RCCL_LIB."""
+    import os
+    import subprocess
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "fake_rccl")
+    src, out = os.path.join(here, "fake_rccl.cpp"), os.path.join(here, "libfake_rccl.so")
+    if not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
+        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+        subprocess.check_call([hipcc, "-O2", "-std=c++17", "-fPIC", "-shared", "-x", "hip", "--offload-arch=gfx950", src, "-o", out, "-lrt"])
+    return out

@@ -691,6 +691,14 @@ int32_t vitx_comm_stats(vitx_handle h, int64_t* out4) {
   return VITX_OK;
 }
 
+int32_t vitx_comm_destroy(vitx_handle h) {
+  CAPI_TRY
+  if (!h) return fail(VITX_ERR_INVALID, "null handle");
+  comm_destroy(h);
+  return VITX_OK;
+  CAPI_CATCH
+}
+
 int32_t vitx_allreduce_grads(vitx_handle h) {
   CAPI_TRY
   if (!h) return fail(VITX_ERR_INVALID, "null handle");

@@ -14,6 +14,7 @@
 // librccl is dlopen'ed (libvitx does not link against it); torch.distributed is NOT involved on this path.
 #include <dlfcn.h>
 
+#include <cstdio>
 #include <cstring>
 
 #include "engine.h"
@@ -33,8 +34,18 @@ struct uid128_t { char b[128]; };   // ncclUniqueId (NCCL_UNIQUE_ID_BYTES = 128)
 constexpr int NCCL_FLOAT32 = 7, NCCL_BFLOAT16 = 9, NCCL_SUM = 0;   // ncclDataType_t / ncclRedOp_t values of RCCL's nccl.h
 typedef int (*all_reduce_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
 
+// VITX_RCCL_LIB=<path>: the collective library to open instead of librccl.so (anything that exports ncclGetUniqueId / ncclCommInitRank / ncclAllReduce /
+// ncclCommDestroy with RCCL's signatures).  tests/fake_rccl/ is such a library: a shared-memory stand-in that lets two ranks meet on a one-GPU box.
 void* rccl_handle() {
   static void* lib = nullptr;
+  if (lib) return lib;
+  if (const char* p = getenv("VITX_RCCL_LIB")) {
+    if (*p) {
+      lib = dlopen(p, RTLD_NOW | RTLD_LOCAL);
+      if (!lib) fprintf(stderr, "[vitx] VITX_RCCL_LIB=%s: %s\n", p, dlerror());
+      return lib;   // (no silent fall-back to the system library: the caller asked for this one)
+    }
+  }
   if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
   if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
   if (!lib) lib = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_LOCAL);
@@ -115,6 +126,7 @@ int ensure_state(vitx_engine* e, std::string& err) {
     c.launched.assign((size_t)nb, 0);
     c.last_launched = -1;
     c.n_launched = 0;
+    c.next_bucket = -1;
   }
   if (c.wire_bf16 && !c.wire) {
     HIPCHK_ERR(hipMalloc((void**)&c.wire, (size_t)e->n_arena * sizeof(bf16_t)), err);
@@ -167,11 +179,17 @@ int comm_overlap(vitx_engine* e, int enable, int64_t bucket_bytes, int wire_bf16
   const int rc = ensure_state(e, err);
   if (rc != VITX_OK) return rc;
   std::fill(c.covered.begin(), c.covered.end(), 0);
+  c.next_bucket = -1;
   c.overlap = enable != 0;
   return VITX_OK;
 }
 
-// engine.hip, report_ready: arena range [off, off + cnt) is final on the compute stream (every producing kernel has been enqueued there)
+// engine.hip, report_ready: arena range [off, off + cnt) is final on the compute stream (every producing kernel has been enqueued there).
+//  RCCL matches the collectives of a communicator by CALL ORDER, and every full bucket has the same element count: the order in which the
+// buckets go out must not depend on what this rank's backward happened to run (CaiT layer dropout with per-rank seeds skips different blocks on
+// different ranks).  Buckets therefore leave in ONE fixed order on every rank -- from the last bucket of the arena to the first, the order the
+// backward completes them in -- and bucket i is launched only once it AND every bucket behind it are covered; a bucket covered early waits for
+// its predecessors, a bucket never reported goes out from vitx_allreduce_grads, which continues the same descending order.
 void comm_on_ready(vitx_engine* e, int64_t off, int64_t cnt) {
   CommState& c = e->cm;
   if (!c.overlap || c.launched.empty()) return;
@@ -185,8 +203,21 @@ void comm_on_ready(vitx_engine* e, int64_t off, int64_t cnt) {
       return;
     }
     c.covered[(size_t)i] += std::max<int64_t>(0, std::min(hi, b1) - std::max(lo, b0));
-    if (c.covered[(size_t)i] >= b1 - b0)
-      if (launch_bucket(e, (int)i, err) != VITX_OK) { c.failed = err; return; }
+  }
+  const int nb = (int)c.launched.size();
+#ifdef VITX_COMM_LEGACY_ORDER   // (variant build only, tools/build_variant.sh: the round-5 rule -- a bucket leaves the moment it is covered -- to show that
+                                //  tests/test_gpu_dp.py::test_ranks_with_different_layer_dropout_draws_exchange_the_same_buckets catches it)
+  for (int i = 0; i < nb; ++i)
+    if (!c.launched[(size_t)i] && c.covered[(size_t)i] >= bucket_size(e, i))
+      if (launch_bucket(e, i, err) != VITX_OK) { c.failed = err; return; }
+  return;
+#endif
+  if (c.next_bucket == -2) return;   // every bucket is out
+  if (c.next_bucket < 0 || c.next_bucket >= nb) c.next_bucket = nb - 1;
+  while (c.next_bucket >= 0 && !c.launched[(size_t)c.next_bucket] && c.covered[(size_t)c.next_bucket] >= bucket_size(e, c.next_bucket)) {
+    if (launch_bucket(e, c.next_bucket, err) != VITX_OK) { c.failed = err; return; }
+    --c.next_bucket;
+    if (c.next_bucket < 0) { c.next_bucket = -2; break; }   // every bucket is out
   }
 }
 
@@ -216,11 +247,12 @@ int comm_finish(vitx_engine* e, std::string& err) {
     std::fill(c.launched.begin(), c.launched.end(), 0);
     c.last_launched = -1;
     c.n_launched = 0;
+    c.next_bucket = -1;
     return VITX_ERR_COMM;
   }
   const int nb = (int)c.launched.size();
   c.last_overlapped = c.n_launched;   // buckets that went out from inside the backward pass
-  for (int i = 0; i < nb; ++i)
+  for (int i = nb - 1; i >= 0; --i)   // the same fixed order as comm_on_ready: last bucket first
     if ((rc = launch_bucket(e, i, err)) != VITX_OK) return rc;
   // the communication stream runs its buckets in order: the newest completion event covers them all
   if (c.last_launched >= 0) HIPCHK_ERR(hipStreamWaitEvent(e->stream, c.done_ev[(size_t)c.last_launched], 0), err);
@@ -228,6 +260,7 @@ int comm_finish(vitx_engine* e, std::string& err) {
   std::fill(c.launched.begin(), c.launched.end(), 0);
   c.last_launched = -1;
   c.n_launched = 0;
+  c.next_bucket = -1;
   return VITX_OK;
 }
 
@@ -256,4 +289,14 @@ void comm_destroy(vitx_engine* e) {
     if (destroy) (void)destroy(e->comm);
   }
   e->comm = nullptr;
+  e->rank = 0;
+  e->world = 1;
+  // single-rank again: no bucket state, no launches from inside the backward (vitx_comm_destroy between steps)
+  c.overlap = 0;
+  c.covered.clear();
+  c.launched.clear();
+  c.last_launched = -1;
+  c.n_launched = 0;
+  c.next_bucket = -1;
+  c.failed.clear();
 }

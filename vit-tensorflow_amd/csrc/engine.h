@@ -31,6 +31,7 @@ struct CommState {
   std::vector<char> launched;
   std::vector<hipEvent_t> ready_ev, done_ev;
   int last_launched = -1, n_launched = 0, last_overlapped = 0;
+  int next_bucket = -1;              // the next bucket of the fixed (descending) launch order; -1 = not started (the last one), -2 = all out
   int64_t busy_hits = 0;
   std::string failed;                // error of a launch made from inside the backward (surfaced by the next vitx_allreduce_grads)
 };
@@ -205,6 +206,7 @@ struct vitx_engine {
   // env switches
   bool force_generic_gemm = false, force_generic_attn = false, wgrad_via_transpose = true;
   int gemm_kernel = 0;
+  int gemm_tail = 0;      // forced tail variant (VITX_GEMM_TAIL_KERNEL; only with a forced main variant)
   int reverse_mask = 7;                  // VITX_REVERSE=bits: 1 forward GEMMs, 2 dgrad GEMMs walk their row tiles last-to-first when the A operand exceeds
   int64_t reverse_min_bytes = 200ll << 20;   //   VITX_REVERSE_MIN_MB (default 200 MB), see decode_tile (gemm_bf16.hip); 4: the fused attention forward (attn_bf16.hip)
   bool bgemm_pairs = true;               // VITX_BGEMM_PAIRS=0: the four batched products of the materialised attention backward as four launches

@@ -469,7 +469,7 @@ static void dense_fwd(vitx_engine* e, const void* X, int64_t ldx, int rows, cons
     Bf16GemmArgs g;
     g.A = (const bf16_t*)X; g.lda = ldx;
     g.B = w.wt; g.ldb = w.in_k;
-    g.M = rows; g.N = w.out; g.K = w.in_k; g.kernel = e->gemm_kernel;
+    g.M = rows; g.N = w.out; g.K = w.in_k; g.kernel = e->gemm_kernel; g.tail = e->gemm_tail;
     g.reverse_m = (e->reverse_mask & 1) && (int64_t)rows * w.in_k * 2 > e->reverse_min_bytes;   // A larger than the memory-side cache, just written
     g.stagger = (mode == EPI_BIAS_GELU || mode == EPI_BIAS_RESID || mode == EPI_PATCH) ? e->gemm_stagger : 0;
     g.shared_gpu = comm_busy(e);
@@ -502,7 +502,7 @@ static void dense_dgrad(vitx_engine* e, const void* dY, int64_t ldy, int rows, c
     Bf16GemmArgs g;
     g.A = (const bf16_t*)dY; g.lda = ldy;
     g.B = w.wn; g.ldb = w.out_k;
-    g.M = rows; g.N = w.in; g.K = w.out_k; g.kernel = e->gemm_kernel;
+    g.M = rows; g.N = w.in; g.K = w.out_k; g.kernel = e->gemm_kernel; g.tail = e->gemm_tail;
     g.reverse_m = (e->reverse_mask & 2) && (int64_t)rows * w.out_k * 2 > e->reverse_min_bytes;
     g.stagger = (mode == EPI_GELU_BWD) ? e->gemm_stagger : 0;
     g.shared_gpu = comm_busy(e);   // a bucket's collective may be running beside this launch (native exchange, comm.hip)
@@ -841,7 +841,7 @@ struct AttnGrad {   // gradients, same addressing conventions as AttnView
   int64_t lddq = 0, lddk = 0, lddv = 0, dqb = 0, dkb = 0, dvb = 0;
 };
 
-static void attn_generic_bwd(vitx_engine* e, const BlockParams& bp, const AttnView& a, const AttnGrad& gr, int b, const BlockActs* keep) {
+static void attn_generic_bwd(vitx_engine* e, const BlockParams& bp, const AttnView& a, const AttnGrad& gr, int b, BlockActs* keep) {
   const int h = e->cfg.heads, dh = e->cfg.dim_head, T = e->bf16;
   const int64_t ld = round_up(a.nk, 4);
   const int64_t hs = (int64_t)a.nq * ld, bs = (int64_t)h * hs;
@@ -898,7 +898,12 @@ static void attn_generic_bwd(vitx_engine* e, const BlockParams& bp, const AttnVi
   const bool chain = !e->unfused_headops && headchain_supported(h, a.nk) && !(kept && keep->sc_no_mixed);
   if (chain && e->cfg.variant == VITX_VARIANT_CAIT) {
     Prof pr(e, "attn_headchain", 0, 0);
-    if (T && a2_lp && e->score_bf16 && cait_chain_bwd_bf16_out_ok()) ds_lp = (bf16_t*)sc[pi];
+    if (T && a2_lp && e->score_bf16 && cait_chain_bwd_bf16_out_ok()) {
+      ds_lp = (bf16_t*)sc[pi];
+      //  d(dots) overwrites the forward's kept mixed softmax: a SECOND backward on the same forward must not read it as attention
+      // weights -- the kept tensors are marked stale and that backward recomputes them (same bits as the forward's)
+      if (kept) keep->sc_geom = -1;
+    }
     launch_cait_chain_bwd(sc[0], sc[1], dA, e->params + bp.mix_pre, e->params + bp.mix_post, e->red_ws, e->grads + bp.mix_pre,
                           e->grads + bp.mix_post, b, h, a.nq, a.nk, ld, e->stream, ds_lp);
   } else if (chain && e->cfg.variant == VITX_VARIANT_DEEPVIT) {
@@ -1377,6 +1382,7 @@ static int engine_create_body(vitx_engine* e, const vitx_config& cfg, std::strin
   gemm_f32_mfma_read_env();
   if (const char* k = getenv("VITX_REVERSE_MIN_MB")) e->reverse_min_bytes = (int64_t)atoi(k) << 20;
   if (const char* k = getenv("VITX_GEMM_KERNEL")) e->gemm_kernel = atoi(k);
+  if (const char* k = getenv("VITX_GEMM_TAIL_KERNEL")) e->gemm_tail = atoi(k);   // with VITX_GEMM_KERNEL=13 / 11: tile variant of the tail launch (1, 3, 10; gemm_bf16.hip, tail balancing)
   if (const char* k = getenv("VITX_UNFUSED_HEADOPS")) e->unfused_headops = atoi(k) != 0;
   e->wgrad_via_transpose = env_flag("VITX_WGRAD_TRANSPOSE");
   e->keep_scores = !env_flag("VITX_RECOMPUTE_SCORES");
@@ -2262,8 +2268,16 @@ int engine_backward(vitx_engine* e, const float* dlogits_dev, float* dimg_dev, s
   if (cait) {
     Stage& s1 = e->stages[1];
     launch_fill_zero(e->g_ctx, (int64_t)b * np * d * 4, e->stream);
-    for (int l = s1.depth - 1; l >= 0; --l)
-      if (e->layer_kept[1][(size_t)l] && (rc = block_backward(e, s1, 1, l, b, 1, np, drop, e->last_seed, err, next_kept(1, l))) != VITX_OK) return rc;
+    for (int l = s1.depth - 1; l >= 0; --l) {
+      if (e->layer_kept[1][(size_t)l]) {
+        if ((rc = block_backward(e, s1, 1, l, b, 1, np, drop, e->last_seed, err, next_kept(1, l))) != VITX_OK) return rc;
+      } else {
+#ifndef VITX_COMM_LEGACY_ORDER   // (defined only in the variant build that shows the two-rank test catching the round-5 behaviour, comm.hip)
+        // a dropped layer's gradients are final zeros (every rank reports every arena range, whatever its layer-dropout draw)
+        report_ready(e, s1.bp[(size_t)l].p_begin, s1.bp[(size_t)l].p_end - s1.bp[(size_t)l].p_begin);
+#endif
+      }
+    }
     {
       Prof pr(e, "embed_bwd", 0, 0);
       launch_batch_reduce(e->g, b, 1, d, 0, 1, e->grads + e->cls, e->stream);          // dcls = sum_b g (cait.py:189 VJP)
@@ -2275,8 +2289,13 @@ int engine_backward(vitx_engine* e, const float* dlogits_dev, float* dimg_dev, s
   for (int l = s0.depth - 1; l >= 0; --l) {
     if (merging && l == e->merge_after && (rc = merger_backward(e, s0.ba[l].x_out, b, ntok, err)) != VITX_OK) return rc;
     const int rows_tok = (merging && l > e->merge_after) ? e->merge_t : ntok;
-    if (e->layer_kept[0][(size_t)l] && (rc = block_backward(e, s0, 0, l, b, rows_tok, 0, drop, e->last_seed, err, merging ? -1 : next_kept(0, l))) != VITX_OK)
-      return rc;
+    if (e->layer_kept[0][(size_t)l]) {
+      if ((rc = block_backward(e, s0, 0, l, b, rows_tok, 0, drop, e->last_seed, err, merging ? -1 : next_kept(0, l))) != VITX_OK) return rc;
+    } else {
+#ifndef VITX_COMM_LEGACY_ORDER
+      report_ready(e, s0.bp[(size_t)l].p_begin, s0.bp[(size_t)l].p_end - s0.bp[(size_t)l].p_begin);   // dropped layer: final zeros
+#endif
+    }
   }
   if (e->last_training && c.emb_dropout > 0.f) {
     Prof pr(e, "dropout", 0, 0);
@@ -2330,7 +2349,7 @@ int engine_check_gemm(vitx_engine* e, int kind, int M, int N, int K, int kernel,
   auto alloc = [&](void** p, size_t bytes) -> hipError_t { hipError_t r = hipMalloc(p, bytes + 8192); if (r == hipSuccess) { bufs.push_back(*p); r = hipMemsetAsync(*p, 0, bytes + 8192, e->stream); } return r; };
   auto cleanup = [&]() { for (void* b : bufs) (void)hipFree(b); (void)hipFree(dmax); };
   if (kind == 0) {
-    const int64_t Mp = round_up(M, 1280), Np = round_up(N, 256);
+    const int64_t Mp = round_up(M, 1280) + 320, Np = round_up(N, 256);   // (+ 320: a tail launch's 192-row tiles start at a row that is no multiple of 192)
     bf16_t *A, *B, *T1[2], *T2[2], *aux; float *F[2], *bias, *R, *cs[2];
     if (alloc((void**)&A, (size_t)Mp * K * 2) || alloc((void**)&B, (size_t)Np * K * 2) || alloc((void**)&bias, (size_t)Np * 4) || alloc((void**)&R, (size_t)Mp * Np * 4) ||
         alloc((void**)&aux, (size_t)Mp * Np * 2) || alloc((void**)&cs[0], (size_t)(Mp / 96 + 8) * Np * 4) || alloc((void**)&cs[1], (size_t)Np * 4 * 64)) { cleanup(); err = "check_gemm: out of memory"; return VITX_ERR_HIP; }
@@ -2349,6 +2368,7 @@ int engine_check_gemm(vitx_engine* e, int kind, int M, int N, int K, int kernel,
     }
     Bf16GemmArgs g;
     g.A = A; g.lda = K; g.B = B; g.ldb = K; g.M = M; g.N = N; g.K = K; g.kernel = kernel & (15 | 256 | 512);
+    g.tail = (kernel >> 10) & 15;   // (round 6) bits 10..13: tile variant of the tail launch (tail balancing, gemm_bf16.hip)
     GenericGemmArgs gg;
     gg.A = A; gg.B = B; gg.M = M; gg.N = N; gg.K = K; gg.sam = K; gg.sak = 1; gg.sbk = 1; gg.sbn = K;
     int mode = EPI_STORE_F32;
@@ -2423,7 +2443,7 @@ int engine_bench_gemm(vitx_engine* e, int M, int N, int K, int kernel, int epilo
   // no DMA issue: WRONG results, faster launches).  A sweep that packs anything else into those bits measures the switch, not its
   // own parameter (profiles/r2/gemm_tile_band_README.txt), so they are refused unless the caller says it wants the experiment.
   if (((kernel >> 4) & 7) && !getenv("VITX_GEMM_XP")) { err = "vitx_bench_gemm: kernel bits 4-6 are timing-experiment switches (results invalid); set VITX_GEMM_XP=1 to use them"; return VITX_ERR_INVALID; }
-  const int64_t Mp = round_up(M, 1280), Np = round_up(N, 256);
+  const int64_t Mp = round_up(M, 1280) + 320, Np = round_up(N, 256);   // (+ 320: a tail launch's 192-row tiles start at a row that is no multiple of 192)
   bf16_t *A, *B; float *C, *R, *bias; bf16_t* C2;
   HIPCHK(hipMalloc((void**)&A, (size_t)Mp * K * 2));
   HIPCHK(hipMalloc((void**)&B, (size_t)Np * K * 2));
@@ -2451,6 +2471,7 @@ int engine_bench_gemm(vitx_engine* e, int M, int N, int K, int kernel, int epilo
   }
   Bf16GemmArgs g;
   g.A = A; g.lda = K; g.B = B; g.ldb = K; g.M = M; g.N = N; g.K = K; g.kernel = kernel & (15 | 256 | 512); g.stagger = (kernel >> 4) & 15;
+  g.tail = (kernel >> 10) & 15;   // (round 6) bits 10..13: tile variant of the tail launch (tail balancing, gemm_bf16.hip)
   EpiParams ep;
   ep.M = M; ep.N = N; ep.zero_pad = 1;
   int mode = EPI_STORE_F32;

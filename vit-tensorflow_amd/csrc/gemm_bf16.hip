@@ -377,6 +377,55 @@ static void dispatch_gemm_bf16(const Bf16GemmArgs& g, const EpiParams& ep, int m
   }
 }
 
+// ---- tail balancing (round 6).  A persistent launch of T tiles on 256 workgroups runs ceil(T / 256) rounds: 591 tiles (M = 50432, N = 768, 256-row
+// tiles) are 2.31 rounds run as 3, 2364 (N = 3072) 9.23 run as 10, ViT-L/16's 788 (N = 1024) 3.08 run as 4, DeepViT cfg4's 260 1.02 run as 2.  Here the rows
+// of the whole rounds go out as one persistent launch (every workgroup the same number of tiles) and the ROWS OF THE LAST PARTIAL ROUND as a second launch of
+// SMALLER tiles, one per workgroup (216 tiles of 192 x 128 or 240 of 128 x 128 instead of 79 / 60 of 256 x 256): every CU has work in the tail and the tail
+// costs ~0.4 of a round instead of a whole one.  A sub-launch is the same GEMM on a row range (operand / output / residual / aux pointers advanced by the
+// first row), so every fused epilogue applies unchanged and -- unlike a split along K (stream-K) -- no fp32 partial leaves the chip and every output element
+// is accumulated in the same K order by one wave: results are bit-identical to the single launch (the per-tile column sums of EPI_GELU_BWD are summed over
+// other row groups: same value up to the order of a fixed-order fp32 sum).  Why not stream-K: the tail's partials would be 256 KiB of fp32 per (tile, slice)
+// -- at K = 768 as many bytes as the operands of the slice -- written, re-read and reduced by a fixup pass; measured alternatives in
+// profiles/r6/gemm_tail_balancing_r6.md.
+static bool tail_split_plan(const Bf16GemmArgs& g, int mode, int main_variant, int* rows_main) {
+  if (g.tail <= 0 || g.split_k > 1 || g_shared_gpu || g.shared_gpu) return false;
+  // (row-remapping / partial epilogues: one launch.  EPI_BIAS_GELU too: only the 256-row tile has LDS to spare for the GELU table, the small tiles evaluate
+  //  the polynomial form -- the tail rows would get another rounding of gelu than the rows in front of them)
+  if (!(mode == EPI_STORE || mode == EPI_BIAS_RESID || mode == EPI_GELU_BWD)) return false;
+  if (!(main_variant == 13 || main_variant == 11)) return false;
+  const int bm = main_variant == 11 ? 320 : 256;
+  const int64_t tiles_n = ceil_div(g.N, 256), tiles_m = ceil_div(g.M, bm), total = tiles_m * tiles_n, grid = 256;
+  if (total <= grid || total % grid == 0) return false;
+  const int64_t main_tm = (total / grid) * grid / tiles_n;   // row tiles the whole rounds cover
+  if (main_tm <= 0 || main_tm >= tiles_m) return false;
+  *rows_main = (int)(main_tm * bm);
+  return true;
+}
+static void dispatch_gemm_bf16_tail(const Bf16GemmArgs& g, const EpiParams& ep, int mode, hipStream_t s) {
+  int r0 = 0;
+  if (!tail_split_plan(g, mode, g.kernel & 15, &r0)) { Bf16GemmArgs g1 = g; g1.tail = 0; dispatch_gemm_bf16(g1, ep, mode, s); return; }
+  Bf16GemmArgs gm = g, gt = g;
+  EpiParams em = ep, et = ep;
+  gm.tail = gt.tail = 0;
+  gm.M = em.M = r0;
+  gt.M = et.M = g.M - r0;
+  gt.kernel = g.tail;
+  gt.A = g.A + (int64_t)r0 * g.lda;
+  const int osz = (mode == EPI_BIAS_RESID) ? 4 : 2;
+  auto adv = [](const void* p, int64_t bytes) -> void* { return p ? (void*)((char*)p + bytes) : nullptr; };
+  et.out = adv(ep.out, (int64_t)r0 * ep.ldo * osz);
+  et.out2 = adv(ep.out2, (int64_t)r0 * ep.ldo2 * 2);
+  et.resid = (const float*)adv(ep.resid, (int64_t)r0 * ep.ldr * 4);
+  et.aux = adv(ep.aux, (int64_t)r0 * ep.ldaux * 2);
+  // per-tile column sums: the main launch writes rows [0, 2 r0 / 256) (one per 128-row wave row; 320-row tiles: per 160), the tail's rows follow
+  // (<= one per 96 rows: the caller's buffer has ceil(M / 96) rows)
+  const int main_cs_rows = (g.kernel & 15) == 11 ? 2 * (r0 / 320) : 2 * (r0 / 256);
+  et.colsum = ep.colsum ? ep.colsum + (int64_t)main_cs_rows * ep.ldcs : nullptr;
+  // row tiles walked from the last to the first (an A operand larger than the memory-side cache, just written front to back): the tail rows are the last
+  if (g.reverse_m) { dispatch_gemm_bf16(gt, et, mode, s); dispatch_gemm_bf16(gm, em, mode, s); }
+  else { dispatch_gemm_bf16(gm, em, mode, s); dispatch_gemm_bf16(gt, et, mode, s); }
+}
+
 // ---- per-shape variant selection by measurement.  The variants differ by a few percent per (shape, epilogue) and the ranking
 // moves with the board's clocks, so with kernel = 0 (automatic) the first launch of each (mode, M, N, K) times the candidates on
 // the caller's stream with the caller's operands (every fused epilogue is a pure function of its inputs -- the launch is
@@ -385,6 +434,16 @@ static void dispatch_gemm_bf16(const Bf16GemmArgs& g, const EpiParams& ep, int m
 // static rule gemm_bf16_pick().
 static std::mutex g_tune_mu;
 static std::map<std::array<int64_t, 6>, int> g_tuned;
+// VITX_GEMM_TAIL=1: the per-shape measurement also times the tail-balanced forms (same results either way).  OFF by default: in isolation the split
+// wins 2-5 % on the launches it applies to (out-proj + residual 117.9 -> 112.7 us, ViT-L/16's N = 1024 launches 174 -> 168, 454 -> 436 us), but inside the
+// training step every extra launch boundary of the input-gradient chain is a gap in which the low-priority weight-gradient stream places its persistent
+// workgroups, and the tail then queues behind them: ViT-B/16 35.24 -> 35.36 ms, ViT-L/16 109.5 -> 111.2 ms, DeepViT / CaiT neutral
+// (profiles/r6/gemm_tail_balancing_r6.md, same box, alternating runs).
+static int tail_enabled() {
+  static int on = -1;
+  if (on < 0) { const char* v = getenv("VITX_GEMM_TAIL"); on = (v && atoi(v) != 0) ? 1 : 0; }
+  return on;
+}
 static int autotune_enabled() {
   static int on = -1;
   if (on < 0) { const char* v = getenv("VITX_GEMM_AUTOTUNE"); on = (v && atoi(v) == 0) ? 0 : 1; }
@@ -396,7 +455,7 @@ void launch_gemm_bf16(const Bf16GemmArgs& g0, const EpiParams& ep, int mode, hip
   const double work = (double)g0.M * g0.N * g0.K;
   const bool tunable = g0.kernel == 0 && autotune_enabled() && (g0.N % 256 == 0 || g0.N > 512) && (work >= 2.0e9 || (few_tiles && work >= 1.0e8)) &&
                        !(mode == EPI_BIAS_RESID && ep.out == (void*)ep.resid);
-  if (!tunable) { dispatch_gemm_bf16(g0, ep, mode, s); return; }
+  if (!tunable) { dispatch_gemm_bf16_tail(g0, ep, mode, s); return; }
   const std::array<int64_t, 6> key = {mode, g0.M, g0.N, g0.K, g0.split_k > 1 ? g0.split_k : 1, (ep.scale != nullptr) + 2 * (g_shared_gpu | (g0.shared_gpu != 0))};
   int best = -1;
   {
@@ -420,30 +479,41 @@ void launch_gemm_bf16(const Bf16GemmArgs& g0, const EpiParams& ep, int mode, hip
     for (auto& x : ev) (void)hipEventCreate(&x);
     float best_ms = 1e30f;
     best = gemm_bf16_pick(g0.M, g0.N);
-    for (int c : cand) {
-      const bool is320 = c == 5 || c == 11;
-      if (is320 && !g_allow_320) continue;
-      if ((c == 1 || c == 3) && !small_m) continue;
-      if (!(g_shared_gpu || g0.shared_gpu) && (c == 2 || c == 5)) continue;   // beside collectives the pipelined kernel runs one tile per workgroup too (launch_pipe) and competes with 2 / 5
-      g.kernel = c;
-      dispatch_gemm_bf16(g, ep, mode, s);   // warm-up (first-use attribute setup, instruction cache)
+    auto measure = [&](int c, int tail) {
+      g.kernel = c; g.tail = tail;
+      dispatch_gemm_bf16_tail(g, ep, mode, s);   // warm-up (first-use attribute setup, instruction cache)
       (void)hipEventRecord(ev[0], s);
       for (int r = 0; r < NREP; ++r) {
-        dispatch_gemm_bf16(g, ep, mode, s);
+        dispatch_gemm_bf16_tail(g, ep, mode, s);
         (void)hipEventRecord(ev[r + 1], s);
       }
-      if (hipEventSynchronize(ev[NREP]) != hipSuccess) continue;
+      if (hipEventSynchronize(ev[NREP]) != hipSuccess) return;
       float fastest = 1e30f;
       for (int r = 0; r < NREP; ++r) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, ev[r], ev[r + 1]) == hipSuccess && ms < fastest) fastest = ms;
       }
-      if (fastest < best_ms * 0.985f) { best_ms = fastest; best = c; }   // a later candidate must win by more than the noise: the same pick run after run
+      if (fastest < best_ms * 0.985f) { best_ms = fastest; best = c + 32 * tail; }   // a later candidate must win by more than the noise: the same pick run after run
+    };
+    for (int c : cand) {
+      const bool is320 = c == 5 || c == 11;
+      if (is320 && !g_allow_320) continue;
+      if ((c == 1 || c == 3) && !small_m) continue;
+      if (!(g_shared_gpu || g0.shared_gpu) && (c == 2 || c == 5)) continue;   // beside collectives the pipelined kernel runs one tile per workgroup too (launch_pipe) and competes with 2 / 5
+      measure(c, 0);
     }
+    // (round 6) tail balancing: the whole rounds on 256-row tiles + the rows of the last partial round on small tiles (dispatch_gemm_bf16_tail)
+    if (tail_enabled()) {
+      int r0 = 0;
+      g.kernel = 13; g.tail = 1;
+      if (tail_split_plan(g, mode, 13, &r0))
+        for (int t : {10, 1, 3}) measure(13, t);
+    }
+    g.tail = 0;
     for (auto& x : ev) (void)hipEventDestroy(x);
     if (getenv("VITX_GEMM_AUTOTUNE_LOG"))
-      fprintf(stderr, "[vitx] gemm autotune: mode %d M %d N %d K %d split %d -> variant %d (%.4f ms)\n", mode, g0.M, g0.N, g0.K, g0.split_k, best,
-              best_ms);
+      fprintf(stderr, "[vitx] gemm autotune: mode %d M %d N %d K %d split %d -> variant %d tail %d (%.4f ms)\n", mode, g0.M, g0.N, g0.K, g0.split_k, best & 31,
+              best >> 5, best_ms);
     // The candidates have different tile heights and each stores its per-tile column sums (EPI_GELU_BWD) with '=' into rows the caller
     // zeroed ONCE: rows a taller-tiled winner does not write would keep what a shorter-tiled candidate left there, and the reduction behind
     // the launch adds every row (the fc1 bias gradient of the first step of a process was wrong by that much).  Clear them again.
@@ -451,8 +521,9 @@ void launch_gemm_bf16(const Bf16GemmArgs& g0, const EpiParams& ep, int mode, hip
     std::lock_guard<std::mutex> lk(g_tune_mu);
     g_tuned[key] = best;
   }
-  g.kernel = best;
-  dispatch_gemm_bf16(g, ep, mode, s);
+  g.kernel = best & 31;
+  g.tail = best >> 5;
+  dispatch_gemm_bf16_tail(g, ep, mode, s);
 }
 
 void launch_gemm_bf16_persistent_lockstep(int bm, int mode, const Bf16GemmArgs& g0, const EpiParams& ep, hipStream_t s) {

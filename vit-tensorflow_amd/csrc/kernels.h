@@ -63,6 +63,8 @@ struct Bf16GemmArgs {
   int shared_gpu = 0;        // 1: a collective of this handle may hold CUs while this launch runs (comm_busy): one tile per workgroup instead of a persistent grid
   int walk = 0;              // set by the launcher of the pipelined kernel: 2 = XCD-owned row bands (see gemm_bf16_nt_pipe_kernel)
   int stagger = 0;           // >0: first-wave workgroups start (cu_slot & 3) * stagger * 2048 cycles late (de-phases store-heavy epilogues)
+  int tail = 0;              // (round 6) tail balancing: > 0 = tile variant (1 = 128 x 128, 3 = 256 x 128, 10 = 192 x 128) for the rows of the last PARTIAL round of the
+                             //   persistent grid, launched on their own behind the full rounds (gemm_bf16.hip: dispatch_gemm_bf16_tail); 0 = one launch
 };
 void launch_gemm_bf16(const Bf16GemmArgs& g, const EpiParams& ep, int mode, hipStream_t s);
 int gemm_bf16_tile_m(int kernel, int M, int N);

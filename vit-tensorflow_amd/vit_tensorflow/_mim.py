@@ -201,6 +201,7 @@ class MimWrapper:
         MAE's decoder Transformer under 'decoder.<name>'."""
         self._check_live("backward")
         l = N.lib()
+        self.encoder._refuse_exchange(type(self).__name__ + ".backward")
         N.check(l.vitx_mim_backward(self._mim))
         g = np.empty(self._n, dtype=np.float32)
         N.check(l.vitx_mim_get_grads(self._mim, g.ctypes.data_as(C.c_void_p), self._n))

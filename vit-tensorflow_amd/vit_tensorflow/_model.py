@@ -409,12 +409,30 @@ class VitxModel:
             dimg = np.empty(self._last_img_shape(), dtype=np.float32)
             dimg_p = dimg.ctypes.data_as(C.c_void_p)
         N.check(N.lib().vitx_backward(self._handle, d.ctypes.data_as(C.c_void_p), dimg_p))
-        if getattr(self, "_comm_world", 0):   # data parallel: the gradients every rank sees are the mean over the ranks (comm_init below)
-            N.check(N.lib().vitx_allreduce_grads(self._handle))
+        self._finish_exchange()   # data parallel: the gradients every rank sees are the mean over the ranks (comm_init below)
         g = np.empty(self._n, dtype=np.float32)
         N.check(N.lib().vitx_get_grads(self._handle, g.ctypes.data_as(C.c_void_p), self._n))
         grads = {n: g[o:o + int(np.prod(s))].reshape(s) for n, s, o in self._table}
         return grads, dimg
+
+    def _finish_exchange(self) -> None:
+        """ EVERY Python backward path on this handle ends here: after comm_init a backward pass launches bucket collectives from inside
+        the engine, and vitx_allreduce_grads must send the rest and join before the gradients are read (one call per backward)."""
+        if getattr(self, "_comm_world", 0):
+            N.check(N.lib().vitx_allreduce_grads(self._handle))
+
+    def _refuse_exchange(self, what: str) -> None:
+        """Wrapper objects (MAE / SimMIM / MPP / DistillWrapper) keep variables of their own OUTSIDE this handle's gradient arena: the native
+        exchange would average the encoder's gradients and leave the wrapper's local.  Refused instead of half-done."""
+        if getattr(self, "_comm_world", 0):
+            raise N.VitxError(N.ERR_STATE, f"{what}: this model has joined an RCCL group (comm_init), but the wrapper's own variables live outside its "
+                                           "gradient arena and would not be exchanged; use vit_tensorflow.parallel.GradSync on the wrapper's gradients instead")
+
+    def comm_destroy(self) -> None:
+        """Leave the RCCL group (communicator, communication stream, wire buffer); backward() returns local gradients again."""
+        if self._handle is not None and getattr(self, "_comm_world", 0):
+            N.check(N.lib().vitx_comm_destroy(self._handle))
+        self._comm_world = 0
 
     # ---- data parallel (no reference counterpart, SURVEY.md 8(e)): one process per GPU, parameters replicated, images sharded, ONE exchange per step --
     # the mean of the gradient arena over the ranks, done by the library itself over RCCL (csrc/comm.hip; no torch.distributed involved)
@@ -475,6 +493,7 @@ class VitxModel:
         dtok = np.empty_like(d) if want_dtokens else None
         N.check(N.lib().vitx_transformer_backward(self._handle, d.ctypes.data_as(C.c_void_p),
                                                   dtok.ctypes.data_as(C.c_void_p) if want_dtokens else None))
+        self._finish_exchange()
         g = np.empty(self._n, dtype=np.float32)
         N.check(N.lib().vitx_get_grads(self._handle, g.ctypes.data_as(C.c_void_p), self._n))
         grads = {n: g[o:o + int(np.prod(s))].reshape(s) for n, s, o in self._table}

@@ -127,6 +127,7 @@ SYMBOLS: List[Tuple[str, object, list]] = [
     ("vitx_comm_init", C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     ("vitx_comm_overlap", C.c_int32, [C.c_void_p, C.c_int32, C.c_int64, C.c_int32]),
     ("vitx_comm_stats", C.c_int32, [C.c_void_p, C.POINTER(C.c_int64)]),
+    ("vitx_comm_destroy", C.c_int32, [C.c_void_p]),
     ("vitx_allreduce_grads", C.c_int32, [C.c_void_p]),
     ("vitx_profile_begin", C.c_int32, [C.c_void_p]),
     ("vitx_profile_end", C.c_int32, [C.c_void_p, _P(KernelStat), C.c_int32, _P(C.c_int32)]),

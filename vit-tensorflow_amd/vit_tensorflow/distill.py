@@ -59,6 +59,7 @@ class DistillableViT(ViT):
         dt = np.empty(self.dim, dtype=np.float32)
         N.check(N.lib().vitx_backward_distill(self._handle, d.ctypes.data_as(C.c_void_p), None if dd is None else dd.ctypes.data_as(C.c_void_p),
                                               dt.ctypes.data_as(C.c_void_p), None))
+        self._finish_exchange()
         g = np.empty(self._n, dtype=np.float32)
         N.check(N.lib().vitx_get_grads(self._handle, g.ctypes.data_as(C.c_void_p), self._n))
         return {n: g[o:o + int(np.prod(s))].reshape(s) for n, s, o in self._table}, dt.reshape(1, 1, -1)
@@ -119,6 +120,7 @@ class DistillableT2TViT(T2TViT):
         dpat = np.empty(m._img_shape, dtype=np.float32)
         N.check(N.lib().vitx_backward_distill(m._handle, d.ctypes.data_as(C.c_void_p), None if dd is None else dd.ctypes.data_as(C.c_void_p),
                                               dt.ctypes.data_as(C.c_void_p), dpat.ctypes.data_as(C.c_void_p)))
+        m._finish_exchange()
         g = np.empty(m._n, dtype=np.float32)
         N.check(N.lib().vitx_get_grads(m._handle, g.ctypes.data_as(C.c_void_p), m._n))
         gm = {n: g[o:o + int(np.prod(s))].reshape(s) for n, s, o in m._table}
@@ -280,6 +282,9 @@ class DistillWrapper:
         if self._h is None or self._stu_gen != self.student._handle_gen:
             raise N.VitxError(N.ERR_STATE, "backward requires a preceding forward")
         l = N.lib()
+        stu = self.student._main if self._t2t else self.student
+        if hasattr(stu, "_refuse_exchange"):
+            stu._refuse_exchange("DistillWrapper.backward")
         dl = None if dloss is None else np.ascontiguousarray(np.asarray(dloss, dtype=np.float32))
         dpat = None
         if self._t2t:
