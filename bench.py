@@ -190,6 +190,12 @@ def main():
             ok = int(flag.item())
         if not ok:
             native_dp = False
+            #  a rank that DID get its communicator must give it up before the torch exchange takes over: left alive, its overlapped
+            # buckets would still be launched from inside the backward pass and wait for peers that never join
+            try:
+                model.comm_destroy()
+            except Exception as ex:   # noqa: BLE001
+                print(f"[bench] rank {rank}: comm_destroy: {ex}", file=sys.stderr)
             dp_group = dist.new_group(backend="nccl") if dist.is_initialized() else None
     if dp and not native_dp:
         # The engine must run on the stream RCCL orders itself against.  torch's default stream has handle 0, which the C ABI

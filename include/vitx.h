@@ -242,6 +242,11 @@ int32_t vitx_comm_destroy(vitx_handle h);
 int32_t vitx_allreduce_grads(vitx_handle h); /* RCCL mean over ranks of the gradient arena (bucketed; finishes an overlapped exchange) */
 
 /* ---- measurement / debugging */
+/* Every VITX_* environment variable the library reads, one line per switch: "NAME<TAB>class<TAB>state<TAB>what it does\n" with class in
+ * {tuning (same results), path (another validated code path; results within the same oracle gates), diag (timing experiment: may corrupt
+ * results)} and state in {unset, set=<value>, ignored (a diag switch in a release build)}.  A release library ignores the diag class; only
+ * lib/libvitx_diag.so (build.py --diag) honours it.  Writes at most cap bytes (NUL-terminated); *needed = bytes of the full text + 1. */
+int32_t vitx_debug_switches(char* out, int64_t cap, int64_t* needed);
 int32_t vitx_profile_begin(vitx_handle h);
 int32_t vitx_profile_end(vitx_handle h, vitx_kernel_stat* out, int32_t cap, int32_t* n_out);
 int32_t vitx_workspace_bytes(vitx_handle h, int64_t* bytes);

@@ -99,3 +99,55 @@ def test_python_front_mirrors_reference_api():
     assert np.allclose(sd["patch_transformer.0.attn.scale"], 0.1) and np.allclose(sd["cls_transformer.1.mlp.scale"], 0.1)
     k = sd["patch_transformer.0.mlp.fc1.kernel"]
     assert np.abs(k).max() <= np.sqrt(6.0 / (k.shape[0] + k.shape[1])) + 1e-6
+
+
+# ---- environment switches: one registry (csrc/env.hip), three classes, diagnostics ignored by the release library
+def test_every_environment_switch_is_registered_classified_and_documented():
+    import glob
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rows = N.debug_switches()
+    names = [r[0] for r in rows]
+    assert len(names) == len(set(names)) >= 40
+    assert {r[1] for r in rows} == {"tuning", "path", "diag"}
+    # no getenv in csrc/ outside the registry (env.hip) and the one reporting call of vitx_debug_switches (capi.hip)
+    hits = []
+    for f in glob.glob(os.path.join(root, "vit-tensorflow_amd", "csrc", "*")):
+        for i, line in enumerate(open(f, errors="replace"), 1):
+            code = line.split("//")[0]
+            if re.search(r"(?<![a-z_])getenv\(", code):
+                hits.append(f"{os.path.basename(f)}:{i}")
+    assert sorted(h.split(":")[0] for h in hits) == ["capi.hip", "env.hip"], hits
+    # every name the sources pass to vitx_env is in the table (an unregistered one aborts at run time: catch it here)
+    used = set()
+    for f in glob.glob(os.path.join(root, "vit-tensorflow_amd", "csrc", "*.h*")):
+        used |= set(re.findall(r'(?:vitx_env|env_flag|vitx_env_flag)\("(VITX_[A-Z0-9_]+)"\)', open(f, errors="replace").read()))
+    assert used <= set(names), sorted(used - set(names))
+    assert set(names) <= used, f"registered but never read: {sorted(set(names) - used)}"
+    # INTEGRATION.md carries the generated table
+    sys_path = os.path.join(root, "tools")
+    import importlib.util
+    spec_ = importlib.util.spec_from_file_location("env_table", os.path.join(sys_path, "env_table.py"))
+    mod = importlib.util.module_from_spec(spec_)
+    spec_.loader.exec_module(mod)
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    assert mod.table() in doc, "INTEGRATION.md is stale: run `python tools/env_table.py --write`"
+
+
+def test_the_release_library_ignores_diagnostic_switches():
+    """A switch of class `diag` (wrong results by design) set in the environment is reported as `ignored` by the shipped library and as `set=...`
+    by lib/libvitx_diag.so (the same objects with env.hip under -DVITX_DIAG); a tuning switch is honoured by both."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path[:0] = [%r]; from vit_tensorflow import _native as N; "
+            "print({r[0]: r[2] for r in N.debug_switches() if r[0] in ('VITX_TN_XP', 'VITX_GEMM_AUTOTUNE', 'VITX_DV_XP')})") % os.path.join(root, "vit-tensorflow_amd")
+    env = dict(os.environ, VITX_TN_XP="7", VITX_GEMM_AUTOTUNE="0")
+    env.pop("VITX_LIB", None)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout
+    assert eval(out) == {"VITX_TN_XP": "ignored", "VITX_GEMM_AUTOTUNE": "set=0", "VITX_DV_XP": "unset"}, out
+    diag = os.path.join(root, "vit-tensorflow_amd", "lib", "libvitx_diag.so")
+    if os.path.exists(diag):
+        out = subprocess.run([sys.executable, "-c", code], env=dict(env, VITX_LIB=diag), capture_output=True, text=True, check=True).stdout
+        assert eval(out)["VITX_TN_XP"] == "set=7", out

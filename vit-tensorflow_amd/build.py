@@ -17,7 +17,7 @@ CSRC = os.path.join(HERE, "csrc")
 BUILD = os.path.join(HERE, "build")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libvitx.so")
-SOURCES = ["elementwise.hip", "gemm_generic.hip", "gemm_f32_mfma.hip", "gemm_bf16x3.hip", "gemm_bf16.hip", "gemm_bf16_pipe.hip", "gemm_bf16_tn.hip", "attn_bf16.hip", "attn_x3.hip", "attn_generic.hip", "attn_bgemm_mfma.hip", "attn_headchain.hip", "attn_deepvit_fused.hip", "attn_cait_fused.hip", "mim_ops.hip", "mim.hip", "distill.hip", "comm.hip", "engine.hip", "capi.hip"]
+SOURCES = ["env.hip", "elementwise.hip", "gemm_generic.hip", "gemm_f32_mfma.hip", "gemm_bf16x3.hip", "gemm_bf16.hip", "gemm_bf16_pipe.hip", "gemm_bf16_tn.hip", "attn_bf16.hip", "attn_x3.hip", "attn_generic.hip", "attn_bgemm_mfma.hip", "attn_headchain.hip", "attn_deepvit_fused.hip", "attn_cait_fused.hip", "mim_ops.hip", "mim.hip", "distill.hip", "comm.hip", "engine.hip", "capi.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
 # per-source additions.  attn_bf16.hip / attn_x3.hip: the running row maxima come straight out of MFMA accumulators; with NaNs honoured every fmaxf first
@@ -131,5 +131,26 @@ def build_asan(force: bool = False) -> str:
     return lib
 
 
+def build_diag(force: bool = False) -> str:
+    """libvitx_diag.so: the release objects with csrc/env.hip recompiled under -DVITX_DIAG, i.e. the library that HONOURS the diagnostic
+    environment switches (timing experiments that may corrupt results; csrc/env.h).  The release library ignores them.  Load with VITX_LIB=<this file>."""
+    build(force)
+    lib = os.path.join(LIBDIR, "libvitx_diag.so")
+    os.makedirs(os.path.join(HERE, "build_diag"), exist_ok=True)
+    obj = os.path.join(HERE, "build_diag", "env.o")
+    src = os.path.join(CSRC, "env.hip")
+    if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), _deps_mtime()):
+        r = subprocess.run([HIPCC, *FLAGS, "-DVITX_DIAG=1", "-c", src, "-o", obj], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc (diag) failed:\n{r.stderr}")
+    objs = [os.path.join(BUILD, s_.replace(".hip", ".o")) for s_ in SOURCES if s_ != "env.hip"] + [obj]
+    if force or not os.path.exists(lib) or any(os.path.getmtime(o) > os.path.getmtime(lib) for o in objs):
+        r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, *objs, "-ldl"], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link (diag) failed:\n{r.stderr}")
+    return lib
+
+
 if __name__ == "__main__":
-    print(build_asan(force="--force" in sys.argv) if "--asan" in sys.argv else build(force="--force" in sys.argv))
+    force = "--force" in sys.argv
+    print(build_asan(force) if "--asan" in sys.argv else build_diag(force) if "--diag" in sys.argv else build(force))

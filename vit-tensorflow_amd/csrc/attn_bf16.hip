@@ -525,11 +525,7 @@ __global__ __launch_bounds__(ATT_THREADS, 4) void attn_bwd_fused_kernel(const bf
 
 template <typename K>
 void set_smem(K kern, int bytes) {   // one attribute call per distinct kernel (function-pointer keyed)
-  static const void* done[32];
-  static int ndone = 0;
-  for (int i = 0; i < ndone; ++i) if (done[i] == (const void*)kern) return;
-  (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-  if (ndone < 32) done[ndone++] = (const void*)kern;
+  vitx_set_max_smem((const void*)kern, bytes);
 }
 
 // 8 waves: 13 one-block waves measured 16 % slower in the backward; 7 waves (tools/probe_attn, r4s) the same forward and a 6 % slower backward
@@ -561,7 +557,7 @@ void launch_attn_bf16_bwd(const bf16_t* qkv, const bf16_t* o, const bf16_t* d_o,
   const int np = 16 * ntp;
   const int smem_dq = 2 * np * ROWB;
   const int smem_dkv = 2 * np * ROWB + 2 * np * 4;
-  const char* split_env = getenv("VITX_ATTN_BWD_SPLIT");   // A/B and the bit-identity test: the two-launch form (read per call)
+  const char* split_env = vitx_env("VITX_ATTN_BWD_SPLIT");   // A/B and the bit-identity test: the two-launch form (read per call)
   const bool split = split_env && atoi(split_env) != 0;
   if (!split) {
 #define CALLF(NTP) { set_smem(attn_bwd_fused_kernel<NTP>, smem_dkv); hipLaunchKernelGGL(attn_bwd_fused_kernel<NTP>, dim3(b * h), dim3(att_threads(n)), smem_dkv, s, qkv, o, d_o, lse, dqkv, n, h, scale, zero_page); }

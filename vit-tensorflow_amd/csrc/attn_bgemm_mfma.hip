@@ -148,8 +148,7 @@ void launch_bgemm_mfma_pair(const GenericGemmArgs& g1, const EpiParams& ep1, int
 #define VITX_PAIR(T1, O1, T2, O2)                                                                                                  \
   {                                                                                                                                \
     auto kern = bgemm_mfma_pair_kernel<T1, O1, T2, O2>;                                                                            \
-    static bool set = false;                                                                                                       \
-    if (!set) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); set = true; } \
+    vitx_set_max_smem((const void*)kern, 80 * 1024);                                                                               \
     hipLaunchKernelGGL(kern, grid, block, smem, s, g1, ep1, Mp1, Np1, Kp1, g2, ep2, Mp2, Np2, Kp2);                                \
   }
   if (ta1 && to1 && ta2 && to2) VITX_PAIR(bf16_t, bf16_t, bf16_t, bf16_t)      // (dV = A'^T dO, dK = dS^T q) / (dQ = dS k, dK = dS^T q) on bf16 score tensors
@@ -167,18 +166,15 @@ void launch_bgemm_mfma(const GenericGemmArgs& g, const EpiParams& ep, int ta, in
   dim3 grid((unsigned)(g.nb * g.nh)), block(256);
   if (ta && to) {
     auto kern = bgemm_mfma_kernel<bf16_t, bf16_t>;
-    static bool set = false;
-    if (!set) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); set = true; }
+    vitx_set_max_smem((const void*)kern, 80 * 1024);
     hipLaunchKernelGGL(kern, grid, block, smem, s, g, ep, Mp, Np, Kp);
   } else if (ta) {
     auto kern = bgemm_mfma_kernel<bf16_t, float>;
-    static bool set = false;
-    if (!set) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); set = true; }
+    vitx_set_max_smem((const void*)kern, 80 * 1024);
     hipLaunchKernelGGL(kern, grid, block, smem, s, g, ep, Mp, Np, Kp);
   } else {
     auto kern = bgemm_mfma_kernel<float, bf16_t>;
-    static bool set = false;
-    if (!set) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); set = true; }
+    vitx_set_max_smem((const void*)kern, 80 * 1024);
     hipLaunchKernelGGL(kern, grid, block, smem, s, g, ep, Mp, Np, Kp);
   }
 }

@@ -250,8 +250,7 @@ void launch_cait_attn_fwd(const bf16_t* q, const bf16_t* k, const bf16_t* v, int
   const int cpi = b >= 192 ? 1 : std::max(1, std::min(ntile, (256 + b - 1) / b));
 #define CALL(HT)                                                                                                                      \
   {                                                                                                                                   \
-    static bool set = false;                                                                                                          \
-    if (!set) { (void)hipFuncSetAttribute((const void*)cait_attn_fwd_kernel<HT>, hipFuncAttributeMaxDynamicSharedMemorySize, ca_fwd_smem<HT>()); set = true; } \
+    vitx_set_max_smem((const void*)cait_attn_fwd_kernel<HT>, ca_fwd_smem<HT>());                                                      \
     hipLaunchKernelGGL(cait_attn_fwd_kernel<HT>, dim3(b * cpi), dim3(CA_THREADS), ca_fwd_smem<HT>(), s, q, k, v, ldq, ldk, ldv, qb, kb, vb, o, ldo,   \
                        ob, wpre, wpost, s0_keep, a1_keep, a2_keep, keep, nq, nk, ld, scale, zero_page, ntile, cpi);                    \
   }

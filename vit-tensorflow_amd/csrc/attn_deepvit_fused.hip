@@ -576,11 +576,7 @@ constexpr int dv_fwd_smem() {
 
 template <typename K>
 void dv_set_smem(K kern, int bytes) {
-  static const void* done[16];
-  static int ndone = 0;
-  for (int i = 0; i < ndone; ++i) if (done[i] == (const void*)kern) return;
-  (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-  if (ndone < 16) done[ndone++] = (const void*)kern;
+  vitx_set_max_smem((const void*)kern, bytes);
 }
 
 }  // namespace
@@ -596,8 +592,8 @@ void launch_deepvit_attn_fwd(const bf16_t* q, const bf16_t* k, const bf16_t* v, 
   const int ntile = (nq + 15) / 16;
   // chunks per image: one workgroup per image once the batch alone fills the chip, otherwise enough chunks to cover the 256 CUs
   int cpi = b >= 192 ? 1 : std::max(1, std::min(ntile, (256 + b - 1) / b));
-  if (const char* e = getenv("VITX_DV_CPI")) cpi = std::max(1, std::min(ntile, atoi(e)));   // tests: the multi-tile loop at small batches
-  static const int xp = [] { const char* e = getenv("VITX_DV_XP"); return e ? atoi(e) : 0; }();   // timing experiments: 1 = no kept tensors, 2 = no stage 2, 4 = no stage 3 (WRONG results)
+  if (const char* e = vitx_env("VITX_DV_CPI")) cpi = std::max(1, std::min(ntile, atoi(e)));   // tests: the multi-tile loop at small batches
+  static const int xp = [] { const char* e = vitx_env("VITX_DV_XP"); return e ? atoi(e) : 0; }();   // timing experiments: 1 = no kept tensors, 2 = no stage 2, 4 = no stage 3 (WRONG results)
   if (xp & 1) keep = 0;
 #define CALL(HT)                                                                                                                  \
   {                                                                                                                               \
@@ -622,7 +618,7 @@ void launch_deepvit_attn_bwd(const bf16_t* q, const bf16_t* k, const bf16_t* v, 
                              int64_t ld, float scale, float eps, const bf16_t* zero_page, hipStream_t s, int ds_bf16) {
   const int ntile = (nq + 15) / 16;
   const int cpi = dv_bwd_cpi(b, ntile);
-  static const int xp = [] { const char* e = getenv("VITX_DVB_XP"); return e ? atoi(e) : 0; }();   // timing experiments (WRONG results): 1 / 2 / 4 / 8 = without stage 1 / 2 / 2b / 3
+  static const int xp = [] { const char* e = vitx_env("VITX_DVB_XP"); return e ? atoi(e) : 0; }();   // timing experiments (WRONG results): 1 / 2 / 4 / 8 = without stage 1 / 2 / 2b / 3
 #define CALL(HT)                                                                                                                       \
   {                                                                                                                                    \
     dv_set_smem(deepvit_attn_bwd_kernel<HT>, dv_bwd_smem<HT>());                                                                       \

@@ -711,7 +711,7 @@ void launch_add_T(void* a, const void* b2, int is_bf16, int64_t n, hipStream_t s
 }
 void launch_scale_grad(const void* fx, int is_bf16, int64_t ldf_, const float* g, int64_t ldg, int rows, int d, float* partial_ws,
                        float* dscale, hipStream_t s, const float* scale, void* out, int64_t ldo, float* dbias) {
-  static const int blocks = [] { const char* v = getenv("VITX_SG_BLOCKS"); return v ? atoi(v) : 2048; }();   // (experiment: blocks per launch)
+  static const int blocks = [] { const char* v = vitx_env("VITX_SG_BLOCKS"); return v ? atoi(v) : 2048; }();   // (experiment: blocks per launch)
   const int cblocks = (int)ceil_div(d, 256);
   const int chunks = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)SG_CHUNKS, ceil_div(rows, 16), ceil_div(blocks, cblocks)}));
   const int want = (dbias != nullptr && out != nullptr) ? 1 : 0;   // partial_ws holds SG_CHUNKS x 2 d sums + 64 d of second-level scratch

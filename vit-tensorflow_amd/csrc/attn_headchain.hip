@@ -566,7 +566,7 @@ void launch_cait_chain_fwd(const float* s0, const float* wpre, const float* wpos
                            int64_t ld, hipStream_t s) {
   const int64_t rows = (int64_t)b * nq;
   const dim3 grid(chain_blocks(rows)), block(64 * HC_WAVES);
-  static const int mfma_mix = [] { const char* v = getenv("VITX_CHAIN_MFMA"); return v ? atoi(v) : 1; }();   // 0: the in-lane FMA form (A/B reference)
+  static const int mfma_mix = [] { const char* v = vitx_env("VITX_CHAIN_MFMA"); return v ? atoi(v) : 1; }();   // 0: the in-lane FMA form (A/B reference)
   if (mfma_mix) {
 #define CALL(H) hipLaunchKernelGGL((cait_chain_fwd_mfma_kernel<H>), grid, block, 0, s, s0, wpre, wpost, a1_or_null, a2, rows, nq, nk, ld)
     HC_DISPATCH(h, CALL);
@@ -578,7 +578,7 @@ void launch_cait_chain_fwd(const float* s0, const float* wpre, const float* wpos
 #undef CALL
 }
 static int chain_mfma_mix() {
-  static const int v = [] { const char* e = getenv("VITX_CHAIN_MFMA"); return e ? atoi(e) : 1; }();
+  static const int v = [] { const char* e = vitx_env("VITX_CHAIN_MFMA"); return e ? atoi(e) : 1; }();
   return v;
 }
 bool cait_chain_bwd_bf16_out_ok() { return chain_mfma_mix() != 0; }   // (only the MFMA form of the kernel has the bf16 output)

@@ -388,11 +388,7 @@ __global__ __launch_bounds__(X3_THREADS) void attn_x3_bwd_kernel(const float* __
 
 template <typename K>
 void set_smem(K kern, int bytes) {   // one attribute call per distinct kernel (function-pointer keyed)
-  static const void* done[16];
-  static int ndone = 0;
-  for (int i = 0; i < ndone; ++i) if (done[i] == (const void*)kern) return;
-  (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-  if (ndone < 16) done[ndone++] = (const void*)kern;
+  vitx_set_max_smem((const void*)kern, bytes);
 }
 inline int pick_ntp(int n) { return n <= 64 ? 4 : n <= 96 ? 6 : n <= 224 ? 14 : 18; }
 

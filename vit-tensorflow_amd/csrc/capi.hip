@@ -708,6 +708,28 @@ int32_t vitx_allreduce_grads(vitx_handle h) {
   CAPI_CATCH
 }
 
+int32_t vitx_debug_switches(char* out, int64_t cap, int64_t* needed) {
+  CAPI_TRY
+  int n = 0;
+  const VitxEnvSwitch* t = vitx_env_table(&n);
+  static const char* cls[] = {"tuning", "path", "diag"};
+  std::string text;
+  for (int i = 0; i < n; ++i) {
+    const char* raw = getenv(t[i].name);      // (the one place that looks past vitx_env: to report a switch that is set but ignored)
+    std::string state = "unset";
+    if (raw) state = (t[i].cls == VITX_ENV_DIAG && !vitx_env_diag_build()) ? "ignored" : std::string("set=") + raw;
+    text += std::string(t[i].name) + "\t" + cls[t[i].cls] + "\t" + state + "\t" + t[i].doc + "\n";
+  }
+  if (needed) *needed = (int64_t)text.size() + 1;
+  if (out && cap > 0) {
+    const size_t m = std::min<size_t>(text.size(), (size_t)cap - 1);
+    std::memcpy(out, text.data(), m);
+    out[m] = 0;
+  }
+  return VITX_OK;
+  CAPI_CATCH
+}
+
 int32_t vitx_profile_begin(vitx_handle h) {
   if (!h) return fail(VITX_ERR_INVALID, "null handle");
   h->prof_events.clear();

@@ -39,7 +39,7 @@ typedef int (*all_reduce_fn)(const void*, void*, size_t, int, int, void*, hipStr
 void* rccl_handle() {
   static void* lib = nullptr;
   if (lib) return lib;
-  if (const char* p = getenv("VITX_RCCL_LIB")) {
+  if (const char* p = vitx_env("VITX_RCCL_LIB")) {
     if (*p) {
       lib = dlopen(p, RTLD_NOW | RTLD_LOCAL);
       if (!lib) fprintf(stderr, "[vitx] VITX_RCCL_LIB=%s: %s\n", p, dlerror());
@@ -226,7 +226,7 @@ void comm_on_ready(vitx_engine* e, int64_t off, int64_t cnt) {
 int comm_busy(vitx_engine* e) {
   CommState& c = e->cm;
   if (!c.overlap || c.last_launched < 0) return 0;
-  static const int honour = [] { const char* v = getenv("VITX_COMM_SHARED"); return v ? atoi(v) : 1; }();   // 0: persistent grids even beside a collective (A/B)
+  static const int honour = [] { const char* v = vitx_env("VITX_COMM_SHARED"); return v ? atoi(v) : 1; }();   // 0: persistent grids even beside a collective (A/B)
   if (!honour) return 0;
   const int busy = hipEventQuery(c.done_ev[(size_t)c.last_launched]) == hipErrorNotReady ? 1 : 0;
   c.busy_hits += busy;

@@ -1,5 +1,6 @@
 // Shared device/host helpers for libvitx (gfx950 only; wave = 64).
 #pragma once
+#include "env.h"
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -198,3 +199,17 @@ __device__ __forceinline__ void vitx_dma16_cont(i32x4 rsrc, uint32_t voff_minus_
 
 static inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a PER-DEVICE setting and one process may drive handles on several GPUs (a per-process
+// `static bool` guard left the second device without it and the launch failed there): remembered per (device, kernel).
+#include <mutex>
+#include <set>
+#include <utility>
+inline void vitx_set_max_smem(const void* kern, int bytes) {
+  static std::mutex mu;
+  static std::set<std::pair<int, const void*>> done;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> lk(mu);
+  if (done.insert({dev, kern}).second) (void)hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}

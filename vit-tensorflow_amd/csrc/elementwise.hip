@@ -205,6 +205,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_any_cols_kernel(const TD* _
 #define VITX_LNB_FUSE_WAVES 3
 #endif
 constexpr int LNB_BLOCKS = 512;
+constexpr int LNB_BLOCKS_MAX = 1024;   // partial rows of the co-resident form (4-wave blocks: twice the blocks for the same waves in flight)
 constexpr int LNB_THREADS = 512;   // 8 waves per block: 4096 waves in flight with only 512 partial rows to reduce
 
 // dx = r * (g*gamma - mean_d(g*gamma) - xhat * mean_d(g*gamma*xhat));  dgamma += g*xhat; dbeta += g
@@ -214,8 +215,12 @@ constexpr int LNB_THREADS = 512;   // 8 waves per block: 4096 waves in flight wi
 // f = Dense(...) was scaled by a LayerScale vector `nscale` and added to the stream -- needs for its LayerScale VJP: g_lp receives g * nscale (the
 // gradient entering that branch's last Dense, in T), and two more partial rows hold column sums of g (x nscale = that Dense's bias gradient) and of
 // g * f (= d nscale).  Replaces a pass of its own over g (fp32), f and the branch gradient (134 MB per branch at cfg5) by one more read of f here.
-template <typename TD, typename TL, int VPL, bool FUSE>
-__global__ __launch_bounds__(LNB_THREADS, (VPL == 4 ? (FUSE ? VITX_LNB_FUSE_WAVES : 4) : 1)) void layernorm_bwd_kernel(const TD* __restrict__ dy, int64_t lddy, const float* __restrict__ x,
+// CO (round 6): the form that fits BESIDE a resident weight-gradient GEMM.  A GEMM workgroup holds 8 waves x 208 VGPRs = 416 of a SIMD's 512 and
+// 128 KiB of the CU's 160 KiB LDS: what is left is ONE wave of <= 96 VGPRs per SIMD and 32 KiB.  4 waves per block (one per SIMD), registers capped at
+// 96 (launch bound 5 waves per SIMD), 12 KiB of LDS at d = 768: the dispatcher places such a block on a CU whose GEMM workgroup is mid K-slice, and the
+// HBM-bound pass runs under the MFMA-bound one instead of waiting for it (tools/probe_coresident.hip; section 5 of DESIGN.md, round 6).
+template <typename TD, typename TL, int VPL, bool FUSE, bool CO = false>
+__global__ __launch_bounds__(CO ? 256 : LNB_THREADS, CO ? 5 : (VPL == 4 ? (FUSE ? VITX_LNB_FUSE_WAVES : 4) : 1)) void layernorm_bwd_kernel(const TD* __restrict__ dy, int64_t lddy, const float* __restrict__ x,
                                                             int64_t ldx, const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             const float* __restrict__ gamma, const float* g_in, int64_t ldgi,
                                                             float* g_out, int64_t ldgo, TL* g_lp, int64_t ldglp,
@@ -234,7 +239,7 @@ __global__ __launch_bounds__(LNB_THREADS, (VPL == 4 ? (FUSE ? VITX_LNB_FUSE_WAVE
     as[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (FUSE) asc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     const int c = (lane + 64 * i) * 4;
-    gm[i] = (!FUSE && c < d) ? *(const float4*)(gamma + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    gm[i] = (!FUSE && !CO && c < d) ? *(const float4*)(gamma + c) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
   const float invd = 1.0f / (float)d;
   for (int row = blockIdx.x * nw + wib; row < rows; row += gridDim.x * nw) {
@@ -256,7 +261,7 @@ __global__ __launch_bounds__(LNB_THREADS, (VPL == 4 ? (FUSE ? VITX_LNB_FUSE_WAVE
         xh[i] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
         ab[i].x += dv.x; ab[i].y += dv.y; ab[i].z += dv.z; ab[i].w += dv.w;
         ag[i].x += dv.x * xh[i].x; ag[i].y += dv.y * xh[i].y; ag[i].z += dv.z * xh[i].z; ag[i].w += dv.w * xh[i].w;
-        const float4 gmv = FUSE ? *(const float4*)(gamma + c) : gm[i];   // FUSE: gamma from L1 per row (16 registers the two extra accumulators need)
+        const float4 gmv = (FUSE || CO) ? *(const float4*)(gamma + c) : gm[i];   // FUSE / CO: gamma from L1 per row (the registers the extra accumulators / the 96-register cap need)
         gg[i] = make_float4(dv.x * gmv.x, dv.y * gmv.y, dv.z * gmv.z, dv.w * gmv.w);
         s1 += (gg[i].x + gg[i].y) + (gg[i].z + gg[i].w);
         s2 += (gg[i].x * xh[i].x + gg[i].y * xh[i].y) + (gg[i].z * xh[i].z + gg[i].w * xh[i].w);
@@ -841,7 +846,7 @@ void launch_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, const
 #undef CALL
 }
 
-int64_t layernorm_bwd_ws_elems(int d) { return (int64_t)(LNB_BLOCKS + 32) * 4 * d; }   // (4 partial rows per block: the LayerScale-fused form)
+int64_t layernorm_bwd_ws_elems(int d) { return (int64_t)(LNB_BLOCKS_MAX + 32) * 4 * d; }   // (4 partial rows per block: the LayerScale-fused form)
 
 // The parameter-gradient sums (dgamma, dbeta, the optional column sums of g_in) are a two-level reduction of per-block partials that nothing in
 // the backward chain consumes: with `deferred` != nullptr the main kernel(s) only are launched and *deferred receives the number of partial rows;
@@ -868,6 +873,22 @@ void launch_layernorm_bwd(const void* dy, int dy_bf16, int64_t lddy, const float
     // (the column kernel runs FIRST: g_out may alias g_in, which it reads)
     if (deferred) *deferred = chunks;
     else launch_layernorm_bwd_reduce(partial_ws, chunks, d, dgamma, dbeta, want_gsum ? gsum : nullptr, s);
+    return;
+  }
+  // VITX_LN_CORESIDENT=1 (experiment, off by default): bf16 rows of 768 floats take the 4-wave, 96-register form that fits beside a resident
+  // weight-gradient GEMM.  Measured (profiles/r6/coresidency_r6.md): with 1024 blocks it is as fast as the 8-wave form and the step is unchanged
+  // (its blocks are placed first and fill the register file themselves); with ONE block per CU (VITX_LN_CO_BLOCKS=256), the only geometry that
+  // leaves the GEMM workgroup its registers, the weight gradients do progress underneath (their kernel intervals shrink by a quarter) but four
+  // waves per CU pull a third of the bandwidth: 338 us per pass instead of 101, step +0.7 ms.
+  static const int co_env = [] { const char* v = vitx_env("VITX_LN_CORESIDENT"); return v ? atoi(v) : 0; }();
+  if (co_env && dy_bf16 && ceil_div(d, 256) == 3) {
+    static const int co_blocks = [] { const char* v = vitx_env("VITX_LN_CO_BLOCKS"); return v ? std::max(1, std::min(LNB_BLOCKS_MAX, atoi(v))) : LNB_BLOCKS_MAX; }();
+    const int nb = (int)std::min<int64_t>(co_blocks, ceil_div(rows, 4));
+    hipLaunchKernelGGL((layernorm_bwd_kernel<bf16_t, bf16_t, 3, false, true>), dim3(nb), dim3(256), (size_t)4 * d * sizeof(float), s, (const bf16_t*)dy, lddy, x, ldx,
+                       mean, rstd, gamma, g_in, ldgi, g_out, ldgo, (bf16_t*)g_lp, ldglp, partial_ws, rows, d, want_gsum, (const bf16_t*)nullptr, (int64_t)0,
+                       (const float*)nullptr);
+    if (deferred) *deferred = nb;
+    else launch_layernorm_bwd_reduce(partial_ws, nb, d, dgamma, dbeta, want_gsum ? gsum : nullptr, s);
     return;
   }
   const int nblk = (int)std::min<int64_t>(LNB_BLOCKS, ceil_div(rows, 8));
@@ -911,7 +932,7 @@ __global__ void mul_vec_kernel(float* __restrict__ a, const float* __restrict__ 
 void launch_layernorm_bwd_scale_reduce(float* partial_ws, int nparts, int d, float* dgamma, float* dbeta, float* dscale, float* dbias, const float* nscale,
                                        hipStream_t s) {
   if (nparts <= 0) return;
-  float* ws2 = partial_ws + (int64_t)LNB_BLOCKS * 4 * d;
+  float* ws2 = partial_ws + (int64_t)LNB_BLOCKS_MAX * 4 * d;
   launch_reduce_partials3(partial_ws, nparts, (int64_t)4 * d, d, 2, dgamma, dbeta, nullptr, ws2, 1.0f, s);
   if (dbias) {
     launch_reduce_partials3(partial_ws + 2 * (int64_t)d, nparts, (int64_t)4 * d, d, 2, dbias, dscale, nullptr, ws2, 1.0f, s);
@@ -923,7 +944,7 @@ void launch_layernorm_bwd_scale_reduce(float* partial_ws, int nparts, int d, flo
 
 void launch_layernorm_bwd_reduce(float* partial_ws, int nparts, int d, float* dgamma, float* dbeta, float* gsum, hipStream_t s) {
   if (nparts <= 0) return;
-  launch_reduce_partials3(partial_ws, nparts, (int64_t)3 * d, d, gsum ? 3 : 2, dgamma, dbeta, gsum, partial_ws + (int64_t)LNB_BLOCKS * 3 * d, 1.0f, s);
+  launch_reduce_partials3(partial_ws, nparts, (int64_t)3 * d, d, gsum ? 3 : 2, dgamma, dbeta, gsum, partial_ws + (int64_t)LNB_BLOCKS_MAX * 3 * d, 1.0f, s);
 }
 
 // level-2 scratch for the two-level path lives behind the level-1 partials (callers size their workspace with *_ws_elems)

@@ -165,7 +165,7 @@ static void finalize_epi(EpiParams& ep) {
   ep.vec_ok = (ep.ldo % 4 == 0) && (ep.ldo2 % 4 == 0) && (ep.ldr % 4 == 0) && (ep.ldaux % 4 == 0) && al(ep.out) && al(ep.out2) &&
               al(ep.bias) && al(ep.resid) && al(ep.scale) && al(ep.aux) && al(ep.pos) && (ep.out_batch_stride % 4 == 0) &&
               (ep.out_head_stride % 4 == 0) && (ep.partial_stride % 4 == 0);
-  static const int wide_env = [] { const char* v = getenv("VITX_EPI_WIDE"); return v ? atoi(v) : 1; }();
+  static const int wide_env = [] { const char* v = vitx_env("VITX_EPI_WIDE"); return v ? atoi(v) : 1; }();
   ep.wide_ok = wide_env && ep.vec_ok && (ep.ldo % 8 == 0) && (ep.ldo2 % 8 == 0) && (ep.ldaux % 8 == 0);
 }
 
@@ -598,7 +598,7 @@ static void dense_wgrad(vitx_engine* e, const void* X, int64_t ldx, const void* 
     //  buffer as large as the operands, and a launch that takes every CU from the input-gradient GEMMs it runs beside; HALF a wave leaves those
     //  their CUs and halves the partial traffic: CaiT cfg5 38.4 -> 36.7 ms, README config -2 %, DeepViT cfg4 neutral; at 50 k rows (ViT-B / L) it
     //  costs 1.0 / 2.0 ms (profiles/r5/sweep_weight_gradient_workgroups_r5t.log).  VITX_WGRAD_WGS=n overrides.
-    static const int wg_env = [] { const char* v = getenv("VITX_WGRAD_WGS"); return v ? std::max(1, atoi(v)) : 0; }();
+    static const int wg_env = [] { const char* v = vitx_env("VITX_WGRAD_WGS"); return v ? std::max(1, atoi(v)) : 0; }();
     const int wg_target = wg_env ? wg_env : (rows <= 24576 ? 128 : 256);
     int split = (int)std::max<int64_t>(1, std::min<int64_t>(ceil_div(nk, 4), std::max<int64_t>(1, wg_target / tiles)));
     while (split > 1 && (int64_t)split * w.in * w.out > e->partial_elems) --split;
@@ -1331,7 +1331,7 @@ static int block_backward(vitx_engine* e, Stage& st, int si, int l, int b, int n
 // ------------------------------------------------------------------------------------------------
 // creation
 // ------------------------------------------------------------------------------------------------
-static bool env_flag(const char* n) { const char* v = getenv(n); return v && v[0] && v[0] != '0'; }
+static bool env_flag(const char* n) { return vitx_env_flag(n); }
 
 // body of engine_create: on any failure the caller (engine_create) releases everything `e` owns so far
 void engine_destroy(vitx_engine* e);
@@ -1349,7 +1349,7 @@ static int engine_create_body(vitx_engine* e, const vitx_config& cfg, std::strin
   e->bf16 = c.compute == VITX_COMPUTE_BF16;
   e->x3 = c.compute == VITX_COMPUTE_BF16X3;
   e->x3_attn = true;   // the materialised attention products too (8.3 vs 9.2 ms per ViT-B/16 step at batch 64); VITX_X3_ATTN=0 keeps them exact
-  if (const char* k = getenv("VITX_X3_ATTN")) { e->x3_attn = atoi(k) != 0; e->x3_fused_attn = atoi(k) == 1; }
+  if (const char* k = vitx_env("VITX_X3_ATTN")) { e->x3_attn = atoi(k) != 0; e->x3_fused_attn = atoi(k) == 1; }
   e->esz = e->bf16 ? 2 : 4;
   e->inner = c.heads * c.dim_head;
   e->np_max = (c.image_h / c.patch_h) * (c.image_w / c.patch_w);
@@ -1368,26 +1368,26 @@ static int engine_create_body(vitx_engine* e, const vitx_config& cfg, std::strin
   if (cait && c.cls_depth < 0) { err = "cls_depth must be >= 0"; return VITX_ERR_INVALID; }
   e->force_generic_gemm = env_flag("VITX_GENERIC_GEMM");
   e->force_generic_attn = env_flag("VITX_GENERIC_ATTN");
-  if (const char* k = getenv("VITX_DEEPVIT_FUSED")) e->deepvit_fused = atoi(k) != 0;
-  if (const char* k = getenv("VITX_DEEPVIT_FUSED_BWD")) e->deepvit_fused_bwd = atoi(k) != 0;
-  if (const char* k = getenv("VITX_CAIT_FUSED")) e->cait_fused = atoi(k) != 0;
-  if (const char* k = getenv("VITX_CAIT_QKV_CAT")) e->cait_qkv_cat = atoi(k) != 0;
-  if (const char* k = getenv("VITX_GLP_SKIP")) e->glp_skip = atoi(k) != 0;
-  if (const char* k = getenv("VITX_SCORE_BF16")) e->score_bf16 = atoi(k) != 0;
-  if (const char* k = getenv("VITX_LN_SCALE_FUSED")) e->ln_scale_fused = atoi(k) != 0;
-  if (const char* k = getenv("VITX_MLP_BWD_ORDER")) e->mlp_bwd_consumers_first = atoi(k) != 0;
-  if (const char* k = getenv("VITX_NT")) e->nt_mask = atoi(k);
-  if (const char* k = getenv("VITX_BGEMM_PAIRS")) e->bgemm_pairs = atoi(k) != 0;
-  if (const char* k = getenv("VITX_REVERSE")) e->reverse_mask = atoi(k);
+  if (const char* k = vitx_env("VITX_DEEPVIT_FUSED")) e->deepvit_fused = atoi(k) != 0;
+  if (const char* k = vitx_env("VITX_DEEPVIT_FUSED_BWD")) e->deepvit_fused_bwd = atoi(k) != 0;
+  if (const char* k = vitx_env("VITX_CAIT_FUSED")) e->cait_fused = atoi(k) != 0;
+  if (const char* k = vitx_env("VITX_CAIT_QKV_CAT")) e->cait_qkv_cat = atoi(k) != 0;
+  if (const char* k = vitx_env("VITX_GLP_SKIP")) e->glp_skip = atoi(k) != 0;
+  if (const char* k = vitx_env("VITX_SCORE_BF16")) e->score_bf16 = atoi(k) != 0;
+  if (const char* k = vitx_env("VITX_LN_SCALE_FUSED")) e->ln_scale_fused = atoi(k) != 0;
+  if (const char* k = vitx_env("VITX_MLP_BWD_ORDER")) e->mlp_bwd_consumers_first = atoi(k) != 0;
+  if (const char* k = vitx_env("VITX_NT")) e->nt_mask = atoi(k);
+  if (const char* k = vitx_env("VITX_BGEMM_PAIRS")) e->bgemm_pairs = atoi(k) != 0;
+  if (const char* k = vitx_env("VITX_REVERSE")) e->reverse_mask = atoi(k);
   gemm_f32_mfma_read_env();
-  if (const char* k = getenv("VITX_REVERSE_MIN_MB")) e->reverse_min_bytes = (int64_t)atoi(k) << 20;
-  if (const char* k = getenv("VITX_GEMM_KERNEL")) e->gemm_kernel = atoi(k);
-  if (const char* k = getenv("VITX_GEMM_TAIL_KERNEL")) e->gemm_tail = atoi(k);   // with VITX_GEMM_KERNEL=13 / 11: tile variant of the tail launch (1, 3, 10; gemm_bf16.hip, tail balancing)
-  if (const char* k = getenv("VITX_UNFUSED_HEADOPS")) e->unfused_headops = atoi(k) != 0;
+  if (const char* k = vitx_env("VITX_REVERSE_MIN_MB")) e->reverse_min_bytes = (int64_t)atoi(k) << 20;
+  if (const char* k = vitx_env("VITX_GEMM_KERNEL")) e->gemm_kernel = atoi(k);
+  if (const char* k = vitx_env("VITX_GEMM_TAIL_KERNEL")) e->gemm_tail = atoi(k);   // with VITX_GEMM_KERNEL=13 / 11: tile variant of the tail launch (1, 3, 10; gemm_bf16.hip, tail balancing)
+  if (const char* k = vitx_env("VITX_UNFUSED_HEADOPS")) e->unfused_headops = atoi(k) != 0;
   e->wgrad_via_transpose = env_flag("VITX_WGRAD_TRANSPOSE");
   e->keep_scores = !env_flag("VITX_RECOMPUTE_SCORES");
-  if (const char* k = getenv("VITX_SC_KEEP_MB")) e->sc_keep_budget = (int64_t)atoll(k) << 20;   // budget of the kept score tensors (blocks beyond it recompute)
-  if (const char* k = getenv("VITX_GEMM_STAGGER")) {
+  if (const char* k = vitx_env("VITX_SC_KEEP_MB")) e->sc_keep_budget = (int64_t)atoll(k) << 20;   // budget of the kept score tensors (blocks beyond it recompute)
+  if (const char* k = vitx_env("VITX_GEMM_STAGGER")) {
     e->gemm_stagger = atoi(k);
     if (e->gemm_stagger & 3) fprintf(stderr, "[vitx] VITX_GEMM_STAGGER=%d: timing experiment bits set -- GEMM results are WRONG in this process\n", e->gemm_stagger);
   }
@@ -1395,8 +1395,8 @@ static int engine_create_body(vitx_engine* e, const vitx_config& cfg, std::strin
   HIPCHK(hipSetDevice(c.device_id));
   HIPCHK(hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking));
   e->stream = e->own_stream;
-  if (const char* k = getenv("VITX_SIDE_STREAM")) e->side_mode = atoi(k);
-  if (const char* k = getenv("VITX_LN_REDUCE_SIDE_ROWS")) e->side2_min_rows = atoi(k);
+  if (const char* k = vitx_env("VITX_SIDE_STREAM")) e->side_mode = atoi(k);
+  if (const char* k = vitx_env("VITX_LN_REDUCE_SIDE_ROWS")) e->side2_min_rows = atoi(k);
   if (e->bf16 && e->side_mode) {
     // lowest priority: the input-gradient chain is the critical path, the weight gradients fill what it leaves free (VITX_SIDE_STREAM=2: same priority)
     int least = 0, greatest = 0;
@@ -2442,7 +2442,7 @@ int engine_bench_gemm(vitx_engine* e, int M, int N, int K, int kernel, int epilo
   // bits 4..7 of `kernel` reach the kernels' `stagger` field, whose low bits double as timing-experiment switches (no DMA wait /
   // no DMA issue: WRONG results, faster launches).  A sweep that packs anything else into those bits measures the switch, not its
   // own parameter (profiles/r2/gemm_tile_band_README.txt), so they are refused unless the caller says it wants the experiment.
-  if (((kernel >> 4) & 7) && !getenv("VITX_GEMM_XP")) { err = "vitx_bench_gemm: kernel bits 4-6 are timing-experiment switches (results invalid); set VITX_GEMM_XP=1 to use them"; return VITX_ERR_INVALID; }
+  if (((kernel >> 4) & 7) && !vitx_env("VITX_GEMM_XP")) { err = "vitx_bench_gemm: kernel bits 4-6 are timing-experiment switches (results invalid); set VITX_GEMM_XP=1 to use them"; return VITX_ERR_INVALID; }
   const int64_t Mp = round_up(M, 1280) + 320, Np = round_up(N, 256);   // (+ 320: a tail launch's 192-row tiles start at a row that is no multiple of 192)
   bf16_t *A, *B; float *C, *R, *bias; bf16_t* C2;
   HIPCHK(hipMalloc((void**)&A, (size_t)Mp * K * 2));
@@ -2451,7 +2451,7 @@ int engine_bench_gemm(vitx_engine* e, int M, int N, int K, int kernel, int epilo
   HIPCHK(hipMalloc((void**)&R, (size_t)Mp * Np * 4));
   HIPCHK(hipMalloc((void**)&C2, (size_t)Mp * Np * 2 * 2));
   HIPCHK(hipMalloc((void**)&bias, (size_t)Np * 4));
-  const float fill_scale = getenv("VITX_BENCH_ZERO") ? 0.0f : 1.0f;   // zero operands: DVFS / power-limit experiment only
+  const float fill_scale = vitx_env("VITX_BENCH_ZERO") ? 0.0f : 1.0f;   // zero operands: DVFS / power-limit experiment only
   launch_fill_random_bf16(A, Mp * K, 1u, fill_scale, e->stream);
   launch_fill_random_bf16(B, Np * K, 2u, fill_scale, e->stream);
   // small problems are checked against the generic kernel: give the fused epilogues non-trivial bias / residual operands
@@ -2490,7 +2490,7 @@ int engine_bench_gemm(vitx_engine* e, int M, int N, int K, int kernel, int epilo
   finalize_epi(ep);
   launch_gemm_bf16(g, ep, mode, e->stream);   // warm-up (+ attribute setup)
   unsigned long long* stamps = nullptr;
-  if (getenv("VITX_GEMM_STAMPS")) {
+  if (vitx_env("VITX_GEMM_STAMPS")) {
     HIPCHK(hipMalloc((void**)&stamps, 512 * 16 * 4 * 8));
     HIPCHK(hipMemsetAsync(stamps, 0, 512 * 16 * 4 * 8, e->stream));
     g.stamps = stamps;
@@ -2510,7 +2510,7 @@ int engine_bench_gemm(vitx_engine* e, int M, int N, int K, int kernel, int epilo
     HIPCHK(hipMemcpy(hs.data(), stamps, hs.size() * 8, hipMemcpyDeviceToHost));
     (void)hipFree(stamps);
     g.stamps = nullptr;
-    if (atoi(getenv("VITX_GEMM_STAMPS")) == 2) {   // raw rows: workgroup, placement (xcc, HW_ID), then (tile start, K loop end, epilogue end, refill end) per tile
+    if (atoi(vitx_env("VITX_GEMM_STAMPS")) == 2) {   // raw rows: workgroup, placement (xcc, HW_ID), then (tile start, K loop end, epilogue end, refill end) per tile
       for (int w = 0; w < 512; ++w) {
         const unsigned long long* p = &hs[(size_t)w * 16 * 4];
         if (!p[0]) continue;

@@ -287,11 +287,7 @@ void launch_variant(const Bf16GemmArgs& g, const EpiParams& ep, hipStream_t s) {
   constexpr int SMEM = 2 * (BM + BN) * BK * 2;
   static_assert(64 * (BN + 4) * 4 <= SMEM, "epilogue staging must fit in the pipeline buffers");
   auto kern = gemm_bf16_nt_kernel<BM, BN, WM, WN, MODE, LDS_EPI, SCHED>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
-    attr_set = true;
-  }
+  vitx_set_max_smem((const void*)kern, SMEM);
   const int tiles_m = (int)ceil_div(g.M, BM), tiles_n = (int)ceil_div(g.N, BN);
   const int nk = g.K / BK;
   const int split = g.split_k > 1 ? g.split_k : 1;
@@ -441,12 +437,12 @@ static std::map<std::array<int64_t, 6>, int> g_tuned;
 // (profiles/r6/gemm_tail_balancing_r6.md, same box, alternating runs).
 static int tail_enabled() {
   static int on = -1;
-  if (on < 0) { const char* v = getenv("VITX_GEMM_TAIL"); on = (v && atoi(v) != 0) ? 1 : 0; }
+  if (on < 0) { const char* v = vitx_env("VITX_GEMM_TAIL"); on = (v && atoi(v) != 0) ? 1 : 0; }
   return on;
 }
 static int autotune_enabled() {
   static int on = -1;
-  if (on < 0) { const char* v = getenv("VITX_GEMM_AUTOTUNE"); on = (v && atoi(v) == 0) ? 0 : 1; }
+  if (on < 0) { const char* v = vitx_env("VITX_GEMM_AUTOTUNE"); on = (v && atoi(v) == 0) ? 0 : 1; }
   return on;
 }
 void launch_gemm_bf16(const Bf16GemmArgs& g0, const EpiParams& ep, int mode, hipStream_t s) {
@@ -511,7 +507,7 @@ void launch_gemm_bf16(const Bf16GemmArgs& g0, const EpiParams& ep, int mode, hip
     }
     g.tail = 0;
     for (auto& x : ev) (void)hipEventDestroy(x);
-    if (getenv("VITX_GEMM_AUTOTUNE_LOG"))
+    if (vitx_env("VITX_GEMM_AUTOTUNE_LOG"))
       fprintf(stderr, "[vitx] gemm autotune: mode %d M %d N %d K %d split %d -> variant %d tail %d (%.4f ms)\n", mode, g0.M, g0.N, g0.K, g0.split_k, best & 31,
               best >> 5, best_ms);
     // The candidates have different tile heights and each stores its per-tile column sums (EPI_GELU_BWD) with '=' into rows the caller

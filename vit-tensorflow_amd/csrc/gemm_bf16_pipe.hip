@@ -622,22 +622,18 @@ void launch_pipe(const Bf16GemmArgs& g, const EpiParams& ep, hipStream_t s, bool
     return;
   }
   auto kern = gemm_bf16_nt_pipe_kernel<BM, BN, WM, WN, MODE>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
-    attr_set = true;
-  }
+  vitx_set_max_smem((const void*)kern, SMEM);
   const int tiles_m = (int)ceil_div(g.M, BM), tiles_n = (int)ceil_div(g.N, BN);
   const int nk = g.K / BK;
   const int split = g.split_k > 1 ? g.split_k : 1;
   const int per = (int)ceil_div(nk, split);
   const int zs = (int)ceil_div(nk, per);
-  static const int phase_env = [] { const char* v = getenv("VITX_GEMM_PHASE"); return v ? atoi(v) : 0; }();
+  static const int phase_env = [] { const char* v = vitx_env("VITX_GEMM_PHASE"); return v ? atoi(v) : 0; }();
   Bf16GemmArgs gp = g;
   if (gp.phase == 0) gp.phase = phase_env;
-  static const int walk_env = [] { const char* v = getenv("VITX_GEMM_WALK"); return v ? atoi(v) : -1; }();   // A/B: 0 = interleaved chunks everywhere
+  static const int walk_env = [] { const char* v = vitx_env("VITX_GEMM_WALK"); return v ? atoi(v) : -1; }();   // A/B: 0 = interleaved chunks everywhere
   // (4-wave tiles: 80 KiB of LDS and <= 256 registers per wave, i.e. TWO workgroups per CU -- one's epilogue runs under the other's K loop)
-  static const int grid_cap = [] { const char* v = getenv("VITX_GEMM_GRID"); return v ? atoi(v) : 256 * (WM * WN == 4 ? 2 : 1); }();   // experiment: fewer persistent workgroups
+  static const int grid_cap = [] { const char* v = vitx_env("VITX_GEMM_GRID"); return v ? atoi(v) : 256 * (WM * WN == 4 ? 2 : 1); }();   // experiment: fewer persistent workgroups
   // Beside collectives (data parallel: RCCL's workgroups hold CUs for as long as a collective runs) a persistent grid with static tile lists waits
   // for the workgroups that could not be placed; one tile per workgroup lets the hardware dispatcher balance.  Same kernel: a workgroup whose tile
   // list has one entry simply never takes the cross-tile path.
@@ -646,7 +642,7 @@ void launch_pipe(const Bf16GemmArgs& g, const EpiParams& ep, hipStream_t s, bool
   // XCD-owned row bands (walk 2): wide outputs on the full persistent grid with enough row tiles for 8-row bands per XCD
   const bool walk2_ok = BM == 256 && zs == 1 && gx == (unsigned)grid_cap && (gx & 7) == 0 && gx < (unsigned)(tiles_m * tiles_n) && tiles_n >= 8 && tiles_m >= 64 && g.stagger != 8;
   gp.walk = (walk2_ok && walk_env != 0) ? 2 : 0;
-  static const int gelu_table_on = [] { const char* v = getenv("VITX_GELU_TABLE"); return v ? atoi(v) : 1; }();   // 0: the polynomial form everywhere (A/B)
+  static const int gelu_table_on = [] { const char* v = vitx_env("VITX_GELU_TABLE"); return v ? atoi(v) : 1; }();   // 0: the polynomial form everywhere (A/B)
   const uint32_t* gtab = (MODE == EPI_BIAS_GELU && BM == 256 && gelu_table_on) ? gelu_table_dev() : nullptr;
   hipLaunchKernelGGL(kern, grid, block, SMEM, s, gp, ep, tiles_m, tiles_n, per, gtab);
 }

@@ -205,11 +205,7 @@ template <int BT, int WM, int WN>
 void launch_tn_variant(const Bf16GemmArgs& g, const EpiParams& ep, hipStream_t s) {
   constexpr int SMEM = 2 * 2 * BK * BT * 2;
   auto kern = gemm_bf16_tn_kernel<BT, WM, WN, EPI_PARTIAL>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
-    attr_set = true;
-  }
+  vitx_set_max_smem((const void*)kern, SMEM);
   const int tiles_m = (int)ceil_div(g.M, BT), tiles_n = (int)ceil_div(g.N, BT);
   const int nk = g.K / BK;
   const int split = g.split_k > 1 ? g.split_k : 1;
@@ -225,7 +221,7 @@ void launch_tn_variant(const Bf16GemmArgs& g, const EpiParams& ep, hipStream_t s
 int gemm_bf16_tn_tile(int kernel, int M, int N) { kernel &= 15; return (kernel == 1 || (M <= 128 && N <= 128)) ? 128 : 256; }
 void launch_gemm_bf16_tn(const Bf16GemmArgs& g0, const EpiParams& ep, hipStream_t s) {
   static const int xp = [] {
-    const char* v = getenv("VITX_TN_XP");
+    const char* v = vitx_env("VITX_TN_XP");
     const int x = v ? atoi(v) : 0;
     if (x) fprintf(stderr, "[vitx] VITX_TN_XP=%d: timing experiment -- weight gradients are WRONG in this process\n", x);
     return x;

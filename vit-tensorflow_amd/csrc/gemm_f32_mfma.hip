@@ -144,7 +144,7 @@ inline bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 // fp32 operands and outputs only; problems too small to fill a 128 x 128 tile stay on the 64 x 64 scalar kernel
 static int g_f32_mfma_on = 1;
 void gemm_f32_mfma_read_env() {   // called by engine_create: the A/B test flips the variable between two handles of one process
-  const char* v = getenv("VITX_F32_MFMA");
+  const char* v = vitx_env("VITX_F32_MFMA");
   g_f32_mfma_on = v ? atoi(v) : 1;
 }
 bool gemm_f32_mfma_supported(const GenericGemmArgs& g, int ta, int tb, int to) {

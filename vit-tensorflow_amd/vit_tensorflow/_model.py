@@ -430,7 +430,7 @@ class VitxModel:
 
     def comm_destroy(self) -> None:
         """Leave the RCCL group (communicator, communication stream, wire buffer); backward() returns local gradients again."""
-        if self._handle is not None and getattr(self, "_comm_world", 0):
+        if self._handle is not None:   # (also after a comm_init that failed half way: a communicator without the overlap state)
             N.check(N.lib().vitx_comm_destroy(self._handle))
         self._comm_world = 0
 

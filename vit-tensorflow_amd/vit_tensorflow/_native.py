@@ -128,6 +128,7 @@ SYMBOLS: List[Tuple[str, object, list]] = [
     ("vitx_comm_overlap", C.c_int32, [C.c_void_p, C.c_int32, C.c_int64, C.c_int32]),
     ("vitx_comm_stats", C.c_int32, [C.c_void_p, C.POINTER(C.c_int64)]),
     ("vitx_comm_destroy", C.c_int32, [C.c_void_p]),
+    ("vitx_debug_switches", C.c_int32, [C.c_char_p, C.c_int64, C.POINTER(C.c_int64)]),
     ("vitx_allreduce_grads", C.c_int32, [C.c_void_p]),
     ("vitx_profile_begin", C.c_int32, [C.c_void_p]),
     ("vitx_profile_end", C.c_int32, [C.c_void_p, _P(KernelStat), C.c_int32, _P(C.c_int32)]),
@@ -219,3 +220,13 @@ def mim_param_table(handle, prefix="vitx_mim"):
         check(entry_fn(handle, i, name, 256, shape, C.byref(rank), C.byref(off)))
         out.append((name.value.decode(), tuple(int(shape[k]) for k in range(rank.value)), int(off.value)))
     return out, int(ne.value)
+
+
+def debug_switches():
+    """[(name, class, state, doc)] for every VITX_* environment variable the library reads (csrc/env.hip): class "tuning" (same results),
+    "path" (another validated code path) or "diag" (may corrupt results; ignored by the release library)."""
+    need = C.c_int64()
+    check(lib().vitx_debug_switches(None, 0, C.byref(need)))
+    buf = C.create_string_buffer(need.value)
+    check(lib().vitx_debug_switches(buf, need.value, None))
+    return [tuple(line.split("\t", 3)) for line in buf.value.decode().splitlines()]
