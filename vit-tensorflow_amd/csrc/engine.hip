@@ -1140,7 +1140,9 @@ static int block_backward(vitx_engine* e, Stage& st, int si, int l, int b, int n
     if (cs_side) side_rotate(e, e->rg_cs, e->cs_part);
     float* cs = cs_side ? e->cs_part : e->red_ws;
     if (fc1_bias_fused) {
-      HIPCHK(hipMemsetAsync(cs, 0, (size_t)cs_rows * m * 4, e->stream));   // rows the chosen tile shape does not reach stay 0
+      // rows the chosen tile shape does not reach stay 0.  (round 6: our own fill kernel, not hipMemsetAsync -- the runtime's blit path cost the chain a
+      //  22-us gap in front of every one of these 6-us fills, 12 per step: profiles/r6/trace_streams_main_queue_gaps_r6i.log)
+      launch_fill_zero(cs, (int64_t)cs_rows * m * 4, e->stream);
       ep.colsum = cs; ep.ldcs = m;
     }
     dense_dgrad(e, dbranch, d, rows, bp.fc2, EPI_GELU_BWD, ep);             // d hpre = (d act) * gelu'(hpre)
