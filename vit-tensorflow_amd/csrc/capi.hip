@@ -148,7 +148,7 @@ int32_t vitx_bind_arenas(vitx_handle h, float* params_dev, float* grads_dev) {
     CAPI_HIP(hipMemcpyAsync(params_dev, h->params, (size_t)h->n_arena * 4, hipMemcpyDeviceToDevice, h->stream));
     CAPI_HIP(hipStreamSynchronize(h->stream));
     h->params = params_dev;
-    h->params_dirty = true;
+    engine_params_moved(h);   // (round 6) the batched operand refresh reads the arena through a device table of absolute pointers
   }
   if (grads_dev && grads_dev != h->grads) {
     CAPI_HIP(hipMemsetAsync(grads_dev, 0, (size_t)h->n_arena * 4, h->stream));

@@ -269,6 +269,7 @@ int engine_head_forward(vitx_engine* e, const float* x_dev, int b, int n, float*
 int engine_head_backward(vitx_engine* e, const float* dlogits_dev, float* dx_dev, std::string& err);
 int engine_embed_backward(vitx_engine* e, const float* dtokens_dev, float* dimg_dev, std::string& err);
 void engine_refresh_weights(vitx_engine* e);
+void engine_params_moved(vitx_engine* e);   // the parameter arena pointer changed (vitx_bind_arenas): re-point the batched operand refresh
 // Dense layers owned by a wrapper object but run with this engine's GEMM kernels, workspaces and stream (bf16 mode: X / dY are
 // row-padded bf16 buffers as everywhere else in the engine; parity mode: fp32).  y / dx are fp32 [rows, out] / [rows, in].
 int engine_ext_dense_init(vitx_engine* e, Dense& w, int in, int out, const float* W, const float* bias, float* gW, float* gbias, std::string& err);

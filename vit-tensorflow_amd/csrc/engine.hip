@@ -212,12 +212,14 @@ static inline const float* dense_b(const vitx_engine* e, const Dense& w) { retur
 static inline float* dense_gw(const vitx_engine* e, const Dense& w) { return w.ext_gw ? w.ext_gw : e->grads + w.w; }
 static inline float* dense_gb(const vitx_engine* e, const Dense& w) { return w.ext_gb ? w.ext_gb : (w.b >= 0 ? e->grads + w.b : nullptr); }
 
-// device table of the batched operand refresh: a function of the model only (arena offsets and operand buffers never move); built once, at
-// creation (not inside a step, which may be under stream capture)
-static void build_convert_table(vitx_engine* e) {
-  if (!e->bf16 || e->conv_descs) return;
-  std::vector<ConvertDesc> t;
-  int blocks = 0;
+// device table of the batched operand refresh: arena offsets and operand buffers of every Dense kernel.  Built at creation (not inside a step, which
+// may be under stream capture) and RE-WRITTEN whenever the parameter arena moves (vitx_bind_arenas hands the library a caller-owned arena: round 6 --
+// until then the table kept pointing into the library's own arena, so after a bind the bf16 operand copies were refreshed from weights nobody
+// updated any more; rank 0 of a data-parallel run never noticed, every other rank computed with its pre-broadcast kernels.  Found the first time two
+// ranks met on the torch exchange: tests/test_gpu_dp.py::test_engine_dp_two_ranks_on_one_gpu_over_gloo_equals_one_rank)
+static void fill_convert_table(vitx_engine* e, std::vector<ConvertDesc>& t, int& blocks) {
+  t.clear();
+  blocks = 0;
   auto add = [&](const Dense& w) {
     if (w.w < 0 || !w.wt) return;
     const int tx = (int)ceil_div(w.out, 64), ty = (int)ceil_div(w.in, 64);
@@ -241,12 +243,29 @@ static void build_convert_table(vitx_engine* e) {
   add(e->head);
   for (auto& st : e->stages)
     for (auto& b : st.bp) { add(b.qkv); add(b.q); add(b.kv); add_cat(b); add(b.out); add(b.fc1); add(b.fc2); }
+}
+static void build_convert_table(vitx_engine* e) {
+  if (!e->bf16 || e->conv_descs) return;
+  std::vector<ConvertDesc> t;
+  int blocks = 0;
+  fill_convert_table(e, t, blocks);
   if (!t.empty() && hipMalloc(&e->conv_descs, t.size() * sizeof(ConvertDesc)) == hipSuccess) {
     e->allocs.push_back(e->conv_descs);
     (void)hipMemcpy(e->conv_descs, t.data(), t.size() * sizeof(ConvertDesc), hipMemcpyHostToDevice);
     e->conv_n = (int)t.size();
     e->conv_blocks = blocks;
   }
+}
+// the parameter arena has moved (vitx_bind_arenas): the same table over the new base pointer
+void engine_params_moved(vitx_engine* e) {
+  e->params_dirty = true;
+  if (!e->bf16 || !e->conv_descs) return;
+  std::vector<ConvertDesc> t;
+  int blocks = 0;
+  fill_convert_table(e, t, blocks);
+  if ((int)t.size() != e->conv_n) return;   // (cannot happen: the table is a function of the model)
+  (void)hipStreamSynchronize(e->stream);   // a refresh in flight still reads the old table
+  (void)hipMemcpy(e->conv_descs, t.data(), t.size() * sizeof(ConvertDesc), hipMemcpyHostToDevice);
 }
 
 void engine_refresh_weights(vitx_engine* e) {
