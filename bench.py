@@ -130,7 +130,14 @@ def main():
     native_dp = args.dp_impl == "native"
     gloo_default = native_dp   # the default process group carries CPU tensors only (rendezvous, barrier, max of the timing)
     # native exchange: torch.distributed only carries the rendezvous (RCCL id, initial weights), the barrier and the max over ranks -- gloo on the CPU
-    rank, local, world = init_from_env(backend="gloo" if native_dp else None, force=force_dp)
+    # VITX_BENCH_ONE_GPU=1 (tests/test_gpu_bench_ranks.py): every rank on GPU 0 -- the N > 1 code path of this file (rendezvous, weight broadcast, exchange,
+    # barrier, max over ranks, one JSON line) on a one-GPU box.  RCCL refuses two ranks on one device: the native exchange then needs VITX_RCCL_LIB
+    # (tests/fake_rccl), the torch exchange runs its buckets over gloo.  Never set for a measurement.
+    one_gpu = bool(os.environ.get("VITX_BENCH_ONE_GPU"))
+    rank, local, world = init_from_env(backend="gloo" if (native_dp or one_gpu) else None, force=force_dp)
+    if one_gpu:
+        local = 0
+        gloo_default = True
     if world != args.gpus and rank == 0:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
     if not torch.cuda.is_available():
