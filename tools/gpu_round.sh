@@ -19,11 +19,15 @@ for s in $STAGES; do
         tag=$(echo $pass | tr ' ' '_' | cut -c1-40)
         (cd /tmp && timeout 300 rocprofv3 --pmc $pass --kernel-trace --output-format csv -d $OLDPWD/$OUT/pmc_$tag -o g -- python $OLDPWD/tools/gemm_bench.py ${PMC_SHAPE:-8192 8192 8192 2 3 3} > $OLDPWD/$OUT/pmc_$tag.log 2>&1); tail -2 $OUT/pmc_$tag.log
       done ;;
-    pmc_sq) for pass in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_WAVES" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU" "SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_SCA GRBM_GUI_ACTIVE"; do
+    pmc_sq) for pass in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_WAVES" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU GRBM_GUI_ACTIVE"; do   # (GRBM has its own two slots: tools/pmc_sq_summary.py needs GRBM_GUI_ACTIVE in the instruction pass)
         tag=$(echo $pass | tr ' ' '_' | cut -c1-40)
         (cd /tmp && timeout 400 rocprofv3 --pmc $pass --kernel-trace --output-format csv -d $OLDPWD/$OUT/sq_$tag -o b -- python $OLDPWD/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-profile > $OLDPWD/$OUT/sq_$tag.json 2> $OLDPWD/$OUT/sq_$tag.err); tail -c 100 $OUT/sq_$tag.json
       done
-      find $OUT -name "*kernel_trace.csv" -delete 2>/dev/null ;;
+      find $OUT -name "*kernel_trace.csv" -delete 2>/dev/null
+      python tools/pmc_sq_summary.py $OUT/sq_SQ_INSTS_VALU_SQ_INSTS_MFMA_SQ_VALU_MFMA/b_counter_collection.csv $OUT/sq_SQ_WAVE_CYCLES_SQ_BUSY_CYCLES_SQ_WAIT_AN/b_counter_collection.csv > $OUT/pmc_sq_summary.txt 2>&1; head -12 $OUT/pmc_sq_summary.txt ;;
+    rocprof1) (cd /tmp && VITX_SIDE_STREAM=0 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$OUT/prof1 -o vitb16 -- python $OLDPWD/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OLDPWD/$OUT/rocprof1_bench.json 2> $OLDPWD/$OUT/rocprof1.err)
+      python tools/rocprof_family_summary.py $(find $OUT/prof1 -name "*kernel_stats.csv" | head -1) $(find $OUT/prof1 -name "*kernel_trace.csv" | head -1) 5 > $OUT/rocprofv3_family_summary.json 2>$OUT/rocprof1_summary.err; head -c 1500 $OUT/rocprofv3_family_summary.json
+      find $OUT/prof1 -name "*kernel_trace*" -delete 2>/dev/null ;;
     pmc_bench) for pass in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
         tag=$(echo $pass | tr ' ' '_' | cut -c1-40)
         (cd /tmp && timeout 400 rocprofv3 --pmc $pass --kernel-trace --output-format csv -d $OLDPWD/$OUT/pmc_$tag -o b -- python $OLDPWD/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-profile > $OLDPWD/$OUT/pmc_$tag.json 2> $OLDPWD/$OUT/pmc_$tag.err); tail -c 300 $OUT/pmc_$tag.json
