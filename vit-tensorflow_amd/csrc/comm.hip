@@ -84,6 +84,15 @@ int launch_bucket(vitx_engine* e, int i, std::string& err) {
   float* g = e->grads + lo;
   HIPCHK_ERR(hipEventRecord(c.ready_ev[(size_t)i], e->stream), err);
   HIPCHK_ERR(hipStreamWaitEvent(c.stream, c.ready_ev[(size_t)i], 0), err);
+  // duration of this bucket's work two exchanges ago (its brackets have fired long since: the host runs at most one step ahead of the GPU)
+  const int par = c.parity & 1;
+  if (c.timed[par][(size_t)i] && hipEventQuery(c.t1_ev[par][(size_t)i]) == hipSuccess) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, c.t0_ev[par][(size_t)i], c.t1_ev[par][(size_t)i]) == hipSuccess) c.coll_ms[(size_t)i] = ms;
+  } else {
+    (void)hipGetLastError();
+  }
+  HIPCHK_ERR(hipEventRecord(c.t0_ev[par][(size_t)i], c.stream), err);
   const float alpha = 1.0f / (float)e->world;
   if (c.wire_bf16) {
     bf16_t* w = c.wire + lo;
@@ -94,9 +103,17 @@ int launch_bucket(vitx_engine* e, int i, std::string& err) {
     if (ar(g, g, (size_t)n, NCCL_FLOAT32, NCCL_SUM, e->comm, c.stream) != 0) { err = "ncclAllReduce failed"; return VITX_ERR_COMM; }
     if (e->world > 1) hipLaunchKernelGGL(comm_scale_kernel, dim3(grid_for(n / 4)), dim3(256), 0, c.stream, g, n / 4, alpha);
   }
+  HIPCHK_ERR(hipEventRecord(c.t1_ev[par][(size_t)i], c.stream), err);
+  c.timed[par][(size_t)i] = 1;
   HIPCHK_ERR(hipEventRecord(c.done_ev[(size_t)i], c.stream), err);
   c.last_launched = i;
   ++c.n_launched;
+  // the Dense launches enqueued from here on are the ones this collective runs beside: as many of them as its measured duration covers
+  // (DENSE_US: a typical Dense launch of the backward pass; a collective not measured yet counts as long -- the conservative form, as before)
+  constexpr float DENSE_US = 150.f;
+  const float ms = c.coll_ms[(size_t)i];
+  const int k = ms < 0.f ? 64 : (ms < 0.05f ? 0 : (int)(ms * 1000.f / DENSE_US) + 1);
+  c.shared_credit = std::max(c.shared_credit, k);
   return VITX_OK;
 }
 
@@ -122,6 +139,18 @@ int ensure_state(vitx_engine* e, std::string& err) {
       HIPCHK_ERR(hipEventCreateWithFlags(&c.ready_ev[(size_t)i], hipEventDisableTiming), err);
       HIPCHK_ERR(hipEventCreateWithFlags(&c.done_ev[(size_t)i], hipEventDisableTiming), err);
     }
+    for (int p = 0; p < 2; ++p) {
+      for (auto ev : c.t0_ev[p]) (void)hipEventDestroy(ev);
+      for (auto ev : c.t1_ev[p]) (void)hipEventDestroy(ev);
+      c.t0_ev[p].assign((size_t)nb, nullptr);
+      c.t1_ev[p].assign((size_t)nb, nullptr);
+      c.timed[p].assign((size_t)nb, 0);
+      for (int i = 0; i < nb; ++i) {
+        HIPCHK_ERR(hipEventCreate(&c.t0_ev[p][(size_t)i]), err);
+        HIPCHK_ERR(hipEventCreate(&c.t1_ev[p][(size_t)i]), err);
+      }
+    }
+    c.coll_ms.assign((size_t)nb, -1.f);
     c.covered.assign((size_t)nb, 0);
     c.launched.assign((size_t)nb, 0);
     c.last_launched = -1;
@@ -221,16 +250,24 @@ void comm_on_ready(vitx_engine* e, int64_t off, int64_t cnt) {
   }
 }
 
-// 1 while a collective launched by this handle may still hold CUs (the newest bucket's completion event has not fired): the Dense launches next to it
-// use one-tile-per-workgroup grids (a persistent grid with static tile lists would wait for the workgroups RCCL's kernels keep off their CUs)
+// the side stream's share of a reported arena range: every bucket launched from now on is ordered behind it (the communication stream is in-order)
+void comm_wait_event(vitx_engine* e, hipEvent_t ev) {
+  if (e->cm.stream) (void)hipStreamWaitEvent(e->cm.stream, ev, 0);
+}
+
+// 1 for the Dense launches that, in STREAM ORDER, run beside a collective of this handle: they use one-tile-per-workgroup grids (a persistent grid with
+// static tile lists would wait for the workgroups RCCL's kernels keep off their CUs).  Round 5 asked the newest bucket's completion event -- at
+// ENQUEUE time, tens of milliseconds before the launch executes, when it has practically never fired: every Dense launch behind the first bucket
+// of a backward pass took the slower form (forced DP on one GPU: +0.8..1.0 ms).  Now each bucket, when it is launched, grants that form to as many
+// following launches as its own measured duration (two exchanges ago) covers; a group of one, whose "collective" is a local copy, grants none.
 int comm_busy(vitx_engine* e) {
   CommState& c = e->cm;
-  if (!c.overlap || c.last_launched < 0) return 0;
+  if (!c.overlap || c.shared_credit <= 0) return 0;
   static const int honour = [] { const char* v = vitx_env("VITX_COMM_SHARED"); return v ? atoi(v) : 1; }();   // 0: persistent grids even beside a collective (A/B)
   if (!honour) return 0;
-  const int busy = hipEventQuery(c.done_ev[(size_t)c.last_launched]) == hipErrorNotReady ? 1 : 0;
-  c.busy_hits += busy;
-  return busy;
+  --c.shared_credit;
+  ++c.busy_hits;
+  return 1;
 }
 
 // vitx_allreduce_grads: finish (overlapped mode) or perform (one-shot mode) the exchange; on return the compute stream is ordered behind it
@@ -256,6 +293,8 @@ int comm_finish(vitx_engine* e, std::string& err) {
     if ((rc = launch_bucket(e, i, err)) != VITX_OK) return rc;
   // the communication stream runs its buckets in order: the newest completion event covers them all
   if (c.last_launched >= 0) HIPCHK_ERR(hipStreamWaitEvent(e->stream, c.done_ev[(size_t)c.last_launched], 0), err);
+  c.parity ^= 1;            // the next exchange records into the other set of brackets and reads this one's the time after
+  c.shared_credit = 0;      // the compute stream is now ordered behind every collective of this exchange
   std::fill(c.covered.begin(), c.covered.end(), 0);
   std::fill(c.launched.begin(), c.launched.end(), 0);
   c.last_launched = -1;
@@ -280,6 +319,13 @@ void comm_destroy(vitx_engine* e) {
   for (auto ev : c.done_ev) (void)hipEventDestroy(ev);
   c.ready_ev.clear();
   c.done_ev.clear();
+  for (int p = 0; p < 2; ++p) {
+    for (auto ev : c.t0_ev[p]) (void)hipEventDestroy(ev);
+    for (auto ev : c.t1_ev[p]) (void)hipEventDestroy(ev);
+    c.t0_ev[p].clear(); c.t1_ev[p].clear(); c.timed[p].clear();
+  }
+  c.coll_ms.clear();
+  c.shared_credit = 0;
   if (c.wire) (void)hipFree(c.wire);
   c.wire = nullptr;
   if (c.stream) (void)hipStreamDestroy(c.stream);

@@ -32,6 +32,15 @@ struct CommState {
   std::vector<hipEvent_t> ready_ev, done_ev;
   int last_launched = -1, n_launched = 0, last_overlapped = 0;
   int next_bucket = -1;              // the next bucket of the fixed (descending) launch order; -1 = not started (the last one), -2 = all out
+  // (round 6) which Dense launches run beside a collective is decided in STREAM ORDER from the collectives' measured durations, not from a host-side
+  // event query (the host enqueues a backward pass tens of milliseconds ahead of the GPU: "has the newest bucket finished" is almost never true
+  // at enqueue time, so every launch behind the first bucket used to take the one-tile-per-workgroup form).  t0_ev / t1_ev[parity][bucket] bracket a
+  // bucket's work on the communication stream; the previous-but-one exchange's brackets are read when the bucket is launched again.
+  std::vector<hipEvent_t> t0_ev[2], t1_ev[2];
+  std::vector<char> timed[2];        // brackets of that parity were recorded
+  std::vector<float> coll_ms;        // last measured duration per bucket; < 0: not measured yet
+  int parity = 0;                    // flips with every finished exchange
+  int shared_credit = 0;             // Dense launches, from now on in stream order, that are taken to run beside a collective
   int64_t busy_hits = 0;
   std::string failed;                // error of a launch made from inside the backward (surfaced by the next vitx_allreduce_grads)
 };
@@ -244,6 +253,7 @@ int comm_init(vitx_engine* e, int rank, int world, const void* uid, std::string&
 int comm_overlap(vitx_engine* e, int enable, int64_t bucket_bytes, int wire_bf16, std::string& err);
 void comm_on_ready(vitx_engine* e, int64_t off, int64_t cnt);
 int comm_busy(vitx_engine* e);
+void comm_wait_event(vitx_engine* e, hipEvent_t ev);   // the communication stream waits for `ev` (side-stream share of a reported range)
 int comm_finish(vitx_engine* e, std::string& err);
 void comm_stats(vitx_engine* e, int64_t* out4);
 void comm_destroy(vitx_engine* e);

@@ -366,7 +366,11 @@ static void side_flush_ready(vitx_engine* e, size_t keep) {
   while (e->side_ready.size() > keep) {
     PendingReady pr = e->side_ready.front();
     e->side_ready.erase(e->side_ready.begin());
-    (void)hipStreamWaitEvent(e->stream, pr.ev, 0);
+    // a caller-run exchange (callback) orders itself against the compute stream, so the compute stream waits for the side stream's share of the range;
+    // the library's own exchange lets its COMMUNICATION stream wait instead (round 6): the input-gradient chain is not held up by the weight gradients
+    // of the block it reports (forced DP on one GPU: the waits were most of what the exchange cost there)
+    if (e->grad_cb || !e->cm.overlap) (void)hipStreamWaitEvent(e->stream, pr.ev, 0);
+    else comm_wait_event(e, pr.ev);
     notify_ready(e, pr.off, pr.cnt);
   }
 }
@@ -377,7 +381,9 @@ static void report_ready(vitx_engine* e, int64_t off, int64_t cnt) {
   hipEvent_t ev = side_event(e);
   (void)hipEventRecord(ev, e->side);
   e->side_ready.push_back({off, cnt, ev});
-  side_flush_ready(e, 1);   // everything but the newest: its side-stream work was queued a block ago
+  // callback: everything but the newest (its side-stream work was queued a block ago: the compute stream's wait is then free);
+  // native exchange: at once -- the wait goes to the communication stream, and the bucket leaves a block earlier
+  side_flush_ready(e, (e->grad_cb || !e->cm.overlap) ? 1 : 0);
 }
 static void side_join(vitx_engine* e) {
   if (e->side_dirty) {
