@@ -154,6 +154,15 @@ def main():
         from vit_tensorflow.cait import CaiT as Model
     else:
         Model = ViT
+    # torch exchange: the stream the engine will run on is created (and used once) BEFORE the handle makes its own streams.  Hardware queues are spread
+    # over the GPU's four command-processor pipes in creation order; a compute stream made later lands on the pipe of the weight-gradient or
+    # small-reduction stream by luck, and two busy queues on one pipe serialise their dispatches
+    dp_stream = None
+    if (world > 1 or force_dp) and not native_dp:
+        dp_stream = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(dp_stream):
+            torch.zeros(1, device=dev)
+        torch.cuda.synchronize()
     model = Model(**kw, compute=args.compute, max_batch=b, device=local, seed=1)
     model.build((b,))
     h = model._handle
@@ -207,7 +216,8 @@ def main():
     if dp and not native_dp:
         # The engine must run on the stream RCCL orders itself against.  torch's default stream has handle 0, which the C ABI
         # reads as "use the library's own stream", so the data-parallel path runs under an explicit side stream.
-        dp_stream = torch.cuda.Stream(device=dev)
+        if dp_stream is None:   # (the fall-back from a native exchange that could not start: created late, wherever it lands)
+            dp_stream = torch.cuda.Stream(device=dev)
         torch.cuda.set_stream(dp_stream)
         n = C.c_int64()
         p = C.c_void_p()

@@ -13,6 +13,10 @@
 //                        collectives by call order: a rank that sends its buckets in another order is caught here instead of summing mismatched data),
 //                        sums the slots in rank order (fp32 accumulation; bf16 wire rounded to nearest even) -> host -> device (hipMemcpyAsync)
 //   ncclCommDestroy      unmaps, the last rank unlinks the segment
+// Optional CU occupancy (VITX_FAKE_RCCL_SPIN_WGS=n, VITX_FAKE_RCCL_SPIN_US=t): before its reduction every collective runs a kernel of n workgroups
+// (256 threads, 96 VGPRs each: no persistent GEMM workgroup fits beside one) that spin for t microseconds -- what RCCL's channel workgroups do to a
+// compute stream for the length of a collective.  With one rank this emulates, on a one-GPU box, the situation the engine's one-tile-per-workgroup
+// GEMM forms exist for (profiles/r6/ab_emulated_collective_occupancy_*.log).
 // Every wait has a deadline (VITX_FAKE_RCCL_TIMEOUT_S, default 120 s): a rank that never arrives turns into an error result (NaN-filled output and a
 // non-zero return from the next call), not a hang.  Sum only (ncclSum), float32 / bfloat16 only -- what comm.hip uses.
 #include <hip/hip_runtime.h>
@@ -32,6 +36,15 @@
 #include <thread>
 
 namespace {
+
+// holds `gridDim.x` CUs' worth of registers for `ticks` periods of the 100-MHz wall clock
+__global__ __launch_bounds__(256) void occupy_kernel(unsigned long long ticks) {
+  asm volatile("v_mov_b32 v95, 0" ::: "v95");
+  const unsigned long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+
+__global__ void empty_kernel() {}
 
 constexpr int MAX_RANKS = 8;
 constexpr int NCCL_FLOAT32 = 7, NCCL_BFLOAT16 = 9, NCCL_SUM = 0;
@@ -59,6 +72,8 @@ struct Comm {
   uint64_t calls = 0;            // collectives enqueued by this rank (host side)
   bool registered = false;
   double timeout_s = 120.0;
+  int spin_wgs = 0;              // emulated channel workgroups per collective (0: none)
+  double spin_us = 0.0;
 };
 
 struct Call { Comm* c; uint64_t k; size_t count; int dtype; };
@@ -165,6 +180,8 @@ int ncclCommInitRank(void** comm_out, int nranks, uid128 id, int rank) {
   c->rank = rank; c->world = nranks;
   memcpy(c->name, id.b, sizeof c->name - 1);
   if (const char* t = getenv("VITX_FAKE_RCCL_TIMEOUT_S")) c->timeout_s = atof(t);
+  if (const char* t = getenv("VITX_FAKE_RCCL_SPIN_WGS")) c->spin_wgs = atoi(t);
+  if (const char* t = getenv("VITX_FAKE_RCCL_SPIN_US")) c->spin_us = atof(t);
   const char* mb = getenv("VITX_FAKE_RCCL_SLOT_MB");
   c->slot_bytes = (size_t)(mb ? atoi(mb) : 64) << 20;
   c->map_bytes = HEADER_BYTES + (size_t)nranks * c->slot_bytes;
@@ -179,6 +196,18 @@ int ncclCommInitRank(void** comm_out, int nranks, uid128 id, int rank) {
   // pinned slots make the device -> host copies truly asynchronous; pageable ones are still stream-ordered (the copy then blocks the calling thread)
   c->registered = hipHostRegister(c->map + HEADER_BYTES + (size_t)rank * c->slot_bytes, c->slot_bytes, hipHostRegisterDefault) == hipSuccess;
   if (!c->registered) (void)hipGetLastError();
+  if (const char* t = getenv("VITX_FAKE_RCCL_DUMMY_STREAMS")) {   // experiment: what real RCCL's own streams do to the stream -> hardware-queue mapping
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    for (int i = 0; i < atoi(t); ++i) {
+      hipStream_t st;
+      const int pr = getenv("VITX_FAKE_RCCL_DUMMY_PRIO") ? atoi(getenv("VITX_FAKE_RCCL_DUMMY_PRIO")) : 0;
+      if (hipStreamCreateWithPriority(&st, hipStreamNonBlocking, pr > 0 ? hi : (pr < 0 ? lo : 0)) == hipSuccess) {
+        hipLaunchKernelGGL(empty_kernel, dim3(1), dim3(64), 0, st);
+        (void)hipStreamSynchronize(st);
+      }
+    }
+  }
   c->hdr->arrived.fetch_add(1, std::memory_order_acq_rel);
   if (!wait_until(c, [&] { return c->hdr->arrived.load(std::memory_order_acquire) >= nranks; })) {
     fprintf(stderr, "[fake_rccl] rank %d: only %d of %d ranks arrived\n", rank, c->hdr->arrived.load(), nranks);
@@ -195,6 +224,15 @@ int ncclAllReduce(const void* send, void* recv, size_t count, int dtype, int op,
   if (bytes > c->slot_bytes) { fprintf(stderr, "[fake_rccl] %zu bytes per collective exceed the slot (VITX_FAKE_RCCL_SLOT_MB)\n", bytes); return ncclInvalidArgument; }
   if (c->hdr->error.load(std::memory_order_acquire)) return ncclSystemError;
   char* slot = c->map + HEADER_BYTES + (size_t)c->rank * c->slot_bytes;
+  if (c->spin_wgs > 0 && c->spin_us > 0.0) {
+    static const int mode = [] { const char* v = getenv("VITX_FAKE_RCCL_SPIN_MODE"); return v ? atoi(v) : 0; }();   // experiments: 1 = no kernel at all, 2 = an empty kernel
+    if (mode == 0) hipLaunchKernelGGL(occupy_kernel, dim3((unsigned)c->spin_wgs), dim3(256), 0, stream, (unsigned long long)(c->spin_us * 100.0));
+    else if (mode == 2) hipLaunchKernelGGL(empty_kernel, dim3((unsigned)c->spin_wgs), dim3(256), 0, stream);
+    if (c->world == 1) {   // occupancy emulation with one rank: the sum over one rank is the identity -- no trip through host memory, only the held CUs
+      if (send != recv && hipMemcpyAsync(recv, send, bytes, hipMemcpyDeviceToDevice, stream) != hipSuccess) return ncclSystemError;
+      return ncclSuccess;
+    }
+  }
   if (hipMemcpyAsync(slot, send, bytes, hipMemcpyDeviceToHost, stream) != hipSuccess) return ncclSystemError;
   Call* call = new Call{c, c->calls++, count, dtype};
   if (hipLaunchHostFunc(stream, reduce_on_host, call) != hipSuccess) { delete call; return ncclSystemError; }

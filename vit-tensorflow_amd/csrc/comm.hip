@@ -85,14 +85,17 @@ int launch_bucket(vitx_engine* e, int i, std::string& err) {
   HIPCHK_ERR(hipEventRecord(c.ready_ev[(size_t)i], e->stream), err);
   HIPCHK_ERR(hipStreamWaitEvent(c.stream, c.ready_ev[(size_t)i], 0), err);
   // duration of this bucket's work two exchanges ago (its brackets have fired long since: the host runs at most one step ahead of the GPU)
+  static const int timing_env = [] { const char* v = vitx_env("VITX_COMM_TIMING"); return v ? atoi(v) : 1; }();   // 0: no event brackets (A/B): every collective counts as unmeasured
   const int par = c.parity & 1;
-  if (c.timed[par][(size_t)i] && hipEventQuery(c.t1_ev[par][(size_t)i]) == hipSuccess) {
-    float ms = 0.f;
-    if (hipEventElapsedTime(&ms, c.t0_ev[par][(size_t)i], c.t1_ev[par][(size_t)i]) == hipSuccess) c.coll_ms[(size_t)i] = ms;
-  } else {
-    (void)hipGetLastError();
+  if (timing_env) {
+    if (c.timed[par][(size_t)i] && hipEventQuery(c.t1_ev[par][(size_t)i]) == hipSuccess) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, c.t0_ev[par][(size_t)i], c.t1_ev[par][(size_t)i]) == hipSuccess) c.coll_ms[(size_t)i] = ms;
+    } else {
+      (void)hipGetLastError();
+    }
   }
-  HIPCHK_ERR(hipEventRecord(c.t0_ev[par][(size_t)i], c.stream), err);
+  if (timing_env) HIPCHK_ERR(hipEventRecord(c.t0_ev[par][(size_t)i], c.stream), err);
   const float alpha = 1.0f / (float)e->world;
   if (c.wire_bf16) {
     bf16_t* w = c.wire + lo;
@@ -103,8 +106,10 @@ int launch_bucket(vitx_engine* e, int i, std::string& err) {
     if (ar(g, g, (size_t)n, NCCL_FLOAT32, NCCL_SUM, e->comm, c.stream) != 0) { err = "ncclAllReduce failed"; return VITX_ERR_COMM; }
     if (e->world > 1) hipLaunchKernelGGL(comm_scale_kernel, dim3(grid_for(n / 4)), dim3(256), 0, c.stream, g, n / 4, alpha);
   }
-  HIPCHK_ERR(hipEventRecord(c.t1_ev[par][(size_t)i], c.stream), err);
-  c.timed[par][(size_t)i] = 1;
+  if (timing_env) {
+    HIPCHK_ERR(hipEventRecord(c.t1_ev[par][(size_t)i], c.stream), err);
+    c.timed[par][(size_t)i] = 1;
+  }
   HIPCHK_ERR(hipEventRecord(c.done_ev[(size_t)i], c.stream), err);
   c.last_launched = i;
   ++c.n_launched;
@@ -126,7 +131,8 @@ int ensure_state(vitx_engine* e, std::string& err) {
   if (!c.stream) {
     int lo = 0, hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&lo, &hi);   // (numerically lowest = highest priority): the few workgroups of a collective should not queue behind a GEMM's
-    HIPCHK_ERR(hipStreamCreateWithPriority(&c.stream, hipStreamNonBlocking, hi), err);
+    static const int prio_env = [] { const char* v = vitx_env("VITX_COMM_PRIORITY"); return v ? atoi(v) : 1; }();   // 1 highest (default), 0 default priority, -1 lowest
+    HIPCHK_ERR(hipStreamCreateWithPriority(&c.stream, hipStreamNonBlocking, prio_env > 0 ? hi : (prio_env < 0 ? lo : 0)), err);
   }
   if (c.bucket <= 0) c.bucket = 8LL << 20;   // 32 MiB of fp32
   const int nb = (int)((e->n_arena + c.bucket - 1) / c.bucket);

@@ -369,7 +369,8 @@ static void side_flush_ready(vitx_engine* e, size_t keep) {
     // a caller-run exchange (callback) orders itself against the compute stream, so the compute stream waits for the side stream's share of the range;
     // the library's own exchange lets its COMMUNICATION stream wait instead (round 6): the input-gradient chain is not held up by the weight gradients
     // of the block it reports (forced DP on one GPU: the waits were most of what the exchange cost there)
-    if (e->grad_cb || !e->cm.overlap) (void)hipStreamWaitEvent(e->stream, pr.ev, 0);
+    static const int chain_env = [] { const char* v = vitx_env("VITX_COMM_WAIT_ON_CHAIN"); return v ? atoi(v) : 0; }();   // 1: the round-5 rule (A/B)
+    if (e->grad_cb || !e->cm.overlap || chain_env) (void)hipStreamWaitEvent(e->stream, pr.ev, 0);
     else comm_wait_event(e, pr.ev);
     notify_ready(e, pr.off, pr.cnt);
   }
@@ -1430,6 +1431,29 @@ static int engine_create_body(vitx_engine* e, const vitx_config& cfg, std::strin
     (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
     HIPCHK(hipStreamCreateWithPriority(&e->side, hipStreamNonBlocking, e->side_mode == 2 ? greatest : least));
     HIPCHK(hipStreamCreateWithPriority(&e->side2, hipStreamNonBlocking, greatest));
+  }
+  // (round 6) The handle's FOUR streams -- compute, weight gradients, small reductions, communication -- are created HERE, back to back, and each is
+  // made to submit something at once.  The driver spreads a process's hardware queues over the GPU's four command-processor pipes in creation order, and
+  // two queues on one pipe are served by one micro-engine: a communication queue whose head is a barrier packet (waiting, for a millisecond, for the
+  // weight gradients of the block it will send) stalls the dispatches of a compute queue behind it on the same pipe.  Created late (at
+  // vitx_comm_overlap, after whatever streams torch / RCCL had made in between) the communication stream landed on the compute stream's pipe or not
+  // by luck: 43.5 ms per ViT-B/16 step instead of 35.0 with a collective that does NOTHING, 48 ms with real RCCL and VITX_SIDE_STREAM=0
+  // (profiles/r6/stream_to_pipe_mapping_r6.md).  Four consecutive queues are four different pipes, whatever was created before them.
+  {
+    int least = 0, greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+    static const int prio_env = [] { const char* v = vitx_env("VITX_COMM_PRIORITY"); return v ? atoi(v) : 1; }();   // 1 highest (default), 0 default priority, -1 lowest
+    static const int early_env = [] { const char* v = vitx_env("VITX_COMM_STREAM_EARLY"); return v ? atoi(v) : 1; }();   // 0: created at vitx_comm_overlap (A/B)
+    if (early_env) {
+      HIPCHK(hipStreamCreateWithPriority(&e->cm.stream, hipStreamNonBlocking, prio_env > 0 ? greatest : (prio_env < 0 ? least : 0)));
+      void* probe = nullptr;
+      HIPCHK(hipMalloc(&probe, 256));
+      e->allocs.push_back(probe);
+      for (hipStream_t st : {e->own_stream, e->side, e->side2, e->cm.stream})   // first submission = the hardware queue exists, in this order
+        if (st) launch_fill_zero(probe, 64, st);
+      for (hipStream_t st : {e->own_stream, e->side, e->side2, e->cm.stream})
+        if (st) HIPCHK(hipStreamSynchronize(st));
+    }
   }
 
   const int d = c.dim, inner = e->inner, m = c.mlp_dim, esz = e->esz;

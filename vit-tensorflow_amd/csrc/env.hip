@@ -53,6 +53,10 @@ const VitxEnvSwitch kSwitches[] = {
     {"VITX_WGRAD_WGS", VITX_ENV_TUNING, "workgroups per weight-gradient launch (default 128 up to 24576 token rows, else 256); changes the split-K slice count: fixed-order sums in another order"},
     {"VITX_SG_BLOCKS", VITX_ENV_TUNING, "blocks per LayerScale-gradient launch"},
     {"VITX_DV_CPI", VITX_ENV_TUNING, "chunks per image of the DeepViT one-kernel forward (tests: the multi-tile loop at small batches)"},
+    {"VITX_COMM_PRIORITY", VITX_ENV_TUNING, "priority of the communication stream: 1 highest (default), 0 default, -1 lowest"},
+    {"VITX_COMM_TIMING", VITX_ENV_TUNING, "0: no event brackets around the collectives (every Dense launch behind a bucket then takes the one-tile form)"},
+    {"VITX_COMM_WAIT_ON_CHAIN", VITX_ENV_TUNING, "1: the compute stream (not the communication stream) waits for the weight-gradient stream's share of a reported range"},
+    {"VITX_COMM_STREAM_EARLY", VITX_ENV_TUNING, "0: the communication stream is created at vitx_comm_overlap instead of with the handle's other streams (A/B: it may then share a command-processor pipe with the compute stream)"},
     {"VITX_COMM_SHARED", VITX_ENV_TUNING, "0: persistent GEMM grids even while a collective of this handle is in flight"},
     {"VITX_RCCL_LIB", VITX_ENV_TUNING, "path of the collective library to dlopen instead of librccl.so (tests/fake_rccl: two ranks on one GPU)"},
     // ---- diagnostics: may corrupt results; diagnostic build only
