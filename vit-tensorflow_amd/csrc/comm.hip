@@ -269,7 +269,11 @@ void comm_wait_event(vitx_engine* e, hipEvent_t ev) {
 int comm_busy(vitx_engine* e) {
   CommState& c = e->cm;
   if (!c.overlap || c.shared_credit <= 0) return 0;
-  static const int honour = [] { const char* v = vitx_env("VITX_COMM_SHARED"); return v ? atoi(v) : 1; }();   // 0: persistent grids even beside a collective (A/B)
+  // VITX_COMM_SHARED=1 enables the rule; OFF by default since round 6: with the stub's emulated collectives (16-128 workgroups holding their CUs for
+  // 0.3-1.5 ms per bucket, one rank, `profiles/r6/ab_emulated_collective_occupancy_rule_vs_persistent_r6ai.log`) persistent grids throughout are 0.1-0.5 ms
+  // per step FASTER than the rule at every point but the widest / longest (64 x 1.5 ms: 38.20 vs 38.45) -- the late workgroups of a persistent launch
+  // cost less than the slower one-tile forms of the 3-8 launches a bucket's duration covers.  Never measured against real multi-rank RCCL kernels.
+  static const int honour = [] { const char* v = vitx_env("VITX_COMM_SHARED"); return v ? atoi(v) : 0; }();
   if (!honour) return 0;
   --c.shared_credit;
   ++c.busy_hits;

@@ -57,7 +57,7 @@ const VitxEnvSwitch kSwitches[] = {
     {"VITX_COMM_TIMING", VITX_ENV_TUNING, "0: no event brackets around the collectives (every Dense launch behind a bucket then takes the one-tile form)"},
     {"VITX_COMM_WAIT_ON_CHAIN", VITX_ENV_TUNING, "1: the compute stream (not the communication stream) waits for the weight-gradient stream's share of a reported range"},
     {"VITX_COMM_STREAM_EARLY", VITX_ENV_TUNING, "0: the communication stream is created at vitx_comm_overlap instead of with the handle's other streams (A/B: it may then share a command-processor pipe with the compute stream)"},
-    {"VITX_COMM_SHARED", VITX_ENV_TUNING, "0: persistent GEMM grids even while a collective of this handle is in flight"},
+    {"VITX_COMM_SHARED", VITX_ENV_TUNING, "1: the Dense launches behind a bucket take the one-tile-per-workgroup form for as long as its collective was measured to last (default 0: persistent grids throughout, faster with emulated collectives)"},
     {"VITX_RCCL_LIB", VITX_ENV_TUNING, "path of the collective library to dlopen instead of librccl.so (tests/fake_rccl: two ranks on one GPU)"},
     // ---- diagnostics: may corrupt results; diagnostic build only
     {"VITX_GEMM_STAGGER", VITX_ENV_DIAG, "bits reach the NT kernels' experiment field: 1 no DMA wait, 2 no DMA issue (WRONG GEMM results)"},
