@@ -1,7 +1,8 @@
 // Per-workgroup timeline of the fused bf16 attention kernels (vit.py:73-82 and its VJP) at the benchmarked shape: the product source
 // attn_bf16.hip compiled with -DVITX_ATTN_PROBE records 100-MHz timestamps at the phase boundaries of wave 0 of every workgroup.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-honor-nans -DVITX_ATTN_PROBE -I vit-tensorflow_amd/csrc -I include tools/probe_attn.hip -o tools/probe_attn
-//   tools/probe_attn [batch=256] [tokens=197] [heads=12]
+//   tools/probe_attn [batch=256] [tokens=197] [heads=12] [planar=0] [threads=512]     planar 1: q | k | v / o / dO as [plane][b n][64] planes (AttnLayout 1), the
+//                                                                        A/B of the access pattern (contiguous n x 128-B blocks per task)
 #include "../vit-tensorflow_amd/csrc/attn_bf16.hip"
 #include <algorithm>
 #include <cstdio>
@@ -63,6 +64,10 @@ static void report(const char* what, const std::vector<unsigned long long>& st, 
 
 int main(int argc, char** argv) {
   const int b = argc > 1 ? atoi(argv[1]) : 256, n = argc > 2 ? atoi(argv[2]) : 197, h = argc > 3 ? atoi(argv[3]) : 12;
+  vitx_attn_probe_planar = argc > 4 ? atoi(argv[4]) : 0;
+  vitx_attn_probe_threads = argc > 5 ? atoi(argv[5]) : 512;
+  printf("%d threads per workgroup\n", vitx_attn_probe_threads);
+  printf("batch %d, %d tokens, %d heads, layout %s\n", b, n, h, vitx_attn_probe_planar ? "planar [3h][b n][64]" : "interleaved [b n][3][h][64] (the engine's)");
   const size_t tok = (size_t)b * n, inner = (size_t)h * 64;
   std::vector<bf16_t> hq(tok * 3 * inner), hd(tok * inner);
   srand(1);

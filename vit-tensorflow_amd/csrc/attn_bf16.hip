@@ -33,6 +33,29 @@ using namespace attn_lds;
 
 constexpr int ATT_THREADS = 512;   // 8 waves share one head's LDS image (2 per SIMD)
 
+// Where one (image, head) task finds its rows.  Layout 0 (the engine's): packed qkv [b, n, 3, h, 64] as the to_qkv Dense emits it and o / dO
+// [b, n, h, 64].  Layout 1 ("planar", tools/probe_attn only so far): 3 h planes [b n][64] for q | k | v (and h planes for o / dO), i.e. every
+// task's q, k, v, o are contiguous n x 128-B blocks -- the A/B that asks what the 128-B-segments-at-4.6-KB-stride access pattern costs.
+struct AttnLayout {
+  int64_t tok_stride;   // elements between consecutive tokens of one head's q (k, v) rows
+  int64_t kv_off;       // q -> k and k -> v offset
+  int64_t o_stride;     // elements between consecutive tokens of one head's o / dO rows
+  int64_t q0, o0;       // offsets of this task's first q row / first o row
+};
+__device__ __forceinline__ AttnLayout attn_layout(int planar, int bi, int hi, int nb, int n, int h) {
+  AttnLayout a;
+  const int64_t inner = (int64_t)h * DH;
+  if (planar) {
+    const int64_t M = (int64_t)nb * n;
+    a.tok_stride = DH; a.kv_off = (int64_t)h * M * DH; a.o_stride = DH;
+    a.q0 = ((int64_t)hi * M + (int64_t)bi * n) * DH; a.o0 = a.q0;
+  } else {
+    a.tok_stride = 3 * inner; a.kv_off = inner; a.o_stride = inner;
+    a.q0 = (int64_t)bi * n * a.tok_stride + hi * DH; a.o0 = (int64_t)bi * n * inner + hi * DH;
+  }
+  return a;
+}
+
 // rows [0, npad) of a [*, 64] bf16 matrix (row stride `stride` elements) -> LDS row-major swizzled image
 // and/or transposed image T[dh][vs]; rows >= nvalid are zero-filled.
 template <bool ROWMAJOR, bool TRANSPOSED>
@@ -143,20 +166,20 @@ __device__ __forceinline__ void fwd_max_pair(const char* k_rm, int u, int qi, in
 
 template <int NTP>
 __global__ __launch_bounds__(ATT_THREADS, 4) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o, float* __restrict__ lse,
-                                                       int n, int h, float scale, const bf16_t* __restrict__ zero_page, int reverse) {
+                                                       int n, int h, float scale, const bf16_t* __restrict__ zero_page, int reverse, int planar) {
   constexpr int NKP = 16 * NTP, QB = QB_FWD;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* k_rm = smem;                                   // [NKP][128 B] swizzled
   char* v_rm = smem + NKP * ROWB;                      // [NKP][128 B] swizzled (read through the hardware transpose)
   const int bh = reverse ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x, bi = bh / h, hi = bh - bi * h;   // reverse: newest qkv rows first (memory-side cache)
-  const int inner = h * DH;
-  const int64_t tok_stride = 3 * (int64_t)inner;
-  const bf16_t* qbase = qkv + (int64_t)bi * n * tok_stride + hi * DH;
+  const AttnLayout L = attn_layout(planar, bi, hi, (int)gridDim.x / h, n, h);
+  const int64_t tok_stride = L.tok_stride;
+  const bf16_t* qbase = qkv + L.q0;
   const int tid = threadIdx.x, lane = tid & 63, nwaves = blockDim.x >> 6;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   ATTN_STAMP(0);
-  stage_head_dma(qbase + inner, tok_stride, n, NKP, k_rm, zero_page, wave, lane, nwaves);
-  stage_head_dma(qbase + 2 * inner, tok_stride, n, NKP, v_rm, zero_page, wave, lane, nwaves);
+  stage_head_dma(qbase + L.kv_off, tok_stride, n, NKP, k_rm, zero_page, wave, lane, nwaves);
+  stage_head_dma(qbase + 2 * L.kv_off, tok_stride, n, NKP, v_rm, zero_page, wave, lane, nwaves);
 
   const int qi = lane & 15, g = lane >> 4;
   const int nqb = (n + 16 * QB - 1) / (16 * QB);
@@ -215,7 +238,7 @@ __global__ __launch_bounds__(ATT_THREADS, 4) void attn_fwd_kernel(const bf16_t* 
       const float inv_l = 1.0f / ls;
       if (g == 0 && q < n) lse[(int64_t)bh * n + q] = (m[s] + log2f(ls)) * 0.69314718055994530942f;  // natural-log LSE
       if (q < n) {
-        bf16_t* op = o + ((int64_t)bi * n + q) * inner + hi * DH;
+        bf16_t* op = o + L.o0 + (int64_t)q * L.o_stride;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
           bf16x4 ov;
@@ -278,7 +301,7 @@ __device__ __forceinline__ void dq_pair(const char* k_rm, const char* v_rm, int 
 // per-lane global operands of one 16-query block (its q, dO and O rows): loaded one block AHEAD of their use, so that the round trip
 // (1.5-2 us under load, tools/probe_attn) runs under the previous block's tile loop instead of in front of this one's
 struct DqOperands { bf16x8 qf[2], dof[2], of[2]; };
-__device__ __forceinline__ void dq_load(DqOperands& x, const bf16_t* qbase, int64_t tok_stride, const bf16_t* o_rows, const bf16_t* do_rows, int inner,
+__device__ __forceinline__ void dq_load(DqOperands& x, const bf16_t* qbase, int64_t tok_stride, const bf16_t* o_rows, const bf16_t* do_rows, int64_t inner,
                                         int qb, int lane, int n) {
   const int qc = min(qb * 16 + (lane & 15), n - 1), g = lane >> 4;   // rows >= n compute on the clamped row n-1 (finite) and are never stored
 #pragma unroll
@@ -329,7 +352,7 @@ __device__ __forceinline__ float dq_block(const char* k_rm, const char* v_rm, co
 // No masks: query rows >= n are zero rows of q / dO with lse = D = 0, so their P = 1 meets dO = 0 and their dS = 1 * (0 - 0); key lanes >= n
 // compute on the clamped key n-1 and are never stored.  Tile pairs past n are skipped.
 struct DkvOperands { bf16x8 kf[2], vf[2]; };   // one 16-key block's k and v rows (the B operands of S and dP), loaded one block ahead as well
-__device__ __forceinline__ void dkv_load(DkvOperands& x, const bf16_t* kbase, int64_t tok_stride, int inner, int kb, int lane, int n) {
+__device__ __forceinline__ void dkv_load(DkvOperands& x, const bf16_t* kbase, int64_t tok_stride, int64_t inner, int kb, int lane, int n) {
   const int kc = min(kb * 16 + (lane & 15), n - 1), g = lane >> 4;
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks) {
@@ -340,7 +363,7 @@ __device__ __forceinline__ void dkv_load(DkvOperands& x, const bf16_t* kbase, in
 
 template <int NTP>
 __device__ __forceinline__ void dkv_block(const char* q_rm, const char* do_rm, const float* lse_s, const float* d_s, const DkvOperands& x,
-                                          int64_t tok_stride, int inner, bf16_t* dk_rows, int kb, int lane, int n, float scale) {
+                                          int64_t tok_stride, int64_t inner, bf16_t* dk_rows, int kb, int lane, int n, float scale) {
   const int ki = lane & 15, g = lane >> 4;
   const int key = kb * 16 + ki;
   const float sl2 = scale * 1.44269504088896340736f;
@@ -467,7 +490,7 @@ template <int NTP>
 __global__ __launch_bounds__(ATT_THREADS, 4) void attn_bwd_fused_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
                                                              const bf16_t* __restrict__ d_o, const float* __restrict__ lse,
                                                              bf16_t* __restrict__ dqkv, int n, int h, float scale,
-                                                             const bf16_t* __restrict__ zero_page) {
+                                                             const bf16_t* __restrict__ zero_page, int planar) {
   constexpr int NKP = 16 * NTP, NQP = 16 * NTP;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* k_rm = smem;                                 // phase 1: K, V      phase 2: Q, dO
@@ -477,9 +500,9 @@ __global__ __launch_bounds__(ATT_THREADS, 4) void attn_bwd_fused_kernel(const bf
   float* lse_s = (float*)(smem + 2 * NKP * ROWB);    // [NQP] (log2 domain), rows >= n: 0
   float* d_s = lse_s + NQP;                          // [NQP] D[q] = sum_d dO O, rows >= n: 0
   const int bh = blockIdx.x, bi = bh / h, hi = bh - bi * h;
-  const int inner = h * DH;
-  const int64_t tok_stride = 3 * (int64_t)inner;
-  const bf16_t* qbase = qkv + (int64_t)bi * n * tok_stride + hi * DH;
+  const AttnLayout L = attn_layout(planar, bi, hi, (int)gridDim.x / h, n, h);
+  const int64_t tok_stride = L.tok_stride, inner = L.kv_off, ostr = L.o_stride;
+  const bf16_t* qbase = qkv + L.q0;
   const int tid = threadIdx.x, lane = tid & 63, nwaves = blockDim.x >> 6;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   stage_head_dma(qbase + inner, tok_stride, n, NKP, k_rm, zero_page, wave, lane, nwaves);
@@ -488,10 +511,10 @@ __global__ __launch_bounds__(ATT_THREADS, 4) void attn_bwd_fused_kernel(const bf
     lse_s[i] = i < n ? lse[(int64_t)bh * n + i] * 1.44269504088896340736f : 0.f;
     d_s[i] = 0.f;
   }
-  const int64_t orow0 = (int64_t)bi * n * inner + hi * DH;
+  const int64_t orow0 = L.o0;
   const int nblk = (n + 15) / 16;
   DqOperands xq;
-  if (wave < nblk) dq_load(xq, qbase, tok_stride, o + orow0, d_o + orow0, inner, wave, lane, n);   // in flight together with the K / V images
+  if (wave < nblk) dq_load(xq, qbase, tok_stride, o + orow0, d_o + orow0, ostr, wave, lane, n);   // in flight together with the K / V images
   ATTN_STAMP(0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -499,8 +522,8 @@ __global__ __launch_bounds__(ATT_THREADS, 4) void attn_bwd_fused_kernel(const bf
   for (int qb = wave; qb < nblk; qb += nwaves) {   // ------------------------------------ phase 1: dQ, D
     const int q = qb * 16 + (lane & 15);
     DqOperands nx;
-    if (qb + nwaves < nblk) dq_load(nx, qbase, tok_stride, o + orow0, d_o + orow0, inner, qb + nwaves, lane, n);
-    const float d = dq_block<NTP>(k_rm, v_rm, xq, tok_stride, dqkv + (int64_t)bi * n * tok_stride + hi * DH, qb, lane, n, scale, lse_s[min(q, n - 1)]);
+    if (qb + nwaves < nblk) dq_load(nx, qbase, tok_stride, o + orow0, d_o + orow0, ostr, qb + nwaves, lane, n);
+    const float d = dq_block<NTP>(k_rm, v_rm, xq, tok_stride, dqkv + L.q0, qb, lane, n, scale, lse_s[min(q, n - 1)]);
     if ((lane >> 4) == 0 && q < n) d_s[q] = d;      // stays in LDS for phase 2
     xq = nx;
   }
@@ -510,14 +533,14 @@ __global__ __launch_bounds__(ATT_THREADS, 4) void attn_bwd_fused_kernel(const bf
   __syncthreads();               // every wave is done with the K / V images; D is complete
   ATTN_STAMP(3);
   stage_head_dma(qbase, tok_stride, n, NQP, q_rm, zero_page, wave, lane, nwaves);
-  stage_head_dma(d_o + orow0, inner, n, NQP, do_rm, zero_page, wave, lane, nwaves);
+  stage_head_dma(d_o + orow0, ostr, n, NQP, do_rm, zero_page, wave, lane, nwaves);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   ATTN_STAMP(4);
   for (int kb = wave; kb < nblk; kb += nwaves) {   // ------------------------------------ phase 2: dK, dV
     DkvOperands nx;
     if (kb + nwaves < nblk) dkv_load(nx, qbase + inner, tok_stride, inner, kb + nwaves, lane, n);
-    dkv_block<NTP>(q_rm, do_rm, lse_s, d_s, xk, tok_stride, inner, dqkv + (int64_t)bi * n * tok_stride + inner + hi * DH, kb, lane, n, scale);
+    dkv_block<NTP>(q_rm, do_rm, lse_s, d_s, xk, tok_stride, inner, dqkv + L.q0 + inner, kb, lane, n, scale);
     xk = nx;
   }
   ATTN_STAMP(5);
@@ -529,15 +552,28 @@ void set_smem(K kern, int bytes) {   // one attribute call per distinct kernel (
 }
 
 // 8 waves: 13 one-block waves measured 16 % slower in the backward; 7 waves (tools/probe_attn, r4s) the same forward and a 6 % slower backward
+#ifdef VITX_ATTN_PROBE   // tools/probe_attn: workgroup size and a 12-tile instantiation (192 keys: 48 KiB of images, three workgroups per CU) as A/B switches
+int vitx_attn_probe_threads = 512;
+inline int att_threads(int n) { (void)n; return vitx_attn_probe_threads; }
+inline int pick_ntp(int n) { return n <= 64 ? 4 : n <= 96 ? 6 : n <= 192 ? 12 : n <= 224 ? 14 : 18; }
+#else
 inline int att_threads(int n) { (void)n; return 512; }
 inline int pick_ntp(int n) { return n <= 64 ? 4 : n <= 96 ? 6 : n <= 224 ? 14 : 18; }
+#endif
 
 }  // namespace
 
 bool attn_bf16_supported(int n, int dim_head) { return dim_head == DH && n >= 1 && n <= 288; }
 
 #define VITX_NTP_DISPATCH(ntp, CALL) \
-  do { if ((ntp) == 4) { CALL(4); } else if ((ntp) == 6) { CALL(6); } else if ((ntp) == 14) { CALL(14); } else { CALL(18); } } while (0)
+  do { if ((ntp) == 4) { CALL(4); } else if ((ntp) == 6) { CALL(6); } else if ((ntp) == 14) { CALL(14); } else if ((ntp) == 12) { VITX_NTP12(CALL); } else { CALL(18); } } while (0)
+#ifdef VITX_ATTN_PROBE
+#define VITX_NTP12(CALL) CALL(12)
+#else
+#define VITX_NTP12(CALL) CALL(14)   /* (never selected outside the probe build) */
+#endif
+
+int vitx_attn_probe_planar = 0;   // tools/probe_attn sets it (layout 1 of AttnLayout); the engine's tensors are layout 0
 
 void launch_attn_bf16_fwd(const bf16_t* qkv, bf16_t* o, float* lse, int b, int n, int h, float scale, const bf16_t* zero_page, int reverse, hipStream_t s) {
   const int ntp = pick_ntp(n);
@@ -546,7 +582,7 @@ void launch_attn_bf16_fwd(const bf16_t* qkv, bf16_t* o, float* lse, int b, int n
   // (image, head) tasks from the last to the first: qkv (232 MB at ViT-B/16, written front to back by the GEMM before) is read newest rows
   // first, while they are still in the 256 MB memory-side cache (1.24 -> 1.15 ms per step); `reverse` = bit 4 of the engine's reverse_mask
   // (VITX_REVERSE, read once per handle)
-#define CALL(NTP) { set_smem(attn_fwd_kernel<NTP>, smem); hipLaunchKernelGGL(attn_fwd_kernel<NTP>, dim3(b * h), dim3(att_threads(n)), smem, s, qkv, o, lse, n, h, scale, zero_page, reverse); }
+#define CALL(NTP) { set_smem(attn_fwd_kernel<NTP>, smem); hipLaunchKernelGGL(attn_fwd_kernel<NTP>, dim3(b * h), dim3(att_threads(n)), smem, s, qkv, o, lse, n, h, scale, zero_page, reverse, vitx_attn_probe_planar); }
   VITX_NTP_DISPATCH(ntp, CALL);
 #undef CALL
 }
@@ -560,7 +596,7 @@ void launch_attn_bf16_bwd(const bf16_t* qkv, const bf16_t* o, const bf16_t* d_o,
   const char* split_env = vitx_env("VITX_ATTN_BWD_SPLIT");   // A/B and the bit-identity test: the two-launch form (read per call)
   const bool split = split_env && atoi(split_env) != 0;
   if (!split) {
-#define CALLF(NTP) { set_smem(attn_bwd_fused_kernel<NTP>, smem_dkv); hipLaunchKernelGGL(attn_bwd_fused_kernel<NTP>, dim3(b * h), dim3(att_threads(n)), smem_dkv, s, qkv, o, d_o, lse, dqkv, n, h, scale, zero_page); }
+#define CALLF(NTP) { set_smem(attn_bwd_fused_kernel<NTP>, smem_dkv); hipLaunchKernelGGL(attn_bwd_fused_kernel<NTP>, dim3(b * h), dim3(att_threads(n)), smem_dkv, s, qkv, o, d_o, lse, dqkv, n, h, scale, zero_page, vitx_attn_probe_planar); }
     VITX_NTP_DISPATCH(ntp, CALLF);
 #undef CALLF
     return;
