@@ -1,0 +1,18 @@
+"""Randomised constructor arguments (the reference's kwargs: vit.py:107-108, deepvit.py:113-114, cait.py:150-151), random batch: forward + full
+backward through the C ABI against the oracle on identical weights.  A fixed-seed slice of tools/fuzz_configs.py (rectangular images and patches,
+one head, to_out as the identity, mean pooling, widths that are not multiples of 4, one- and two-token images ...)."""
+import os
+import sys
+
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("compute,n,seed", [("fp32", 30, 0), ("bf16x3", 16, 2), ("bf16", 30, 1)])
+def test_random_configurations_match_the_oracle(compute, n, seed):
+    import fuzz_configs
+    fails = fuzz_configs.run(n, seed, compute)
+    assert not fails, fails

@@ -1,0 +1,110 @@
+#!/usr/bin/env python3
+"""Randomised-configuration parity sweep: random ViT / DeepViT / CaiT constructor arguments (the reference's kwargs, vit.py:107-108,
+deepvit.py:113-114, cait.py:150-151), random batch, forward + full backward on the GPU through the C ABI against the oracle
+(oracle/ref_torch.py, fp64) on identical weights and inputs.
+
+    python tools/fuzz_configs.py [n=40] [seed=0] [compute=fp32|bf16|bf16x3]
+
+fp32 / bf16x3: logits <= 1e-3 abs, every gradient <= 1e-3 of its tensor's max (north_star's tolerance).  bf16: dims are drawn as multiples of 64
+(the mode's requirement); gates = about twice what 80 configurations produced on MI355X (`profiles/r6/fuzz_*_r6ao.log`): logits 2e-2 of
+max(1, max |logit|), gradients 9e-2 of the tensor's max -- 1.7e-1 for the [h, h] head-mix matrices (reattn_weights, mix_heads_*), whose gradient is
+a sum over every score of the batch that largely cancels (with one head it is a single number).  Prints one line per configuration and a
+summary; exit code 1 on any failure.  tests/test_gpu_fuzz.py runs a fixed-seed slice of it."""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "vit-tensorflow_amd")]
+
+
+def draw(rng, compute):
+    variant = ["vit", "deepvit", "cait"][int(rng.integers(0, 3))]
+    lowp = compute != "fp32"
+    ph, pw = (int(rng.choice([4, 8, 16])), int(rng.choice([4, 8, 16])))
+    if variant != "vit":
+        pw = ph                                   # deepvit.py:117 / cait.py:155: int sizes only
+    gh, gw = int(rng.integers(1, 7)), int(rng.integers(1, 7))
+    if variant != "vit":
+        gw = gh
+    if variant == "cait" and gh * gw < 2:
+        gh = gw = 2
+    H, W = gh * ph, gw * pw
+    heads = int(rng.choice([1, 2, 3, 4, 6]))
+    if lowp:
+        dim_head = 64 if rng.random() < 0.6 else int(rng.choice([32, 64, 128]))
+        if (heads * dim_head) % 64:
+            heads = 2
+        dim = 64 * int(rng.integers(1, 5))
+        mlp = 64 * int(rng.integers(1, 7))
+    else:
+        dim_head = int(rng.choice([8, 12, 16, 20, 32, 64]))
+        dim = int(rng.choice([24, 36, 40, 64, 72, 100, 128]))
+        mlp = int(rng.choice([20, 48, 64, 100, 130, 192]))
+    kw = dict(image_size=(H, W) if variant == "vit" else H, patch_size=(ph, pw) if variant == "vit" else ph,
+              num_classes=int(rng.choice([3, 10, 17, 64, 100])), dim=dim, depth=int(rng.integers(1, 4)), heads=heads, mlp_dim=mlp, dim_head=dim_head)
+    if variant == "vit":
+        kw["pool"] = "cls" if rng.random() < 0.6 else "mean"
+        if heads == 1 and rng.random() < 0.4:
+            kw["dim_head"] = dim                  # vit.py:53: to_out is the identity
+            if lowp and dim % 64:
+                kw["dim_head"] = 64
+    if variant == "cait":
+        kw["cls_depth"] = int(rng.integers(1, 3))
+    b = int(rng.integers(1, 6))
+    return variant, kw, b
+
+
+def run(n, seed, compute):
+    from oracle import ref_torch, spec
+    from vit_tensorflow import ViT
+    from vit_tensorflow.cait import CaiT
+    from vit_tensorflow.deepvit import DeepViT
+    classes = {"vit": ViT, "deepvit": DeepViT, "cait": CaiT}
+    ltol, gtol, mixtol = {"fp32": (1e-3, 1e-3, 1e-3), "bf16x3": (1e-3, 1e-3, 1e-3), "bf16": (2e-2, 9e-2, 1.7e-1)}[compute]
+    is_mix = lambda k: k.endswith("reattn_weights") or "mix_heads" in k
+    rng = np.random.default_rng(seed)
+    fails, worst_l, worst_g = [], 0.0, 0.0
+    t0 = time.time()
+    for i in range(n):
+        variant, kw, b = draw(rng, compute)
+        cfg = spec.make_config(variant, **kw)
+        P = spec.init_params(cfg, 1000 + i, randomize_all=True)
+        H, W = cfg["image_size"]
+        img = rng.standard_normal((b, H, W, 3)).astype(np.float32)
+        dl = (rng.standard_normal((b, kw["num_classes"])) / 2).astype(np.float32)
+        tag = f"#{i} {variant} b={b} {kw}"
+        try:
+            ref_logits, ref_grads, _ = ref_torch.forward_backward(cfg, P, img, dl)
+            m = classes[variant](**kw, compute=compute, max_batch=b, seed=0)
+            m.load_state_dict({k: v.astype(np.float32) for k, v in P.items()})
+            logits = m(img, training=False)
+            grads, _ = m.backward(dl)
+            le = float(np.abs(logits - ref_logits).max())
+            lscale = float(np.abs(ref_logits).max()) + 1e-30
+            rel = {k: float(np.abs(grads[k] - ref_grads[k]).max() / (np.abs(ref_grads[k]).max() + 1e-30)) for k in ref_grads}
+            ge, gk = max((v / (mixtol if is_mix(k) else gtol), k) for k, v in rel.items())   # worst in units of its gate
+            ge = rel[gk]
+            lerr = le if compute != "bf16" else le / max(1.0, lscale)
+            ok = lerr <= ltol and all(np.isfinite(v) and v <= (mixtol if is_mix(k) else gtol) for k, v in rel.items()) and np.isfinite(le)
+            worst_l, worst_g = max(worst_l, lerr), max(worst_g, ge)
+            print(f"{'ok  ' if ok else 'FAIL'} {tag}: logits {le:.2e} (max |logit| {lscale:.2f}), worst gradient {ge:.2e} ({gk})", flush=True)
+            if not ok:
+                fails.append(tag)
+            del m
+        except Exception as ex:   # an error on a configuration the reference accepts is a failure too
+            print(f"FAIL {tag}: {type(ex).__name__}: {ex}", flush=True)
+            fails.append(tag)
+    print(f"{n - len(fails)} / {n} configurations within the {compute} gates (logits {ltol:g}, gradients {gtol:g}, head-mix matrices {mixtol:g}); worst logits {worst_l:.2e}, "
+          f"worst gradient (nearest its gate) {worst_g:.2e}; "
+          f"{time.time() - t0:.0f} s")
+    for f in fails:
+        print("failed:", f)
+    return fails
+
+
+if __name__ == "__main__":
+    sys.exit(1 if run(int(sys.argv[1]) if len(sys.argv) > 1 else 40, int(sys.argv[2]) if len(sys.argv) > 2 else 0,
+                      sys.argv[3] if len(sys.argv) > 3 else "fp32") else 0)
