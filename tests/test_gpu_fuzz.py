@@ -16,3 +16,12 @@ def test_random_configurations_match_the_oracle(compute, n, seed):
     import fuzz_configs
     fails = fuzz_configs.run(n, seed, compute)
     assert not fails, fails
+
+
+@pytest.mark.parametrize("compute,n,seed", [("fp32", 16, 11), ("bf16x3", 12, 11), ("bf16", 24, 11)])
+def test_token_counts_around_the_attention_dispatch_boundaries(compute, n, seed):
+    """63 .. 400 tokens per image: the 4 / 6 / 14 / 18-tile instantiations of the fused attention kernels, the materialised path past 288 tokens, the
+    64-key sweeps of the DeepViT / CaiT head-axis kernels."""
+    import fuzz_configs
+    fails = fuzz_configs.run(n, seed, compute, "tokens")
+    assert not fails, fails
