@@ -25,3 +25,11 @@ def test_token_counts_around_the_attention_dispatch_boundaries(compute, n, seed)
     import fuzz_configs
     fails = fuzz_configs.run(n, seed, compute, "tokens")
     assert not fails, fails
+
+
+@pytest.mark.parametrize("compute,n,seed", [("fp32", 20, 31), ("bf16", 20, 31)])
+def test_random_sibling_models_match_the_oracle(compute, n, seed):
+    """parallel_vit.ViT with 2-3 branches and vit_with_patch_merger.ViT with a random merge layer / token count"""
+    import fuzz_configs
+    fails = fuzz_configs.run(n, seed, compute, "siblings")
+    assert not fails, fails

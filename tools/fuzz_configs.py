@@ -3,8 +3,9 @@
 deepvit.py:113-114, cait.py:150-151), random batch, forward + full backward on the GPU through the C ABI against the oracle
 (oracle/ref_torch.py, fp64) on identical weights and inputs.
 
-    python tools/fuzz_configs.py [n=40] [seed=0] [compute=fp32|bf16|bf16x3] [mode=shapes|tokens]
+    python tools/fuzz_configs.py [n=40] [seed=0] [compute=fp32|bf16|bf16x3] [mode=shapes|tokens|siblings]
 
+mode "siblings": parallel_vit.ViT (2-3 branches) and vit_with_patch_merger.ViT (random merge layer / token count).
 mode "tokens": 64 .. 400 tokens per image (the dispatch boundaries of the fused attention kernels and of the 64-key sweeps of the head-axis kernels).
 
 fp32 / bf16x3: logits <= 1e-3 abs, every gradient <= 1e-3 of its tensor's max (north_star's tolerance).  bf16: dims are drawn as multiples of 64
@@ -22,8 +23,22 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "vit-tensorflow_amd")]
 
 
-def draw(rng, compute):
-    variant = ["vit", "deepvit", "cait"][int(rng.integers(0, 3))]
+def draw_siblings(rng, compute):
+    """parallel_vit.ViT (parallel_vit.py:119-172) and vit_with_patch_merger.ViT (vit_with_patch_merger.py:136-183): the ViT kwargs plus their own"""
+    _, kw, b = draw(rng, compute, force="vit")
+    kw.pop("pool", None)
+    if rng.random() < 0.5:
+        kw["num_parallel_branches"] = int(rng.integers(2, 4))
+        kw["pool"] = "cls" if rng.random() < 0.5 else "mean"
+        return "parallel_vit", kw, b
+    kw["depth"] = int(rng.integers(2, 5))
+    kw["patch_merge_layer"] = None if rng.random() < 0.5 else int(rng.integers(1, kw["depth"]))
+    kw["patch_merge_num_tokens"] = int(rng.integers(1, 10))
+    return "patch_merger", kw, b
+
+
+def draw(rng, compute, force=None):
+    variant = force or ["vit", "deepvit", "cait"][int(rng.integers(0, 3))]
     lowp = compute != "fp32"
     ph, pw = (int(rng.choice([4, 8, 16])), int(rng.choice([4, 8, 16])))
     if variant != "vit":
@@ -87,15 +102,17 @@ def run(n, seed, compute, mode="shapes"):
     from vit_tensorflow import ViT
     from vit_tensorflow.cait import CaiT
     from vit_tensorflow.deepvit import DeepViT
-    classes = {"vit": ViT, "deepvit": DeepViT, "cait": CaiT}
+    from vit_tensorflow.parallel_vit import ViT as ParallelViT
+    from vit_tensorflow.vit_with_patch_merger import ViT as MergerViT
+    classes = {"vit": ViT, "deepvit": DeepViT, "cait": CaiT, "parallel_vit": ParallelViT, "patch_merger": MergerViT}
     ltol, gtol, mixtol = {"fp32": (1e-3, 1e-3, 1e-3), "bf16x3": (1e-3, 1e-3, 1e-3), "bf16": (2e-2, 9e-2, 1.7e-1)}[compute]
     is_mix = lambda k: k.endswith("reattn_weights") or "mix_heads" in k
     rng = np.random.default_rng(seed)
     fails, worst_l, worst_g = [], 0.0, 0.0
     t0 = time.time()
     for i in range(n):
-        variant, kw, b = (draw_tokens if mode == "tokens" else draw)(rng, compute)
-        cfg = spec.make_config(variant, **kw)
+        variant, kw, b = {"tokens": draw_tokens, "siblings": draw_siblings}.get(mode, draw)(rng, compute)
+        cfg = spec.make_config("vit" if variant == "parallel_vit" else variant, **kw)
         P = spec.init_params(cfg, 1000 + i, randomize_all=True)
         H, W = cfg["image_size"]
         img = rng.standard_normal((b, H, W, 3)).astype(np.float32)
