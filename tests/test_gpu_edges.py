@@ -5,28 +5,39 @@ import numpy as np
 import pytest
 
 from oracle import ref_numpy, ref_torch, spec
-from util import gate, make_engine_model, oracle_cfg, rand_images
+from util import rel_max_err, gate, make_engine_model, oracle_cfg, rand_images
 from vit_tensorflow import _native as N
 
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("name,compute,tol", [("vit_small", "fp32", 1e-4), ("vit_bf16_small", "bf16", 6e-3), ("cait_small", "fp32", 1e-4)])
-def test_batch_geometry_changes_on_one_handle(name, compute, tol):
-    """b = 4 -> 1 -> 3 on the same handle: each call must match the oracle (stale rows of the larger batch must not leak in)."""
+@pytest.mark.parametrize("name,compute,tol,gtol", [("vit_small", "fp32", 1e-4, 1e-3), ("vit_bf16_small", "bf16", 6e-3, 4e-2), ("cait_small", "fp32", 1e-4, 1e-3),
+                                                   ("cait_bf16_small", "bf16", 2e-2, 9e-2), ("deepvit_bf16_small", "bf16", 2e-2, 9e-2)])
+def test_batch_geometry_changes_on_one_handle(name, compute, tol, gtol):
+    """b = 4 -> 1 -> 3 on the same handle, then a smaller image: each call must match the oracle -- logits AND every gradient (stale rows of the larger
+    batch must not leak in; nothing that is not an activation may be touched by the re-zeroing of the row padding).
+    Round 6: the bf16 CaiT rows are the regression test of the concatenated [to_q | to_kv] operand copies, which were registered as activation
+    buffers and wiped by the first call with another geometry (found by tools/fuzz_configs.py "sequences"): until this round the backward of the
+    changed geometry was only checked for finiteness."""
+    from oracle import ref_torch
     cfg = oracle_cfg(name)
     P = spec.init_params(cfg, 1, randomize_all=True)
     m = make_engine_model(name, compute, 4, P)
-    for b in (4, 1, 3, 4):
-        img = rand_images(cfg, b, seed=10 + b)
+    H, W = cfg["image_size"]
+    ph, pw = cfg["patch_size"]
+    for b, hw in ((4, None), (1, None), (3, None), (4, None), (2, (H - ph, W - pw))):
+        img = rand_images(cfg, b, seed=10 + b, hw=hw)
         got = m(img, training=False)
-        ref = ref_numpy.forward(cfg, P, img)
+        dl = (np.random.default_rng(b).standard_normal(got.shape) / b).astype(np.float32)
+        ref, rg, _ = ref_torch.forward_backward(cfg, P, img, dl)
         assert got.shape == ref.shape
         gate(np.abs(got - ref).max() / max(1.0, np.abs(ref).max()), tol, f"logits at b={b}", "logits")
-        # backward on the changed geometry as well
-        dl = np.random.default_rng(b).standard_normal(ref.shape).astype(np.float32) / b
         grads, _ = m.backward(dl)
-        assert all(np.isfinite(g).all() for g in grads.values())
+        for k in rg:
+            if np.asarray(rg[k]).size == 1 and compute == "bf16":
+                continue   # (one-element head-mix tensors: a single, almost completely cancelling sum -- not resolvable in bf16, see tools/fuzz_configs.py)
+            mix = k.endswith("reattn_weights") or "mix_heads" in k
+            gate(rel_max_err(grads[k], rg[k]), (1.7e-1 if mix else gtol) if compute == "bf16" else gtol, f"{k} at b={b} image {img.shape[1:3]}", "gradients after a geometry change")
 
 
 def test_batch_larger_than_max_batch():

@@ -33,3 +33,13 @@ def test_random_sibling_models_match_the_oracle(compute, n, seed):
     import fuzz_configs
     fails = fuzz_configs.run(n, seed, compute, "siblings")
     assert not fails, fails
+
+
+@pytest.mark.parametrize("compute,n,seed", [("fp32", 12, 41), ("bf16", 20, 41)])
+def test_call_sequences_on_one_handle_match_the_oracle(compute, n, seed):
+    """One handle per random configuration, five calls with a changing batch / a smaller image / new weights / two backward passes on one forward,
+    every call against the oracle.  (Round 6: this sweep found that a bf16 CaiT handle computed its patch-stage attention from zeroed [to_q | to_kv]
+    operand copies after the first change of geometry -- profiles/r6/fuzz_sequences_bf16_BEFORE_the_qkvcat_fix_r6as.log.)"""
+    import fuzz_configs
+    fails = fuzz_configs.run_sequences(n, seed, compute)
+    assert not fails, fails

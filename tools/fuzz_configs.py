@@ -3,8 +3,9 @@
 deepvit.py:113-114, cait.py:150-151), random batch, forward + full backward on the GPU through the C ABI against the oracle
 (oracle/ref_torch.py, fp64) on identical weights and inputs.
 
-    python tools/fuzz_configs.py [n=40] [seed=0] [compute=fp32|bf16|bf16x3] [mode=shapes|tokens|siblings]
+    python tools/fuzz_configs.py [n=40] [seed=0] [compute=fp32|bf16|bf16x3] [mode=shapes|tokens|siblings|sequences]
 
+mode "sequences": one handle per configuration, several calls with changing batch / image size / weights, one or two backward passes per forward.
 mode "siblings": parallel_vit.ViT (2-3 branches) and vit_with_patch_merger.ViT (random merge layer / token count).
 mode "tokens": 64 .. 400 tokens per image (the dispatch boundaries of the fused attention kernels and of the 64-key sweeps of the head-axis kernels).
 
@@ -151,6 +152,76 @@ def run(n, seed, compute, mode="shapes"):
     return fails
 
 
+def run_sequences(n, seed, compute, steps=5):
+    """Stale-state hunt: ONE handle per random configuration, then `steps` calls with a random batch (<= the handle's plan), a random SMALLER image
+    (vit.py:165: pos_embedding[:, :n + 1] -- fewer patches than image_size are legal), new weights every now and then (the bf16 operand refresh),
+    and sometimes two backward passes on one forward; every call against the oracle."""
+    from oracle import ref_torch, spec
+    from vit_tensorflow import ViT
+    from vit_tensorflow.cait import CaiT
+    from vit_tensorflow.deepvit import DeepViT
+    classes = {"vit": ViT, "deepvit": DeepViT, "cait": CaiT}
+    ltol, gtol, mixtol = {"fp32": (1e-3, 1e-3, 1e-3), "bf16x3": (1e-3, 1e-3, 1e-3), "bf16": (2e-2, 9e-2, 1.7e-1)}[compute]
+    is_mix = lambda k: k.endswith("reattn_weights") or "mix_heads" in k
+    rng = np.random.default_rng(seed)
+    fails, calls = [], 0
+    t0 = time.time()
+    for i in range(n):
+        variant, kw, _ = draw(rng, compute)
+        cfg = spec.make_config(variant, **kw)
+        (H, W), (ph, pw) = cfg["image_size"], cfg["patch_size"]
+        P = spec.init_params(cfg, 2000 + i, randomize_all=True)
+        m = classes[variant](**kw, compute=compute, max_batch=5, seed=0)
+        m.load_state_dict({k: v.astype(np.float32) for k, v in P.items()})
+        for st in range(steps):
+            b = int(rng.integers(1, 6))
+            gh, gw = H // ph, W // pw
+            if rng.random() < 0.4:
+                gh, gw = int(rng.integers(1, gh + 1)), int(rng.integers(1, gw + 1))
+                if variant != "vit":
+                    gw = gh = min(gh, gw)
+                if variant == "cait" and gh * gw < 2:
+                    gh, gw = H // ph, W // pw
+            if rng.random() < 0.3:
+                P = spec.init_params(cfg, 3000 + 17 * i + st, randomize_all=True)
+                m.load_state_dict({k: v.astype(np.float32) for k, v in P.items()})
+            img = rng.standard_normal((b, gh * ph, gw * pw, 3)).astype(np.float32)
+            tag = f"#{i}.{st} {variant} b={b} image {gh * ph}x{gw * pw} of {kw}"
+            try:
+                logits = m(img, training=False)
+                nback = 0 if rng.random() < 0.1 else (2 if rng.random() < 0.25 else 1)
+                ok, msg = True, ""
+                ref_logits = None
+                for _ in range(max(1, nback)):
+                    dl = (rng.standard_normal((b, kw["num_classes"])) / 2).astype(np.float32)
+                    ref_logits, ref_grads, _ = ref_torch.forward_backward(cfg, P, img, dl)
+                    if nback == 0:
+                        break
+                    grads, _g = m.backward(dl)
+                    rel = {k: float(np.abs(grads[k] - ref_grads[k]).max() / (np.abs(ref_grads[k]).max() + 1e-30)) for k in ref_grads}
+                    if compute == "bf16":
+                        rel = {k: v for k, v in rel.items() if np.asarray(ref_grads[k]).size > 1}
+                    bad = {k: v for k, v in rel.items() if not (np.isfinite(v) and v <= (mixtol if is_mix(k) else gtol))}
+                    if bad:
+                        ok, msg = False, f"gradients {bad}"
+                le = float(np.abs(logits - ref_logits).max())
+                lerr = le if compute != "bf16" else le / max(1.0, float(np.abs(ref_logits).max()))
+                if not (np.isfinite(le) and lerr <= ltol):
+                    ok, msg = False, msg + f" logits {le:.2e}"
+                calls += 1
+                if not ok:
+                    print(f"FAIL {tag}: {msg}", flush=True)
+                    fails.append(tag)
+            except Exception as ex:
+                print(f"FAIL {tag}: {type(ex).__name__}: {ex}", flush=True)
+                fails.append(tag)
+        del m
+    print(f"{calls - len(fails)} / {calls} calls on {n} handles within the {compute} gates; {time.time() - t0:.0f} s")
+    return fails
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 4 and sys.argv[4] == "sequences":
+        sys.exit(1 if run_sequences(int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]) else 0)
     sys.exit(1 if run(int(sys.argv[1]) if len(sys.argv) > 1 else 40, int(sys.argv[2]) if len(sys.argv) > 2 else 0,
                       sys.argv[3] if len(sys.argv) > 3 else "fp32", sys.argv[4] if len(sys.argv) > 4 else "shapes") else 0)

@@ -1497,8 +1497,12 @@ static int engine_create_body(vitx_engine* e, const vitx_config& cfg, std::strin
         if (cat) {
           Dense& w = bp.qkvcat;
           w.in = d; w.out = 3 * inner; w.in_k = (int)round_up(d, 64); w.out_k = (int)round_up(3 * inner, 64);
-          DALLOC(w.wt, (size_t)round_up(w.out, 256) * w.in_k * 2, true);
-          DALLOC(w.wn, (size_t)round_up(w.in, 256) * w.out_k * 2, true);
+          // NOT t-buffers (round 6; found by tools/fuzz_configs.py "sequences"): ensure_geometry re-zeroes every registered T buffer when the batch
+          // or image size of a handle changes, and these are WEIGHTS -- registered (as they were since round 5) they were wiped by the first call
+          // with another geometry and stayed zero until the next parameter update refreshed them: a bf16 CaiT handle evaluated at a second batch
+          // size computed its patch-stage attention from q = k = v = 0 (logits off by ~1e-2, every gradient through to_q / to_kv zero).
+          DALLOC(w.wt, (size_t)round_up(w.out, 256) * w.in_k * 2, false);
+          DALLOC(w.wn, (size_t)round_up(w.in, 256) * w.out_k * 2, false);
         }
         bp.mix_pre = find_param(e, pre + ".attn.mix_heads_pre_attn");
         bp.mix_post = find_param(e, pre + ".attn.mix_heads_post_attn");
