@@ -269,3 +269,58 @@ def test_mpp_matches_the_oracle(key, literal, drop):
             assert not np.asarray(grads["encoder." + k]).any(), k
         else:
             _close(grads["encoder." + k], t.grad.numpy(), gtol, "encoder." + k, nrm)
+
+
+@pytest.mark.parametrize("compute", ["fp32", "bf16"])
+def test_wrappers_follow_a_changing_batch_on_one_object(compute):
+    """MAE and SimMIM objects (mae.py:47-92, simmim.py:86-130) called with b = 3 -> 1 -> 4 -> 2 images: loss, prediction and every gradient
+    against the oracle at each call (the encoder / decoder handles re-establish their row padding; nothing of the previous batch leaks in)."""
+    from vit_tensorflow.mae import MAE
+    from vit_tensorflow.simmim import SimMIM
+    bmax = 4
+    q = ref_torch.bf16_round if compute == "bf16" else None
+    tol = 1e-4 if compute == "fp32" else 1e-2
+    # --- MAE
+    ecfg, E, enc = _encoder(compute, bmax)
+    dkw = dict(DEC[compute])
+    mae = MAE(image_size=ecfg["image_size"], encoder=enc, masking_ratio=0.75, literal_loss=False, seed=3, **dkw)
+    Wm = _randomize(mae, 11)
+    dcfg = spec.make_config("vit", image_size=ecfg["image_size"], patch_size=ecfg["patch_size"], num_classes=1, dim=dkw["decoder_dim"],
+                            depth=dkw["decoder_depth"], heads=dkw["decoder_heads"], mlp_dim=4 * dkw["decoder_dim"], dim_head=dkw["decoder_dim_head"])
+    D = spec.init_params(dcfg, 5, randomize_all=True)
+    mae.decoder.load_state_dict({k: np.asarray(a, np.float32) for k, a in D.items()})
+    npat, _ = mae.num_masked()
+    for step, b in enumerate((3, 1, 4, 2)):
+        img = _images(ecfg, b, 20 + step)
+        perm = np.argsort(np.random.default_rng(30 + step).uniform(size=(b, npat)), axis=-1).astype(np.int32)
+        loss = mae(img, indices=perm)
+        grads = mae.backward()
+        rl, rpred, ge, gd, gw = RW.mae_forward_backward(ecfg, dcfg, E, D, Wm, img, perm, 0.75, literal_loss=False, q=q)
+        assert abs(loss - rl) <= tol * abs(rl), (b, loss, rl)
+        _close(mae.read("pred"), rpred, tol, f"pred_pixel_values at b={b}")
+        gtol = tol if compute == "fp32" else 2e-2
+        for k, r in gw.items():
+            _close(grads[k], r, gtol, f"{k} at b={b}")
+        for k, r in ge.items():
+            _close(grads["encoder." + k], r, gtol, f"encoder.{k} at b={b}")
+        for k, r in gd.items():
+            if k.startswith("transformer."):
+                _close(grads["decoder." + k], r, gtol, f"decoder.{k} at b={b}")
+    # --- SimMIM (its own encoder handle)
+    ecfg, E, enc = _encoder(compute, bmax)
+    mim = SimMIM(image_size=ecfg["image_size"], encoder=enc, masking_ratio=0.5, seed=3)
+    Ws = _randomize(mim, 12)
+    npat, nm = mim.num_masked()
+    for step, b in enumerate((3, 1, 4, 2)):
+        img = _images(ecfg, b, 40 + step)
+        midx = np.argsort(-np.random.default_rng(50 + step).uniform(size=(b, npat)), axis=-1)[:, :nm].astype(np.int32)
+        loss = mim(img, indices=midx)
+        grads = mim.backward()
+        rl, rpred, ge, gw = RW.simmim_forward_backward(ecfg, E, Ws, img, midx, 0.5, q=q)
+        assert abs(loss - rl) <= tol * abs(rl), (b, loss, rl)
+        _close(mim.read("pred"), rpred, tol, f"pred_pixel_values at b={b}")
+        gtol, nrm = (tol, False) if compute == "fp32" else (8e-2, True)
+        for k, r in gw.items():
+            _close(grads[k], r, gtol, f"{k} at b={b}", nrm)
+        for k, r in ge.items():
+            _close(grads["encoder." + k], r, gtol, f"encoder.{k} at b={b}", nrm)

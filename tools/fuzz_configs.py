@@ -3,7 +3,7 @@
 deepvit.py:113-114, cait.py:150-151), random batch, forward + full backward on the GPU through the C ABI against the oracle
 (oracle/ref_torch.py, fp64) on identical weights and inputs.
 
-    python tools/fuzz_configs.py [n=40] [seed=0] [compute=fp32|bf16|bf16x3] [mode=shapes|tokens|siblings|sequences]
+    python tools/fuzz_configs.py [n=40] [seed=0] [compute=fp32|bf16|bf16x3] [mode=shapes|tokens|siblings|sequences|sibling_sequences]
 
 mode "sequences": one handle per configuration, several calls with changing batch / image size / weights, one or two backward passes per forward.
 mode "siblings": parallel_vit.ViT (2-3 branches) and vit_with_patch_merger.ViT (random merge layer / token count).
@@ -152,7 +152,7 @@ def run(n, seed, compute, mode="shapes"):
     return fails
 
 
-def run_sequences(n, seed, compute, steps=5):
+def run_sequences(n, seed, compute, steps=5, siblings=False):
     """Stale-state hunt: ONE handle per random configuration, then `steps` calls with a random batch (<= the handle's plan), a random SMALLER image
     (vit.py:165: pos_embedding[:, :n + 1] -- fewer patches than image_size are legal), new weights every now and then (the bf16 operand refresh),
     and sometimes two backward passes on one forward; every call against the oracle."""
@@ -160,15 +160,17 @@ def run_sequences(n, seed, compute, steps=5):
     from vit_tensorflow import ViT
     from vit_tensorflow.cait import CaiT
     from vit_tensorflow.deepvit import DeepViT
-    classes = {"vit": ViT, "deepvit": DeepViT, "cait": CaiT}
+    from vit_tensorflow.parallel_vit import ViT as ParallelViT
+    from vit_tensorflow.vit_with_patch_merger import ViT as MergerViT
+    classes = {"vit": ViT, "deepvit": DeepViT, "cait": CaiT, "parallel_vit": ParallelViT, "patch_merger": MergerViT}
     ltol, gtol, mixtol = {"fp32": (1e-3, 1e-3, 1e-3), "bf16x3": (1e-3, 1e-3, 1e-3), "bf16": (2e-2, 9e-2, 1.7e-1)}[compute]
     is_mix = lambda k: k.endswith("reattn_weights") or "mix_heads" in k
     rng = np.random.default_rng(seed)
     fails, calls = [], 0
     t0 = time.time()
     for i in range(n):
-        variant, kw, _ = draw(rng, compute)
-        cfg = spec.make_config(variant, **kw)
+        variant, kw, _ = (draw_siblings if siblings else draw)(rng, compute)
+        cfg = spec.make_config("vit" if variant == "parallel_vit" else variant, **kw)
         (H, W), (ph, pw) = cfg["image_size"], cfg["patch_size"]
         P = spec.init_params(cfg, 2000 + i, randomize_all=True)
         m = classes[variant](**kw, compute=compute, max_batch=5, seed=0)
@@ -178,7 +180,7 @@ def run_sequences(n, seed, compute, steps=5):
             gh, gw = H // ph, W // pw
             if rng.random() < 0.4:
                 gh, gw = int(rng.integers(1, gh + 1)), int(rng.integers(1, gw + 1))
-                if variant != "vit":
+                if variant in ("deepvit", "cait"):
                     gw = gh = min(gh, gw)
                 if variant == "cait" and gh * gw < 2:
                     gh, gw = H // ph, W // pw
@@ -221,7 +223,7 @@ def run_sequences(n, seed, compute, steps=5):
 
 
 if __name__ == "__main__":
-    if len(sys.argv) > 4 and sys.argv[4] == "sequences":
-        sys.exit(1 if run_sequences(int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]) else 0)
+    if len(sys.argv) > 4 and sys.argv[4] in ("sequences", "sibling_sequences"):
+        sys.exit(1 if run_sequences(int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], siblings=sys.argv[4] == "sibling_sequences") else 0)
     sys.exit(1 if run(int(sys.argv[1]) if len(sys.argv) > 1 else 40, int(sys.argv[2]) if len(sys.argv) > 2 else 0,
                       sys.argv[3] if len(sys.argv) > 3 else "fp32", sys.argv[4] if len(sys.argv) > 4 else "shapes") else 0)

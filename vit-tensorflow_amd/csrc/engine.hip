@@ -1657,7 +1657,11 @@ static int engine_create_body(vitx_engine* e, const vitx_config& cfg, std::strin
   const int64_t crow_max = cait ? round_up(B * (1 + e->np_max), 256) + 320 : e->mp;
   const int64_t rmax = std::max(e->mp, crow_max);
   DALLOC(e->img_dev, (size_t)B * c.image_h * c.image_w * c.channels * 4, false);
-  DALLOC(e->patches, (size_t)e->mpp * e->pd_k * esz, true);
+  // (NOT a t-buffer: its row padding is kept by prepare_patch_rows, which every writer calls.  Registered -- as it was until round 6 -- it was wiped by
+  //  the ensure_geometry of a LATER call of the same logical step: MAE / SimMIM run patch_tokens_forward [writes e->patches] and then
+  //  transformer_forward on another geometry (b, visible tokens), so from the second batch size on the patch-embedding weight gradient of a bf16
+  //  wrapper was computed from zeroed patches = exactly zero.  tests/test_gpu_wrappers.py::test_wrappers_follow_a_changing_batch_on_one_object)
+  DALLOC(e->patches, (size_t)e->mpp * e->pd_k * esz, false);
   DALLOC(e->pooled, (size_t)e->bp * d * 4, false);
   DALLOC(e->yh, (size_t)e->bp * d * esz, true);
   DALLOC(e->mean_h, (size_t)e->bp * 4, false);
