@@ -215,6 +215,15 @@ def test_efficient_vit_shell_matches_the_oracle(compute, pool, middle):
         assert checked >= 10
     if middle == "torch":
         assert m.last_transformer_grads and all(v is not None for v in m.last_transformer_grads.values())
+    # another batch size on the same objects (round 6: the bf16 operand buffers' row padding is re-established per geometry; nothing else may be wiped)
+    for b2 in (1, 2):
+        rl2, rg2, rdimg2, _ = R.shell_forward_backward(cfg, P, img[:b2], dl[:b2], ref_mid, q=q)
+        l2 = m(img[:b2], training=False)
+        g2, dimg2 = m.backward(dl[:b2], want_dimg=True)
+        assert np.abs(l2 - rl2).max() <= ltol * max(1.0, np.abs(rl2).max()), b2
+        for k, r in rg2.items():
+            assert np.abs(g2[k] - r).max() <= gtol * max(1e-6, np.abs(r).max()) + 1e-7, (b2, k)
+        assert np.abs(dimg2 - rdimg2).max() <= gtol * max(1e-6, np.abs(rdimg2).max()) + 1e-7, b2
     # smaller image than configured: pos_embedding is sliced (efficient.py:45) and the unused rows get zero gradient
     if compute == "fp32" and middle == "torch":
         img2 = img[:, :16, :24]

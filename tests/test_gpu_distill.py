@@ -122,3 +122,34 @@ def test_distill_errors():
     img = np.zeros((2, 32, 32, 3), np.float32)
     with pytest.raises(AssertionError, match="labels must be"):
         w((img, np.zeros((2, 3), np.float32)))
+
+
+@pytest.mark.parametrize("compute", ["fp32", "bf16"])
+def test_distill_wrapper_follows_a_changing_batch_on_one_object(compute):
+    """b = 4 -> 1 -> 3 -> 2 on ONE DistillWrapper / student handle: loss, both logits and every gradient against the oracle at each call (round 6:
+    the row padding of the bf16 operand buffers is re-established per geometry; nothing that is not an activation may be wiped by it)."""
+    from vit_tensorflow.distill import DistillWrapper
+    cfg, P, stu = _student(compute, "cls", 4)
+    rng = np.random.default_rng(16)
+    holder = {}
+    w = DistillWrapper(teacher=lambda im, training=True: holder["t"], student=stu, temperature=2.0, alpha=0.5, hard=False, literal_loss=False, seed=2)
+    sd = {n: (0.4 * rng.standard_normal(v.shape)).astype(np.float32) for n, v in w.state_dict().items()}
+    w.load_state_dict(sd)
+    q = ref_torch.bf16_round if compute == "bf16" else None
+    tol, gtol = (1e-4, 1e-4) if compute == "fp32" else (1e-2, 2e-2)
+    for b in (4, 1, 3, 2):
+        img = rng.standard_normal((b,) + tuple(cfg["image_size"]) + (3,)).astype(np.float32)
+        labels = np.eye(cfg["num_classes"], dtype=np.float32)[rng.integers(0, cfg["num_classes"], b)]
+        holder["t"] = (2 * rng.standard_normal((b, cfg["num_classes"]))).astype(np.float32)
+        dloss = rng.standard_normal(b).astype(np.float32)
+        loss = w((img, labels), training=False)
+        grads = w.backward(dloss)
+        rl, rsl, rdl, gP, gW = RD.wrapper_forward_backward(cfg, P, {k: v.astype(np.float64) for k, v in sd.items()}, img, labels, holder["t"], dloss=dloss,
+                                                         temperature=2.0, alpha=0.5, hard=False, literal_loss=False, q=q)
+        _close(loss, rl, tol, "loss")
+        _close(w.read("student_logits"), rsl, tol, "student_logits")
+        _close(w.read("distill_logits"), rdl, tol, "distill_logits")
+        for k, r in gW.items():
+            _close(grads[k], r, gtol, f"{k} at b={b}")
+        for k, r in gP.items():
+            _close(grads["student." + k], r, gtol, f"student.{k} at b={b}")

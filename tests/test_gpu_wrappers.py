@@ -324,3 +324,39 @@ def test_wrappers_follow_a_changing_batch_on_one_object(compute):
             _close(grads[k], r, gtol, f"{k} at b={b}", nrm)
         for k, r in ge.items():
             _close(grads["encoder." + k], r, gtol, f"encoder.{k} at b={b}", nrm)
+
+
+@pytest.mark.parametrize("key", ["fp32", "bf16"])
+def test_mpp_follows_a_changing_batch_on_one_object(key):
+    """MPP (mpp.py:140-236) called with b = 3 -> 1 -> 4 -> 2 images on one object: loss, logits and every gradient against the oracle at each call."""
+    import torch
+    from vit_tensorflow import ViT
+    from vit_tensorflow.mpp import MPP
+    ecfg = spec.make_config("vit", **ENC[key])
+    E = spec.init_params(ecfg, 1, randomize_all=True)
+    enc = ViT(**ENC[key], compute=key, max_batch=4, seed=0)
+    enc.load_state_dict({k: np.asarray(a, np.float32) for k, a in E.items()})
+    mean, std = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
+    mpp = MPP(image_size=ecfg["image_size"], transformer=enc, patch_size=8, output_channel_bits=3, mask_prob=0.4, mean=mean, std=std, literal_loss=False, seed=3)
+    Ws = _randomize(mpp, 12)
+    npat, nm = mpp.num_masked()
+    q = ref_torch.bf16_round if key == "bf16" else None
+    tol = 1e-4 if key == "fp32" else 1.5e-2
+    for step, b in enumerate((3, 1, 4, 2)):
+        img = ((np.random.default_rng(60 + step).uniform(0, 1, (b, *ecfg["image_size"], 3)) - mean) / std).astype(np.float32)
+        midx = np.argsort(-np.random.default_rng(70 + step).uniform(size=(b, npat)), axis=-1)[:, :nm].astype(np.int32)
+        loss = mpp(img, indices=midx)
+        grads = mpp.backward()
+        Et = {k: torch.tensor(np.asarray(v, np.float64), requires_grad=True) for k, v in E.items()}
+        Wt = {k: torch.tensor(np.asarray(v, np.float64), requires_grad=True) for k, v in Ws.items()}
+        rl, rlogits = RW.mpp_forward(ecfg, Et, Wt, torch.tensor(np.asarray(img, np.float64)), midx, 3, 1.0, mean, std, literal=False, q=q)
+        rl.backward()
+        assert abs(loss - float(rl.detach())) <= tol * max(1.0, abs(float(rl.detach()))), (b, loss, float(rl.detach()))
+        _close(mpp.read("pred"), rlogits.detach().numpy(), tol if key == "fp32" else 3e-2, "pred_pixel_values")
+        gtol, nrm = (tol, False) if key == "fp32" else (8e-2, True)
+        for k, t in Wt.items():
+            if t.grad is not None:
+                _close(grads[k], t.grad.numpy(), gtol, f"{k} at b={b}", nrm)
+        for k, t in Et.items():
+            if t.grad is not None:
+                _close(grads["encoder." + k], t.grad.numpy(), gtol, f"encoder.{k} at b={b}", nrm)
