@@ -166,6 +166,46 @@ def test_transformer_backward_entry_point(name, compute, b, n):
         m.transformer.backward(dout)
 
 
+@pytest.mark.parametrize("name,compute", [("vit_small", "fp32"), ("vit_bf16_small", "bf16"), ("deepvit_bf16_small", "bf16")])
+def test_transformer_entry_point_follows_changing_token_counts_and_batches(name, compute):
+    """encoder.transformer(tokens) on ONE handle with (b, n) = (2, 5) -> (1, 17) -> (3, 4) -> (2, 17) -> a full forward + backward -> (2, 9): outputs,
+    d(tokens) and parameter gradients against the autograd twin at each call (MAE calls it with b x visible tokens, mae.py:69)."""
+    cfg = oracle_cfg(name)
+    P = spec.init_params(cfg, 1, randomize_all=True)
+    m = make_engine_model(name, compute, 3, P)
+    rng = np.random.default_rng(23)
+    qf = ref_torch.bf16_round if compute == "bf16" else None
+    tol = 1e-4 if compute == "fp32" else BF16_GRAD_RTOL
+
+    def one(b, n):
+        tok = rng.standard_normal((b, n, cfg["dim"])).astype(np.float32)
+        dout = rng.standard_normal((b, n, cfg["dim"])).astype(np.float32)
+        out = m.transformer(tok, training=False)
+        grads, dtok = m.transformer.backward(dout)
+        ref_out, ref_g, ref_dtok = ref_torch.transformer_forward_backward(cfg, P, tok, dout, q=qf)
+        assert np.abs(out - ref_out).max() <= tol * max(1.0, np.abs(ref_out).max()), (b, n)
+        assert np.abs(dtok - ref_dtok).max() <= tol * max(1.0, np.abs(ref_dtok).max()), (b, n)
+        for k, g in grads.items():
+            if k.startswith("transformer."):
+                r = ref_g[k]
+                if compute == "bf16" and r.size == 1:
+                    continue
+                assert np.abs(g - r).max() <= tol * max(1e-6, np.abs(r).max()) + 1e-6, (b, n, k)
+    for b, n in ((2, 5), (1, 17), (3, 4), (2, 17)):
+        one(b, n)
+    img = rand_images(cfg, 2, seed=4)
+    dl = (rng.standard_normal((2, cfg["num_classes"])) / 2).astype(np.float32)
+    logits = m(img, training=False)
+    grads, _ = m.backward(dl)
+    rl, rg, _ = ref_torch.forward_backward(cfg, P, img, dl)
+    assert np.abs(logits - rl).max() <= (1e-4 if compute == "fp32" else BF16_LOGIT_TOL_VS_EXACT) * max(1.0, np.abs(rl).max())
+    for k in rg:
+        if compute == "bf16" and rg[k].size == 1:
+            continue
+        assert rel_max_err(grads[k], rg[k]) <= (1e-3 if compute == "fp32" else 9e-2), k
+    one(2, 9)
+
+
 # ------------------------------------------------------------------------------------------------ bf16 throughput mode
 BF16_LOGIT_TOL_VS_EMULATED = 2.5e-2  # same rounding points, different accumulation order / exp2 / bf16 P in attention (observed 0.6e-2 .. 1.3e-2)
 BF16_LOGIT_TOL_VS_EXACT = 3.4e-2     # 2x the worst observed (0.9e-2 .. 1.7e-2 on logits of std ~1; SURVEY.md 7.2 #1 predicted ~1.5e-2)
