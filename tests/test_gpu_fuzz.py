@@ -43,3 +43,11 @@ def test_call_sequences_on_one_handle_match_the_oracle(compute, n, seed):
     import fuzz_configs
     fails = fuzz_configs.run_sequences(n, seed, compute)
     assert not fails, fails
+
+
+@pytest.mark.parametrize("compute,n,seed", [("fp32", 6, 61), ("bf16", 10, 61)])
+def test_wide_models_match_the_oracle(compute, n, seed):
+    """dim 768 .. 4096, 8 .. 32 heads, mlp_dim up to 8192 on a handful of tokens: every LayerNorm row form, the head-axis kernels at 24 / 32 heads"""
+    import fuzz_configs
+    fails = fuzz_configs.run(n, seed, compute, "wide")
+    assert not fails, fails

@@ -3,9 +3,10 @@
 deepvit.py:113-114, cait.py:150-151), random batch, forward + full backward on the GPU through the C ABI against the oracle
 (oracle/ref_torch.py, fp64) on identical weights and inputs.
 
-    python tools/fuzz_configs.py [n=40] [seed=0] [compute=fp32|bf16|bf16x3] [mode=shapes|tokens|siblings|sequences|sibling_sequences]
+    python tools/fuzz_configs.py [n=40] [seed=0] [compute=fp32|bf16|bf16x3] [mode=shapes|tokens|siblings|wide|sequences|sibling_sequences]
 
 mode "sequences": one handle per configuration, several calls with changing batch / image size / weights, one or two backward passes per forward.
+mode "wide": dim 768 .. 4096, 8 .. 32 heads, mlp_dim up to 8192 on 5 .. 17 tokens.
 mode "siblings": parallel_vit.ViT (2-3 branches) and vit_with_patch_merger.ViT (random merge layer / token count).
 mode "tokens": 64 .. 400 tokens per image (the dispatch boundaries of the fused attention kernels and of the 64-key sweeps of the head-axis kernels).
 
@@ -98,6 +99,23 @@ def draw_tokens(rng, compute):
     return variant, kw, int(rng.integers(1, 3))
 
 
+def draw_wide(rng, compute):
+    """model widths up to the engine's limit (dim <= 4096; heads <= 32 for DeepViT / CaiT) on a handful of tokens: the LayerNorm row forms (d / 256 = 3 .. 16
+    values per lane), the GEMM column counts, the head-axis kernels at 24 / 32 heads"""
+    variant = ["vit", "deepvit", "cait"][int(rng.integers(0, 3))]
+    dim = int(rng.choice([768, 1024, 1280, 1536, 2048, 2560, 3072, 4096]))
+    heads = int(rng.choice([8, 12, 16, 24, 32]))
+    dh = 64 if rng.random() < 0.7 else 128
+    g = int(rng.integers(2, 5))
+    kw = dict(image_size=8 * g, patch_size=8, num_classes=int(rng.choice([10, 1000])), dim=dim, depth=1, heads=heads,
+              mlp_dim=int(rng.choice([dim, 2 * dim, min(4 * dim, 8192)])), dim_head=dh)
+    if variant == "vit":
+        kw["pool"] = "cls" if rng.random() < 0.5 else "mean"
+    if variant == "cait":
+        kw["cls_depth"] = 1
+    return variant, kw, int(rng.integers(1, 4))
+
+
 def run(n, seed, compute, mode="shapes"):
     from oracle import ref_torch, spec
     from vit_tensorflow import ViT
@@ -112,7 +130,7 @@ def run(n, seed, compute, mode="shapes"):
     fails, worst_l, worst_g = [], 0.0, 0.0
     t0 = time.time()
     for i in range(n):
-        variant, kw, b = {"tokens": draw_tokens, "siblings": draw_siblings}.get(mode, draw)(rng, compute)
+        variant, kw, b = {"tokens": draw_tokens, "siblings": draw_siblings, "wide": draw_wide}.get(mode, draw)(rng, compute)
         cfg = spec.make_config("vit" if variant == "parallel_vit" else variant, **kw)
         P = spec.init_params(cfg, 1000 + i, randomize_all=True)
         H, W = cfg["image_size"]
