@@ -25,6 +25,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "vit-tensorflow_amd")]
 
 
+def _ungated(compute):
+    """Tensors of at most this many elements are compared but NOT gated: with one head the head-mix "matrices" (cait.py:97-98, deepvit.py:57) and the
+    head-axis LayerNorm parameters (deepvit.py:59-63) are single numbers -- ONE sum over every score of the batch that cancels almost completely, so
+    the error relative to the tensor's own value says nothing (a float32 run of the ORACLE is 1.3 % off its float64 run on such a gradient of 1.7e-7;
+    bf16 is 30-90 % off at 150-250 tokens while the same configuration is at 1e-5 in BF16X3); in bf16 the same holds for two heads (2 x 2 matrices,
+    a LayerNorm over two values is +-1 whatever they are)."""
+    return 4 if compute == "bf16" else 1
+
+
 def draw_siblings(rng, compute):
     """parallel_vit.ViT (parallel_vit.py:119-172) and vit_with_patch_merger.ViT (vit_with_patch_merger.py:136-183): the ViT kwargs plus their own"""
     _, kw, b = draw(rng, compute, force="vit")
@@ -138,18 +147,19 @@ def run(n, seed, compute, mode="shapes"):
         dl = (rng.standard_normal((b, kw["num_classes"])) / 2).astype(np.float32)
         tag = f"#{i} {variant} b={b} {kw}"
         try:
-            ref_logits, ref_grads, _ = ref_torch.forward_backward(cfg, P, img, dl)
+            ref_logits, ref_grads, ref_dimg = ref_torch.forward_backward(cfg, P, img, dl, want_dimg=True)
             m = classes[variant](**kw, compute=compute, max_batch=b, seed=0)
             m.load_state_dict({k: v.astype(np.float32) for k, v in P.items()})
             logits = m(img, training=False)
-            grads, _ = m.backward(dl)
+            want_dimg = rng.random() < 0.3
+            grads, dimg = m.backward(dl, want_dimg=want_dimg)
+            if want_dimg:   # d(image): the VJP of the patch unfold + projection (vit.py:142-143)
+                grads = dict(grads, **{"d(img)": dimg})
+                ref_grads = dict(ref_grads, **{"d(img)": ref_dimg})
             le = float(np.abs(logits - ref_logits).max())
             lscale = float(np.abs(ref_logits).max()) + 1e-30
             rel = {k: float(np.abs(grads[k] - ref_grads[k]).max() / (np.abs(ref_grads[k]).max() + 1e-30)) for k in ref_grads}
-            if compute == "bf16":   # one-element tensors (the head-mix "matrices" and the head-axis LayerNorm of ONE head): their gradient is a single sum over every
-                # score of the batch that cancels almost completely -- bf16 rounding of the addends is a large fraction of it (30-90 % at 150-250 tokens;
-                # the same configurations are at 1e-5 in BF16X3).  Reported by the line below when they are the worst, not gated.
-                rel = {k: v for k, v in rel.items() if np.asarray(ref_grads[k]).size > 1}
+            rel = {k: v for k, v in rel.items() if np.asarray(ref_grads[k]).size > _ungated(compute)}
             ge, gk = max((v / (mixtol if is_mix(k) else gtol), k) for k, v in rel.items())   # worst in units of its gate
             ge = rel[gk]
             lerr = le if compute != "bf16" else le / max(1.0, lscale)
@@ -219,11 +229,14 @@ def run_sequences(n, seed, compute, steps=5, siblings=False):
                         break
                     grads, _g = m.backward(dl)
                     rel = {k: float(np.abs(grads[k] - ref_grads[k]).max() / (np.abs(ref_grads[k]).max() + 1e-30)) for k in ref_grads}
-                    if compute == "bf16":
-                        rel = {k: v for k, v in rel.items() if np.asarray(ref_grads[k]).size > 1}
+                    rel = {k: v for k, v in rel.items() if np.asarray(ref_grads[k]).size > _ungated(compute)}
                     bad = {k: v for k, v in rel.items() if not (np.isfinite(v) and v <= (mixtol if is_mix(k) else gtol))}
                     if bad:
                         ok, msg = False, f"gradients {bad}"
+                    if rng.random() < 0.3:   # an optimizer step inside the library: the next call must see the new weights (bf16 operand refresh)
+                        m.apply_gradients("sgd" if rng.random() < 0.5 else "adamw", lr=3e-3)
+                        P = {k: np.asarray(v, np.float64) for k, v in m.state_dict().items()}
+                        break
                 le = float(np.abs(logits - ref_logits).max())
                 lerr = le if compute != "bf16" else le / max(1.0, float(np.abs(ref_logits).max()))
                 if not (np.isfinite(le) and lerr <= ltol):
