@@ -51,3 +51,11 @@ def test_wide_models_match_the_oracle(compute, n, seed):
     import fuzz_configs
     fails = fuzz_configs.run(n, seed, compute, "wide")
     assert not fails, fails
+
+
+def test_call_sequences_at_the_shapes_the_big_kernels_take():
+    """256 .. 768 wide, 101 .. 257 tokens, up to 24 images, changing batch / image size / weights on one bf16 handle: thousands of token rows, i.e. the
+    pipelined persistent GEMM with its fused epilogues, the fused attention kernels at 14 / 18 key tiles, split-K weight gradients."""
+    import fuzz_configs
+    fails = fuzz_configs.run_sequences(8, 101, "bf16", steps=3, medium=True)
+    assert not fails, fails

@@ -3,9 +3,10 @@
 deepvit.py:113-114, cait.py:150-151), random batch, forward + full backward on the GPU through the C ABI against the oracle
 (oracle/ref_torch.py, fp64) on identical weights and inputs.
 
-    python tools/fuzz_configs.py [n=40] [seed=0] [compute=fp32|bf16|bf16x3] [mode=shapes|tokens|siblings|wide|sequences|sibling_sequences]
+    python tools/fuzz_configs.py [n=40] [seed=0] [compute=fp32|bf16|bf16x3] [mode=shapes|tokens|siblings|wide|medium|sequences|sibling_sequences|medium_sequences]
 
 mode "sequences": one handle per configuration, several calls with changing batch / image size / weights, one or two backward passes per forward.
+mode "medium" (and "medium_sequences"): 256 .. 768 wide, 101 .. 257 tokens, 4 .. 24 images -- the shapes the big kernels take.
 mode "wide": dim 768 .. 4096, 8 .. 32 heads, mlp_dim up to 8192 on 5 .. 17 tokens.
 mode "siblings": parallel_vit.ViT (2-3 branches) and vit_with_patch_merger.ViT (random merge layer / token count).
 mode "tokens": 64 .. 400 tokens per image (the dispatch boundaries of the fused attention kernels and of the 64-key sweeps of the head-axis kernels).
@@ -125,6 +126,21 @@ def draw_wide(rng, compute):
     return variant, kw, int(rng.integers(1, 4))
 
 
+def draw_medium(rng, compute):
+    """the shapes the big kernels take: 256 .. 768 wide, 101 .. 257 tokens, 4 .. 24 images (thousands of token rows: the pipelined persistent GEMM with
+    256- / 320-row tiles and its fused epilogues, the fused attention kernels at 14 / 18 key tiles, split-K weight gradients)"""
+    variant = ["vit", "vit", "deepvit", "cait"][int(rng.integers(0, 4))]
+    dim = int(rng.choice([256, 384, 512, 768]))
+    g = int(rng.choice([10, 13, 14, 16])) if variant == "vit" else int(rng.choice([8, 10, 12]))
+    kw = dict(image_size=16 * g, patch_size=16, num_classes=int(rng.choice([10, 100, 1000])), dim=dim, depth=int(rng.integers(1, 3)), heads=dim // 64,
+              mlp_dim=int(rng.choice([dim, 2 * dim, 4 * dim])), dim_head=64)
+    if variant == "vit":
+        kw["pool"] = "cls" if rng.random() < 0.5 else "mean"
+    if variant == "cait":
+        kw["cls_depth"] = 1
+    return variant, kw, int(rng.integers(4, 25))
+
+
 def run(n, seed, compute, mode="shapes"):
     from oracle import ref_torch, spec
     from vit_tensorflow import ViT
@@ -139,7 +155,7 @@ def run(n, seed, compute, mode="shapes"):
     fails, worst_l, worst_g = [], 0.0, 0.0
     t0 = time.time()
     for i in range(n):
-        variant, kw, b = {"tokens": draw_tokens, "siblings": draw_siblings, "wide": draw_wide}.get(mode, draw)(rng, compute)
+        variant, kw, b = {"tokens": draw_tokens, "siblings": draw_siblings, "wide": draw_wide, "medium": draw_medium}.get(mode, draw)(rng, compute)
         cfg = spec.make_config("vit" if variant == "parallel_vit" else variant, **kw)
         P = spec.init_params(cfg, 1000 + i, randomize_all=True)
         H, W = cfg["image_size"]
@@ -180,7 +196,7 @@ def run(n, seed, compute, mode="shapes"):
     return fails
 
 
-def run_sequences(n, seed, compute, steps=5, siblings=False):
+def run_sequences(n, seed, compute, steps=5, siblings=False, medium=False):
     """Stale-state hunt: ONE handle per random configuration, then `steps` calls with a random batch (<= the handle's plan), a random SMALLER image
     (vit.py:165: pos_embedding[:, :n + 1] -- fewer patches than image_size are legal), new weights every now and then (the bf16 operand refresh),
     and sometimes two backward passes on one forward; every call against the oracle."""
@@ -197,14 +213,15 @@ def run_sequences(n, seed, compute, steps=5, siblings=False):
     fails, calls = [], 0
     t0 = time.time()
     for i in range(n):
-        variant, kw, _ = (draw_siblings if siblings else draw)(rng, compute)
+        variant, kw, bmax = (draw_medium if medium else draw_siblings if siblings else draw)(rng, compute)
+        bmax = max(bmax, 5) if medium else 5
         cfg = spec.make_config("vit" if variant == "parallel_vit" else variant, **kw)
         (H, W), (ph, pw) = cfg["image_size"], cfg["patch_size"]
         P = spec.init_params(cfg, 2000 + i, randomize_all=True)
-        m = classes[variant](**kw, compute=compute, max_batch=5, seed=0)
+        m = classes[variant](**kw, compute=compute, max_batch=bmax, seed=0)
         m.load_state_dict({k: v.astype(np.float32) for k, v in P.items()})
         for st in range(steps):
-            b = int(rng.integers(1, 6))
+            b = int(rng.integers(1, bmax + 1))
             gh, gw = H // ph, W // pw
             if rng.random() < 0.4:
                 gh, gw = int(rng.integers(1, gh + 1)), int(rng.integers(1, gw + 1))
@@ -254,7 +271,8 @@ def run_sequences(n, seed, compute, steps=5, siblings=False):
 
 
 if __name__ == "__main__":
-    if len(sys.argv) > 4 and sys.argv[4] in ("sequences", "sibling_sequences"):
-        sys.exit(1 if run_sequences(int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], siblings=sys.argv[4] == "sibling_sequences") else 0)
+    if len(sys.argv) > 4 and sys.argv[4] in ("sequences", "sibling_sequences", "medium_sequences"):
+        sys.exit(1 if run_sequences(int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], siblings=sys.argv[4] == "sibling_sequences",
+                                    medium=sys.argv[4] == "medium_sequences", steps=3 if sys.argv[4] == "medium_sequences" else 5) else 0)
     sys.exit(1 if run(int(sys.argv[1]) if len(sys.argv) > 1 else 40, int(sys.argv[2]) if len(sys.argv) > 2 else 0,
                       sys.argv[3] if len(sys.argv) > 3 else "fp32", sys.argv[4] if len(sys.argv) > 4 else "shapes") else 0)
