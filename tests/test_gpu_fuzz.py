@@ -59,3 +59,11 @@ def test_call_sequences_at_the_shapes_the_big_kernels_take():
     import fuzz_configs
     fails = fuzz_configs.run_sequences(8, 101, "bf16", steps=3, medium=True)
     assert not fails, fails
+
+
+@pytest.mark.parametrize("compute", ["fp32", "bf16"])
+def test_random_mae_and_simmim_wrappers_match_the_oracle(compute):
+    """random encoders, image / patch sizes, masking ratios from one masked patch to all but one, decoder widths (tools/fuzz_wrappers.py)"""
+    import fuzz_wrappers
+    fails = fuzz_wrappers.run(16, 0, compute)
+    assert not fails, fails
