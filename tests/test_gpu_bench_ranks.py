@@ -22,13 +22,14 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("impl, world", [("native", 2), ("torch", 2), ("native", 8)])
-def test_bench_with_several_ranks_on_one_gpu_prints_one_contract_line(impl, world):
+@pytest.mark.parametrize("impl, world, workload", [("native", 2, "vit_b16_224"), ("torch", 2, "vit_b16_224"), ("native", 8, "vit_b16_224"),
+                                                   ("native", 2, "vit_l16_224"), ("native", 2, "cait_256"), ("native", 2, "deepvit_256")])   # BASELINE configs[2] / [4] are data-parallel runs
+def test_bench_with_several_ranks_on_one_gpu_prints_one_contract_line(impl, world, workload):
     from util import fake_rccl_lib
     env = dict(os.environ, VITX_BENCH_ONE_GPU="1", VITX_RCCL_LIB=fake_rccl_lib(), VITX_FAKE_RCCL_SLOT_MB="64", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1", "--master-port",
            str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "2", "--warmup", "1", "--batch", "8", "--no-cpu-baseline",
-           "--no-profile", "--dp-impl", impl]
+           "--no-profile", "--dp-impl", impl, "--workload", workload]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
     lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
