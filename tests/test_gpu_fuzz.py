@@ -67,3 +67,12 @@ def test_random_mae_and_simmim_wrappers_match_the_oracle(compute):
     import fuzz_wrappers
     fails = fuzz_wrappers.run(16, 0, compute)
     assert not fails, fails
+
+
+@pytest.mark.parametrize("compute", ["fp32", "bf16"])
+def test_random_t2t_vits_match_the_oracle(compute):
+    """random tokenizer layers / image sizes (tf.image.extract_patches 'SAME' geometries, tokenizer transformers of odd widths), two batch sizes per object
+    (tools/fuzz_t2t.py; configurations the reference's own size formula rejects are skipped)"""
+    import fuzz_t2t
+    fails = fuzz_t2t.run(40, 2, compute)
+    assert not fails, fails
