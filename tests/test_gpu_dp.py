@@ -76,14 +76,18 @@ def _free_port():
     return p
 
 
-def _single_process_gradient(tmp):
+DEEPVIT_KW = dict(image_size=64, patch_size=16, num_classes=10, dim=128, depth=3, heads=4, mlp_dim=256, dim_head=32)
+
+
+def _single_process_gradient(tmp, deepvit=False):
     """The same global batch on ONE handle without any of the DP plumbing."""
     import ctypes as C
     from vit_tensorflow import ViT, _native as N
+    from vit_tensorflow.deepvit import DeepViT
     kw = dict(image_size=64, patch_size=16, num_classes=10, dim=128, depth=3, heads=2, mlp_dim=256, dim_head=64)
     img, lab, w = np.load(tmp / "img.npy"), np.load(tmp / "lab.npy"), np.load(tmp / "params.npy")
     gb = img.shape[0]
-    m = ViT(**kw, compute="bf16", max_batch=gb, seed=0)
+    m = DeepViT(**DEEPVIT_KW, compute="bf16", max_batch=gb, seed=0) if deepvit else ViT(**kw, compute="bf16", max_batch=gb, seed=0)
     m.build((gb,))
     N.check(N.lib().vitx_set_params(m._handle, w.ctypes.data_as(C.c_void_p), m._n))
     logits = np.asarray(m(img, training=False), np.float64)
@@ -280,6 +284,10 @@ b = gb // world
 if mode == "cait":
     kw = dict(image_size=64, patch_size=16, num_classes=10, dim=128, depth=6, cls_depth=2, heads=4, mlp_dim=256, dim_head=32, layer_dropout=0.5)
     m = CaiT(**kw, compute="bf16", max_batch=b, device=0, seed=1)
+elif mode == "deepvit":
+    from vit_tensorflow.deepvit import DeepViT
+    kw = dict(image_size=64, patch_size=16, num_classes=10, dim=128, depth=3, heads=4, mlp_dim=256, dim_head=32)
+    m = DeepViT(**kw, compute="bf16", max_batch=b, device=0, seed=1)
 else:
     kw = dict(image_size=64, patch_size=16, num_classes=10, dim=128, depth=3, heads=2, mlp_dim=256, dim_head=64)
     m = ViT(**kw, compute="bf16", max_batch=b, device=0, seed=1)          # same seed: identical replicas; BOTH ranks on GPU 0
@@ -367,6 +375,15 @@ def test_native_exchange_two_ranks_on_one_gpu_equals_one_rank(wire, tmp_path):
     assert np.abs(g0 - ref).max() <= 2e-2 * np.abs(ref).max()       # bf16 mode: shard sums round differently from the whole batch
     st = np.load(tmp_path / "stats.npy")
     print(f"[stub, {wire} wire] buckets {st[0]}, sent during the backward {st[1]}, Dense launches beside a collective {st[3]}")
+
+
+def test_native_exchange_two_deepvit_ranks_on_one_gpu_equal_one_rank(tmp_path):
+    """the same with DeepViT replicas (another arena: Re-attention weights and head-axis LayerNorm parameters between the Dense kernels)"""
+    _launch_stub(2, tmp_path, 4, "fp32", "deepvit")
+    g0, g1 = np.load(tmp_path / "native_grads_rank0.npy"), np.load(tmp_path / "native_grads_rank1.npy")
+    assert np.isfinite(g0).all() and np.array_equal(g0, g1)
+    ref = _single_process_gradient(tmp_path, deepvit=True)
+    assert np.abs(g0 - ref).max() <= 2e-2 * np.abs(ref).max()
 
 
 @pytest.mark.parametrize("world", [1, 2])
